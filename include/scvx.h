@@ -1,0 +1,149 @@
+/*
+ * scvx.h — C ABI of the MI355X-native successive-convexification (SCvx) hot path.
+ *
+ * This is the drop-in boundary for the SCvx inner loop of BenChung/SuccessiveConvexification
+ * (reference citations are file:line into that repository):
+ *
+ *   Dynamics.linearize_dynamics   dynamics.jl:321-334  ->  scvx_linearize_f64[_host]
+ *   Dynamics.predict_state        dynamics.jl:315-317  ->  scvx_propagate_f64[_host]
+ *   Rocketland.create_initial     rocketland.jl:34-39  ->  scvx_batch_create + scvx_batch_init
+ *   Rocketland.solve_step         rocketland.jl:226-321->  scvx_solve_step
+ *   Rocketland.solve_problem      rocketland.jl:432-443->  scvx_solve
+ *   MOI.optimize! (conic solve)   rocketland.jl:271    ->  scvx_socp_solve (batched ADMM, device)
+ *
+ * Conventions (reference: dynamics.jl:13-19, 136-139):
+ *   state  x[14] = [m, r(3), v(3), q(4, scalar first), w(3)]
+ *   control u[3] = thrust in the body frame
+ *   augmented input inp[21] = [x; u_k; u_{k+1}; sigma]
+ *   LinRes.derivative is Julia column-major 14x21: element (i,j) at j*14 + i   (master.jl:90-93)
+ *
+ * All pointers named *_dev are device (HBM) pointers valid on the context's device; all others are
+ * host pointers.  Device entry points are asynchronous on the context's stream (scvx_set_stream);
+ * the *_host entry points copy in, run, copy out and synchronise.  Every function returns 0 on
+ * success and a negative code on failure; scvx_last_error(ctx) then describes the failure.
+ * No C++ types and no exceptions cross this boundary.
+ */
+#ifndef SCVX_H
+#define SCVX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCVX_NX 14
+#define SCVX_NU 3
+#define SCVX_NP 21 /* 14 + 3 + 3 + 1 */
+
+#define SCVX_OK 0
+#define SCVX_ERR_ARG -1
+#define SCVX_ERR_HIP -2
+#define SCVX_ERR_STATE -3
+#define SCVX_ERR_NOMEM -4
+
+/* per-trajectory status codes written by scvx_solve_step / scvx_solve */
+#define SCVX_ST_CONVERGED 0   /* ||nu|| <= nuTol and dJ <= delTol             (rocketland.jl:436) */
+#define SCVX_ST_RUNNING 1     /* accepted step, not yet converged / imax hit                      */
+#define SCVX_ST_REJECTED 2    /* rho < rh0: iterate kept, radius shrunk, dJ=Inf (rocketland.jl:299-301) */
+#define SCVX_ST_SOLVER 3      /* conic solver did not reach tolerance        (rocketland.jl:273-276) */
+#define SCVX_ST_NONFINITE 4   /* NaN/Inf encountered                                              */
+
+/* Flat image of DescentProblem (master.jl:17-71) + the aero scalars of AtmosphericData (master.jl:10-16).
+ * Angles in degrees exactly as the reference stores them.  jB is column-major 3x3. */
+typedef struct scvx_problem {
+    double g, mdry, mwet, Tmin, Tmax;
+    double deltaMax, thetaMax, gammaGs, omMax, dpMax;
+    double jB[9];
+    double alpha, rho, sos;
+    double rTB[3], rFB[3];
+    double rIi[3], rIf[3], vIi[3], vIf[3];
+    double qBIi[4], qBIf[4];
+    double wBi[3], wBf[3];
+    double wNu, wID, wDS, wCst, wTviol, nuTol, delTol, tf_guess;
+    double ri, rh0, rh1, rh2, alph, bet;
+    double force_scalar, length_scalar; /* AtmosphericData scalars; ignored when aero_kind == 0 */
+    int32_t K, imax;
+    int32_t aero_kind; /* 0 = ExoatmosphericData, 1 = AtmosphericData */
+    int32_t reserved;
+} scvx_problem;
+
+/* Tunables of the batched operator-splitting conic solver that replaces MOI.optimize!. */
+typedef struct scvx_admm_opts {
+    int32_t max_iter;    /* ADMM iteration cap per SOCP                */
+    int32_t check_every; /* residual evaluation period                 */
+    double eps_abs;      /* absolute tolerance on primal/dual residual */
+    double eps_rel;      /* relative tolerance                         */
+    double rho;          /* initial penalty                            */
+    double alpha;        /* over-relaxation in (0,2)                   */
+    int32_t adapt_rho;   /* 1: residual-balancing refactorisation      */
+    int32_t warm_start;  /* 1: start from the previous SCvx iterate    */
+} scvx_admm_opts;
+
+typedef struct scvx_ctx scvx_ctx;     /* owns device, stream, problem constants, aero tables */
+typedef struct scvx_batch scvx_batch; /* owns the batched iterate (ProblemIteration x B)     */
+
+/* ---- context ------------------------------------------------------------------------------- */
+int scvx_ctx_create(const scvx_problem *p, int device, scvx_ctx **out);
+void scvx_ctx_destroy(scvx_ctx *ctx);
+const char *scvx_last_error(const scvx_ctx *ctx);
+int scvx_set_stream(scvx_ctx *ctx, void *hip_stream); /* NULL = the context's own stream */
+int scvx_synchronize(scvx_ctx *ctx);
+/* RK4 substeps per segment: the `npts` keyword of Dynamics.rk4 (dynamics.jl:112, default 10). */
+int scvx_set_nsub(scvx_ctx *ctx, int nsub);
+int scvx_get_nsub(const scvx_ctx *ctx);
+/* Aerodynamics.load_aerodata tables (aerodynamics.jl:11-28): three n_aoa x n_mach grids, cos(AoA)
+ * fastest, on axes aoa0 + i*daoa, mach0 + j*dmach.  Host pointers; prefiltered on the host, uploaded. */
+int scvx_set_aero_table(scvx_ctx *ctx, const double *drag, const double *lift, const double *trq,
+                        int n_aoa, int n_mach, double aoa0, double daoa, double mach0, double dmach);
+
+/* ---- discretisation: Dynamics.linearize_dynamics / predict_state ---------------------------- */
+/* x [B][K+1][14], u [B][K+1][3], sigma [B]; endpoint [B][K][14]; deriv [B][K][21][14]. */
+int scvx_linearize_f64(scvx_ctx *ctx, int B, int K, const double *x_dev, const double *u_dev,
+                       const double *sigma_dev, double dt, double *endpoint_dev, double *deriv_dev);
+int scvx_linearize_f64_host(scvx_ctx *ctx, int B, int K, const double *x, const double *u,
+                            const double *sigma, double dt, double *endpoint, double *deriv);
+/* xnext [B][K][14]: state at the end of each segment started from node k with FOH (u_k,u_{k+1}). */
+int scvx_propagate_f64(scvx_ctx *ctx, int B, int K, const double *x_dev, const double *u_dev,
+                       const double *sigma_dev, double dt, double *xnext_dev);
+int scvx_propagate_f64_host(scvx_ctx *ctx, int B, int K, const double *x, const double *u,
+                            const double *sigma, double dt, double *xnext);
+
+/* ---- batched SCvx: create_initial / solve_step / solve_problem ------------------------------ */
+int scvx_admm_default_opts(scvx_admm_opts *o);
+int scvx_batch_create(scvx_ctx *ctx, int B, scvx_batch **out);
+void scvx_batch_destroy(scvx_batch *b);
+int scvx_batch_set_admm(scvx_batch *b, const scvx_admm_opts *o);
+/* ic [B][6] = per-trajectory (rIi, vIi) overriding the problem's (Monte-Carlo dispersions); NULL =
+ * every trajectory uses the problem's own.  Builds the straight-line guess (initial_solve.jl:113-129),
+ * linearises it and sets rk=100, cost=Inf, iter=0 (rocketland.jl:38). */
+int scvx_batch_init(scvx_batch *b, const double *ic);
+/* One Rocketland.solve_step for every trajectory of the batch.  Outputs are host arrays of
+ * length B (any may be NULL): status codes above, ||nu||_F and dJ (Inf on rejection). */
+int scvx_solve_step(scvx_batch *b, int32_t *status, double *nu_norm, double *dJ);
+/* Asynchronous form for timing loops: enqueue one solve_step on the stream, no host read-back. */
+int scvx_solve_step_async(scvx_batch *b);
+/* Rocketland.solve_problem: iterate until converged or imax; iters[B] = solve_step calls used. */
+int scvx_solve(scvx_batch *b, int32_t *status, int32_t *iters, double *nu_norm, double *dJ);
+
+/* ---- iterate access (the batched ProblemIteration) ------------------------------------------ */
+/* traj [B][(K+1)*17 + 1]: per trajectory x[K+1][14], u[K+1][3], sigma.  */
+int scvx_batch_get_trajectory(scvx_batch *b, double *traj);
+int scvx_batch_set_trajectory(scvx_batch *b, const double *traj);
+/* device pointer to the same layout (for RCCL all-gather by the caller); valid until destroy */
+int scvx_batch_trajectory_dev(scvx_batch *b, double **traj_dev, int64_t *n_doubles);
+int scvx_batch_get_linearization(scvx_batch *b, double *endpoint, double *deriv);
+int scvx_batch_get_scalars(scvx_batch *b, double *rk, double *cost, int32_t *iter);
+int scvx_batch_set_scalars(scvx_batch *b, const double *rk, const double *cost, const int32_t *iter);
+/* last SOCP solve: per-trajectory ADMM iterations used, primal and dual residuals */
+int scvx_batch_get_solver_stats(scvx_batch *b, int32_t *admm_iters, double *r_prim, double *r_dual);
+
+/* ---- the conic subproblem alone (replaces MOI.optimize!, rocketland.jl:271) ------------------ */
+/* Solves the trust-region SOCP at the batch's current (about, dynam, rk).  sol [B][(K+1)*17+1] as
+ * the trajectory layout but sigma slot holds sigma + dsigma; nu [B][K][14] (nu_2..nu_{K+1}). */
+int scvx_socp_solve(scvx_batch *b, double *sol, double *nu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCVX_H */

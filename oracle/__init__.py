@@ -1,0 +1,46 @@
+"""CPU oracle for the SCvx hot path — TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import
+this package, and only as the checker.  The product package ``successiveconvexification_amd`` never
+imports it.
+
+PARITY UNPINNED.  The reference (BenChung/SuccessiveConvexification, Julia) cannot be executed in the
+build container (no ``julia`` binary, no network), ships no tests / golden vectors / recorded outputs
+for this path, and delegates its numerics to un-vendored, un-versioned Julia packages
+(DifferentialEquations ``BS3``, DiffEqSensitivity, Zygote, Interpolations, MathOptInterface + Mosek
+with ECOS imported, Rotations).  The oracle therefore restates the reference's own equations
+(citations in each module) and the published algorithms of those dependencies, and is validated by
+mathematical self-consistency (finite differences, high-order ODE integration, KKT certificates),
+not against reference output.
+
+Modules
+    model     problem data: DescentProblem defaults, normalize_problem, sample problems, linear_points
+    dynamics  ctypes front-end of scvx_oracle.c (RHS, Jacobians, RK4 discretisation, aero tables)
+    socp      the trust-region SOCP exactly as Rocketland.build_model assembles it
+    ipm       primal-dual interior-point conic solver (the role Mosek/ECOS play in the reference)
+    scvx      solve_step / solve_problem on top of the three
+    port      ctypes front-end of scvx_port.c — C twin of the device algorithm (RK4 + ADMM), the
+              ``cpu_baseline`` of bench.py
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc (recipe: oracle/Makefile)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("scvx_oracle.c", "scvx_port.c")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+    return _LIB
