@@ -1,0 +1,106 @@
+"""ctypes binding of libscvx_hip.so — the only door from the Python host layer to the HIP path.
+
+There is no CPU fallback: if the shared library is missing or does not export a symbol declared in
+include/scvx.h, importing this module's `lib()` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscvx_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class ScvxProblem(C.Structure):
+    """struct scvx_problem (include/scvx.h) — flat image of DescentProblem, master.jl:17-71."""
+    _fields_ = [
+        ("g", C.c_double), ("mdry", C.c_double), ("mwet", C.c_double), ("Tmin", C.c_double), ("Tmax", C.c_double),
+        ("deltaMax", C.c_double), ("thetaMax", C.c_double), ("gammaGs", C.c_double), ("omMax", C.c_double),
+        ("dpMax", C.c_double),
+        ("jB", C.c_double * 9),
+        ("alpha", C.c_double), ("rho", C.c_double), ("sos", C.c_double),
+        ("rTB", C.c_double * 3), ("rFB", C.c_double * 3),
+        ("rIi", C.c_double * 3), ("rIf", C.c_double * 3), ("vIi", C.c_double * 3), ("vIf", C.c_double * 3),
+        ("qBIi", C.c_double * 4), ("qBIf", C.c_double * 4),
+        ("wBi", C.c_double * 3), ("wBf", C.c_double * 3),
+        ("wNu", C.c_double), ("wID", C.c_double), ("wDS", C.c_double), ("wCst", C.c_double),
+        ("wTviol", C.c_double), ("nuTol", C.c_double), ("delTol", C.c_double), ("tf_guess", C.c_double),
+        ("ri", C.c_double), ("rh0", C.c_double), ("rh1", C.c_double), ("rh2", C.c_double),
+        ("alph", C.c_double), ("bet", C.c_double),
+        ("force_scalar", C.c_double), ("length_scalar", C.c_double),
+        ("K", C.c_int32), ("imax", C.c_int32), ("aero_kind", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class ScvxAdmmOpts(C.Structure):
+    _fields_ = [
+        ("max_iter", C.c_int32), ("check_every", C.c_int32),
+        ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("rho", C.c_double), ("alpha", C.c_double),
+        ("adapt_rho", C.c_int32), ("warm_start", C.c_int32),
+    ]
+
+
+_vp = C.c_void_p
+# name -> (restype, argtypes); must list every symbol include/scvx.h declares (tests check this)
+SIGNATURES = {
+    "scvx_ctx_create": (C.c_int, [C.POINTER(ScvxProblem), C.c_int, C.POINTER(_vp)]),
+    "scvx_ctx_destroy": (None, [_vp]),
+    "scvx_last_error": (C.c_char_p, [_vp]),
+    "scvx_set_stream": (C.c_int, [_vp, _vp]),
+    "scvx_synchronize": (C.c_int, [_vp]),
+    "scvx_set_nsub": (C.c_int, [_vp, C.c_int]),
+    "scvx_get_nsub": (C.c_int, [_vp]),
+    "scvx_set_aero_table": (C.c_int, [_vp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "scvx_linearize_f64": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp, _vp]),
+    "scvx_linearize_f64_host": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp]),
+    "scvx_propagate_f64": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
+    "scvx_propagate_f64_host": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp]),
+    "scvx_admm_default_opts": (C.c_int, [C.POINTER(ScvxAdmmOpts)]),
+    "scvx_batch_create": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "scvx_batch_destroy": (None, [_vp]),
+    "scvx_batch_set_admm": (C.c_int, [_vp, C.POINTER(ScvxAdmmOpts)]),
+    "scvx_batch_init": (C.c_int, [_vp, _dp]),
+    "scvx_solve_step": (C.c_int, [_vp, _ip, _dp, _dp]),
+    "scvx_solve_step_async": (C.c_int, [_vp]),
+    "scvx_solve": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
+    "scvx_batch_get_trajectory": (C.c_int, [_vp, _dp]),
+    "scvx_batch_set_trajectory": (C.c_int, [_vp, _dp]),
+    "scvx_batch_trajectory_dev": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int64)]),
+    "scvx_batch_get_linearization": (C.c_int, [_vp, _dp, _dp]),
+    "scvx_batch_get_scalars": (C.c_int, [_vp, _dp, _dp, _ip]),
+    "scvx_batch_set_scalars": (C.c_int, [_vp, _dp, _dp, _ip]),
+    "scvx_batch_get_solver_stats": (C.c_int, [_vp, _ip, _dp, _dp]),
+    "scvx_socp_solve": (C.c_int, [_vp, _dp, _dp]),
+}
+
+_LIB = None
+
+
+class ScvxError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libscvx_hip.so and bind every ABI symbol; raises if the HIP extension is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ScvxError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -m successiveconvexification_amd.build` or __graft_entry__.build().")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the library lacks an ABI symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def check(ctx_handle, rc: int, what: str):
+    if rc != 0:
+        msg = lib().scvx_last_error(ctx_handle)
+        raise ScvxError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,206 @@
+// K1 `linearize` and K2 `propagate`: the per-segment discretisation of the SCvx inner loop on gfx950.
+//
+// Replaces Dynamics.linearize_dynamics (dynamics.jl:321-334 -> sensitivity :298-305) and
+// Dynamics.predict_state (dynamics.jl:315-317 -> simulate :288-296) of the reference, using the
+// fixed-step RK4 it names in Dynamics.rk4 (dynamics.jl:112-134, `npts` substeps, FOH control at
+// substep start / middle / end) without that routine's stage bug (:126-128 drop the step size).
+//
+// K1 work decomposition (wave64): the 21 columns of the 14x21 sensitivity
+//     d x(t) / d [x_k | u_k | u_{k+1} | sigma]
+// obey independent linear ODEs once the state trajectory is known, so ONE LANE OWNS ONE COLUMN and
+// keeps it, its RK4 accumulator and its stage value in VGPRs (no LDS traffic, no cross-lane
+// dependency inside the integration).  A wavefront carries three consecutive segments
+// (3 x 21 = 63 lanes; lane 63 idles); every lane integrates its segment's 14 states redundantly,
+// which is cheaper than broadcasting them.  df/dx is never materialised: each lane applies the ~48
+// structural non-zeros straight to its column (scvx_dyn.hpp).  The finished 3 x 14 x 21 tile is
+// transposed through LDS so that the wavefront writes its 7,056 contiguous output bytes with
+// 16-byte-per-lane coalesced stores in the reference's column-major LinRes layout.
+#include "scvx_internal.hpp"
+
+namespace scvx {
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int SEG_PER_WAVE = 3;
+constexpr int TILE = SEG_PER_WAVE * 21 * 14;  // 882 doubles per wavefront
+
+template <bool AERO>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void linearize_kernel(
+    DynParams p, long nseg, int K, const double* __restrict__ x, const double* __restrict__ u,
+    const double* __restrict__ sigma, double dt, int nsub, double* __restrict__ endpoint,
+    double* __restrict__ deriv) {
+    __shared__ __attribute__((aligned(16))) double tile[WAVES_PER_BLOCK][64 * 14];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long gwave = (long)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const int sl = lane / 21;
+    const int col = lane - sl * 21;
+    const long seg0 = gwave * SEG_PER_WAVE;
+    long seg = seg0 + sl;
+    const bool active = (sl < SEG_PER_WAVE) && (seg < nseg);
+    if (!active) seg = (seg0 < nseg) ? seg0 : nseg - 1;  // idle lanes shadow a valid segment, never store
+    const long b = seg / K;
+    const int k = (int)(seg - b * K);
+    const double* xk = x + ((size_t)b * (K + 1) + k) * 14;
+    const double* uk = u + ((size_t)b * (K + 1) + k) * 3;
+    const double sig = sigma[b];
+
+    double xs[14], c[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        xs[i] = xk[i];
+        c[i] = (col == i) ? 1.0 : 0.0;
+    }
+    const double uk0 = uk[0], uk1 = uk[1], uk2 = uk[2];
+    const double up0 = uk[3], up1 = uk[4], up2 = uk[5];
+    const bool is_uk = (col >= 14) && (col < 17);
+    const bool is_up = (col >= 17) && (col < 20);
+    const int comp = is_uk ? col - 14 : (is_up ? col - 17 : -1);
+    const double gsel = (col == 20) ? 1.0 : 0.0;
+    const double e0 = (comp == 0) ? 1.0 : 0.0, e1 = (comp == 1) ? 1.0 : 0.0, e2 = (comp == 2) ? 1.0 : 0.0;
+
+    const double h = dt / (double)nsub;
+    const double inv_n = 1.0 / (double)nsub;
+    for (int s = 0; s < nsub; s++) {
+        double xa[14], ca[14], xt[14], ct[14];
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            xa[i] = xs[i];
+            ca[i] = c[i];
+            xt[i] = xs[i];
+            ct[i] = c[i];
+        }
+#pragma unroll
+        for (int stg = 0; stg < 4; stg++) {
+            const double lkp = ((double)s + (stg == 0 ? 0.0 : (stg == 3 ? 1.0 : 0.5))) * inv_n;
+            const double lkm = 1.0 - lkp;
+            double uu[3] = {fma(uk0, lkm, up0 * lkp), fma(uk1, lkm, up1 * lkp), fma(uk2, lkm, up2 * lkp)};
+            const double wk = is_uk ? lkm : (is_up ? lkp : 0.0);
+            const double wc[3] = {e0 * wk, e1 * wk, e2 * wk};
+            Stage<AERO> st;
+            stage_eval<AERO>(p, xt, uu, st);
+            double dc[14];
+            column_deriv<AERO>(p, st, xt, uu, ct, wc, gsel, sig, dc);
+            const double wacc = h * ((stg == 0 || stg == 3) ? (1.0 / 6.0) : (1.0 / 3.0));
+            const double wnext = h * (stg == 2 ? 1.0 : 0.5);
+#pragma unroll
+            for (int i = 0; i < 14; i++) {
+                const double dx = sig * st.g[i];
+                xa[i] = fma(wacc, dx, xa[i]);
+                ca[i] = fma(wacc, dc[i], ca[i]);
+                if (stg < 3) {
+                    xt[i] = fma(wnext, dx, xs[i]);
+                    ct[i] = fma(wnext, dc[i], c[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            xs[i] = xa[i];
+            c[i] = ca[i];
+        }
+    }
+
+    // ---- epilogue: LDS transpose -> coalesced 16-byte stores of the wave's contiguous tile ----
+    double* t = tile[wave];
+#pragma unroll
+    for (int i = 0; i < 14; i++) t[lane * 14 + i] = c[i];
+    __syncthreads();
+    if (seg0 < nseg) {
+        const long rem = nseg - seg0;
+        const int nvalid = rem < SEG_PER_WAVE ? (int)rem : SEG_PER_WAVE;
+        const int n2 = nvalid * 147;  // double2 elements in the tile (294 / 2 per segment)
+        double2* out = reinterpret_cast<double2*>(deriv + (size_t)seg0 * 294);
+        const double2* src = reinterpret_cast<const double2*>(t);
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            const int e = lane + 64 * r;
+            if (e < n2) out[e] = src[e];
+        }
+        if (active && col == 0) {
+            double* ep = endpoint + (size_t)seg * 14;
+#pragma unroll
+            for (int i = 0; i < 14; i++) ep[i] = xs[i];
+        }
+    }
+}
+
+template <bool AERO>
+__global__ __launch_bounds__(256) void propagate_kernel(DynParams p, long nseg, int K, const double* __restrict__ x,
+                                                        const double* __restrict__ u,
+                                                        const double* __restrict__ sigma, double dt, int nsub,
+                                                        double* __restrict__ xnext) {
+    const long seg = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg >= nseg) return;
+    const long b = seg / K;
+    const int k = (int)(seg - b * K);
+    const double* xk = x + ((size_t)b * (K + 1) + k) * 14;
+    const double* uk = u + ((size_t)b * (K + 1) + k) * 3;
+    const double sig = sigma[b];
+    double xs[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) xs[i] = xk[i];
+    const double uk0 = uk[0], uk1 = uk[1], uk2 = uk[2];
+    const double up0 = uk[3], up1 = uk[4], up2 = uk[5];
+    const double h = dt / (double)nsub;
+    const double inv_n = 1.0 / (double)nsub;
+    for (int s = 0; s < nsub; s++) {
+        double xa[14], xt[14];
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            xa[i] = xs[i];
+            xt[i] = xs[i];
+        }
+#pragma unroll
+        for (int stg = 0; stg < 4; stg++) {
+            const double lkp = ((double)s + (stg == 0 ? 0.0 : (stg == 3 ? 1.0 : 0.5))) * inv_n;
+            const double lkm = 1.0 - lkp;
+            double uu[3] = {fma(uk0, lkm, up0 * lkp), fma(uk1, lkm, up1 * lkp), fma(uk2, lkm, up2 * lkp)};
+            double g[14];
+            rhs_only<AERO>(p, xt, uu, g);
+            const double wacc = h * ((stg == 0 || stg == 3) ? (1.0 / 6.0) : (1.0 / 3.0));
+            const double wnext = h * (stg == 2 ? 1.0 : 0.5);
+#pragma unroll
+            for (int i = 0; i < 14; i++) {
+                const double dx = sig * g[i];
+                xa[i] = fma(wacc, dx, xa[i]);
+                if (stg < 3) xt[i] = fma(wnext, dx, xs[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 14; i++) xs[i] = xa[i];
+    }
+    double* o = xnext + (size_t)seg * 14;
+#pragma unroll
+    for (int i = 0; i < 14; i++) o[i] = xs[i];
+}
+
+hipError_t launch_linearize(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
+                            double dt, double* endpoint, double* deriv, hipStream_t st) {
+    const long nseg = (long)B * K;
+    if (nseg == 0) return hipSuccess;
+    const long nwave = (nseg + SEG_PER_WAVE - 1) / SEG_PER_WAVE;
+    const unsigned grid = (unsigned)((nwave + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    if (ctx->dyn.aero)
+        hipLaunchKernelGGL(linearize_kernel<true>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, st, ctx->dyn, nseg, K, x,
+                           u, sigma, dt, ctx->nsub, endpoint, deriv);
+    else
+        hipLaunchKernelGGL(linearize_kernel<false>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, st, ctx->dyn, nseg, K,
+                           x, u, sigma, dt, ctx->nsub, endpoint, deriv);
+    return hipGetLastError();
+}
+
+hipError_t launch_propagate(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
+                            double dt, double* xnext, hipStream_t st) {
+    const long nseg = (long)B * K;
+    if (nseg == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((nseg + 255) / 256);
+    if (ctx->dyn.aero)
+        hipLaunchKernelGGL(propagate_kernel<true>, dim3(grid), dim3(256), 0, st, ctx->dyn, nseg, K, x, u, sigma, dt,
+                           ctx->nsub, xnext);
+    else
+        hipLaunchKernelGGL(propagate_kernel<false>, dim3(grid), dim3(256), 0, st, ctx->dyn, nseg, K, x, u, sigma, dt,
+                           ctx->nsub, xnext);
+    return hipGetLastError();
+}
+
+}  // namespace scvx

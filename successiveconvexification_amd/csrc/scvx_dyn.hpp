@@ -1,0 +1,351 @@
+// Device-side 6-DoF rigid-body dynamics for the SCvx discretisation kernels (gfx950).
+//
+// What the reference computes here (file:line into BenChung/SuccessiveConvexification):
+//   RHS                       Dynamics.dx_static        dynamics.jl:54-77 (DCM :29-44, Omega :46-52)
+//   first-order-hold control  current_control           dynamics.jl:108-110, 144-150
+//   aerodynamic force         Aerodynamics.aero_force   aerodynamics.jl:60-77 + shims dynamics.jl:162-207
+//   table interpolation       load_aerodata             aerodynamics.jl:17-21 (cubic B-spline, Flat)
+// The reference obtains Jacobians by forward-mode AD over generated code (dynamics.jl:245-256); here
+// they are written out analytically and applied column-wise: a lane never forms the 14x14 matrix, it
+// applies the ~48 structural non-zeros of df/dx directly to the sensitivity column it owns.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace scvx {
+
+struct DynParams {
+    double alpha, g0, sos;
+    double J[9];     // row-major inertia
+    double Jinv[9];  // row-major inverse inertia
+    double rTB[3];
+    double JrT[9];   // row-major Jinv * [rTB]x  (d wdot / du, constant)
+    int aero;        // 0 exo, 1 atmospheric
+    int n_aoa, n_mach;
+    int pad;
+    double aoa0, inv_daoa, mach0, inv_dmach, force_scalar;
+    const double* cdrag;  // prefiltered coefficients, (n_mach+2) x (n_aoa+2), aoa fastest
+    const double* clift;
+};
+
+// Everything one RK stage needs about the state trajectory, evaluated once per stage per lane.
+template <bool AERO>
+struct Stage {
+    double g[14];      // un-scaled RHS
+    double C[9];       // DCM, row-major
+    double invm;
+    double am[3];      // d vdot / d m
+    double Dq[12];     // d vdot / d q   (3x4 row-major)
+    double Dv[AERO ? 9 : 1];  // d vdot / d v (aero only)
+    double Mw[9];      // d wdot / d w
+};
+
+__device__ __forceinline__ void bspline_weights(double t, int n, int& i0, double w[4], double dw[4]) {
+    int i = (int)floor(t);
+    i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+    double d = t - (double)i;
+    double d2 = d * d, d3 = d2 * d;
+    const double s = 1.0 / 6.0;
+    w[0] = (1.0 - 3.0 * d + 3.0 * d2 - d3) * s;
+    w[1] = (4.0 - 6.0 * d2 + 3.0 * d3) * s;
+    w[2] = (1.0 + 3.0 * d + 3.0 * d2 - 3.0 * d3) * s;
+    w[3] = d3 * s;
+    dw[0] = (-3.0 + 6.0 * d - 3.0 * d2) * s;
+    dw[1] = (-12.0 * d + 9.0 * d2) * s;
+    dw[2] = (3.0 + 6.0 * d - 9.0 * d2) * s;
+    dw[3] = (3.0 * d2) * s;
+    i0 = i;
+}
+
+// drag and lift tables at (aoa, mach): value, d/daoa, d/dmach each; Flat() extrapolation.
+__device__ __forceinline__ void aero_tables(const DynParams& p, double aoa, double mach, double td[3], double tl[3]) {
+    const int na = p.n_aoa, nm = p.n_mach;
+    double ta = (aoa - p.aoa0) * p.inv_daoa, tm = (mach - p.mach0) * p.inv_dmach;
+    bool fa = false, fm = false;
+    if (ta < 0.0) { ta = 0.0; fa = true; }
+    if (ta > (double)(na - 1)) { ta = (double)(na - 1); fa = true; }
+    if (tm < 0.0) { tm = 0.0; fm = true; }
+    if (tm > (double)(nm - 1)) { tm = (double)(nm - 1); fm = true; }
+    int ia, im;
+    double wa[4], dwa[4], wm[4], dwm[4];
+    bspline_weights(ta, na, ia, wa, dwa);
+    bspline_weights(tm, nm, im, wm, dwm);
+    const int lda = na + 2;
+    double vd = 0, vda = 0, vdm = 0, vl = 0, vla = 0, vlm = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const double* rd = p.cdrag + (size_t)(im + b) * lda + ia;
+        const double* rl = p.clift + (size_t)(im + b) * lda + ia;
+        double sd = 0, sda = 0, sl = 0, sla = 0;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            double cd = rd[a], cl = rl[a];
+            sd = fma(wa[a], cd, sd);
+            sda = fma(dwa[a], cd, sda);
+            sl = fma(wa[a], cl, sl);
+            sla = fma(dwa[a], cl, sla);
+        }
+        vd = fma(wm[b], sd, vd);
+        vda = fma(wm[b], sda, vda);
+        vdm = fma(dwm[b], sd, vdm);
+        vl = fma(wm[b], sl, vl);
+        vla = fma(wm[b], sla, vla);
+        vlm = fma(dwm[b], sl, vlm);
+    }
+    td[0] = vd;
+    td[1] = fa ? 0.0 : vda * p.inv_daoa;
+    td[2] = fm ? 0.0 : vdm * p.inv_dmach;
+    tl[0] = vl;
+    tl[1] = fa ? 0.0 : vla * p.inv_daoa;
+    tl[2] = fm ? 0.0 : vlm * p.inv_dmach;
+}
+
+// F[3] and (JAC) dF/d(q0..q3, v1..v3) as 3x7 row-major.
+template <bool JAC>
+__device__ __forceinline__ void aero_force(const DynParams& p, const double* q, const double* v, const double* C,
+                                           double F[3], double dF[21]) {
+    F[0] = F[1] = F[2] = 0.0;
+    if (JAC) {
+#pragma unroll
+        for (int i = 0; i < 21; i++) dF[i] = 0.0;
+    }
+    const double bv[3] = {C[0], C[3], C[6]};
+    const double vn2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const double vn = sqrt(vn2);
+    if (!(vn > 0.0)) return;
+    const double ivn = 1.0 / vn;
+    const double c = bv[0] * v[0] + bv[1] * v[1] + bv[2] * v[2];
+    const double mach = vn / p.sos;
+    double arg = c / (mach * p.sos);
+    bool clamped = false;
+    if (arg < -1.0) { arg = -1.0; clamped = true; }
+    if (arg > 1.0) { arg = 1.0; clamped = true; }
+    double td[3], tl[3];
+    aero_tables(p, arg, mach, td, tl);
+    const double fs = p.force_scalar;
+    const double drag = td[0] * fs, lift = tl[0] * fs;
+    // liftd = (bv x v) x v = c v - |v|^2 bv
+    double ld[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) ld[i] = c * v[i] - vn2 * bv[i];
+    const double ln = sqrt(ld[0] * ld[0] + ld[1] * ld[1] + ld[2] * ld[2]);
+    const bool has_lift = ln > 0.0;
+    const double iln = has_lift ? 1.0 / ln : 0.0;
+    double l[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        l[i] = ld[i] * iln;
+        F[i] = drag * v[i] * ivn + (has_lift ? lift * l[i] : 0.0);
+    }
+    if (!JAC) return;
+    const double dbv[12] = {0.0, 0.0, -4.0 * q[2], -4.0 * q[3],
+                            2.0 * q[3], 2.0 * q[2], 2.0 * q[1], 2.0 * q[0],
+                            -2.0 * q[2], 2.0 * q[3], -2.0 * q[0], 2.0 * q[1]};
+    double dc[4];  // d c / d q
+#pragma unroll
+    for (int j = 0; j < 4; j++) dc[j] = dbv[j] * v[0] + dbv[4 + j] * v[1] + dbv[8 + j] * v[2];
+    double darg[7], dmach[7];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        darg[j] = clamped ? 0.0 : dc[j] * ivn;
+        dmach[j] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        darg[4 + j] = clamped ? 0.0 : (bv[j] * ivn - c * v[j] * ivn * ivn * ivn);
+        dmach[4 + j] = v[j] * ivn / p.sos;
+    }
+    double ddrag[7], dlift[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        ddrag[j] = fs * (td[1] * darg[j] + td[2] * dmach[j]);
+        dlift[j] = fs * (tl[1] * darg[j] + tl[2] * dmach[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) dF[i * 7 + j] = ddrag[j] * v[i] * ivn;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            dF[i * 7 + 4 + j] += drag * ((i == j ? ivn : 0.0) - v[i] * v[j] * ivn * ivn * ivn);
+    }
+    if (has_lift) {
+        double dld[21];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) dld[i * 7 + j] = v[i] * dc[j] - vn2 * dbv[i * 4 + j];
+#pragma unroll
+            for (int j = 0; j < 3; j++) dld[i * 7 + 4 + j] = (i == j ? c : 0.0) + v[i] * bv[j] - 2.0 * bv[i] * v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const double proj = l[0] * dld[j] + l[1] * dld[7 + j] + l[2] * dld[14 + j];
+#pragma unroll
+            for (int i = 0; i < 3; i++) dF[i * 7 + j] += dlift[j] * l[i] + lift * (dld[i * 7 + j] - l[i] * proj) * iln;
+        }
+    }
+}
+
+__device__ __forceinline__ void dcm(const double* q, double* C) {
+    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    C[0] = 1.0 - 2.0 * (q2 * q2 + q3 * q3);
+    C[1] = 2.0 * (q1 * q2 - q0 * q3);
+    C[2] = 2.0 * (q1 * q3 + q0 * q2);
+    C[3] = 2.0 * (q1 * q2 + q0 * q3);
+    C[4] = 1.0 - 2.0 * (q1 * q1 + q3 * q3);
+    C[5] = 2.0 * (q2 * q3 - q0 * q1);
+    C[6] = 2.0 * (q1 * q3 - q0 * q2);
+    C[7] = 2.0 * (q2 * q3 + q0 * q1);
+    C[8] = 1.0 - 2.0 * (q1 * q1 + q2 * q2);
+}
+
+// RHS only (K2 propagate and the state part of K1).
+template <bool AERO>
+__device__ __forceinline__ void rhs_only(const DynParams& p, const double* x, const double* u, double* g) {
+    const double* v = x + 4;
+    const double* q = x + 7;
+    const double* w = x + 11;
+    double C[9], F[3] = {0.0, 0.0, 0.0};
+    dcm(q, C);
+    if (AERO) aero_force<false>(p, q, v, C, F, nullptr);
+    const double invm = 1.0 / x[0];
+    g[0] = -p.alpha * sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    g[1] = v[0]; g[2] = v[1]; g[3] = v[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) g[4 + i] = (C[3 * i] * u[0] + C[3 * i + 1] * u[1] + C[3 * i + 2] * u[2] + F[i]) * invm;
+    g[4] -= p.g0;
+    g[7] = 0.5 * (-w[0] * q[1] - w[1] * q[2] - w[2] * q[3]);
+    g[8] = 0.5 * (w[0] * q[0] + w[2] * q[2] - w[1] * q[3]);
+    g[9] = 0.5 * (w[1] * q[0] - w[2] * q[1] + w[0] * q[3]);
+    g[10] = 0.5 * (w[2] * q[0] + w[1] * q[1] - w[0] * q[2]);
+    double Jw[3], t[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) Jw[i] = p.J[3 * i] * w[0] + p.J[3 * i + 1] * w[1] + p.J[3 * i + 2] * w[2];
+    t[0] = (p.rTB[1] * u[2] - p.rTB[2] * u[1]) - (w[1] * Jw[2] - w[2] * Jw[1]);
+    t[1] = (p.rTB[2] * u[0] - p.rTB[0] * u[2]) - (w[2] * Jw[0] - w[0] * Jw[2]);
+    t[2] = (p.rTB[0] * u[1] - p.rTB[1] * u[0]) - (w[0] * Jw[1] - w[1] * Jw[0]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) g[11 + i] = p.Jinv[3 * i] * t[0] + p.Jinv[3 * i + 1] * t[1] + p.Jinv[3 * i + 2] * t[2];
+}
+
+// RHS + the structural non-zeros of df/dx at (x,u).
+template <bool AERO>
+__device__ __forceinline__ void stage_eval(const DynParams& p, const double* x, const double* u, Stage<AERO>& s) {
+    const double* v = x + 4;
+    const double* q = x + 7;
+    const double* w = x + 11;
+    dcm(q, s.C);
+    double F[3] = {0.0, 0.0, 0.0};
+    double dF[AERO ? 21 : 1];
+    if (AERO) aero_force<true>(p, q, v, s.C, F, dF);
+    const double invm = 1.0 / x[0];
+    s.invm = invm;
+    s.g[0] = -p.alpha * sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    s.g[1] = v[0]; s.g[2] = v[1]; s.g[3] = v[2];
+    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const double u1 = u[0], u2 = u[1], u3 = u[2];
+    // d(C u)/dq, 3x4 row-major
+    double D[12];
+    D[0] = 2.0 * (-q3 * u2 + q2 * u3);
+    D[4] = 2.0 * (q3 * u1 - q1 * u3);
+    D[8] = 2.0 * (-q2 * u1 + q1 * u2);
+    D[1] = 2.0 * (q2 * u2 + q3 * u3);
+    D[5] = 2.0 * (q2 * u1 - 2.0 * q1 * u2 - q0 * u3);
+    D[9] = 2.0 * (q3 * u1 + q0 * u2 - 2.0 * q1 * u3);
+    D[2] = 2.0 * (-2.0 * q2 * u1 + q1 * u2 + q0 * u3);
+    D[6] = 2.0 * (q1 * u1 + q3 * u3);
+    D[10] = 2.0 * (-q0 * u1 + q3 * u2 - 2.0 * q2 * u3);
+    D[3] = 2.0 * (-2.0 * q3 * u1 - q0 * u2 + q1 * u3);
+    D[7] = 2.0 * (q0 * u1 - 2.0 * q3 * u2 + q2 * u3);
+    D[11] = 2.0 * (q1 * u1 + q2 * u2);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double acc = (s.C[3 * i] * u1 + s.C[3 * i + 1] * u2 + s.C[3 * i + 2] * u3 + F[i]) * invm;
+        s.g[4 + i] = acc;
+        s.am[i] = -acc * invm;
+#pragma unroll
+        for (int j = 0; j < 4; j++) s.Dq[4 * i + j] = (D[4 * i + j] + (AERO ? dF[7 * i + j] : 0.0)) * invm;
+        if (AERO) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) s.Dv[3 * i + j] = dF[7 * i + 4 + j] * invm;
+        }
+    }
+    s.g[4] -= p.g0;
+    s.g[7] = 0.5 * (-w[0] * q1 - w[1] * q2 - w[2] * q3);
+    s.g[8] = 0.5 * (w[0] * q0 + w[2] * q2 - w[1] * q3);
+    s.g[9] = 0.5 * (w[1] * q0 - w[2] * q1 + w[0] * q3);
+    s.g[10] = 0.5 * (w[2] * q0 + w[1] * q1 - w[0] * q2);
+    double Jw[3], t[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) Jw[i] = p.J[3 * i] * w[0] + p.J[3 * i + 1] * w[1] + p.J[3 * i + 2] * w[2];
+    t[0] = (p.rTB[1] * u3 - p.rTB[2] * u2) - (w[1] * Jw[2] - w[2] * Jw[1]);
+    t[1] = (p.rTB[2] * u1 - p.rTB[0] * u3) - (w[2] * Jw[0] - w[0] * Jw[2]);
+    t[2] = (p.rTB[0] * u2 - p.rTB[1] * u1) - (w[0] * Jw[1] - w[1] * Jw[0]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) s.g[11 + i] = p.Jinv[3 * i] * t[0] + p.Jinv[3 * i + 1] * t[1] + p.Jinv[3 * i + 2] * t[2];
+    // T = [w]x J - [Jw]x ; Mw = -Jinv T
+    double T[9];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        T[0 + j] = -w[2] * p.J[3 + j] + w[1] * p.J[6 + j];
+        T[3 + j] = w[2] * p.J[0 + j] - w[0] * p.J[6 + j];
+        T[6 + j] = -w[1] * p.J[0 + j] + w[0] * p.J[3 + j];
+    }
+    T[1] += Jw[2]; T[2] -= Jw[1];
+    T[3] -= Jw[2]; T[5] += Jw[0];
+    T[6] += Jw[1]; T[7] -= Jw[0];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            s.Mw[3 * i + j] = -(p.Jinv[3 * i] * T[j] + p.Jinv[3 * i + 1] * T[3 + j] + p.Jinv[3 * i + 2] * T[6 + j]);
+}
+
+// d/dt of one sensitivity column c (14 values):  sigma * (A c + Bu * wc) + gsel * g
+// wc[3] = FOH weight of this column's control component (zero for state / sigma columns).
+template <bool AERO>
+__device__ __forceinline__ void column_deriv(const DynParams& p, const Stage<AERO>& s, const double* x, const double* u,
+                                             const double* c, const double* wc, double gsel, double sigma, double* dc) {
+    const double* q = x + 7;
+    const double* w = x + 11;
+    const double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    const double iun = un > 0.0 ? 1.0 / un : 0.0;
+    double a[14];
+    a[0] = -p.alpha * iun * (u[0] * wc[0] + u[1] * wc[1] + u[2] * wc[2]);
+    a[1] = c[4]; a[2] = c[5]; a[3] = c[6];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double t = s.am[i] * c[0];
+        t = fma(s.Dq[4 * i], c[7], t);
+        t = fma(s.Dq[4 * i + 1], c[8], t);
+        t = fma(s.Dq[4 * i + 2], c[9], t);
+        t = fma(s.Dq[4 * i + 3], c[10], t);
+        if (AERO) {
+            t = fma(s.Dv[3 * i], c[4], t);
+            t = fma(s.Dv[3 * i + 1], c[5], t);
+            t = fma(s.Dv[3 * i + 2], c[6], t);
+        }
+        t = fma((s.C[3 * i] * wc[0] + s.C[3 * i + 1] * wc[1] + s.C[3 * i + 2] * wc[2]), s.invm, t);
+        a[4 + i] = t;
+    }
+    const double cq0 = c[7], cq1 = c[8], cq2 = c[9], cq3 = c[10];
+    const double cw0 = c[11], cw1 = c[12], cw2 = c[13];
+    a[7] = 0.5 * (-w[0] * cq1 - w[1] * cq2 - w[2] * cq3 - q[1] * cw0 - q[2] * cw1 - q[3] * cw2);
+    a[8] = 0.5 * (w[0] * cq0 + w[2] * cq2 - w[1] * cq3 + q[0] * cw0 - q[3] * cw1 + q[2] * cw2);
+    a[9] = 0.5 * (w[1] * cq0 - w[2] * cq1 + w[0] * cq3 + q[3] * cw0 + q[0] * cw1 - q[1] * cw2);
+    a[10] = 0.5 * (w[2] * cq0 + w[1] * cq1 - w[0] * cq2 - q[2] * cw0 + q[1] * cw1 + q[0] * cw2);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double t = s.Mw[3 * i] * cw0;
+        t = fma(s.Mw[3 * i + 1], cw1, t);
+        t = fma(s.Mw[3 * i + 2], cw2, t);
+        t = fma(p.JrT[3 * i], wc[0], t);
+        t = fma(p.JrT[3 * i + 1], wc[1], t);
+        t = fma(p.JrT[3 * i + 2], wc[2], t);
+        a[11 + i] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) dc[i] = fma(sigma, a[i], gsel * s.g[i]);
+}
+
+}  // namespace scvx

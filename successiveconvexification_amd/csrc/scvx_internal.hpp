@@ -1,0 +1,41 @@
+// Internal declarations shared by the translation units of libscvx_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include "scvx.h"
+#include "scvx_dyn.hpp"
+
+struct scvx_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    scvx_problem prob{};
+    scvx::DynParams dyn{};
+    int nsub = 10;
+    double* d_cdrag = nullptr;
+    double* d_clift = nullptr;
+    std::string err;
+};
+
+namespace scvx {
+
+// K1: endpoint[B*K][14], deriv[B*K][21][14] from x[B][K+1][14], u[B][K+1][3], sigma[B].
+hipError_t launch_linearize(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
+                            double dt, double* endpoint, double* deriv, hipStream_t st);
+// K2: xnext[B*K][14].
+hipError_t launch_propagate(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
+                            double dt, double* xnext, hipStream_t st);
+
+inline int fail(scvx_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+}  // namespace scvx
+
+#define SCVX_HIP(ctx, call)                                                                        \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return scvx::fail((ctx), SCVX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)

@@ -1,0 +1,107 @@
+"""K1 linearize / K2 propagate on the MI355X vs the CPU oracle (same RK4, fp64).
+
+Tolerance: the kernel and the oracle run the same tableau in fp64 but associate sums differently
+(sparse column-wise products vs dense loops, fma contraction on the device), so agreement is to
+rounding: 1e-11 absolute on O(1) quantities, stated per assert.
+"""
+import numpy as np
+import pytest
+
+from conftest import random_segments
+
+pytestmark = pytest.mark.gpu
+
+
+def _cache(p, npts=10):
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    return IntegratorCache(p, npts=npts)
+
+
+def _product_problem(aero_tables=None):
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.defns import AtmosphericData
+    if aero_tables is None:
+        return sp.base_prob_scaled
+    d, l, t = aero_tables
+    return sp.base_prob_aero_scaled(AtmosphericData(d, l, t))
+
+
+def _oracle_problem(aero_tables=None):
+    from oracle import model
+    if aero_tables is None:
+        return model.base_prob_scaled()
+    d, l, t = aero_tables
+    return model.base_prob_scaled(model.AeroData(d, l, t))
+
+
+@pytest.mark.parametrize("B,K,npts", [(1, 50, 10), (7, 50, 4), (64, 30, 1), (3, 1, 2), (5, 100, 10)])
+def test_linearize_matches_oracle_exo(B, K, npts):
+    from oracle import dynamics as od
+    from successiveconvexification_amd.dynamics import linearize_batch, propagate_batch
+    po = _oracle_problem()
+    x, u, sigma = random_segments(po, B, K, 20261006 + B)
+    dt = 1.0 / (K + 1)
+    e_ref, d_ref = od.linearize(od.Params(po), x, u, sigma, dt, npts)
+    c = _cache(_product_problem(), npts)
+    e, d = linearize_batch(c, x, u, sigma, dt)
+    assert np.abs(e - e_ref).max() < 1e-12
+    assert np.abs(d - d_ref).max() < 1e-11
+    xn = propagate_batch(c, x, u, sigma, dt)
+    assert np.abs(xn - e_ref).max() < 1e-12
+    # K1's endpoint and K2 are the same map
+    assert np.abs(xn - e).max() < 1e-13
+
+
+def test_linearize_matches_oracle_aero(aero_tables):
+    from oracle import dynamics as od
+    from successiveconvexification_amd.dynamics import linearize_batch, propagate_batch
+    po = _oracle_problem(aero_tables)
+    B, K, npts = 16, 50, 10
+    x, u, sigma = random_segments(po, B, K, 20261003)
+    # put a few nodes on the special branches: v = 0 (ifnz guards) and v parallel to the body axis (no lift)
+    x[0, 3, 4:7] = 0.0
+    x[1, 5, 7:11] = [1, 0, 0, 0]
+    x[1, 5, 4:7] = [-0.2, 0, 0]
+    dt = 1.0 / (K + 1)
+    e_ref, d_ref = od.linearize(od.Params(po), x, u, sigma, dt, npts)
+    c = _cache(_product_problem(aero_tables), npts)
+    e, d = linearize_batch(c, x, u, sigma, dt)
+    assert np.isfinite(d).all()
+    assert np.abs(e - e_ref).max() < 1e-12
+    assert np.abs(d - d_ref).max() < 1e-10
+    xn = propagate_batch(c, x, u, sigma, dt)
+    assert np.abs(xn - e_ref).max() < 1e-12
+
+
+def test_first_order_taylor_property():
+    """Size-independent property at the full batch: endpoint(inp + eps*delta) - endpoint(inp) ~ deriv @ (eps*delta)."""
+    from successiveconvexification_amd.dynamics import linearize_batch, propagate_batch
+    from oracle import model
+    po = model.base_prob_scaled()
+    B, K = 8192, 50
+    x, u, sigma = random_segments(po, B, K, 20261004)
+    dt = 1.0 / (K + 1)
+    c = _cache(_product_problem(), 4)
+    e, d = linearize_batch(c, x, u, sigma, dt)
+    rng = np.random.default_rng(1)
+    eps = 1e-6
+    dx = rng.normal(size=x.shape) * eps
+    du = rng.normal(size=u.shape) * eps
+    ds = rng.normal(size=sigma.shape) * eps
+    e2 = propagate_batch(c, x + dx, u + du, sigma + ds, dt)
+    delta = np.concatenate([dx[:, :-1], du[:, :-1], du[:, 1:], np.broadcast_to(ds[:, None, None], (B, K, 1))], axis=-1)
+    pred = np.einsum("bkji,bkj->bki", d, delta)
+    err = np.abs(e2 - e - pred).max()
+    assert err < 50 * eps * eps * 1e3, err  # second-order remainder
+
+
+def test_empty_and_errors():
+    from successiveconvexification_amd import _lib
+    from successiveconvexification_amd.dynamics import linearize_batch
+    c = _cache(_product_problem())
+    e, d = linearize_batch(c, np.zeros((0, 51, 14)), np.zeros((0, 51, 3)), np.zeros(0), 1 / 51)
+    assert e.shape == (0, 50, 14) and d.shape == (0, 50, 21, 14)
+    with pytest.raises(ValueError):
+        linearize_batch(c, np.zeros((2, 51, 14)), np.zeros((2, 50, 3)), np.zeros(2), 1 / 51)
+    with pytest.raises(_lib.ScvxError):
+        c.set_npts(0)
