@@ -30,12 +30,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
+def _stale(so, srcs):
+    return not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+
+
 def build(force: bool = False) -> str:
-    """Compile liboracle.so with gcc (recipe: oracle/Makefile)."""
+    """Compile liboracle.so (gcc) and liboracle_port.so (g++); recipe: oracle/Makefile."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("scvx_oracle.c", "scvx_port.c")]
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+    port = os.path.join(_HERE, "liboracle_port.so")
+    core = os.path.join(os.path.dirname(_HERE), "successiveconvexification_amd", "csrc", "scvx_ipm_core.hpp")
+    if force or _stale(so, [os.path.join(_HERE, "scvx_oracle.c")]):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    if force or _stale(port, [os.path.join(_HERE, "scvx_port.cpp"), core]):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle_port.so"], stdout=subprocess.DEVNULL)
     return so
 
 
@@ -44,3 +51,14 @@ def lib() -> ctypes.CDLL:
     if _LIB is None:
         _LIB = ctypes.CDLL(build())
     return _LIB
+
+
+_PORT = None
+
+
+def port_lib() -> ctypes.CDLL:
+    global _PORT
+    if _PORT is None:
+        build()
+        _PORT = ctypes.CDLL(os.path.join(_HERE, "liboracle_port.so"))
+    return _PORT

@@ -1,0 +1,67 @@
+// scvx_port.cpp — CPU twin of the device SCvx step (TEST INFRASTRUCTURE; bench.py's cpu_baseline "port").
+//
+// Compiles the SAME portable interior-point core the HIP kernel uses
+// (successiveconvexification_amd/csrc/scvx_ipm_core.hpp) with a one-lane host executor, one OpenMP
+// thread per trajectory, together with the oracle's own discretisation (scvx_oracle.c).  It is the
+// "C++ fp64 restatement of the same algorithm" BASELINE.md §4 asks to be timed on the host cores, and
+// the debug twin of the device kernel.  The independent check of the optimum is oracle/ipm.py.
+// The product never loads this library.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <omp.h>
+#include "../successiveconvexification_amd/csrc/scvx_ipm_core.hpp"
+
+namespace {
+struct HostEx {
+    double sc[1024];
+    int lane() const { return 0; }
+    int nlanes() const { return 1; }
+    void sync() {}
+    double sum(double x) { return x; }
+    double min(double x) { return x; }
+    bool all(bool b) { return b; }
+    double* scratch() { return sc; }
+};
+}  // namespace
+
+extern "C" {
+
+size_t scvx_port_work_doubles(int K) {
+    scvx::ipm::Layout L;
+    L.init(K);
+    return L.work_doubles();
+}
+
+// Solve B subproblems.  Layouts as include/scvx.h: xbar [B][K+1][14], ubar [B][K+1][3], endpoint [B][K][14],
+// deriv [B][K][21][14], rk [B], ic [B][6].  Outputs: sol [B][(K+1)*17+1] = dx, du, dsigma ; nu [B][K][14];
+// info [B][4] = status, iters, merit, pobj.
+int scvx_port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
+                   const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
+                   int nthreads) {
+    const int K = C->K;
+    scvx::ipm::Layout L;
+    L.init(K);
+    const size_t nw = L.work_doubles();
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+    {
+        std::vector<double> work(nw);
+        HostEx ex;
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < B; b++) {
+            scvx::ipm::Solver<HostEx> S(ex, *C);
+            scvx::ipm::Result r = S.solve(xbar + (size_t)b * (K + 1) * 14, ubar + (size_t)b * (K + 1) * 3,
+                                          endpoint + (size_t)b * K * 14, deriv + (size_t)b * K * 294, rk[b],
+                                          ic + (size_t)b * 6, work.data());
+            double* so = sol + (size_t)b * ((K + 1) * 17 + 1);
+            std::memcpy(so, S.V, sizeof(double) * (size_t)(L.nx + L.nu_));
+            so[L.nx + L.nu_] = S.V[L.iS];
+            std::memcpy(nu + (size_t)b * K * 14, S.V + L.nx + L.nu_, sizeof(double) * (size_t)L.ny);
+            info[4 * b + 0] = r.status; info[4 * b + 1] = r.iters; info[4 * b + 2] = r.merit; info[4 * b + 3] = r.pobj;
+        }
+    }
+    return 0;
+}
+}

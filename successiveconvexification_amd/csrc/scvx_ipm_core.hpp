@@ -1,0 +1,1200 @@
+// Structure-exploiting interior-point solver for the SCvx trust-region SOCP — portable core.
+//
+// Replaces MOI.optimize!(model) (rocketland.jl:271; Mosek / ECOS interior-point solvers) for the model
+// Rocketland.build_model assembles (rocketland.jl:53-219).  One *executor* solves one trajectory's
+// subproblem; the executor abstraction `Ex` supplies lane(), nlanes(), sync(), sum(), min(), scratch():
+//     device  : one 64-lane wavefront per trajectory (scvx_socp.hip), reductions by cross-lane shuffles,
+//               scratch tiles in LDS
+//     host    : one thread per trajectory (the CPU twin timed as bench.py's cpu_baseline)
+// The algorithm (Mehrotra predictor-corrector, Nesterov-Todd scaling, CVXOPT-style initial point) and
+// every formula follow the validated numpy twin oracle/ipm_struct.py; see DESIGN.md §SOCP for the maths.
+//
+// Reduced variables  w = (dx[K+1][14], du[K+1][3], nu[K][14], s, tnu, ttr, ts)   ("var vector", NV)
+// Cone vector layout ("cone vector", NC):
+//     gs[K][3] tilt[K][3] rate[K][4] mass[K] tb[K+1][4] tc[K+1][4] lb[K+1] nu[14K+1] tr[17(K+1)+1] sg[2] rk[1]
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SCVX_HD __host__ __device__ __forceinline__
+#else
+#define SCVX_HD inline
+#endif
+#if defined(SCVX_IPM_DEBUG) && !defined(__HIPCC__)
+#include <stdio.h>
+#define SCVX_DBG(...) fprintf(stderr, __VA_ARGS__)
+#else
+#define SCVX_DBG(...)
+#endif
+
+namespace scvx {
+namespace ipm {
+
+struct Consts {
+    int K, max_iter, refine, pad;
+    double tol;
+    double itan, sqcm, icos, Tmax, Tmin, omMax, mdry, wNu, mwet;
+    double rIf[3], vIf[3], qBIf[4], wBi[3], wBf[3];
+};
+
+struct Layout {
+    int K, nx, nu_, nloc, nv, iS, iTNU, iTTR, iTS;
+    int o_gs, o_tilt, o_rate, o_mass, o_tb, o_tc, o_lb, o_nu, o_tr, o_sg, o_rk, nc;
+    int c_gs, c_tilt, c_rate, c_mass, c_tb, c_tc, c_lb, c_nu, c_tr, c_sg, c_rk, ncones, nsmall;
+    int ny;
+    SCVX_HD void init(int K_) {
+        K = K_;
+        nx = 14 * (K + 1);
+        nu_ = 3 * (K + 1);
+        nloc = nx + nu_ + 14 * K;
+        iS = nloc; iTNU = nloc + 1; iTTR = nloc + 2; iTS = nloc + 3;
+        nv = nloc + 4;
+        ny = 14 * K;
+        o_gs = 0; o_tilt = 3 * K; o_rate = 6 * K; o_mass = 10 * K; o_tb = 11 * K;
+        o_tc = o_tb + 4 * (K + 1); o_lb = o_tc + 4 * (K + 1); o_nu = o_lb + (K + 1);
+        o_tr = o_nu + 14 * K + 1; o_sg = o_tr + 17 * (K + 1) + 1; o_rk = o_sg + 2; nc = o_rk + 1;
+        c_gs = 0; c_tilt = K; c_rate = 2 * K; c_mass = 3 * K; c_tb = 4 * K; c_tc = c_tb + K + 1; c_lb = c_tc + K + 1;
+        nsmall = c_lb + K + 1;
+        c_nu = nsmall; c_tr = nsmall + 1; c_sg = nsmall + 2; c_rk = nsmall + 3; ncones = nsmall + 4;
+    }
+    // small cone c in [0, nsmall): offset into the cone vector and dimension
+    SCVX_HD void small(int c, int& off, int& dim) const {
+        if (c < c_tilt) { off = o_gs + 3 * c; dim = 3; }
+        else if (c < c_rate) { off = o_tilt + 3 * (c - c_tilt); dim = 3; }
+        else if (c < c_mass) { off = o_rate + 4 * (c - c_rate); dim = 4; }
+        else if (c < c_tb) { off = o_mass + (c - c_mass); dim = 1; }
+        else if (c < c_tc) { off = o_tb + 4 * (c - c_tb); dim = 4; }
+        else if (c < c_lb) { off = o_tc + 4 * (c - c_tc); dim = 4; }
+        else { off = o_lb + (c - c_lb); dim = 1; }
+    }
+    // doubles of per-trajectory workspace
+    SCVX_HD size_t work_doubles() const {
+        size_t n = 0;
+        n += (size_t)ny;                 // dk
+        n += (size_t)nv * 8;             // V, rx, gx, dw, r1, cw, Vbest, tmpv
+        n += (size_t)ny * 7;             // y, ry, dy, r2, cy, tmpy, tmpy2
+        n += (size_t)nc * 12;            // S, Z, rz, lam, Wv, t, Wibz, dS, dZ, sds, sdz, tmpc
+        n += (size_t)ncones;             // Wbeta
+        n += (size_t)(K + 1) * 25 + (size_t)(K + 1) * 9;  // hx, hu
+        n += (size_t)K * 196 * 3;        // Sd->Linv, So->Wb, (spare)
+        n += (size_t)(nloc + ny) * 3;    // ls,ys, ltr,ytr, lnu,ynu
+        n += (size_t)nloc * 2;           // tmpl, tmpl2
+        n += (size_t)3 * (K + 1);        // uhat
+        n += (size_t)(K + 1);            // lb0
+        n += 64;                         // scalars
+        return n;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// scalar helpers for small second-order cones (dim <= 4), W = beta (2 v v' - J)
+// ------------------------------------------------------------------------------------------------
+SCVX_HD void soc_nt_small(const double* s, const double* z, int d, double* v, double& beta) {
+    double s1 = 0, z1 = 0, sz = 0;
+    for (int i = 1; i < d; i++) { s1 += s[i] * s[i]; z1 += z[i] * z[i]; sz += s[i] * z[i]; }
+    const double sj = sqrt(s[0] * s[0] - s1), zj = sqrt(z[0] * z[0] - z1);
+    const double isj = 1.0 / sj, izj = 1.0 / zj;
+    const double gam = sqrt(0.5 * (1.0 + (s[0] * z[0] + sz) * isj * izj));
+    const double ig = 0.5 / gam;
+    const double wb0 = (s[0] * isj + z[0] * izj) * ig;
+    const double den = 1.0 / sqrt(2.0 * (wb0 + 1.0));
+    v[0] = (wb0 + 1.0) * den;
+    for (int i = 1; i < d; i++) v[i] = (s[i] * isj - z[i] * izj) * ig * den;
+    beta = sqrt(sj * izj);
+}
+// y = W x (inverse=false) or W^-1 x
+SCVX_HD void soc_W_small(const double* v, double beta, int d, const double* x, double* y, bool inverse) {
+    double vx = v[0] * x[0];
+    if (!inverse) { for (int i = 1; i < d; i++) vx += v[i] * x[i]; }
+    else { for (int i = 1; i < d; i++) vx -= v[i] * x[i]; }
+    const double sc = inverse ? 1.0 / beta : beta;
+    const double y0 = (2.0 * vx * v[0] - x[0]) * sc;
+    for (int i = 1; i < d; i++) y[i] = ((inverse ? -2.0 : 2.0) * vx * v[i] + x[i]) * sc;
+    y[0] = y0;
+}
+// W^-2 = [[h00, h01 v1'],[h01 v1, b2 I + h11 v1 v1']]
+SCVX_HD void soc_w2(const double v0, const double n1, const double beta, double& h00, double& h01, double& h11, double& b2) {
+    b2 = 1.0 / (beta * beta);
+    const double a = 2.0 * v0 * v0 - 1.0;
+    h00 = b2 * (a * a + 4.0 * v0 * v0 * n1);
+    h01 = b2 * (-4.0 * v0 * (v0 * v0 + n1));
+    h11 = b2 * 8.0 * v0 * v0;
+}
+SCVX_HD double soc_maxstep_parts(double l0, double d0, double ll, double ld, double dd) {
+    // ll = lam'J lam, ld = lam'J d, dd = d'J d
+    double amax = INFINITY;
+    if (d0 < 0.0) amax = -l0 / d0;
+    const double a = dd, b = 2.0 * ld, c = ll;
+    const double disc = b * b - 4.0 * a * c;
+    if (disc >= 0.0) {
+        const double sq = sqrt(disc);
+        const double qq = -0.5 * (b + (b >= 0.0 ? sq : -sq));
+        const double r1 = (qq != 0.0) ? c / qq : INFINITY;
+        const double r2 = (a != 0.0) ? qq / a : INFINITY;
+        if (r1 > 0.0 && r1 < amax) amax = r1;
+        if (r2 > 0.0 && r2 < amax) amax = r2;
+    }
+    return amax;
+}
+// inverse of a symmetric positive definite 3x3 (row-major in/out) through its Cholesky factor: backward
+// stable for the nearly rank-one blocks d I + kappa v v' an active cone produces (the cofactor formula is not)
+SCVX_HD void inv3(const double* M, double* Mi) {
+    const double l00 = sqrt(M[0]);
+    const double l10 = M[3] / l00, l20 = M[6] / l00;
+    const double l11 = sqrt(M[4] - l10 * l10);
+    const double l21 = (M[7] - l20 * l10) / l11;
+    const double l22 = sqrt(M[8] - l20 * l20 - l21 * l21);
+    // Linv (lower)
+    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const double i10 = -l10 * i00 * i11;
+    const double i21 = -l21 * i11 * i22;
+    const double i20 = -(l20 * i00 + l21 * i10) * i22;
+    // Mi = Linv' Linv
+    Mi[0] = i00 * i00 + i10 * i10 + i20 * i20;
+    Mi[1] = Mi[3] = i10 * i11 + i20 * i21;
+    Mi[2] = Mi[6] = i20 * i22;
+    Mi[4] = i11 * i11 + i21 * i21;
+    Mi[5] = Mi[7] = i21 * i22;
+    Mi[8] = i22 * i22;
+}
+SCVX_HD void inv2(double a, double b, double d, double* Mi) {  // [[a b],[b d]] SPD
+    const double l00 = sqrt(a), l10 = b / l00, l11 = sqrt(d - l10 * l10);
+    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i10 = -l10 * i00 * i11;
+    Mi[0] = i00 * i00 + i10 * i10; Mi[1] = Mi[2] = i10 * i11; Mi[3] = i11 * i11;
+}
+
+// compact per-node inverse of the x-block of Hb: [hm | Hr 3x3 | hv | hq | Hq34 2x2 | Hw 3x3] = 25 doubles
+enum { HX_M = 0, HX_R = 1, HX_V = 10, HX_Q = 11, HX_Q34 = 12, HX_W = 16, HX_SZ = 25 };
+SCVX_HD double hxi_entry(const double* h, int a, int b) {
+    if (a == 0) return b == 0 ? h[HX_M] : 0.0;
+    if (a < 4) return (b >= 1 && b < 4) ? h[HX_R + 3 * (a - 1) + (b - 1)] : 0.0;
+    if (a < 7) return a == b ? h[HX_V] : 0.0;
+    if (a < 9) return a == b ? h[HX_Q] : 0.0;
+    if (a < 11) return (b >= 9 && b < 11) ? h[HX_Q34 + 2 * (a - 9) + (b - 9)] : 0.0;
+    return (b >= 11) ? h[HX_W + 3 * (a - 11) + (b - 11)] : 0.0;
+}
+// y = Hxi * x for one node (14-vectors)
+SCVX_HD void hxi_apply(const double* h, const double* x, double* y) {
+    y[0] = h[HX_M] * x[0];
+    for (int i = 0; i < 3; i++) y[1 + i] = h[HX_R + 3 * i] * x[1] + h[HX_R + 3 * i + 1] * x[2] + h[HX_R + 3 * i + 2] * x[3];
+    for (int i = 4; i < 7; i++) y[i] = h[HX_V] * x[i];
+    y[7] = h[HX_Q] * x[7]; y[8] = h[HX_Q] * x[8];
+    y[9] = h[HX_Q34] * x[9] + h[HX_Q34 + 1] * x[10];
+    y[10] = h[HX_Q34 + 2] * x[9] + h[HX_Q34 + 3] * x[10];
+    for (int i = 0; i < 3; i++) y[11 + i] = h[HX_W + 3 * i] * x[11] + h[HX_W + 3 * i + 1] * x[12] + h[HX_W + 3 * i + 2] * x[13];
+}
+// a' Hxi b where a, b are rows i, j of a 14x14 column-major (stride 14) matrix: a[c] = A[c*14 + i]
+SCVX_HD double hxi_quad(const double* h, const double* A, int i, const double* Bm, int j) {
+    double s = h[HX_M] * A[i] * Bm[j];
+    for (int a = 0; a < 3; a++) {
+        const double ai = A[(1 + a) * 14 + i];
+        s += ai * (h[HX_R + 3 * a] * Bm[14 + j] + h[HX_R + 3 * a + 1] * Bm[28 + j] + h[HX_R + 3 * a + 2] * Bm[42 + j]);
+    }
+    double t = 0;
+    for (int a = 4; a < 7; a++) t += A[a * 14 + i] * Bm[a * 14 + j];
+    s += h[HX_V] * t;
+    s += h[HX_Q] * (A[7 * 14 + i] * Bm[7 * 14 + j] + A[8 * 14 + i] * Bm[8 * 14 + j]);
+    {
+        const double a9 = A[9 * 14 + i], a10 = A[10 * 14 + i], b9 = Bm[9 * 14 + j], b10 = Bm[10 * 14 + j];
+        s += a9 * (h[HX_Q34] * b9 + h[HX_Q34 + 1] * b10) + a10 * (h[HX_Q34 + 2] * b9 + h[HX_Q34 + 3] * b10);
+    }
+    for (int a = 0; a < 3; a++) {
+        const double ai = A[(11 + a) * 14 + i];
+        s += ai * (h[HX_W + 3 * a] * Bm[11 * 14 + j] + h[HX_W + 3 * a + 1] * Bm[12 * 14 + j] + h[HX_W + 3 * a + 2] * Bm[13 * 14 + j]);
+    }
+    return s;
+}
+// a' Hui b with a = row i of a 14x3 col-major block (stride 14), b = row j of another
+SCVX_HD double hui_quad(const double* hu, const double* Ba, int i, const double* Bb, int j) {
+    double s = 0;
+    for (int c = 0; c < 3; c++) {
+        const double t = hu[3 * c] * Bb[j] + hu[3 * c + 1] * Bb[14 + j] + hu[3 * c + 2] * Bb[28 + j];
+        s += Ba[c * 14 + i] * t;
+    }
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the solver
+// ------------------------------------------------------------------------------------------------
+struct Result {
+    int status;  // 0 optimal, 1 max_iter, 2 stalled / kkt failure (best iterate returned), 3 non-finite
+    int iters;
+    double merit, pobj;
+};
+
+template <class Ex>
+struct Solver {
+    Ex& ex;
+    const Consts& C;
+    Layout L;
+    // inputs
+    const double *xbar, *ubar, *D, *endpoint;
+    double x0fix[10];  // mwet, rIi(3), vIi(3), wBi(3)
+    double rk;
+    // workspace
+    double *dk, *V, *rx, *gx, *dw, *r1, *cw, *Vbest, *tmpv;
+    double *y, *ry, *dy, *r2, *cy, *tmpy, *tmpy2;
+    double *S, *Z, *rz, *lam, *Wv, *tt, *Wibz, *dS, *dZ, *sds, *sdz, *tmpc;
+    double* Wbeta;
+    double *hx, *hu;
+    double *Linv, *Wb, *Sd;
+    double *ls, *ys, *ltr, *ytr, *lnu, *ynu;
+    double *tmpl, *tmpl2;
+    double *uhat, *lb0;
+    // per-factorisation scalars
+    double h_tr[4], h_nu[4], Msg[4], hrk, hnui;
+    double css, cst, csn, cts, ctt, ctn, cns, cnt_, cnn;
+
+    SCVX_HD Solver(Ex& e, const Consts& c) : ex(e), C(c) { L.init(c.K); }
+
+    SCVX_HD void carve(double* w) {
+        const int nv = L.nv, ny = L.ny, nc = L.nc, nloc = L.nloc, K = L.K;
+        dk = w; w += ny;
+        V = w; w += nv; rx = w; w += nv; gx = w; w += nv; dw = w; w += nv; r1 = w; w += nv; cw = w; w += nv;
+        Vbest = w; w += nv; tmpv = w; w += nv;
+        y = w; w += ny; ry = w; w += ny; dy = w; w += ny; r2 = w; w += ny; cy = w; w += ny; tmpy = w; w += ny; tmpy2 = w; w += ny;
+        S = w; w += nc; Z = w; w += nc; rz = w; w += nc; lam = w; w += nc; Wv = w; w += nc; tt = w; w += nc;
+        Wibz = w; w += nc; dS = w; w += nc; dZ = w; w += nc; sds = w; w += nc; sdz = w; w += nc; tmpc = w; w += nc;
+        Wbeta = w; w += L.ncones;
+        hx = w; w += (size_t)(K + 1) * HX_SZ; hu = w; w += (size_t)(K + 1) * 9;
+        Linv = w; w += (size_t)K * 196; Wb = w; w += (size_t)K * 196; Sd = w; w += (size_t)K * 196;
+        ls = w; w += nloc; ys = w; w += ny; ltr = w; w += nloc; ytr = w; w += ny; lnu = w; w += nloc; ynu = w; w += ny;
+        tmpl = w; w += nloc; tmpl2 = w; w += nloc;
+        uhat = w; w += 3 * (K + 1); lb0 = w; w += (K + 1);
+    }
+
+    // ---- fixed-component masks (rocketland.jl:109-115) ----
+    SCVX_HD bool fixed_x(int k, int j) const {
+        if (k == 0) return !(j >= 7 && j < 11);
+        if (k == L.K) return j != 0;
+        return false;
+    }
+    SCVX_HD bool fixed_u(int k, int c) const { return k == L.K && c > 0; }
+
+    // ---- parallel vector helpers ----
+    SCVX_HD double dot(const double* a, const double* b, int n) {
+        double s = 0;
+        for (int i = ex.lane(); i < n; i += ex.nlanes()) s += a[i] * b[i];
+        return ex.sum(s);
+    }
+    SCVX_HD void axpy_set(double* o, const double* a, double al, const double* b, int n) {  // o = a + al b
+        for (int i = ex.lane(); i < n; i += ex.nlanes()) o[i] = a[i] + al * b[i];
+    }
+    SCVX_HD void zero(double* o, int n) {
+        for (int i = ex.lane(); i < n; i += ex.nlanes()) o[i] = 0.0;
+        ex.sync();
+    }
+    SCVX_HD void copy(double* o, const double* a, int n) {
+        for (int i = ex.lane(); i < n; i += ex.nlanes()) o[i] = a[i];
+        ex.sync();
+    }
+
+    // ---- E (linearised dynamics rows, rocketland.jl:117-133) ----
+    // out[k][i] = sum_j D_k[i][j] [dx_k; du_k; du_{k+1}; s]_j + nu_k[i] - dx_{k+1}[i]   (with_s: include the s column)
+    SCVX_HD void E_apply(const double* v, double* out, bool with_s) {
+        const int K = L.K;
+        const double s = with_s ? v[L.iS] : 0.0;
+        for (int r = ex.lane(); r < 14 * K; r += ex.nlanes()) {
+            const int k = r / 14, i = r - 14 * k;
+            const double* Dk = D + (size_t)k * 294 + i;
+            const double* dx = v + 14 * k;
+            const double* du = v + L.nx + 3 * k;
+            double a = 0;
+            for (int j = 0; j < 14; j++) a += Dk[14 * j] * dx[j];
+            for (int j = 0; j < 6; j++) a += Dk[14 * (14 + j)] * du[j];  // du_k then du_{k+1} are adjacent
+            a += Dk[14 * 20] * s;
+            a += v[L.nx + L.nu_ + r] - v[14 * (k + 1) + i];
+            out[r] = a;
+        }
+        ex.sync();
+    }
+    // g = E_loc' y on the local part (dx, du, nu); returns Sg . y (the s entry) to every lane
+    SCVX_HD double Et_apply(const double* yy, double* g) {
+        const int K = L.K;
+        for (int t = ex.lane(); t < L.nx; t += ex.nlanes()) {
+            const int k = t / 14, j = t - 14 * k;
+            double a = 0;
+            if (k < K) {
+                const double* col = D + (size_t)k * 294 + 14 * j;
+                const double* yk = yy + 14 * k;
+                for (int i = 0; i < 14; i++) a += col[i] * yk[i];
+            }
+            if (k > 0) a -= yy[14 * (k - 1) + j];
+            g[t] = a;
+        }
+        for (int t = ex.lane(); t < L.nu_; t += ex.nlanes()) {
+            const int k = t / 3, c = t - 3 * k;
+            double a = 0;
+            if (k < K) {
+                const double* col = D + (size_t)k * 294 + 14 * (14 + c);
+                const double* yk = yy + 14 * k;
+                for (int i = 0; i < 14; i++) a += col[i] * yk[i];
+            }
+            if (k > 0) {
+                const double* col = D + (size_t)(k - 1) * 294 + 14 * (17 + c);
+                const double* yk = yy + 14 * (k - 1);
+                for (int i = 0; i < 14; i++) a += col[i] * yk[i];
+            }
+            g[L.nx + t] = a;
+        }
+        double sg = 0;
+        for (int r = ex.lane(); r < 14 * K; r += ex.nlanes()) {
+            const int k = r / 14, i = r - 14 * k;
+            g[L.nx + L.nu_ + r] = yy[r];
+            sg += D[(size_t)k * 294 + 14 * 20 + i] * yy[r];
+        }
+        ex.sync();
+        return ex.sum(sg);
+    }
+
+    // ---- cone maps: a(w), J dw, J' z ----
+    // out = a(v) if affine else J v
+    SCVX_HD void cone_map(const double* v, double* out, bool affine) {
+        const int K = L.K;
+        const double af = affine ? 1.0 : 0.0;
+        for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
+            const double* dx = v + 14 * k;
+            const double* du = v + L.nx + 3 * k;
+            double x[14], u[3];
+            for (int j = 0; j < 14; j++) x[j] = af * xbar[14 * k + j] + dx[j];
+            for (int c = 0; c < 3; c++) u[c] = af * ubar[3 * k + c] + du[c];
+            if (k < K) {
+                double* g = out + L.o_gs + 3 * k;
+                g[0] = x[1] * C.itan; g[1] = x[2]; g[2] = x[3];
+                double* t = out + L.o_tilt + 3 * k;
+                t[0] = af * C.sqcm; t[1] = x[9]; t[2] = x[10];
+                double* r = out + L.o_rate + 4 * k;
+                r[0] = af * C.omMax; r[1] = x[11]; r[2] = x[12]; r[3] = x[13];
+            }
+            if (k >= 1) out[L.o_mass + (k - 1)] = x[0] - af * C.mdry;
+            double* tb = out + L.o_tb + 4 * k;
+            tb[0] = af * C.Tmax; tb[1] = u[0]; tb[2] = u[1]; tb[3] = u[2];
+            double* tc = out + L.o_tc + 4 * k;
+            tc[0] = u[0] * C.icos; tc[1] = u[0]; tc[2] = u[1]; tc[3] = u[2];
+            out[L.o_lb + k] = uhat[3 * k] * du[0] + uhat[3 * k + 1] * du[1] + uhat[3 * k + 2] * du[2] - af * lb0[k];
+        }
+        for (int i = ex.lane(); i < 14 * K; i += ex.nlanes()) out[L.o_nu + 1 + i] = v[L.nx + L.nu_ + i];
+        for (int i = ex.lane(); i < L.nx + L.nu_; i += ex.nlanes()) out[L.o_tr + 1 + i] = v[i];
+        if (ex.lane() == 0) {
+            out[L.o_nu] = v[L.iTNU];
+            out[L.o_tr] = v[L.iTTR];
+            out[L.o_sg] = v[L.iTS];
+            out[L.o_sg + 1] = v[L.iS];
+            out[L.o_rk] = af * rk - v[L.iTTR];
+        }
+        ex.sync();
+    }
+    // g = J' z (var-shaped, all nv entries written)
+    SCVX_HD void cone_map_t(const double* z, double* g) {
+        const int K = L.K;
+        for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
+            double* gx_ = g + 14 * k;
+            const double* trx = z + L.o_tr + 1 + 14 * k;
+            for (int j = 0; j < 14; j++) gx_[j] = trx[j];
+            if (k >= 1) gx_[0] += z[L.o_mass + (k - 1)];
+            if (k < K) {
+                const double* gs = z + L.o_gs + 3 * k;
+                gx_[1] += gs[0] * C.itan; gx_[2] += gs[1]; gx_[3] += gs[2];
+                const double* t = z + L.o_tilt + 3 * k;
+                gx_[9] += t[1]; gx_[10] += t[2];
+                const double* r = z + L.o_rate + 4 * k;
+                gx_[11] += r[1]; gx_[12] += r[2]; gx_[13] += r[3];
+            }
+            double* gu = g + L.nx + 3 * k;
+            const double* tru = z + L.o_tr + 1 + L.nx + 3 * k;
+            const double* tb = z + L.o_tb + 4 * k;
+            const double* tc = z + L.o_tc + 4 * k;
+            const double zl = z[L.o_lb + k];
+            for (int c = 0; c < 3; c++) gu[c] = tru[c] + tb[1 + c] + tc[1 + c] + zl * uhat[3 * k + c];
+            gu[0] += tc[0] * C.icos;
+        }
+        for (int i = ex.lane(); i < 14 * K; i += ex.nlanes()) g[L.nx + L.nu_ + i] = z[L.o_nu + 1 + i];
+        if (ex.lane() == 0) {
+            g[L.iTNU] = z[L.o_nu];
+            g[L.iTTR] = z[L.o_tr] - z[L.o_rk];
+            g[L.iTS] = z[L.o_sg];
+            g[L.iS] = z[L.o_sg + 1];
+        }
+        ex.sync();
+    }
+    SCVX_HD void mask_fixed(double* g) {
+        for (int j = ex.lane(); j < 14; j += ex.nlanes()) {
+            if (fixed_x(0, j)) g[j] = 0.0;
+            if (fixed_x(L.K, j)) g[14 * L.K + j] = 0.0;
+        }
+        if (ex.lane() == 0) { g[L.nx + 3 * L.K + 1] = 0.0; g[L.nx + 3 * L.K + 2] = 0.0; }
+        ex.sync();
+    }
+
+    // ---- big-cone helpers (all lanes cooperate) ----
+    SCVX_HD void big_nt(int off, int dim, int cidx) {
+        const double* s = S + off; const double* z = Z + off;
+        double a = 0, b = 0, c = 0;
+        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) { a += s[i] * s[i]; b += z[i] * z[i]; c += s[i] * z[i]; }
+        a = ex.sum(a); b = ex.sum(b); c = ex.sum(c);
+        const double sj = sqrt(s[0] * s[0] - a), zj = sqrt(z[0] * z[0] - b);
+        const double isj = 1.0 / sj, izj = 1.0 / zj;
+        const double gam = sqrt(0.5 * (1.0 + (s[0] * z[0] + c) * isj * izj));
+        const double ig = 0.5 / gam;
+        const double wb0 = (s[0] * isj + z[0] * izj) * ig;
+        const double den = 1.0 / sqrt(2.0 * (wb0 + 1.0));
+        double* v = Wv + off;
+        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) v[i] = (s[i] * isj - z[i] * izj) * ig * den;
+        if (ex.lane() == 0) { v[0] = (wb0 + 1.0) * den; Wbeta[cidx] = sqrt(sj * izj); }
+    }
+    SCVX_HD void big_W(int off, int dim, int cidx, const double* x, double* yv, bool inverse) {
+        const double* v = Wv + off;
+        double vx = 0;
+        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) vx += v[i] * x[off + i];
+        vx = ex.sum(vx);
+        vx = v[0] * x[off] + (inverse ? -vx : vx);
+        const double beta = Wbeta[cidx];
+        const double sc = inverse ? 1.0 / beta : beta;
+        const double x0 = x[off];
+        ex.sync();  // x may alias yv: every lane has read x[off] before lane 0 overwrites it
+        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) yv[off + i] = ((inverse ? -2.0 : 2.0) * vx * v[i] + x[off + i]) * sc;
+        if (ex.lane() == 0) yv[off] = (2.0 * vx * v[0] - x0) * sc;
+    }
+    // t = lam \ d on a big cone
+    SCVX_HD void big_div(int off, int dim, const double* d, double* out) {
+        const double* l = lam + off;
+        double ld = 0, ll = 0;
+        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) { ld += l[i] * d[off + i]; ll += l[i] * l[i]; }
+        ld = ex.sum(ld); ll = ex.sum(ll);
+        const double det = l[0] * l[0] - ll;
+        const double x0 = (l[0] * d[off] - ld) / det;
+        const double il0 = 1.0 / l[0];
+        ex.sync();
+        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) out[off + i] = (d[off + i] - x0 * l[i]) * il0;
+        if (ex.lane() == 0) out[off] = x0;
+    }
+    // out = a o b on a big cone
+    SCVX_HD void big_prod(int off, int dim, const double* a, const double* b, double* out) {
+        double ab = 0;
+        for (int i = ex.lane(); i < dim; i += ex.nlanes()) ab += a[off + i] * b[off + i];
+        ab = ex.sum(ab);
+        const double a0 = a[off], b0 = b[off];
+        ex.sync();
+        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) out[off + i] = a0 * b[off + i] + b0 * a[off + i];
+        if (ex.lane() == 0) out[off] = ab;
+    }
+    SCVX_HD double big_maxstep(int off, int dim, const double* d) {
+        const double* l = lam + off;
+        double ll = 0, ld = 0, dd = 0;
+        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) { ll += l[i] * l[i]; ld += l[i] * d[off + i]; dd += d[off + i] * d[off + i]; }
+        ll = ex.sum(ll); ld = ex.sum(ld); dd = ex.sum(dd);
+        return soc_maxstep_parts(l[0], d[off], l[0] * l[0] - ll, l[0] * d[off] - ld, d[off] * d[off] - dd);
+    }
+
+    // ---- NT scalings for every cone, lam = W z ----
+    SCVX_HD void nt_all() {
+        for (int c = ex.lane(); c < L.nsmall; c += ex.nlanes()) {
+            int off, d; L.small(c, off, d);
+            if (d == 1) {
+                Wbeta[c] = sqrt(S[off] / Z[off]);
+                lam[off] = sqrt(S[off] * Z[off]);
+                Wv[off] = 1.0;
+            } else {
+                double beta;
+                soc_nt_small(S + off, Z + off, d, Wv + off, beta);
+                Wbeta[c] = beta;
+                soc_W_small(Wv + off, beta, d, Z + off, lam + off, false);
+            }
+        }
+        big_nt(L.o_nu, 14 * L.K + 1, L.c_nu);
+        big_nt(L.o_tr, 17 * (L.K + 1) + 1, L.c_tr);
+        if (ex.lane() == 0) {
+            double beta;
+            soc_nt_small(S + L.o_sg, Z + L.o_sg, 2, Wv + L.o_sg, beta);
+            Wbeta[L.c_sg] = beta;
+            Wbeta[L.c_rk] = sqrt(S[L.o_rk] / Z[L.o_rk]);
+            Wv[L.o_rk] = 1.0;
+        }
+        ex.sync();
+        big_W(L.o_nu, 14 * L.K + 1, L.c_nu, Z, lam, false);
+        big_W(L.o_tr, 17 * (L.K + 1) + 1, L.c_tr, Z, lam, false);
+        if (ex.lane() == 0) {
+            soc_W_small(Wv + L.o_sg, Wbeta[L.c_sg], 2, Z + L.o_sg, lam + L.o_sg, false);
+            lam[L.o_rk] = sqrt(S[L.o_rk] * Z[L.o_rk]);
+        }
+        ex.sync();
+    }
+    SCVX_HD void identity_scaling() {
+        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) Wv[i] = 0.0;
+        ex.sync();
+        for (int c = ex.lane(); c < L.nsmall; c += ex.nlanes()) {
+            int off, d; L.small(c, off, d);
+            Wv[off] = 1.0; Wbeta[c] = 1.0;
+        }
+        if (ex.lane() == 0) {
+            Wv[L.o_nu] = 1.0; Wv[L.o_tr] = 1.0; Wv[L.o_sg] = 1.0; Wv[L.o_rk] = 1.0;
+            Wbeta[L.c_nu] = Wbeta[L.c_tr] = Wbeta[L.c_sg] = Wbeta[L.c_rk] = 1.0;
+        }
+        ex.sync();
+    }
+    // out = W in  /  W^-1 in   (cone vectors; in may alias out)
+    SCVX_HD void W_all(const double* in, double* out, bool inverse) {
+        for (int c = ex.lane(); c < L.nsmall; c += ex.nlanes()) {
+            int off, d; L.small(c, off, d);
+            if (d == 1) out[off] = inverse ? in[off] / Wbeta[c] : in[off] * Wbeta[c];
+            else {
+                double tmp[4];
+                for (int i = 0; i < d; i++) tmp[i] = in[off + i];
+                soc_W_small(Wv + off, Wbeta[c], d, tmp, out + off, inverse);
+            }
+        }
+        big_W(L.o_nu, 14 * L.K + 1, L.c_nu, in, out, inverse);
+        big_W(L.o_tr, 17 * (L.K + 1) + 1, L.c_tr, in, out, inverse);
+        if (ex.lane() == 0) {
+            double tmp[2] = {in[L.o_sg], in[L.o_sg + 1]};
+            soc_W_small(Wv + L.o_sg, Wbeta[L.c_sg], 2, tmp, out + L.o_sg, inverse);
+            out[L.o_rk] = inverse ? in[L.o_rk] / Wbeta[L.c_rk] : in[L.o_rk] * Wbeta[L.c_rk];
+        }
+        ex.sync();
+    }
+    // out = lam \ d
+    SCVX_HD void div_all(const double* d, double* out) {
+        for (int c = ex.lane(); c < L.nsmall + 1; c += ex.nlanes()) {
+            int off, dm;
+            if (c < L.nsmall) L.small(c, off, dm); else { off = L.o_sg; dm = 2; }
+            if (dm == 1) out[off] = d[off] / lam[off];
+            else {
+                const double* l = lam + off;
+                double ld = 0, ll = 0;
+                for (int i = 1; i < dm; i++) { ld += l[i] * d[off + i]; ll += l[i] * l[i]; }
+                const double x0 = (l[0] * d[off] - ld) / (l[0] * l[0] - ll);
+                for (int i = 1; i < dm; i++) out[off + i] = (d[off + i] - x0 * l[i]) / l[0];
+                out[off] = x0;
+            }
+        }
+        if (ex.lane() == 0) out[L.o_rk] = d[L.o_rk] / lam[L.o_rk];
+        big_div(L.o_nu, 14 * L.K + 1, d, out);
+        big_div(L.o_tr, 17 * (L.K + 1) + 1, d, out);
+        ex.sync();
+    }
+    // out = base_sign * (lam o lam)  [mode 0: out = -lam o lam]
+    //       mode 1: out = -lam o lam - sds o sdz + sigmu * e
+    SCVX_HD void centering_rhs(double* out, bool combined, double sigmu) {
+        for (int c = ex.lane(); c < L.nsmall + 1; c += ex.nlanes()) {
+            int off, dm;
+            if (c < L.nsmall) L.small(c, off, dm); else { off = L.o_sg; dm = 2; }
+            if (dm == 1) {
+                out[off] = -lam[off] * lam[off] + (combined ? (-sds[off] * sdz[off] + sigmu) : 0.0);
+            } else {
+                const double* l = lam + off;
+                double ll = 0, ab = 0;
+                for (int i = 0; i < dm; i++) { ll += l[i] * l[i]; if (combined) ab += sds[off + i] * sdz[off + i]; }
+                for (int i = 1; i < dm; i++)
+                    out[off + i] = -2.0 * l[0] * l[i] - (combined ? (sds[off] * sdz[off + i] + sdz[off] * sds[off + i]) : 0.0);
+                out[off] = -ll + (combined ? (-ab + sigmu) : 0.0);
+            }
+        }
+        if (ex.lane() == 0) {
+            const int off = L.o_rk;
+            out[off] = -lam[off] * lam[off] + (combined ? (-sds[off] * sdz[off] + sigmu) : 0.0);
+        }
+        const int offs[2] = {L.o_nu, L.o_tr};
+        const int dims[2] = {14 * L.K + 1, 17 * (L.K + 1) + 1};
+        for (int q = 0; q < 2; q++) {
+            big_prod(offs[q], dims[q], lam, lam, out);
+            ex.sync();
+            if (combined) {
+                big_prod(offs[q], dims[q], sds, sdz, tmpc);
+                ex.sync();
+                for (int i = ex.lane(); i < dims[q]; i += ex.nlanes()) out[offs[q] + i] = -out[offs[q] + i] - tmpc[offs[q] + i];
+                if (ex.lane() == 0) out[offs[q]] += sigmu;
+            } else {
+                for (int i = ex.lane(); i < dims[q]; i += ex.nlanes()) out[offs[q] + i] = -out[offs[q] + i];
+            }
+        }
+        ex.sync();
+    }
+    SCVX_HD double maxstep_all(const double* d) {
+        double amax = INFINITY;
+        for (int c = ex.lane(); c < L.nsmall + 1; c += ex.nlanes()) {
+            int off, dm;
+            if (c < L.nsmall) L.small(c, off, dm); else { off = L.o_sg; dm = 2; }
+            double a;
+            if (dm == 1) a = d[off] < 0.0 ? -lam[off] / d[off] : INFINITY;
+            else {
+                const double* l = lam + off;
+                double ll = 0, ld = 0, dd = 0;
+                for (int i = 1; i < dm; i++) { ll += l[i] * l[i]; ld += l[i] * d[off + i]; dd += d[off + i] * d[off + i]; }
+                a = soc_maxstep_parts(l[0], d[off], l[0] * l[0] - ll, l[0] * d[off] - ld, d[off] * d[off] - dd);
+            }
+            if (a < amax) amax = a;
+        }
+        if (d[L.o_rk] < 0.0) { const double a = -lam[L.o_rk] / d[L.o_rk]; if (a < amax) amax = a; }
+        amax = ex.min(amax);
+        const double a1 = big_maxstep(L.o_nu, 14 * L.K + 1, d);
+        const double a2 = big_maxstep(L.o_tr, 17 * (L.K + 1) + 1, d);
+        if (a1 < amax) amax = a1;
+        if (a2 < amax) amax = a2;
+        return amax;
+    }
+
+    // ---- Hb^-1 on a local vector (dx, du, nu); in may alias out ----
+    SCVX_HD void Hb_inv(const double* g, double* out) {
+        const int K = L.K;
+        for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
+            double xin[14], yo[14];
+            for (int j = 0; j < 14; j++) xin[j] = g[14 * k + j];
+            hxi_apply(hx + (size_t)k * HX_SZ, xin, yo);
+            for (int j = 0; j < 14; j++) out[14 * k + j] = yo[j];
+            const double* h = hu + 9 * k;
+            const double u0 = g[L.nx + 3 * k], u1 = g[L.nx + 3 * k + 1], u2 = g[L.nx + 3 * k + 2];
+            for (int c = 0; c < 3; c++) out[L.nx + 3 * k + c] = h[3 * c] * u0 + h[3 * c + 1] * u1 + h[3 * c + 2] * u2;
+        }
+        for (int i = ex.lane(); i < 14 * K; i += ex.nlanes()) out[L.nx + L.nu_ + i] = hnui * g[L.nx + L.nu_ + i];
+        ex.sync();
+    }
+
+    // ---- block-tridiagonal solve S x = r  (r, x: [K][14]; x may alias r) using Linv, Wb ----
+    SCVX_HD void S_solve(const double* r, double* x) {
+        const int K = L.K;
+        double* sc = ex.scratch();  // [0..13] t_prev / x_next, [16..29] rr
+        for (int k = 0; k < K; k++) {
+            for (int i = ex.lane(); i < 14; i += ex.nlanes()) {
+                double a = r[14 * k + i];
+                if (k > 0) {
+                    const double* W = Wb + (size_t)(k - 1) * 196 + 14 * i;  // row i of Wb[k-1] (row-major)
+                    for (int j = 0; j < 14; j++) a -= W[j] * sc[j];
+                }
+                sc[16 + i] = a;
+            }
+            ex.sync();
+            for (int i = ex.lane(); i < 14; i += ex.nlanes()) {
+                const double* Li = Linv + (size_t)k * 196 + 14 * i;  // row i of Linv[k] (lower triangular)
+                double a = 0;
+                for (int j = 0; j <= i; j++) a += Li[j] * sc[16 + j];
+                sc[i] = a;
+                x[14 * k + i] = a;  // t[k]
+            }
+            ex.sync();
+        }
+        // backward: x[k] = Linv[k]' (t[k] - Wb[k]' x[k+1])
+        for (int k = K - 1; k >= 0; k--) {
+            for (int i = ex.lane(); i < 14; i += ex.nlanes()) {
+                double a = x[14 * k + i];
+                if (k + 1 < K) {
+                    const double* W = Wb + (size_t)k * 196;  // Wb[k][j][i], column i
+                    for (int j = 0; j < 14; j++) a -= W[14 * j + i] * sc[j];
+                }
+                sc[16 + i] = a;
+            }
+            ex.sync();
+            for (int i = ex.lane(); i < 14; i += ex.nlanes()) {
+                const double* Lk = Linv + (size_t)k * 196;
+                double a = 0;
+                for (int j = i; j < 14; j++) a += Lk[14 * j + i] * sc[16 + j];
+                sc[i] = a;
+                x[14 * k + i] = a;
+            }
+            ex.sync();
+        }
+    }
+
+    // [Hb E'; E 0][dl; dyv] = [gl; ryv]   (gl: local part of a var vector; outputs may not alias inputs)
+    SCVX_HD void band_solve(const double* gl, const double* ryv, double* dl, double* dyv) {
+        Hb_inv(gl, tmpl);
+        E_apply(tmpl, tmpy, false);
+        ex.sync();
+        if (ryv) for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) tmpy[i] -= ryv[i];
+        ex.sync();
+        S_solve(tmpy, dyv);
+        (void)Et_apply(dyv, tmpl2);
+        ex.sync();
+        for (int i = ex.lane(); i < L.nloc; i += ex.nlanes()) tmpl2[i] = gl[i] - tmpl2[i];
+        ex.sync();
+        Hb_inv(tmpl2, dl);
+    }
+
+    // ---- factorisation for the current scaling (Wv, Wbeta) ----
+    SCVX_HD bool build_kkt() {
+        const int K = L.K;
+        // big-cone scalars
+        {
+            const int dn = 14 * K + 1, dt = 17 * (K + 1) + 1;
+            double n1 = 0, n2 = 0;
+            for (int i = 1 + ex.lane(); i < dn; i += ex.nlanes()) n1 += Wv[L.o_nu + i] * Wv[L.o_nu + i];
+            for (int i = 1 + ex.lane(); i < dt; i += ex.nlanes()) n2 += Wv[L.o_tr + i] * Wv[L.o_tr + i];
+            n1 = ex.sum(n1); n2 = ex.sum(n2);
+            soc_w2(Wv[L.o_nu], n1, Wbeta[L.c_nu], h_nu[0], h_nu[1], h_nu[2], h_nu[3]);
+            soc_w2(Wv[L.o_tr], n2, Wbeta[L.c_tr], h_tr[0], h_tr[1], h_tr[2], h_tr[3]);
+            hnui = 1.0 / h_nu[3];
+            double h00, h01, h11, b2;
+            const double vs = Wv[L.o_sg + 1];
+            soc_w2(Wv[L.o_sg], vs * vs, Wbeta[L.c_sg], h00, h01, h11, b2);
+            Msg[0] = h00; Msg[1] = h01 * vs; Msg[2] = h01 * vs; Msg[3] = b2 + h11 * vs * vs;
+            hrk = 1.0 / (Wbeta[L.c_rk] * Wbeta[L.c_rk]);
+        }
+        // node blocks -> compact inverses
+        const double dtr = h_tr[3];
+        for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
+            double* h = hx + (size_t)k * HX_SZ;
+            for (int i = 0; i < HX_SZ; i++) h[i] = 0.0;
+            const bool first = (k == 0), last = (k == K);
+            // mass
+            if (!first) {
+                double hm = dtr;
+                const double wm = Wbeta[L.c_mass + (k - 1)];
+                hm += 1.0 / (wm * wm);
+                h[HX_M] = 1.0 / hm;
+            }
+            if (!first && !last) {
+                // r block with glideslope cone
+                const double* v = Wv + L.o_gs + 3 * k;
+                double h00, h01, h11, b2;
+                soc_w2(v[0], v[1] * v[1] + v[2] * v[2], Wbeta[L.c_gs + k], h00, h01, h11, b2);
+                double M[9];
+                M[0] = dtr + h00 * C.itan * C.itan;
+                M[1] = M[3] = h01 * v[1] * C.itan;
+                M[2] = M[6] = h01 * v[2] * C.itan;
+                M[4] = dtr + b2 + h11 * v[1] * v[1];
+                M[5] = M[7] = h11 * v[1] * v[2];
+                M[8] = dtr + b2 + h11 * v[2] * v[2];
+                inv3(M, h + HX_R);
+                h[HX_V] = 1.0 / dtr;
+            }
+            if (!last) {
+                h[HX_Q] = 1.0 / dtr;
+                const double* v = Wv + L.o_tilt + 3 * k;
+                double h00, h01, h11, b2;
+                soc_w2(v[0], v[1] * v[1] + v[2] * v[2], Wbeta[L.c_tilt + k], h00, h01, h11, b2);
+                inv2(dtr + b2 + h11 * v[1] * v[1], h11 * v[1] * v[2], dtr + b2 + h11 * v[2] * v[2], h + HX_Q34);
+            }
+            if (!first && !last) {
+                const double* v = Wv + L.o_rate + 4 * k;
+                double h00, h01, h11, b2;
+                soc_w2(v[0], v[1] * v[1] + v[2] * v[2] + v[3] * v[3], Wbeta[L.c_rate + k], h00, h01, h11, b2);
+                double M[9];
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < 3; b++) M[3 * a + b] = h11 * v[1 + a] * v[1 + b] + (a == b ? dtr + b2 : 0.0);
+                inv3(M, h + HX_W);
+            }
+            // u block
+            {
+                double M[9];
+                for (int i = 0; i < 9; i++) M[i] = 0.0;
+                M[0] = M[4] = M[8] = dtr;
+                const double* v = Wv + L.o_tb + 4 * k;
+                double h00, h01, h11, b2;
+                soc_w2(v[0], v[1] * v[1] + v[2] * v[2] + v[3] * v[3], Wbeta[L.c_tb + k], h00, h01, h11, b2);
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < 3; b++) M[3 * a + b] += h11 * v[1 + a] * v[1 + b] + (a == b ? b2 : 0.0);
+                v = Wv + L.o_tc + 4 * k;
+                soc_w2(v[0], v[1] * v[1] + v[2] * v[2] + v[3] * v[3], Wbeta[L.c_tc + k], h00, h01, h11, b2);
+                // Jc' M4 Jc with Jc = [icos e1'; I]
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < 3; b++) M[3 * a + b] += h11 * v[1 + a] * v[1 + b] + (a == b ? b2 : 0.0);
+                M[0] += h00 * C.icos * C.icos;
+                for (int b = 0; b < 3; b++) { M[b] += C.icos * h01 * v[1 + b]; M[3 * b] += C.icos * h01 * v[1 + b]; }
+                const double wl = Wbeta[L.c_lb + k];
+                const double il2 = 1.0 / (wl * wl);
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < 3; b++) M[3 * a + b] += il2 * uhat[3 * k + a] * uhat[3 * k + b];
+                double* hi = hu + 9 * k;
+                if (last) {
+                    for (int i = 0; i < 9; i++) hi[i] = 0.0;
+                    hi[0] = 1.0 / M[0];
+                } else inv3(M, hi);
+            }
+        }
+        ex.sync();
+        // S blocks: Sd[k] (row-major 14x14), So[k] = block (k+1,k) -> stored in Wb[k] temporarily
+        for (int e = ex.lane(); e < K * 196; e += ex.nlanes()) {
+            const int k = e / 196, r = e - 196 * k, i = r / 14, j = r - 14 * i;
+            const double* Dk = D + (size_t)k * 294;
+            double s = hxi_quad(hx + (size_t)k * HX_SZ, Dk, i, Dk, j);
+            s += hui_quad(hu + 9 * k, Dk + 14 * 14, i, Dk + 14 * 14, j);
+            s += hui_quad(hu + 9 * (k + 1), Dk + 14 * 17, i, Dk + 14 * 17, j);
+            s += hxi_entry(hx + (size_t)(k + 1) * HX_SZ, i, j);
+            if (i == j) s += hnui;
+            Sd[e] = s;
+            if (k + 1 < K) {
+                // So[k][i][j]: i row of segment k+1, j row of segment k
+                const double* Dn = D + (size_t)(k + 1) * 294;
+                const double* hn = hx + (size_t)(k + 1) * HX_SZ;
+                double t = 0;
+                for (int a = 0; a < 14; a++) { const double he = hxi_entry(hn, a, j); if (he != 0.0) t += Dn[14 * a + i] * he; }
+                double so = -t + hui_quad(hu + 9 * (k + 1), Dn + 14 * 14, i, Dk + 14 * 17, j);
+                Wb[e] = so;
+            }
+        }
+        ex.sync();
+        // block Cholesky, sequential in k; tiles in scratch
+        double* sc = ex.scratch();
+        double* M = sc + 32;        // 196
+        double* Wp = sc + 32 + 196;  // previous Wb tile (196)
+        double* Li = sc + 32 + 392;  // Linv tile (196)
+        bool ok = true;
+        for (int k = 0; k < K; k++) {
+            for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
+                const int i = e / 14, j = e - 14 * i;
+                double s = Sd[(size_t)k * 196 + e];
+                if (k > 0) for (int c = 0; c < 14; c++) s -= Wp[14 * i + c] * Wp[14 * j + c];
+                M[e] = s;
+            }
+            ex.sync();
+            // right-looking Cholesky in place (lower triangle)
+            for (int j = 0; j < 14; j++) {
+                const double piv = M[15 * j];
+                if (!(piv > 0.0)) ok = false;
+                const double ip = 1.0 / sqrt(piv > 0.0 ? piv : 1.0);
+                ex.sync();
+                for (int i = j + ex.lane(); i < 14; i += ex.nlanes()) M[14 * i + j] *= ip;
+                ex.sync();
+                const int n = 13 - j;
+                for (int e = ex.lane(); e < n * n; e += ex.nlanes()) {
+                    const int a = j + 1 + e / n, b = j + 1 + (e - (e / n) * n);
+                    if (b <= a) M[14 * a + b] -= M[14 * a + j] * M[14 * b + j];
+                }
+                ex.sync();
+            }
+            // Linv: column c solved by lane c
+            for (int c = ex.lane(); c < 14; c += ex.nlanes()) {
+                for (int i = 0; i < 14; i++) {
+                    if (i < c) { Li[14 * i + c] = 0.0; continue; }
+                    double s = (i == c) ? 1.0 : 0.0;
+                    for (int t = c; t < i; t++) s -= M[14 * i + t] * Li[14 * t + c];
+                    Li[14 * i + c] = s / M[15 * i];
+                }
+            }
+            ex.sync();
+            for (int e = ex.lane(); e < 196; e += ex.nlanes()) Linv[(size_t)k * 196 + e] = Li[e];
+            if (k + 1 < K) {
+                // Wb[k] = So[k] Linv'
+                for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
+                    const int i = e / 14, j = e - 14 * i;
+                    const double* So = Wb + (size_t)k * 196 + 14 * i;
+                    double s = 0;
+                    for (int c = 0; c <= j; c++) s += So[c] * Li[14 * j + c];
+                    M[e] = s;  // M is free now
+                }
+                ex.sync();
+                for (int e = ex.lane(); e < 196; e += ex.nlanes()) { Wp[e] = M[e]; Wb[(size_t)k * 196 + e] = M[e]; }
+            }
+            ex.sync();
+        }
+        // border solves
+        zero(tmpv, L.nloc);
+        ex.sync();
+        // sol_s = band(0, -Sg)
+        for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) { const int k = r / 14, i = r - 14 * k; r2[r] = -D[(size_t)k * 294 + 14 * 20 + i]; }
+        ex.sync();
+        band_solve(tmpv, r2, ls, ys);
+        // sol_tr = band(Ptr, 0): Ptr = Wv[o_tr+1 ..] on (dx,du), 0 on nu
+        for (int i = ex.lane(); i < L.nx + L.nu_; i += ex.nlanes()) tmpv[i] = Wv[L.o_tr + 1 + i];
+        ex.sync();
+        band_solve(tmpv, nullptr, ltr, ytr);
+        zero(tmpv, L.nx + L.nu_);
+        for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) tmpv[L.nx + L.nu_ + i] = Wv[L.o_nu + 1 + i];
+        ex.sync();
+        band_solve(tmpv, nullptr, lnu, ynu);
+        // border coefficients
+        {
+            double a = 0, b = 0, c = 0;
+            for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) {
+                const int k = r / 14, i = r - 14 * k;
+                const double sg = D[(size_t)k * 294 + 14 * 20 + i];
+                a += sg * ys[r]; b += sg * ytr[r]; c += sg * ynu[r];
+            }
+            css = ex.sum(a); cst = -ex.sum(b); csn = -ex.sum(c);
+            const double* Ptr = Wv + L.o_tr + 1; const int nt = L.nx + L.nu_;
+            cts = dot(Ptr, ls, nt); ctt = -dot(Ptr, ltr, nt); ctn = -dot(Ptr, lnu, nt);
+            const double* Pnu = Wv + L.o_nu + 1; const int o = L.nx + L.nu_;
+            cns = dot(Pnu, ls + o, L.ny); cnt_ = -dot(Pnu, ltr + o, L.ny); cnn = -dot(Pnu, lnu + o, L.ny);
+        }
+        return ex.all(ok);
+    }
+
+    // full reduced KKT: [H E'; E 0][dwv; dyv] = [g; ryv]  (g var-shaped incl. 4 globals)
+    SCVX_HD void kkt_solve(const double* g, const double* ryv, double* dwv, double* dyv) {
+        band_solve(g, ryv, dwv, dyv);
+        double a = 0;
+        for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) {
+            const int k = r / 14, i = r - 14 * k;
+            a += D[(size_t)k * 294 + 14 * 20 + i] * dyv[r];
+        }
+        const double c0s = ex.sum(a);
+        const double c0t = dot(Wv + L.o_tr + 1, dwv, L.nx + L.nu_);
+        const double c0n = dot(Wv + L.o_nu + 1, dwv + L.nx + L.nu_, L.ny);
+        // unknowns: s, ts, tnu, ttr, atr, anu
+        double M[36], r[6];
+        for (int i = 0; i < 36; i++) M[i] = 0.0;
+        const double h01t = h_tr[1], h01n = h_nu[1];
+        M[0 * 6 + 0] = Msg[3] + css; M[0 * 6 + 1] = Msg[2]; M[0 * 6 + 3] = cst * h01t; M[0 * 6 + 4] = cst;
+        M[0 * 6 + 2] = csn * h01n; M[0 * 6 + 5] = csn; r[0] = g[L.iS] - c0s;
+        M[1 * 6 + 1] = Msg[0]; M[1 * 6 + 0] = Msg[1]; r[1] = g[L.iTS];
+        M[2 * 6 + 2] = h_nu[0] + h01n * cnn * h01n; M[2 * 6 + 0] = h01n * cns; M[2 * 6 + 3] = h01n * cnt_ * h01t;
+        M[2 * 6 + 4] = h01n * cnt_; M[2 * 6 + 5] = h01n * cnn; r[2] = g[L.iTNU] - h01n * c0n;
+        M[5 * 6 + 0] = cns; M[5 * 6 + 2] = cnn * h01n; M[5 * 6 + 3] = cnt_ * h01t; M[5 * 6 + 4] = cnt_;
+        M[5 * 6 + 5] = cnn - 1.0 / h_nu[2]; r[5] = -c0n;
+        M[3 * 6 + 3] = h_tr[0] + hrk + h01t * ctt * h01t; M[3 * 6 + 0] = h01t * cts; M[3 * 6 + 2] = h01t * ctn * h01n;
+        M[3 * 6 + 4] = h01t * ctt; M[3 * 6 + 5] = h01t * ctn; r[3] = g[L.iTTR] - h01t * c0t;
+        M[4 * 6 + 0] = cts; M[4 * 6 + 2] = ctn * h01n; M[4 * 6 + 3] = ctt * h01t; M[4 * 6 + 4] = ctt - 1.0 / h_tr[2];
+        M[4 * 6 + 5] = ctn; r[4] = -c0t;
+        // Gaussian elimination with partial pivoting (every lane redundantly)
+        for (int c = 0; c < 6; c++) {
+            int p = c; double best = fabs(M[c * 6 + c]);
+            for (int i = c + 1; i < 6; i++) if (fabs(M[i * 6 + c]) > best) { best = fabs(M[i * 6 + c]); p = i; }
+            if (p != c) { for (int j = 0; j < 6; j++) { const double t = M[c * 6 + j]; M[c * 6 + j] = M[p * 6 + j]; M[p * 6 + j] = t; } const double t = r[c]; r[c] = r[p]; r[p] = t; }
+            const double ip = 1.0 / M[c * 6 + c];
+            for (int i = c + 1; i < 6; i++) {
+                const double f = M[i * 6 + c] * ip;
+                for (int j = c; j < 6; j++) M[i * 6 + j] -= f * M[c * 6 + j];
+                r[i] -= f * r[c];
+            }
+        }
+        double b[6];
+        for (int i = 5; i >= 0; i--) { double s = r[i]; for (int j = i + 1; j < 6; j++) s -= M[i * 6 + j] * b[j]; b[i] = s / M[i * 6 + i]; }
+        const double s_ = b[0], ts_ = b[1], tnu_ = b[2], ttr_ = b[3];
+        const double ctr = h01t * ttr_ + b[4], cnu = h01n * tnu_ + b[5];
+        ex.sync();
+        for (int i = ex.lane(); i < L.nloc; i += ex.nlanes()) dwv[i] = dwv[i] + ls[i] * s_ - ltr[i] * ctr - lnu[i] * cnu;
+        for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) dyv[i] = dyv[i] + ys[i] * s_ - ytr[i] * ctr - ynu[i] * cnu;
+        if (ex.lane() == 0) { dwv[L.iS] = s_; dwv[L.iTS] = ts_; dwv[L.iTNU] = tnu_; dwv[L.iTTR] = ttr_; }
+        ex.sync();
+    }
+
+    // H dwv (var-shaped, incl. globals) in operator form: J' W^-1 W^-1 J dwv
+    SCVX_HD void H_apply(const double* dwv, double* out) {
+        cone_map(dwv, tmpc, false);
+        ex.sync();
+        W_all(tmpc, tmpc, true);
+        W_all(tmpc, tmpc, true);
+        cone_map_t(tmpc, out);
+        ex.sync();
+    }
+
+    // Newton step for centering right-hand side ds_rhs (cone vector); results in dw, dy, dZ, dS
+    SCVX_HD void newton(const double* ds_rhs) {
+        div_all(ds_rhs, tt);
+        W_all(rz, tmpc, true);
+        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) Wibz[i] = -tmpc[i] - tt[i];
+        ex.sync();
+        W_all(Wibz, tmpc, true);
+        cone_map_t(tmpc, gx);
+        ex.sync();
+        for (int i = ex.lane(); i < L.nv; i += ex.nlanes()) gx[i] = -rx[i] - gx[i];
+        ex.sync();
+        mask_fixed(gx);
+        for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) r2[i] = -ry[i];
+        ex.sync();
+        kkt_solve(gx, r2, dw, dy);
+#if defined(SCVX_IPM_DEBUG) && !defined(__HIPCC__)
+        {
+            H_apply(dw, r1);
+            const double sgy = Et_apply(dy, tmpl);
+            double e1 = 0, e2 = 0, e3 = 0;
+            for (int i = 0; i < L.nloc; i++) { double r = gx[i] - r1[i] - tmpl[i]; bool fx = false;
+                if (i < 14) fx = fixed_x(0, i); else if (i >= 14 * L.K && i < L.nx) fx = fixed_x(L.K, i - 14 * L.K); else if (i == L.nx + 3 * L.K + 1 || i == L.nx + 3 * L.K + 2) fx = true;
+                if (!fx) { if (i < L.nx + L.nu_) e1 += r * r; else e2 += r * r; } }
+            E_apply(dw, tmpy2, true);
+            for (int i = 0; i < L.ny; i++) { double r = r2[i] - tmpy2[i]; e3 += r * r; }
+            SCVX_DBG("      kkt res: xu %.2e nu %.2e s %.2e tnu %.2e ttr %.2e ts %.2e | E %.2e\n", sqrt(e1), sqrt(e2), gx[L.iS] - r1[L.iS] - sgy,
+                     gx[L.iTNU] - r1[L.iTNU], gx[L.iTTR] - r1[L.iTTR], gx[L.iTS] - r1[L.iTS], sqrt(e3));
+        }
+#endif
+        for (int it = 0; it < C.refine; it++) {
+            H_apply(dw, r1);
+            const double sgy = Et_apply(dy, tmpl);
+            ex.sync();
+            for (int i = ex.lane(); i < L.nloc; i += ex.nlanes()) r1[i] = gx[i] - r1[i] - tmpl[i];
+            ex.sync();
+            if (ex.lane() == 0) {
+                r1[L.iS] = gx[L.iS] - r1[L.iS] - sgy;
+                r1[L.iTNU] = gx[L.iTNU] - r1[L.iTNU];
+                r1[L.iTTR] = gx[L.iTTR] - r1[L.iTTR];
+                r1[L.iTS] = gx[L.iTS] - r1[L.iTS];
+            }
+            ex.sync();
+            mask_fixed(r1);
+            E_apply(dw, tmpy2, true);
+            ex.sync();
+            for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) tmpy2[i] = -ry[i] - tmpy2[i];
+            ex.sync();
+            kkt_solve(r1, tmpy2, cw, cy);
+            for (int i = ex.lane(); i < L.nv; i += ex.nlanes()) dw[i] += cw[i];
+            for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) dy[i] += cy[i];
+            ex.sync();
+        }
+        cone_map(dw, dS, false);  // J dw
+        ex.sync();
+        W_all(dS, tmpc, true);
+        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) tmpc[i] += Wibz[i];
+        ex.sync();
+        W_all(tmpc, dZ, true);
+        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) { dZ[i] = -dZ[i]; dS[i] = dS[i] - rz[i]; }
+        ex.sync();
+    }
+
+    SCVX_HD void shift_into_cone(double* X) {
+        double t = -INFINITY;
+        for (int c = ex.lane(); c < L.nsmall + 1; c += ex.nlanes()) {
+            int off, dm;
+            if (c < L.nsmall) L.small(c, off, dm); else { off = L.o_sg; dm = 2; }
+            double n = 0;
+            for (int i = 1; i < dm; i++) n += X[off + i] * X[off + i];
+            const double m = sqrt(n) - X[off];
+            if (m > t) t = m;
+        }
+        { const double m = -X[L.o_rk]; if (m > t) t = m; }
+        t = -ex.min(-t);
+        const int offs[2] = {L.o_nu, L.o_tr};
+        const int dims[2] = {14 * L.K + 1, 17 * (L.K + 1) + 1};
+        for (int q = 0; q < 2; q++) {
+            double n = 0;
+            for (int i = 1 + ex.lane(); i < dims[q]; i += ex.nlanes()) n += X[offs[q] + i] * X[offs[q] + i];
+            n = ex.sum(n);
+            const double m = sqrt(n) - X[offs[q]];
+            if (m > t) t = m;
+        }
+        ex.sync();
+        if (t >= -1e-8) {
+            const double sh = 1.0 + t;
+            for (int c = ex.lane(); c < L.nsmall; c += ex.nlanes()) { int off, dm; L.small(c, off, dm); X[off] += sh; }
+            if (ex.lane() == 0) { X[L.o_nu] += sh; X[L.o_tr] += sh; X[L.o_sg] += sh; X[L.o_rk] += sh; }
+        }
+        ex.sync();
+    }
+
+    // ---- the solve.  ic: (rIi, vIi) of this trajectory.  Outputs in V (dx, du, nu, s, ...). ----
+    SCVX_HD Result solve(const double* xbar_, const double* ubar_, const double* endpoint_, const double* D_,
+                         double rk_, const double* ic, double* work) {
+        xbar = xbar_; ubar = ubar_; endpoint = endpoint_; D = D_; rk = rk_;
+        carve(work);
+        const int K = L.K;
+        // constants of this subproblem
+        for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) dk[r] = endpoint[r] - xbar[14 + r];
+        for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
+            const double* u = ubar + 3 * k;
+            const double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+            for (int c = 0; c < 3; c++) uhat[3 * k + c] = u[c] / un;  // rocketland.jl:199 (un = 0 -> NaN, as in the reference)
+            lb0[k] = C.Tmin - un;
+        }
+        ex.sync();
+        zero(V, L.nv); zero(y, L.ny);
+        if (ex.lane() == 0) {
+            // fixed components: w = bc - xbar (rocketland.jl:109-115)
+            V[0] = C.mwet - xbar[0];
+            for (int i = 0; i < 3; i++) { V[1 + i] = ic[i] - xbar[1 + i]; V[4 + i] = ic[3 + i] - xbar[4 + i]; V[11 + i] = C.wBi[i] - xbar[11 + i]; }
+            const double* xK = xbar + 14 * K;
+            double* vK = V + 14 * K;
+            for (int i = 0; i < 3; i++) { vK[1 + i] = C.rIf[i] - xK[1 + i]; vK[4 + i] = C.vIf[i] - xK[4 + i]; vK[11 + i] = C.wBf[i] - xK[11 + i]; }
+            for (int i = 0; i < 4; i++) vK[7 + i] = C.qBIf[i] - xK[7 + i];
+            V[L.nx + 3 * K + 1] = 0.0 - ubar[3 * K + 1];
+            V[L.nx + 3 * K + 2] = 0.0 - ubar[3 * K + 2];
+        }
+        ex.sync();
+        Result res; res.status = 1; res.iters = 0; res.merit = INFINITY; res.pobj = 0;
+        // ---- initial point: least-squares slacks with identity scaling, then shift into the cone ----
+        identity_scaling();
+        if (!build_kkt()) { res.status = 2; return res; }
+        cone_map(V, S, true);   // a0
+        ex.sync();
+        cone_map_t(S, gx);
+        ex.sync();
+        for (int i = ex.lane(); i < L.nv; i += ex.nlanes()) gx[i] = -gx[i];
+        ex.sync();
+        if (ex.lane() == 0) { gx[14 * K] += 1.0; gx[L.iTNU] -= C.wNu; gx[L.iTTR] -= 0.5; gx[L.iTS] -= 1.0; }  // -cost
+        ex.sync();
+        mask_fixed(gx);
+        E_apply(V, ry, true);
+        ex.sync();
+        for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) r2[i] = -(ry[i] + dk[i]);
+        ex.sync();
+        kkt_solve(gx, r2, dw, y);
+        for (int i = ex.lane(); i < L.nv; i += ex.nlanes()) V[i] += dw[i];
+        ex.sync();
+        cone_map(V, S, true);
+        ex.sync();
+        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) Z[i] = -S[i];
+        ex.sync();
+        SCVX_DBG("init: |V|^2 %.12e s %.6e tnu %.6e ttr %.6e ts %.6e |y|^2 %.6e |S|^2 %.12e\n", dot(V, V, L.nv), V[L.iS], V[L.iTNU], V[L.iTTR], V[L.iTS], dot(y, y, L.ny), dot(S, S, L.nc));
+        shift_into_cone(S);
+        shift_into_cone(Z);
+        SCVX_DBG("shifted: |S|^2 %.12e |Z|^2 %.12e\n", dot(S, S, L.nc), dot(Z, Z, L.nc));
+
+        double best_merit = INFINITY; int best_it = 0;
+        const int degree = L.ncones;
+        for (int it = 1; it <= C.max_iter; it++) {
+            res.iters = it;
+            // residuals
+            cone_map(V, tmpc, true);
+            ex.sync();
+            for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) rz[i] = S[i] - tmpc[i];
+            ex.sync();
+            cone_map_t(Z, rx);
+            const double sgy = Et_apply(y, tmpl);
+            ex.sync();
+            for (int i = ex.lane(); i < L.nloc; i += ex.nlanes()) rx[i] = -rx[i] + tmpl[i];
+            ex.sync();
+            if (ex.lane() == 0) {
+                rx[14 * K] += -1.0;
+                rx[L.iS] = -rx[L.iS] + sgy;
+                rx[L.iTNU] = C.wNu - rx[L.iTNU];
+                rx[L.iTTR] = 0.5 - rx[L.iTTR];
+                rx[L.iTS] = 1.0 - rx[L.iTS];
+            }
+            ex.sync();
+            mask_fixed(rx);
+            E_apply(V, ry, true);
+            ex.sync();
+            for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) ry[i] += dk[i];
+            ex.sync();
+            const double gap = dot(S, Z, L.nc);
+            const double pobj = -V[14 * K] + C.wNu * V[L.iTNU] + 0.5 * V[L.iTTR] + V[L.iTS];
+            const double nrx = sqrt(dot(rx, rx, L.nv)), nry = sqrt(dot(ry, ry, L.ny)), nrz = sqrt(dot(rz, rz, L.nc));
+            const double pres = nry > nrz ? nry : nrz;
+            const double dres = nrx / (C.wNu > 1.0 ? C.wNu : 1.0);
+            const double relgap = gap / (fabs(pobj) > 1.0 ? fabs(pobj) : 1.0);
+            double merit = pres > dres ? pres : dres;
+            if (relgap > merit) merit = relgap;
+            SCVX_DBG("%3d pobj %+.8e gap %.2e pres %.2e (ry %.2e rz %.2e) dres %.2e\n", it, pobj, gap, pres, nry, nrz, dres);
+            if (!(merit == merit) || !(gap == gap)) { res.status = 3; break; }
+            if (merit < best_merit) {
+                best_merit = merit; best_it = it; res.pobj = pobj;
+                copy(Vbest, V, L.nv);
+                ex.sync();
+            }
+            if (pres < C.tol && dres < C.tol && relgap < C.tol) { res.status = 0; break; }
+            if (it - best_it >= 3 && best_merit < 1e-5) { res.status = best_merit < 100.0 * C.tol ? 0 : 2; break; }
+            if (it == C.max_iter) { res.status = best_merit < 100.0 * C.tol ? 0 : 1; break; }
+            nt_all();
+            if (!build_kkt()) { res.status = best_merit < 100.0 * C.tol ? 0 : 2; break; }
+            const double mu = gap / degree;
+            centering_rhs(tt, false, 0.0);   // affine (predictor) right-hand side, consumed in place by newton
+            newton(tt);
+            W_all(dS, sds, true);
+            W_all(dZ, sdz, false);
+            double a1 = maxstep_all(sds), a2 = maxstep_all(sdz);
+            double alpha = a1 < a2 ? a1 : a2;
+            if (alpha > 1.0) alpha = 1.0;
+            const double sig = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
+            SCVX_DBG("    aff alpha %.6e (a1 %.3e a2 %.3e) |dw|^2 %.6e ds %.6e dtnu %.6e dttr %.6e\n", alpha, a1, a2, dot(dw, dw, L.nv), dw[L.iS], dw[L.iTNU], dw[L.iTTR]);
+            centering_rhs(tt, true, sig * mu);
+            newton(tt);
+            W_all(dS, sds, true);
+            W_all(dZ, sdz, false);
+            a1 = maxstep_all(sds); a2 = maxstep_all(sdz);
+            alpha = 0.99 * (a1 < a2 ? a1 : a2);
+            if (alpha > 1.0) alpha = 1.0;
+            SCVX_DBG("    cmb alpha %.6e |dw|^2 %.6e\n", alpha, dot(dw, dw, L.nv));
+            if (!(alpha == alpha)) { res.status = best_merit < 100.0 * C.tol ? 0 : 3; break; }
+            if (alpha < 1e-9) { res.status = best_merit < 100.0 * C.tol ? 0 : 2; break; }
+            for (int i = ex.lane(); i < L.nv; i += ex.nlanes()) V[i] += alpha * dw[i];
+            for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) y[i] += alpha * dy[i];
+            for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) { S[i] += alpha * dS[i]; Z[i] += alpha * dZ[i]; }
+            ex.sync();
+        }
+        res.merit = best_merit;
+        if (best_it > 0) { copy(V, Vbest, L.nv); ex.sync(); }
+        return res;
+    }
+};
+
+}  // namespace ipm
+}  // namespace scvx
