@@ -9,7 +9,7 @@
  *   Rocketland.create_initial     rocketland.jl:34-39  ->  scvx_batch_create + scvx_batch_init
  *   Rocketland.solve_step         rocketland.jl:226-321->  scvx_solve_step
  *   Rocketland.solve_problem      rocketland.jl:432-443->  scvx_solve
- *   MOI.optimize! (conic solve)   rocketland.jl:271    ->  scvx_socp_solve (batched ADMM, device)
+ *   MOI.optimize! (conic solve)   rocketland.jl:271    ->  scvx_socp_solve (batched interior-point, device)
  *
  * Conventions (reference: dynamics.jl:13-19, 136-139):
  *   state  x[14] = [m, r(3), v(3), q(4, scalar first), w(3)]
@@ -68,17 +68,14 @@ typedef struct scvx_problem {
     int32_t reserved;
 } scvx_problem;
 
-/* Tunables of the batched operator-splitting conic solver that replaces MOI.optimize!. */
-typedef struct scvx_admm_opts {
-    int32_t max_iter;    /* ADMM iteration cap per SOCP                */
-    int32_t check_every; /* residual evaluation period                 */
-    double eps_abs;      /* absolute tolerance on primal/dual residual */
-    double eps_rel;      /* relative tolerance                         */
-    double rho;          /* initial penalty                            */
-    double alpha;        /* over-relaxation in (0,2)                   */
-    int32_t adapt_rho;   /* 1: residual-balancing refactorisation      */
-    int32_t warm_start;  /* 1: start from the previous SCvx iterate    */
-} scvx_admm_opts;
+/* Tunables of the batched conic solver that replaces MOI.optimize! (rocketland.jl:271): a structure-
+ * exploiting primal-dual interior-point method (the algorithm class of the reference's Mosek / ECOS),
+ * one wavefront per trajectory.  DESIGN.md explains why it is not the first-order splitting first planned. */
+typedef struct scvx_solver_opts {
+    int32_t max_iter; /* interior-point iteration cap per SOCP (default 60)                   */
+    int32_t refine;   /* iterative-refinement passes per Newton solve (default 1)            */
+    double tol;       /* primal / dual residual and relative-gap tolerance (default 1e-8)    */
+} scvx_solver_opts;
 
 typedef struct scvx_ctx scvx_ctx;     /* owns device, stream, problem constants, aero tables */
 typedef struct scvx_batch scvx_batch; /* owns the batched iterate (ProblemIteration x B)     */
@@ -110,10 +107,10 @@ int scvx_propagate_f64_host(scvx_ctx *ctx, int B, int K, const double *x, const 
                             const double *sigma, double dt, double *xnext);
 
 /* ---- batched SCvx: create_initial / solve_step / solve_problem ------------------------------ */
-int scvx_admm_default_opts(scvx_admm_opts *o);
+int scvx_solver_default_opts(scvx_solver_opts *o);
 int scvx_batch_create(scvx_ctx *ctx, int B, scvx_batch **out);
 void scvx_batch_destroy(scvx_batch *b);
-int scvx_batch_set_admm(scvx_batch *b, const scvx_admm_opts *o);
+int scvx_batch_set_solver(scvx_batch *b, const scvx_solver_opts *o);
 /* ic [B][6] = per-trajectory (rIi, vIi) overriding the problem's (Monte-Carlo dispersions); NULL =
  * every trajectory uses the problem's own.  Builds the straight-line guess (initial_solve.jl:113-129),
  * linearises it and sets rk=100, cost=Inf, iter=0 (rocketland.jl:38). */
@@ -135,8 +132,9 @@ int scvx_batch_trajectory_dev(scvx_batch *b, double **traj_dev, int64_t *n_doubl
 int scvx_batch_get_linearization(scvx_batch *b, double *endpoint, double *deriv);
 int scvx_batch_get_scalars(scvx_batch *b, double *rk, double *cost, int32_t *iter);
 int scvx_batch_set_scalars(scvx_batch *b, const double *rk, const double *cost, const int32_t *iter);
-/* last SOCP solve: per-trajectory ADMM iterations used, primal and dual residuals */
-int scvx_batch_get_solver_stats(scvx_batch *b, int32_t *admm_iters, double *r_prim, double *r_dual);
+/* last SOCP solve, per trajectory: solver status (0 optimal, 1 iteration cap, 2 numerical floor above
+ * tolerance, 3 non-finite), interior-point iterations, final merit max(pres, dres, relgap), objective */
+int scvx_batch_get_solver_stats(scvx_batch *b, int32_t *status, int32_t *iters, double *merit, double *pobj);
 
 /* ---- the conic subproblem alone (replaces MOI.optimize!, rocketland.jl:271) ------------------ */
 /* Solves the trust-region SOCP at the batch's current (about, dynam, rk).  sol [B][(K+1)*17+1] as

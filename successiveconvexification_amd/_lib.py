@@ -34,12 +34,8 @@ class ScvxProblem(C.Structure):
     ]
 
 
-class ScvxAdmmOpts(C.Structure):
-    _fields_ = [
-        ("max_iter", C.c_int32), ("check_every", C.c_int32),
-        ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("rho", C.c_double), ("alpha", C.c_double),
-        ("adapt_rho", C.c_int32), ("warm_start", C.c_int32),
-    ]
+class ScvxSolverOpts(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("refine", C.c_int32), ("tol", C.c_double)]
 
 
 _vp = C.c_void_p
@@ -57,10 +53,10 @@ SIGNATURES = {
     "scvx_linearize_f64_host": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp]),
     "scvx_propagate_f64": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
     "scvx_propagate_f64_host": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp]),
-    "scvx_admm_default_opts": (C.c_int, [C.POINTER(ScvxAdmmOpts)]),
+    "scvx_solver_default_opts": (C.c_int, [C.POINTER(ScvxSolverOpts)]),
     "scvx_batch_create": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "scvx_batch_destroy": (None, [_vp]),
-    "scvx_batch_set_admm": (C.c_int, [_vp, C.POINTER(ScvxAdmmOpts)]),
+    "scvx_batch_set_solver": (C.c_int, [_vp, C.POINTER(ScvxSolverOpts)]),
     "scvx_batch_init": (C.c_int, [_vp, _dp]),
     "scvx_solve_step": (C.c_int, [_vp, _ip, _dp, _dp]),
     "scvx_solve_step_async": (C.c_int, [_vp]),
@@ -71,7 +67,7 @@ SIGNATURES = {
     "scvx_batch_get_linearization": (C.c_int, [_vp, _dp, _dp]),
     "scvx_batch_get_scalars": (C.c_int, [_vp, _dp, _dp, _ip]),
     "scvx_batch_set_scalars": (C.c_int, [_vp, _dp, _dp, _ip]),
-    "scvx_batch_get_solver_stats": (C.c_int, [_vp, _ip, _dp, _dp]),
+    "scvx_batch_get_solver_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
     "scvx_socp_solve": (C.c_int, [_vp, _dp, _dp]),
 }
 

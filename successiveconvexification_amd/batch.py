@@ -1,0 +1,157 @@
+"""Batched SCvx driver over libscvx_hip.so (new relative to the reference, which solves one trajectory
+serially): B independent DescentProblem instances that differ in their initial condition, advanced by
+Rocketland.solve_step in lock-step on one GPU; `solve_sharded` spreads a Monte-Carlo batch over the GPUs
+of a node, one process per GPU, and all-gathers the final trajectories over RCCL."""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from .dynamics import IntegratorCache
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _pi(a):
+    return a.ctypes.data_as(_ip)
+
+
+STATUS = {0: "converged", 1: "running", 2: "rejected", 3: "solver", 4: "nonfinite"}
+
+
+class ScvxBatch:
+    """The batched ProblemIteration (master.jl:122-134) living in HBM."""
+
+    def __init__(self, cache: IntegratorCache, B: int, tol: float = None, max_iter: int = None, refine: int = None):
+        self.cache = cache
+        self.B = int(B)
+        self.K = cache.problem.K
+        self.nrec = (self.K + 1) * 17 + 1
+        self._L = cache._L
+        h = C.c_void_p()
+        _lib.check(cache.handle, self._L.scvx_batch_create(cache.handle, self.B, C.byref(h)), "scvx_batch_create")
+        self.handle = h
+        if tol is not None or max_iter is not None or refine is not None:
+            o = _lib.ScvxSolverOpts()
+            self._L.scvx_solver_default_opts(C.byref(o))
+            if tol is not None:
+                o.tol = tol
+            if max_iter is not None:
+                o.max_iter = max_iter
+            if refine is not None:
+                o.refine = refine
+            _lib.check(cache.handle, self._L.scvx_batch_set_solver(h, C.byref(o)), "scvx_batch_set_solver")
+
+    def _chk(self, rc, what):
+        _lib.check(self.cache.handle, rc, what)
+
+    # create_initial (rocketland.jl:34-39) for every trajectory
+    def init(self, ic=None):
+        if ic is not None:
+            ic = np.ascontiguousarray(ic, np.float64)
+            if ic.shape != (self.B, 6):
+                raise ValueError("ic must be [B][6] = (rIi, vIi)")
+        self._chk(self._L.scvx_batch_init(self.handle, _p(ic) if ic is not None else None), "scvx_batch_init")
+        return self
+
+    # solve_step (rocketland.jl:226-321)
+    def solve_step(self):
+        st = np.zeros(self.B, np.int32)
+        nu = np.zeros(self.B)
+        dj = np.zeros(self.B)
+        self._chk(self._L.scvx_solve_step(self.handle, _pi(st), _p(nu), _p(dj)), "scvx_solve_step")
+        return st, nu, dj
+
+    def solve_step_async(self):
+        self._chk(self._L.scvx_solve_step_async(self.handle), "scvx_solve_step_async")
+
+    # solve_problem (rocketland.jl:432-443)
+    def solve(self):
+        st = np.zeros(self.B, np.int32)
+        it = np.zeros(self.B, np.int32)
+        nu = np.zeros(self.B)
+        dj = np.zeros(self.B)
+        self._chk(self._L.scvx_solve(self.handle, _pi(st), _pi(it), _p(nu), _p(dj)), "scvx_solve")
+        return st, it, nu, dj
+
+    def socp_solve(self):
+        """The conic subproblem alone at the current iterate: returns (x, u, sigma_new, nu)."""
+        sol = np.zeros((self.B, self.nrec))
+        nu = np.zeros((self.B, self.K, 14))
+        self._chk(self._L.scvx_socp_solve(self.handle, _p(sol), _p(nu)), "scvx_socp_solve")
+        x, u, s = self._split(sol)
+        return x, u, s, nu
+
+    def _split(self, rec):
+        K, B = self.K, self.B
+        nx = (K + 1) * 14
+        return (rec[:, :nx].reshape(B, K + 1, 14).copy(), rec[:, nx:nx + (K + 1) * 3].reshape(B, K + 1, 3).copy(),
+                rec[:, -1].copy())
+
+    def trajectory(self):
+        rec = np.zeros((self.B, self.nrec))
+        self._chk(self._L.scvx_batch_get_trajectory(self.handle, _p(rec)), "scvx_batch_get_trajectory")
+        return self._split(rec)
+
+    def trajectory_record(self):
+        rec = np.zeros((self.B, self.nrec))
+        self._chk(self._L.scvx_batch_get_trajectory(self.handle, _p(rec)), "scvx_batch_get_trajectory")
+        return rec
+
+    def set_trajectory(self, x, u, sigma):
+        rec = np.concatenate([np.asarray(x, float).reshape(self.B, -1), np.asarray(u, float).reshape(self.B, -1),
+                              np.asarray(sigma, float).reshape(self.B, 1)], axis=1)
+        rec = np.ascontiguousarray(rec)
+        assert rec.shape == (self.B, self.nrec)
+        self._chk(self._L.scvx_batch_set_trajectory(self.handle, _p(rec)), "scvx_batch_set_trajectory")
+
+    def trajectory_dev(self):
+        ptr = C.c_void_p()
+        n = C.c_int64()
+        self._chk(self._L.scvx_batch_trajectory_dev(self.handle, C.byref(ptr), C.byref(n)), "scvx_batch_trajectory_dev")
+        return ptr.value, n.value
+
+    def linearization(self):
+        e = np.zeros((self.B, self.K, 14))
+        d = np.zeros((self.B, self.K, 21, 14))
+        self._chk(self._L.scvx_batch_get_linearization(self.handle, _p(e), _p(d)), "scvx_batch_get_linearization")
+        return e, d
+
+    def scalars(self):
+        rk = np.zeros(self.B)
+        cost = np.zeros(self.B)
+        it = np.zeros(self.B, np.int32)
+        self._chk(self._L.scvx_batch_get_scalars(self.handle, _p(rk), _p(cost), _pi(it)), "scvx_batch_get_scalars")
+        return rk, cost, it
+
+    def set_scalars(self, rk=None, cost=None, it=None):
+        rk = None if rk is None else np.ascontiguousarray(np.broadcast_to(np.asarray(rk, float), (self.B,)))
+        cost = None if cost is None else np.ascontiguousarray(np.broadcast_to(np.asarray(cost, float), (self.B,)))
+        it = None if it is None else np.ascontiguousarray(np.broadcast_to(np.asarray(it, np.int32), (self.B,)))
+        self._chk(self._L.scvx_batch_set_scalars(self.handle, _p(rk) if rk is not None else None,
+                                                 _p(cost) if cost is not None else None,
+                                                 _pi(it) if it is not None else None), "scvx_batch_set_scalars")
+
+    def solver_stats(self):
+        st = np.zeros(self.B, np.int32)
+        it = np.zeros(self.B, np.int32)
+        merit = np.zeros(self.B)
+        pobj = np.zeros(self.B)
+        self._chk(self._L.scvx_batch_get_solver_stats(self.handle, _pi(st), _pi(it), _p(merit), _p(pobj)),
+                  "scvx_batch_get_solver_stats")
+        return st, it, merit, pobj
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._L.scvx_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,20 +1,551 @@
-// placeholder: batched SCvx entry points (filled in by the SOCP milestone)
+// Batched SCvx on the device: the conic subproblem kernel (K4), the glue kernels (K3/K5) and the
+// batch entry points of include/scvx.h.
+//
+// One Rocketland.solve_step (rocketland.jl:226-321) for B independent trajectories is the kernel chain
+//     socp_kernel      : MOI data update + MOI.optimize! + primal extraction     (:245-283)
+//     candidate_kernel : x = about + dx, u = about + du, sigma + dsigma          (:278-280, :317)
+//     propagate_kernel : K predict_state calls per trajectory (K2)               (:289)
+//     tr_update_kernel : jK, lK, rho test, accept / reject, radius update        (:286-313)
+//     linearize_kernel : Dynamics.linearize_dynamics on the new reference (K1)   (:318)
+// all on one stream, nothing returning to the host in between.
+//
+// socp_kernel runs ONE 64-LANE WAVEFRONT PER TRAJECTORY over the portable interior-point core
+// (scvx_ipm_core.hpp): lanes split the per-node cone work, the 14x14 tile arithmetic of the block-
+// tridiagonal Schur complement and the long dot products of the two big trust-region cones; reductions
+// are cross-lane shuffles; the 14x14 pivot tiles of the block Cholesky live in LDS.  Each trajectory's
+// working set is one contiguous slab of HBM so every strided lane loop is a coalesced access.
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <vector>
 #include "scvx_internal.hpp"
-extern "C" {
-int scvx_admm_default_opts(scvx_admm_opts*) { return SCVX_ERR_STATE; }
-int scvx_batch_create(scvx_ctx*, int, scvx_batch**) { return SCVX_ERR_STATE; }
-void scvx_batch_destroy(scvx_batch*) {}
-int scvx_batch_set_admm(scvx_batch*, const scvx_admm_opts*) { return SCVX_ERR_STATE; }
-int scvx_batch_init(scvx_batch*, const double*) { return SCVX_ERR_STATE; }
-int scvx_solve_step(scvx_batch*, int32_t*, double*, double*) { return SCVX_ERR_STATE; }
-int scvx_solve_step_async(scvx_batch*) { return SCVX_ERR_STATE; }
-int scvx_solve(scvx_batch*, int32_t*, int32_t*, double*, double*) { return SCVX_ERR_STATE; }
-int scvx_batch_get_trajectory(scvx_batch*, double*) { return SCVX_ERR_STATE; }
-int scvx_batch_set_trajectory(scvx_batch*, const double*) { return SCVX_ERR_STATE; }
-int scvx_batch_trajectory_dev(scvx_batch*, double**, int64_t*) { return SCVX_ERR_STATE; }
-int scvx_batch_get_linearization(scvx_batch*, double*, double*) { return SCVX_ERR_STATE; }
-int scvx_batch_get_scalars(scvx_batch*, double*, double*, int32_t*) { return SCVX_ERR_STATE; }
-int scvx_batch_set_scalars(scvx_batch*, const double*, const double*, const int32_t*) { return SCVX_ERR_STATE; }
-int scvx_batch_get_solver_stats(scvx_batch*, int32_t*, double*, double*) { return SCVX_ERR_STATE; }
-int scvx_socp_solve(scvx_batch*, double*, double*) { return SCVX_ERR_STATE; }
+#include "scvx_ipm_core.hpp"
+
+using scvx::fail;
+
+namespace scvx {
+
+struct WaveEx {
+    double* sc;
+    __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
+    __device__ __forceinline__ int nlanes() const { return 64; }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    __device__ __forceinline__ double sum(double x) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        return x;
+    }
+    __device__ __forceinline__ double min(double x) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o, 64));
+        return x;
+    }
+    __device__ __forceinline__ bool all(bool b) { return __all(b) != 0; }
+    __device__ __forceinline__ double* scratch() { return sc; }
+};
+
+// info[b] = {status, iters, merit, pobj}
+__global__ __launch_bounds__(64) void socp_kernel(ipm::Consts C, int B, size_t work_stride,
+                                                  const double* __restrict__ x, const double* __restrict__ u,
+                                                  const double* __restrict__ endpoint, const double* __restrict__ deriv,
+                                                  const double* __restrict__ rk, const double* __restrict__ ic,
+                                                  const int* __restrict__ active, double* __restrict__ work,
+                                                  double* __restrict__ sol, double* __restrict__ nu,
+                                                  double* __restrict__ info) {
+    __shared__ __attribute__((aligned(16))) double lds[640];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    if (active && !active[b]) return;
+    const int K = C.K;
+    WaveEx ex{lds};
+    ipm::Solver<WaveEx> S(ex, C);
+    const ipm::Result r = S.solve(x + (size_t)b * (K + 1) * 14, u + (size_t)b * (K + 1) * 3,
+                                  endpoint + (size_t)b * K * 14, deriv + (size_t)b * K * 294, rk[b], ic + (size_t)b * 6,
+                                  work + (size_t)b * work_stride);
+    const int nxu = S.L.nx + S.L.nu_;
+    double* so = sol + (size_t)b * (nxu + 1);
+    for (int i = threadIdx.x; i < nxu; i += 64) so[i] = S.V[i];
+    double* no = nu + (size_t)b * S.L.ny;
+    for (int i = threadIdx.x; i < S.L.ny; i += 64) no[i] = S.V[nxu + i];
+    if (threadIdx.x == 0) {
+        so[nxu] = S.V[S.L.iS];
+        info[4 * b + 0] = (double)r.status;
+        info[4 * b + 1] = (double)r.iters;
+        info[4 * b + 2] = r.merit;
+        info[4 * b + 3] = r.pobj;
+    }
 }
+
+// cand = about + step (x, u in one contiguous [B][(K+1)*17+1] trajectory record, sigma last)
+__global__ void candidate_kernel(int B, int nrec, const double* __restrict__ traj, const double* __restrict__ sol,
+                                 double* __restrict__ cand) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)B * nrec) cand[i] = traj[i] + sol[i];
+}
+
+// split / join between the contiguous trajectory record and the (x, u, sigma) arrays the kernels read
+__global__ void unpack_kernel(int B, int K, const double* __restrict__ rec, double* __restrict__ x,
+                              double* __restrict__ u, double* __restrict__ sigma) {
+    const int nrec = (K + 1) * 17 + 1, nx = (K + 1) * 14, nu = (K + 1) * 3;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * nrec) return;
+    const size_t b = i / nrec;
+    const int r = (int)(i - b * nrec);
+    const double v = rec[i];
+    if (r < nx) x[b * nx + r] = v;
+    else if (r < nx + nu) u[b * nu + (r - nx)] = v;
+    else sigma[b] = v;
+}
+
+struct TrParams {
+    double wNu, rh0, rh1, rh2, alph, bet, ri, nuTol, delTol;
+    int K, imax;
+};
+
+// One wavefront per trajectory: rocketland.jl:286-313 plus the commit of the accepted candidate.
+// status codes: include/scvx.h.  out[b] = {nu_norm, dJ}
+__global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const double* __restrict__ cand,
+                                                       const double* __restrict__ xprop, const double* __restrict__ nu,
+                                                       const double* __restrict__ info, double* __restrict__ traj,
+                                                       double* __restrict__ rk, double* __restrict__ cost,
+                                                       int* __restrict__ iter, int* __restrict__ status,
+                                                       int* __restrict__ active, double* __restrict__ out) {
+    const int b = blockIdx.x;
+    if (b >= B || !active[b]) return;
+    const int K = P.K, nrec = (K + 1) * 17 + 1;
+    const double* c = cand + (size_t)b * nrec;
+    const double* xp = xprop + (size_t)b * K * 14;
+    const double* nv = nu + (size_t)b * K * 14;
+    double d2 = 0, n2 = 0;
+    for (int i = threadIdx.x; i < K * 14; i += 64) {
+        const double d = c[14 + i] - xp[i];  // x_{k+1} - predict_state(x_k, u_k, u_{k+1}, sigma + dsigma)
+        d2 += d * d;
+        n2 += nv[i] * nv[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { d2 += __shfl_xor(d2, o, 64); n2 += __shfl_xor(n2, o, 64); }
+    const double mf = c[14 * K];  // x[1, K+1]
+    const double jK = -mf + P.wNu * sqrt(d2);
+    const double nun = sqrt(n2);
+    const double lK = -mf + P.wNu * nun;
+    const int sstat = (int)info[4 * b];
+    int st;
+    bool accept = false;
+    double next_rk = rk[b], dJ = INFINITY;
+    if (sstat != 0) {
+        st = (sstat == 3) ? SCVX_ST_NONFINITE : SCVX_ST_SOLVER;  // rocketland.jl:273-276: error(...)
+    } else if (!(jK == jK) || !(lK == lK)) {
+        st = SCVX_ST_NONFINITE;
+    } else {
+        const double jKm = cost[b];
+        const double djk = jKm - jK, dlk = jKm - lK;
+        const double rhk = djk / dlk;  // NaN on the first call (cost = Inf): falls through to the grow branch
+        if (rk[b] == INFINITY) { next_rk = P.ri; accept = true; dJ = NAN; }
+        else if (rhk < P.rh0) { next_rk = rk[b] / P.alph; accept = false; dJ = INFINITY; }
+        else {
+            accept = true;
+            dJ = djk;
+            if (rhk < P.rh1) next_rk = rk[b] / P.alph;
+            else if (P.rh1 <= rhk && rhk < P.rh2) next_rk = rk[b];
+            else next_rk = P.bet * rk[b];
+        }
+        st = accept ? SCVX_ST_RUNNING : SCVX_ST_REJECTED;
+    }
+    if (accept) {
+        double* t = traj + (size_t)b * nrec;
+        for (int i = threadIdx.x; i < nrec; i += 64) t[i] = c[i];
+    }
+    if (threadIdx.x == 0) {
+        const int it = iter[b] + 1;
+        iter[b] = it;
+        if (st == SCVX_ST_SOLVER || st == SCVX_ST_NONFINITE) {
+            active[b] = 0;
+        } else {
+            rk[b] = next_rk;
+            if (accept) cost[b] = jK;
+            // solve_problem's loop test (rocketland.jl:436): stop when nu and dJ are both within tolerance
+            if (accept && nun <= P.nuTol && dJ <= P.delTol) { st = SCVX_ST_CONVERGED; active[b] = 0; }
+        }
+        status[b] = st;
+        out[2 * b] = nun;
+        out[2 * b + 1] = dJ;
+    }
+}
+
+}  // namespace scvx
+
+// ---------------------------------------------------------------------------------------------------
+struct scvx_batch {
+    scvx_ctx* ctx = nullptr;
+    int B = 0, K = 0, nrec = 0;
+    scvx_solver_opts opts{};
+    scvx::ipm::Consts C{};
+    scvx::TrParams tr{};
+    size_t work_stride = 0;
+    // device state
+    double *traj = nullptr, *cand = nullptr, *sol = nullptr;      // [B][nrec]
+    double *x = nullptr, *u = nullptr, *sigma = nullptr;          // split views of traj (kernels' input layout)
+    double *cx = nullptr, *cu = nullptr, *csigma = nullptr;       // split views of cand
+    double *endpoint = nullptr, *deriv = nullptr, *xprop = nullptr, *nu = nullptr;
+    double *rk = nullptr, *cost = nullptr, *ic = nullptr, *info = nullptr, *out = nullptr, *work = nullptr;
+    int *iter = nullptr, *status = nullptr, *active = nullptr;
+    bool initialised = false;
+};
+
+namespace {
+
+void rotation_between_e1(const double* b, double* q) {
+    // Rotations.rotation_between([1,0,0], b) as [w,x,y,z] (initial_solve.jl:121-122)
+    const double nb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+    double w = nb + b[0];
+    double v[3];
+    if (std::fabs(w) < 100 * std::numeric_limits<double>::epsilon()) {
+        v[0] = 0; v[1] = 0; v[2] = 1;  // any vector perpendicular to e1
+        w = 0;
+    } else {
+        v[0] = 0; v[1] = -b[2]; v[2] = b[1];  // e1 x b
+    }
+    const double n = std::sqrt(w * w + v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    q[0] = w / n; q[1] = v[0] / n; q[2] = v[1] / n; q[3] = v[2] / n;
+}
+
+template <class T>
+int dmalloc(scvx_ctx* ctx, T** p, size_t n) {
+    SCVX_HIP(ctx, hipMalloc((void**)p, n * sizeof(T)));
+    return SCVX_OK;
+}
+
+int split_views(scvx_batch* b, const double* rec, double* x, double* u, double* sigma) {
+    const size_t n = (size_t)b->B * b->nrec;
+    hipLaunchKernelGGL(scvx::unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->ctx->stream, b->B, b->K,
+                       rec, x, u, sigma);
+    SCVX_HIP(b->ctx, hipGetLastError());
+    return SCVX_OK;
+}
+
+int enqueue_socp(scvx_batch* b) {
+    hipLaunchKernelGGL(scvx::socp_kernel, dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
+                       b->endpoint, b->deriv, b->rk, b->ic, b->active, b->work, b->sol, b->nu, b->info);
+    SCVX_HIP(b->ctx, hipGetLastError());
+    return SCVX_OK;
+}
+
+int enqueue_step(scvx_batch* b) {
+    scvx_ctx* ctx = b->ctx;
+    hipStream_t st = ctx->stream;
+    const double dt = 1.0 / (b->K + 1);
+    int rc = enqueue_socp(b);
+    if (rc) return rc;
+    const size_t n = (size_t)b->B * b->nrec;
+    hipLaunchKernelGGL(scvx::candidate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b->B, b->nrec, b->traj,
+                       b->sol, b->cand);
+    SCVX_HIP(ctx, hipGetLastError());
+    rc = split_views(b, b->cand, b->cx, b->cu, b->csigma);
+    if (rc) return rc;
+    SCVX_HIP(ctx, scvx::launch_propagate(ctx, b->B, b->K, b->cx, b->cu, b->csigma, dt, b->xprop, st));
+    hipLaunchKernelGGL(scvx::tr_update_kernel, dim3(b->B), dim3(64), 0, st, b->tr, b->B, b->cand, b->xprop, b->nu, b->info,
+                       b->traj, b->rk, b->cost, b->iter, b->status, b->active, b->out);
+    SCVX_HIP(ctx, hipGetLastError());
+    rc = split_views(b, b->traj, b->x, b->u, b->sigma);
+    if (rc) return rc;
+    SCVX_HIP(ctx, scvx::launch_linearize(ctx, b->B, b->K, b->x, b->u, b->sigma, dt, b->endpoint, b->deriv, st));
+    return SCVX_OK;
+}
+
+int check_batch(scvx_batch* b, bool need_init) {
+    if (!b || !b->ctx) return SCVX_ERR_ARG;
+    if (need_init && !b->initialised) return fail(b->ctx, SCVX_ERR_STATE, "call scvx_batch_init first");
+    if (b->ctx->prob.aero_kind == 1 && !b->ctx->dyn.aero)
+        return fail(b->ctx, SCVX_ERR_STATE, "AtmosphericData problem: call scvx_set_aero_table first");
+    hipError_t e = hipSetDevice(b->ctx->device);
+    if (e != hipSuccess) return fail(b->ctx, SCVX_ERR_HIP, "hipSetDevice failed");
+    return SCVX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int scvx_solver_default_opts(scvx_solver_opts* o) {
+    if (!o) return SCVX_ERR_ARG;
+    o->max_iter = 60;
+    o->refine = 1;
+    o->tol = 1e-8;
+    return SCVX_OK;
+}
+
+int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
+    if (!ctx || !out) return SCVX_ERR_ARG;
+    *out = nullptr;
+    if (B < 1) return fail(ctx, SCVX_ERR_ARG, "B >= 1 required");
+    SCVX_HIP(ctx, hipSetDevice(ctx->device));
+    scvx_batch* b = new (std::nothrow) scvx_batch();
+    if (!b) return SCVX_ERR_NOMEM;
+    b->ctx = ctx;
+    b->B = B;
+    const scvx_problem& p = ctx->prob;
+    const int K = p.K;
+    b->K = K;
+    b->nrec = (K + 1) * 17 + 1;
+    scvx_solver_default_opts(&b->opts);
+    scvx::ipm::Consts& C = b->C;
+    const double d2r = M_PI / 180.0;
+    C.K = K; C.max_iter = b->opts.max_iter; C.refine = b->opts.refine; C.pad = 0; C.tol = b->opts.tol;
+    C.itan = 1.0 / std::tan(p.gammaGs * d2r);                       // rocketland.jl:63
+    C.sqcm = std::sqrt((1.0 - std::cos(p.thetaMax * d2r)) / 2.0);   // :64
+    C.icos = 1.0 / std::cos(p.deltaMax * d2r);                      // :65
+    C.Tmax = p.Tmax; C.Tmin = p.Tmin; C.omMax = p.omMax; C.mdry = p.mdry; C.wNu = p.wNu; C.mwet = p.mwet;
+    for (int i = 0; i < 3; i++) { C.rIf[i] = p.rIf[i]; C.vIf[i] = p.vIf[i]; C.wBi[i] = p.wBi[i]; C.wBf[i] = p.wBf[i]; }
+    for (int i = 0; i < 4; i++) C.qBIf[i] = p.qBIf[i];
+    scvx::TrParams& T = b->tr;
+    T.wNu = p.wNu; T.rh0 = p.rh0; T.rh1 = p.rh1; T.rh2 = p.rh2; T.alph = p.alph; T.bet = p.bet; T.ri = p.ri;
+    T.nuTol = p.nuTol; T.delTol = p.delTol; T.K = K; T.imax = p.imax;
+    scvx::ipm::Layout L;
+    L.init(K);
+    b->work_stride = (L.work_doubles() + 7) & ~(size_t)7;
+    const size_t nB = (size_t)B;
+    int rc = 0;
+    rc |= dmalloc(ctx, &b->traj, nB * b->nrec);
+    rc |= dmalloc(ctx, &b->cand, nB * b->nrec);
+    rc |= dmalloc(ctx, &b->sol, nB * b->nrec);
+    rc |= dmalloc(ctx, &b->x, nB * (K + 1) * 14);
+    rc |= dmalloc(ctx, &b->u, nB * (K + 1) * 3);
+    rc |= dmalloc(ctx, &b->sigma, nB);
+    rc |= dmalloc(ctx, &b->cx, nB * (K + 1) * 14);
+    rc |= dmalloc(ctx, &b->cu, nB * (K + 1) * 3);
+    rc |= dmalloc(ctx, &b->csigma, nB);
+    rc |= dmalloc(ctx, &b->endpoint, nB * K * 14);
+    rc |= dmalloc(ctx, &b->deriv, nB * K * 294);
+    rc |= dmalloc(ctx, &b->xprop, nB * K * 14);
+    rc |= dmalloc(ctx, &b->nu, nB * K * 14);
+    rc |= dmalloc(ctx, &b->rk, nB);
+    rc |= dmalloc(ctx, &b->cost, nB);
+    rc |= dmalloc(ctx, &b->ic, nB * 6);
+    rc |= dmalloc(ctx, &b->info, nB * 4);
+    rc |= dmalloc(ctx, &b->out, nB * 2);
+    rc |= dmalloc(ctx, &b->work, nB * b->work_stride);
+    rc |= dmalloc(ctx, &b->iter, nB);
+    rc |= dmalloc(ctx, &b->status, nB);
+    rc |= dmalloc(ctx, &b->active, nB);
+    if (rc) {
+        scvx_batch_destroy(b);
+        return fail(ctx, SCVX_ERR_NOMEM, "device allocation failed for the batch (" + std::to_string(nB * b->work_stride * 8 >> 20) + " MiB of solver workspace)");
+    }
+    *out = b;
+    return SCVX_OK;
+}
+
+void scvx_batch_destroy(scvx_batch* b) {
+    if (!b) return;
+    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    void* ptrs[] = {b->traj, b->cand, b->sol, b->x, b->u, b->sigma, b->cx, b->cu, b->csigma, b->endpoint, b->deriv, b->xprop,
+                    b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete b;
+}
+
+int scvx_batch_set_solver(scvx_batch* b, const scvx_solver_opts* o) {
+    if (!b || !o) return SCVX_ERR_ARG;
+    if (o->max_iter < 1 || o->refine < 0 || !(o->tol > 0)) return fail(b->ctx, SCVX_ERR_ARG, "bad solver options");
+    b->opts = *o;
+    b->C.max_iter = o->max_iter;
+    b->C.refine = o->refine;
+    b->C.tol = o->tol;
+    return SCVX_OK;
+}
+
+int scvx_batch_init(scvx_batch* b, const double* ic) {
+    int rc = check_batch(b, false);
+    if (rc) return rc;
+    scvx_ctx* ctx = b->ctx;
+    const scvx_problem& p = ctx->prob;
+    const int K = b->K, B = b->B, nrec = b->nrec;
+    std::vector<double> rec((size_t)B * nrec), hic((size_t)B * 6), hrk(B, 100.0), hcost(B, INFINITY);
+    std::vector<int> hiter(B, 0), hstat(B, SCVX_ST_RUNNING), hact(B, 1);
+    for (int t = 0; t < B; t++) {
+        double* c = &hic[(size_t)t * 6];
+        for (int i = 0; i < 3; i++) { c[i] = ic ? ic[(size_t)t * 6 + i] : p.rIi[i]; c[3 + i] = ic ? ic[(size_t)t * 6 + 3 + i] : p.vIi[i]; }
+        double* r = &rec[(size_t)t * nrec];
+        double* X = r;
+        double* U = r + (size_t)(K + 1) * 14;
+        // FirstRound.linear_points, initial_solve.jl:113-129
+        for (int k = 0; k <= K; k++) {
+            const double a = (double)(K - k) / K, bb = (double)k / K;
+            double* xk = X + 14 * k;
+            const double mk = a * p.mwet + bb * p.mdry;
+            xk[0] = mk;
+            double nv[3];
+            for (int i = 0; i < 3; i++) {
+                xk[1 + i] = a * c[i] + bb * p.rIf[i];
+                xk[4 + i] = a * c[3 + i] + bb * p.vIf[i];
+                nv[i] = -xk[4 + i];
+                xk[11 + i] = 0.0;
+            }
+            rotation_between_e1(nv, xk + 7);
+            U[3 * k] = mk * p.g; U[3 * k + 1] = 0.0; U[3 * k + 2] = 0.0;
+        }
+        r[nrec - 1] = p.tf_guess;
+    }
+    hipStream_t st = ctx->stream;
+    SCVX_HIP(ctx, hipMemcpyAsync(b->traj, rec.data(), rec.size() * 8, hipMemcpyHostToDevice, st));
+    SCVX_HIP(ctx, hipMemcpyAsync(b->ic, hic.data(), hic.size() * 8, hipMemcpyHostToDevice, st));
+    SCVX_HIP(ctx, hipMemcpyAsync(b->rk, hrk.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
+    SCVX_HIP(ctx, hipMemcpyAsync(b->cost, hcost.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
+    SCVX_HIP(ctx, hipMemcpyAsync(b->iter, hiter.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    SCVX_HIP(ctx, hipMemcpyAsync(b->status, hstat.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    SCVX_HIP(ctx, hipMemcpyAsync(b->active, hact.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    SCVX_HIP(ctx, hipMemsetAsync(b->out, 0, (size_t)B * 16, st));
+    SCVX_HIP(ctx, hipMemsetAsync(b->info, 0, (size_t)B * 32, st));
+    rc = split_views(b, b->traj, b->x, b->u, b->sigma);
+    if (rc) return rc;
+    SCVX_HIP(ctx, scvx::launch_linearize(ctx, B, K, b->x, b->u, b->sigma, 1.0 / (K + 1), b->endpoint, b->deriv, st));
+    SCVX_HIP(ctx, hipStreamSynchronize(st));  // host staging buffers go out of scope
+    b->initialised = true;
+    return SCVX_OK;
+}
+
+int scvx_solve_step_async(scvx_batch* b) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    return enqueue_step(b);
+}
+
+static int read_step_outputs(scvx_batch* b, int32_t* status, double* nu_norm, double* dJ) {
+    scvx_ctx* ctx = b->ctx;
+    const int B = b->B;
+    std::vector<double> out((size_t)B * 2);
+    SCVX_HIP(ctx, hipMemcpyAsync(out.data(), b->out, out.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (status) SCVX_HIP(ctx, hipMemcpyAsync(status, b->status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int t = 0; t < B; t++) {
+        if (nu_norm) nu_norm[t] = out[2 * t];
+        if (dJ) dJ[t] = out[2 * t + 1];
+    }
+    return SCVX_OK;
+}
+
+int scvx_solve_step(scvx_batch* b, int32_t* status, double* nu_norm, double* dJ) {
+    int rc = scvx_solve_step_async(b);
+    if (rc) return rc;
+    return read_step_outputs(b, status, nu_norm, dJ);
+}
+
+int scvx_solve(scvx_batch* b, int32_t* status, int32_t* iters, double* nu_norm, double* dJ) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    scvx_ctx* ctx = b->ctx;
+    const int B = b->B;
+    std::vector<int> act(B);
+    // Rocketland.solve_problem (rocketland.jl:432-443): iter starts at 1 and the loop runs while iter < imax
+    for (int it = 1; it < ctx->prob.imax; it++) {
+        rc = enqueue_step(b);
+        if (rc) return rc;
+        SCVX_HIP(ctx, hipMemcpyAsync(act.data(), b->active, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        bool any = false;
+        for (int t = 0; t < B; t++) any = any || act[t];
+        if (!any) break;
+    }
+    if (iters) {
+        SCVX_HIP(ctx, hipMemcpyAsync(iters, b->iter, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return read_step_outputs(b, status, nu_norm, dJ);
+}
+
+int scvx_batch_get_trajectory(scvx_batch* b, double* traj) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    if (!traj) return fail(b->ctx, SCVX_ERR_ARG, "null buffer");
+    SCVX_HIP(b->ctx, hipMemcpyAsync(traj, b->traj, (size_t)b->B * b->nrec * 8, hipMemcpyDeviceToHost, b->ctx->stream));
+    SCVX_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    return SCVX_OK;
+}
+
+int scvx_batch_set_trajectory(scvx_batch* b, const double* traj) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    if (!traj) return fail(b->ctx, SCVX_ERR_ARG, "null buffer");
+    scvx_ctx* ctx = b->ctx;
+    SCVX_HIP(ctx, hipMemcpyAsync(b->traj, traj, (size_t)b->B * b->nrec * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = split_views(b, b->traj, b->x, b->u, b->sigma);
+    if (rc) return rc;
+    SCVX_HIP(ctx, scvx::launch_linearize(ctx, b->B, b->K, b->x, b->u, b->sigma, 1.0 / (b->K + 1), b->endpoint, b->deriv,
+                                        ctx->stream));
+    SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCVX_OK;
+}
+
+int scvx_batch_trajectory_dev(scvx_batch* b, double** traj_dev, int64_t* n_doubles) {
+    if (!b || !traj_dev || !n_doubles) return SCVX_ERR_ARG;
+    *traj_dev = b->traj;
+    *n_doubles = (int64_t)b->B * b->nrec;
+    return SCVX_OK;
+}
+
+int scvx_batch_get_linearization(scvx_batch* b, double* endpoint, double* deriv) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    scvx_ctx* ctx = b->ctx;
+    if (endpoint) SCVX_HIP(ctx, hipMemcpyAsync(endpoint, b->endpoint, (size_t)b->B * b->K * 14 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (deriv) SCVX_HIP(ctx, hipMemcpyAsync(deriv, b->deriv, (size_t)b->B * b->K * 294 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCVX_OK;
+}
+
+int scvx_batch_get_scalars(scvx_batch* b, double* rk, double* cost, int32_t* iter) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    scvx_ctx* ctx = b->ctx;
+    if (rk) SCVX_HIP(ctx, hipMemcpyAsync(rk, b->rk, (size_t)b->B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (cost) SCVX_HIP(ctx, hipMemcpyAsync(cost, b->cost, (size_t)b->B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (iter) SCVX_HIP(ctx, hipMemcpyAsync(iter, b->iter, (size_t)b->B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCVX_OK;
+}
+
+int scvx_batch_set_scalars(scvx_batch* b, const double* rk, const double* cost, const int32_t* iter) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    scvx_ctx* ctx = b->ctx;
+    if (rk) SCVX_HIP(ctx, hipMemcpyAsync(b->rk, rk, (size_t)b->B * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (cost) SCVX_HIP(ctx, hipMemcpyAsync(b->cost, cost, (size_t)b->B * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (iter) SCVX_HIP(ctx, hipMemcpyAsync(b->iter, iter, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
+    SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCVX_OK;
+}
+
+int scvx_batch_get_solver_stats(scvx_batch* b, int32_t* status, int32_t* iters, double* merit, double* pobj) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    scvx_ctx* ctx = b->ctx;
+    std::vector<double> info((size_t)b->B * 4);
+    SCVX_HIP(ctx, hipMemcpyAsync(info.data(), b->info, info.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int t = 0; t < b->B; t++) {
+        if (status) status[t] = (int32_t)info[4 * t];
+        if (iters) iters[t] = (int32_t)info[4 * t + 1];
+        if (merit) merit[t] = info[4 * t + 2];
+        if (pobj) pobj[t] = info[4 * t + 3];
+    }
+    return SCVX_OK;
+}
+
+int scvx_socp_solve(scvx_batch* b, double* sol, double* nu) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    scvx_ctx* ctx = b->ctx;
+    rc = enqueue_socp(b);
+    if (rc) return rc;
+    const size_t n = (size_t)b->B * b->nrec;
+    hipLaunchKernelGGL(scvx::candidate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, b->B, b->nrec,
+                       b->traj, b->sol, b->cand);
+    SCVX_HIP(ctx, hipGetLastError());
+    if (sol) SCVX_HIP(ctx, hipMemcpyAsync(sol, b->cand, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (nu) SCVX_HIP(ctx, hipMemcpyAsync(nu, b->nu, (size_t)b->B * b->K * 14 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCVX_OK;
+}
+
+}  // extern "C"
