@@ -136,6 +136,12 @@ int scvx_batch_set_scalars(scvx_batch *b, const double *rk, const double *cost, 
  * tolerance, 3 non-finite), interior-point iterations, final merit max(pres, dres, relgap), objective */
 int scvx_batch_get_solver_stats(scvx_batch *b, int32_t *status, int32_t *iters, double *merit, double *pobj);
 
+/* ---- per-kernel device time of the solve_step chain (HIP events on the context's stream) ------ */
+int scvx_batch_set_profiling(scvx_batch *b, int enable);
+/* ms[5] = {socp (K4), propagate (K2), tr_update (K5), linearize (K1), glue (K3: candidate/unpack)}
+ * summed over the `steps` solve_steps enqueued since the last call; synchronises and resets. */
+int scvx_batch_get_profile(scvx_batch *b, double *ms, int64_t *steps);
+
 /* ---- the conic subproblem alone (replaces MOI.optimize!, rocketland.jl:271) ------------------ */
 /* Solves the trust-region SOCP at the batch's current (about, dynam, rk).  sol [B][(K+1)*17+1] as
  * the trajectory layout but sigma slot holds sigma + dsigma; nu [B][K][14] (nu_2..nu_{K+1}). */

@@ -69,6 +69,8 @@ SIGNATURES = {
     "scvx_batch_set_scalars": (C.c_int, [_vp, _dp, _dp, _ip]),
     "scvx_batch_get_solver_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
     "scvx_socp_solve": (C.c_int, [_vp, _dp, _dp]),
+    "scvx_batch_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "scvx_batch_get_profile": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64)]),
 }
 
 _LIB = None

@@ -145,6 +145,16 @@ class ScvxBatch:
                   "scvx_batch_get_solver_stats")
         return st, it, merit, pobj
 
+    def set_profiling(self, on: bool):
+        self._chk(self._L.scvx_batch_set_profiling(self.handle, 1 if on else 0), "scvx_batch_set_profiling")
+
+    def profile(self):
+        """(dict of summed ms per kernel, steps) since the last call; synchronises."""
+        ms = np.zeros(5)
+        n = C.c_int64()
+        self._chk(self._L.scvx_batch_get_profile(self.handle, _p(ms), C.byref(n)), "scvx_batch_get_profile")
+        return dict(zip(("socp", "propagate", "tr_update", "linearize", "glue"), ms.tolist())), n.value
+
     def close(self):
         if getattr(self, "handle", None):
             self._L.scvx_batch_destroy(self.handle)
@@ -155,3 +165,27 @@ class ScvxBatch:
             self.close()
         except Exception:
             pass
+
+
+# ---- multi-GPU: independent trajectories shard with no data-path collective ----------
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of `total` trajectories for `rank`; sizes differ by at most one."""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_trajectories(rec, group=None):
+    """All-gather the per-rank trajectory records ([B_r][(K+1)*17+1] torch tensors, equal B_r) into
+    [world][B_r][...] — the single exchange step of the path (RCCL on GPUs, gloo in the CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
+    if rec.is_cuda:
+        dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
+    else:
+        parts = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(parts, rec.contiguous(), group=group)
+        out = torch.stack(parts)
+    return out

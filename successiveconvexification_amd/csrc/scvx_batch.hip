@@ -191,6 +191,8 @@ struct scvx_batch {
     double *rk = nullptr, *cost = nullptr, *ic = nullptr, *info = nullptr, *out = nullptr, *work = nullptr;
     int *iter = nullptr, *status = nullptr, *active = nullptr;
     bool initialised = false;
+    bool profiling = false;
+    std::vector<hipEvent_t> events;  // 7 per profiled step
 };
 
 namespace {
@@ -231,25 +233,42 @@ int enqueue_socp(scvx_batch* b) {
     return SCVX_OK;
 }
 
+int mark(scvx_batch* b) {
+    if (!b->profiling) return SCVX_OK;
+    hipEvent_t e;
+    SCVX_HIP(b->ctx, hipEventCreate(&e));
+    SCVX_HIP(b->ctx, hipEventRecord(e, b->ctx->stream));
+    b->events.push_back(e);
+    return SCVX_OK;
+}
+
 int enqueue_step(scvx_batch* b) {
     scvx_ctx* ctx = b->ctx;
     hipStream_t st = ctx->stream;
     const double dt = 1.0 / (b->K + 1);
-    int rc = enqueue_socp(b);
+    int rc = mark(b);
     if (rc) return rc;
+    rc = enqueue_socp(b);
+    if (rc) return rc;
+    if ((rc = mark(b))) return rc;
     const size_t n = (size_t)b->B * b->nrec;
     hipLaunchKernelGGL(scvx::candidate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b->B, b->nrec, b->traj,
                        b->sol, b->cand);
     SCVX_HIP(ctx, hipGetLastError());
     rc = split_views(b, b->cand, b->cx, b->cu, b->csigma);
     if (rc) return rc;
+    if ((rc = mark(b))) return rc;
     SCVX_HIP(ctx, scvx::launch_propagate(ctx, b->B, b->K, b->cx, b->cu, b->csigma, dt, b->xprop, st));
+    if ((rc = mark(b))) return rc;
     hipLaunchKernelGGL(scvx::tr_update_kernel, dim3(b->B), dim3(64), 0, st, b->tr, b->B, b->cand, b->xprop, b->nu, b->info,
                        b->traj, b->rk, b->cost, b->iter, b->status, b->active, b->out);
     SCVX_HIP(ctx, hipGetLastError());
+    if ((rc = mark(b))) return rc;
     rc = split_views(b, b->traj, b->x, b->u, b->sigma);
     if (rc) return rc;
+    if ((rc = mark(b))) return rc;
     SCVX_HIP(ctx, scvx::launch_linearize(ctx, b->B, b->K, b->x, b->u, b->sigma, dt, b->endpoint, b->deriv, st));
+    if ((rc = mark(b))) return rc;
     return SCVX_OK;
 }
 
@@ -339,6 +358,7 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
 void scvx_batch_destroy(scvx_batch* b) {
     if (!b) return;
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
     void* ptrs[] = {b->traj, b->cand, b->sol, b->x, b->u, b->sigma, b->cx, b->cu, b->csigma, b->endpoint, b->deriv, b->xprop,
                     b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active};
     for (void* p : ptrs)
@@ -529,6 +549,36 @@ int scvx_batch_get_solver_stats(scvx_batch* b, int32_t* status, int32_t* iters, 
         if (merit) merit[t] = info[4 * t + 2];
         if (pobj) pobj[t] = info[4 * t + 3];
     }
+    return SCVX_OK;
+}
+
+int scvx_batch_set_profiling(scvx_batch* b, int enable) {
+    if (!b) return SCVX_ERR_ARG;
+    for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
+    b->events.clear();
+    b->profiling = enable != 0;
+    return SCVX_OK;
+}
+
+int scvx_batch_get_profile(scvx_batch* b, double* ms, int64_t* steps) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    if (!ms || !steps) return fail(b->ctx, SCVX_ERR_ARG, "null buffer");
+    scvx_ctx* ctx = b->ctx;
+    SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 5; i++) ms[i] = 0.0;
+    const size_t n = b->events.size() / 7;
+    // marks per step: 0 | socp | 1 | candidate+unpack | 2 | propagate | 3 | tr_update | 4 | unpack | 5 | linearize | 6
+    static const int slot[6] = {0, 4, 1, 2, 4, 3};
+    for (size_t s = 0; s < n; s++)
+        for (int i = 0; i < 6; i++) {
+            float t = 0.f;
+            SCVX_HIP(ctx, hipEventElapsedTime(&t, b->events[7 * s + i], b->events[7 * s + i + 1]));
+            ms[slot[i]] += (double)t;
+        }
+    *steps = (int64_t)n;
+    for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
+    b->events.clear();
     return SCVX_OK;
 }
 

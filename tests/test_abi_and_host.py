@@ -1,0 +1,128 @@
+"""C-ABI surface and host-side logic that need no GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "scvx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(scvx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from successiveconvexification_amd import _lib, build
+    so = build.build()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    exported = set(re.findall(r"\bT (scvx_[a-z0-9_]+)", out))
+    declared = _header_symbols()
+    assert len(declared) >= 30
+    assert set(declared) <= exported, set(declared) - exported
+    assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
+    # the shared object loads and binds without touching a GPU
+    _lib.lib()
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    from successiveconvexification_amd import _lib
+    c = tmp_path / "sz.c"
+    c.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "scvx.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(scvx_problem), '
+                 'offsetof(scvx_problem, K), offsetof(scvx_problem, wNu), sizeof(scvx_solver_opts));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    a, b, cc, d = map(int, subprocess.check_output([str(exe)], text=True).split())
+    P = _lib.ScvxProblem
+    assert (ctypes.sizeof(P), P.K.offset, P.wNu.offset, ctypes.sizeof(_lib.ScvxSolverOpts)) == (a, b, cc, d)
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    from successiveconvexification_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libscvx_hip.so")
+    with pytest.raises(_lib.ScvxError):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "successiveconvexification_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "liboracle" not in txt, f
+
+
+def test_sample_problem_numbers():
+    """SampleProblems.base_prob through normalize_problem (Ul=1000, Ut=1, Um=66018)."""
+    from successiveconvexification_amd import sample_problems as sp
+    p = sp.base_prob_scaled
+    assert p.g == pytest.approx(0.00982) and p.mwet == 1.0 and p.mdry == pytest.approx(0.998924535733, rel=1e-10)
+    assert p.Tmax == pytest.approx(0.0709895483, rel=1e-8) and p.Tmin == pytest.approx(0.00709895483, rel=1e-8)
+    assert p.alpha == pytest.approx(0.345) and p.sos == pytest.approx(0.352)
+    assert np.allclose(np.diag(p.jB), [1.09798890e-6, 3.14068512e-5, 3.14068512e-5], rtol=1e-7)
+    assert np.allclose(p.rTB, [-0.00426114, 0, 0]) and np.allclose(p.rIi, [1, 1, 0.1])
+    assert np.allclose(p.vIi, [-0.1, -0.2, 0]) and np.allclose(p.vIf, p.vIi)  # quirk: vIf built from vIi
+    assert np.allclose(p.rFB, [2.0, 0, 0])                                    # quirk: rFB scaled by 1/Ut
+    assert p.omMax == 60.0 and p.nuTol == 1e-10 and p.wNu == 1e4 and p.K == 50 and p.imax == 15
+
+
+def test_product_and_oracle_problem_definitions_agree():
+    from dataclasses import fields
+    from oracle import model
+    from successiveconvexification_amd import sample_problems as sp
+    po, pp = model.base_prob_scaled(), sp.base_prob_scaled
+    for f in fields(po):
+        if f.name == "aero":
+            continue
+        a, b = getattr(po, f.name), getattr(pp, f.name)
+        assert np.all(np.asarray(a) == np.asarray(b)), f.name
+    d = model.DescentProblem()
+    from successiveconvexification_amd.defns import DescentProblem
+    q = DescentProblem()
+    assert (d.wNu, d.Tmax, d.K, d.imax, d.bet, d.sos) == (q.wNu, q.Tmax, q.K, q.imax, q.bet, q.sos) == (1e5, 5.0, 50, 15, 3.2, 5.0)
+
+
+def test_linear_points_and_rotation_between():
+    from oracle import model
+    p = model.base_prob_scaled()
+    x, u = model.linear_points(p)
+    K = p.K
+    assert np.allclose(x[0, 1:4], p.rIi) and np.allclose(x[K, 1:4], p.rIf) and x[0, 0] == p.mwet and x[K, 0] == p.mdry
+    assert np.allclose(u[:, 0], x[:, 0] * p.g) and np.all(u[:, 1:] == 0)
+    # the quaternion rotates e1 onto -v/|v| (initial_solve.jl:121)
+    from oracle import dynamics as od
+    for k in (0, 17, K):
+        q = x[k, 7:11]
+        assert np.linalg.norm(q) == pytest.approx(1.0)
+        C = np.array([[1 - 2 * (q[2]**2 + q[3]**2), 2 * (q[1] * q[2] - q[0] * q[3]), 2 * (q[1] * q[3] + q[0] * q[2])],
+                      [2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[1]**2 + q[3]**2), 2 * (q[2] * q[3] - q[0] * q[1])],
+                      [2 * (q[1] * q[3] - q[0] * q[2]), 2 * (q[2] * q[3] + q[0] * q[1]), 1 - 2 * (q[1]**2 + q[2]**2)]])
+        v = -x[k, 4:7]
+        assert np.allclose(C @ [1, 0, 0], v / np.linalg.norm(v), atol=1e-12)
+    assert np.allclose(model.rotation_between([1, 0, 0], [1, 0, 0]), [1, 0, 0, 0])
+
+
+def test_dispersion_is_deterministic_per_trajectory():
+    import bench
+    from oracle import model
+    p = model.base_prob_scaled()
+    a = model.disperse_ics(p, 10, 20261004)
+    assert np.array_equal(a[3:7], bench.disperse_ics(p, 3, 7, 20261004))  # bench shards by global index
+    assert np.abs(a[:, :3] / p.rIi - 1).max() <= 0.1 + 1e-15
+    assert not np.array_equal(a[0], a[1])
+
+
+def test_shard_range_covers_everything():
+    from successiveconvexification_amd.batch import shard_range
+    for total, world in [(8192, 8), (10, 3), (5, 8), (0, 2)]:
+        cuts = [shard_range(total, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == total
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        assert max(hi - lo for lo, hi in cuts) - min(hi - lo for lo, hi in cuts) <= 1

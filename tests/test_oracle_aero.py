@@ -1,0 +1,85 @@
+"""Cubic B-spline tables and the aerodynamic force model of the oracle (aerodynamics.jl:11-36, 60-77). CPU."""
+import numpy as np
+import pytest
+
+from oracle import dynamics as od
+from oracle import model
+
+
+@pytest.fixture(scope="module")
+def aero(aero_tables):
+    d, l, t = aero_tables
+    p = model.base_prob_scaled(model.AeroData(d, l, t))
+    return p, od.Params(p), d, l
+
+
+def test_table_facts(aero_tables):
+    d, l, t = aero_tables
+    assert d.shape == (61, 181)
+    assert d.max() <= 0.0 and d.min() == pytest.approx(-1332.5787, abs=1e-3)
+    assert np.all(d[0] == 0) and np.all(l[0] == 0)        # Mach-0 column all zero
+    assert np.all(l[:, 0] == 0) and np.all(l[:, -1] == 0)  # no lift at cos(AoA) = +-1
+
+
+def test_spline_interpolates_every_grid_node(aero):
+    p, par, d, l = aero
+    a = p.aero
+    rng = np.random.default_rng(0)
+    idx = [(j, i) for j in range(61) for i in range(181)]
+    for j, i in [idx[k] for k in rng.choice(len(idx), 600, replace=False)] + [(0, 0), (60, 180), (0, 180), (60, 0)]:
+        v = od.table_eval(par, 0, a.aoa0 + i * a.daoa, a.mach0 + j * a.dmach)[0]
+        assert v == pytest.approx(d[j, i], abs=1e-9 * max(1.0, abs(d[j, i])))
+        v = od.table_eval(par, 1, a.aoa0 + i * a.daoa, a.mach0 + j * a.dmach)[0]
+        assert v == pytest.approx(l[j, i], abs=1e-9 * max(1.0, abs(l[j, i])))
+
+
+def test_prefilter_is_a_natural_spline():
+    M = od.prefilter_1d(9)
+    f = np.random.default_rng(1).normal(size=9)
+    c = np.linalg.solve(M, np.concatenate([[0], f, [0]]))
+    assert np.allclose((c[:-2] + 4 * c[1:-1] + c[2:]) / 6, f)
+    assert abs(c[0] - 2 * c[1] + c[2]) < 1e-12 and abs(c[-3] - 2 * c[-2] + c[-1]) < 1e-12  # Line(OnGrid())
+
+
+def test_gradient_continuity_and_flat_extrapolation(aero):
+    p, par, d, l = aero
+    a = p.aero
+    aoa, mach = 0.3123, 0.6350
+    v = od.table_eval(par, 0, aoa, mach)
+    h = 1e-6
+    ga = (od.table_eval(par, 0, aoa + h, mach)[0] - od.table_eval(par, 0, aoa - h, mach)[0]) / (2 * h)
+    gm = (od.table_eval(par, 0, aoa, mach + h)[0] - od.table_eval(par, 0, aoa, mach - h)[0]) / (2 * h)
+    assert v[1] == pytest.approx(ga, rel=1e-6, abs=1e-6) and v[2] == pytest.approx(gm, rel=1e-6, abs=1e-6)
+    # C1 across a knot
+    knot = a.aoa0 + 100 * a.daoa
+    assert od.table_eval(par, 1, knot - 1e-9, mach)[1] == pytest.approx(od.table_eval(par, 1, knot + 1e-9, mach)[1], abs=1e-4)
+    # Flat(): value frozen, gradient zero beyond the Mach range
+    inside = od.table_eval(par, 0, aoa, 1.5)
+    out = od.table_eval(par, 0, aoa, 2.5)
+    assert out[0] == pytest.approx(inside[0]) and out[2] == 0.0
+
+
+def test_force_model_and_its_jacobian(aero):
+    p, par, d, l = aero
+    rng = np.random.default_rng(4)
+    for _ in range(4):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        v = rng.uniform(-0.25, 0.25, 3)
+        F, dF = od.aero_force(par, q, v)
+        assert np.isfinite(F).all() and np.linalg.norm(F) > 0
+        h = 1e-7
+        for j in range(7):
+            e = np.zeros(7)
+            e[j] = h
+            Fp, _ = od.aero_force(par, q + e[:4], v + e[4:])
+            Fm, _ = od.aero_force(par, q - e[:4], v - e[4:])
+            assert np.abs((Fp - Fm) / (2 * h) - dF[:, j]).max() < 1e-6 * max(1.0, np.abs(dF).max())
+    # guards (dynamics.jl:162-168, 198-204): zero velocity -> zero force; body axis along the velocity -> pure drag
+    F, dF = od.aero_force(par, [1, 0, 0, 0], [0, 0, 0])
+    assert np.all(F == 0) and np.all(dF == 0)
+    F, _ = od.aero_force(par, [1, 0, 0, 0], [-0.2, 0, 0])
+    assert F[1] == 0 and F[2] == 0 and F[0] > 0  # drag opposes the velocity (table drag <= 0)
+    # exo problem: no force at all
+    Fe, _ = od.aero_force(od.Params(model.base_prob_scaled()), [1, 0, 0, 0], [-0.2, 0.1, 0])
+    assert np.all(Fe == 0)

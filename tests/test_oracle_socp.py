@@ -1,0 +1,111 @@
+"""The SOCP oracle: build_model sizes, the interior-point solver on known answers, KKT certificates, and
+the three solver implementations against each other.  CPU."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import ipm, ipm_struct, model, port, scvx, socp
+
+
+def test_sizes_match_build_model():
+    # K=30: 1,614 / 1,062 / 124 / 124 (1,389); K=50: 2,654 / 1,742 / 204 / 204 (2,289)
+    for K, n, neq, nlin, ncone, cdim in [(30, 1614, 1062, 124, 124, 1389), (50, 2654, 1742, 204, 204, 2289)]:
+        from dataclasses import replace
+        p = replace(model.base_prob_scaled(), K=K)
+        it = scvx.create_initial(p, 2)
+        c, A, b, G, h, l, q, ix = socp.build(p, it.x, it.u, it.endpoint, it.deriv, it.rk)
+        assert (ix.n, A.shape[0], l, len(q), sum(q)) == (n, neq, nlin, ncone, cdim)
+        assert G.shape == (l + sum(q), n)
+
+
+def test_ipm_known_answers():
+    # min x1 + x2  s.t. ||(x1, x2)|| <= 1  ->  -sqrt(2) at (-1,-1)/sqrt(2)
+    G = sp.csc_matrix(np.array([[0, 0], [-1.0, 0], [0, -1.0]]))
+    s = ipm.solve(np.array([1.0, 1.0]), sp.csc_matrix((0, 2)), np.zeros(0), G, np.array([1.0, 0, 0]), 0, [3])
+    assert s.status == "optimal" and s.pobj == pytest.approx(-np.sqrt(2), abs=1e-8)
+    assert np.allclose(s.x, -np.ones(2) / np.sqrt(2), atol=1e-7)
+    # LP with an equality: min -x1 - 2 x2, x1 + x2 = 1, x >= 0 -> x = (0, 1)
+    s = ipm.solve(np.array([-1.0, -2.0]), sp.csc_matrix(np.array([[1.0, 1.0]])), np.array([1.0]),
+                  sp.csc_matrix(-np.eye(2)), np.zeros(2), 2, [])
+    assert s.status == "optimal" and np.allclose(s.x, [0, 1], atol=1e-7)
+    # epigraph of a norm with a linear inequality: min t s.t. ||x - a|| <= t, x1 <= 0, a = (1, 2) -> t = 1
+    c = np.array([1.0, 0, 0])
+    G = sp.csc_matrix(np.array([[0, 1.0, 0], [-1.0, 0, 0], [0, -1.0, 0], [0, 0, -1.0]]))
+    h = np.array([0.0, 0.0, -1.0, -2.0])
+    s = ipm.solve(c, sp.csc_matrix((0, 3)), np.zeros(0), G, h, 1, [3])
+    assert s.status == "optimal" and s.pobj == pytest.approx(1.0, abs=1e-7)
+
+
+@pytest.fixture(scope="module")
+def first_subproblem():
+    p = model.base_prob_scaled()
+    it = scvx.create_initial(p, 10)
+    sol, ix = scvx.solve_socp(it)
+    return p, it, sol, ix
+
+
+def test_kkt_certificate_on_the_real_subproblem(first_subproblem):
+    p, it, sol, ix = first_subproblem
+    assert sol.status == "optimal"
+    c, A, b, G, h, l, q, _ = socp.build(p, it.x, it.u, it.endpoint, it.deriv, it.rk)
+    x, y, z, s = sol.x, sol.y, sol.z, sol.s
+    assert np.abs(A @ x - b).max() < 1e-8 and np.abs(G @ x + s - h).max() < 1e-8
+    assert np.abs(A.T @ y + G.T @ z + c).max() < 1e-6
+    assert s @ z < 1e-6 * max(1.0, abs(sol.pobj))
+    cone = ipm.Cone(l, q)
+    assert cone.interior_shift(s) < 1e-9 and cone.interior_shift(z) < 1e-9  # both in the cone
+    # the model's helper variables equal what the reduced form substitutes for them
+    zz = sol.x
+    assert np.allclose(zz[ix.gshelp], zz[ix.xv[1, :p.K]] / np.tan(np.radians(p.gammaGs)), atol=1e-8)
+    assert np.allclose(zz[ix.xv], it.x.T + zz[ix.dxv], atol=1e-8)
+
+
+def test_three_solvers_agree(first_subproblem):
+    p, it, sol, ix = first_subproblem
+    z = sol.x
+    V = ipm_struct.solve(p, it.x, it.u, it.endpoint, it.deriv, it.rk, tol=1e-9)
+    tw = port.socp(p, it.x[None], it.u[None], it.endpoint[None], it.deriv[None], it.rk, tol=1e-8)
+    assert V["status"] == "optimal" and tw["status"][0] == 0
+    # objectives: the reduced form drops the constant -xbar[K][0]
+    const = -it.x[p.K, 0]
+    assert V["pobj"] + const == pytest.approx(sol.pobj, rel=1e-7)
+    assert tw["pobj"][0] + const == pytest.approx(sol.pobj, rel=1e-6)
+    for dx, du, ds, nu in ((V["dx"], V["du"], V["s"], V["nu"]), (tw["dx"][0], tw["du"][0], tw["ds"][0], tw["nu"][0])):
+        assert np.abs(dx - z[ix.dxv].T).max() < 1e-4
+        assert np.abs(du - z[ix.duv].T).max() < 1e-4
+        assert abs(ds - z[ix.dsig]) < 1e-4
+        assert np.abs(nu - z[ix.nuv].T[1:]).max() < 1e-4
+
+
+def test_cpu_twin_on_a_dispersed_batch_is_feasible():
+    from oracle import dynamics as od
+    p = model.base_prob_scaled()
+    B = 6
+    ic = model.disperse_ics(p, B, 20261004)
+    x = np.zeros((B, p.K + 1, 14))
+    u = np.zeros((B, p.K + 1, 3))
+    for b in range(B):
+        x[b], u[b] = model.linear_points(p, ic[b, :3], ic[b, 3:])
+    e, d = od.linearize(od.Params(p), x, u, np.full(B, p.tf_guess), 1 / (p.K + 1), 4)
+    r = port.socp(p, x, u, e, d, 100.0, ic)
+    assert np.all(r["status"] == 0) and np.all(r["merit"] < 1e-6)
+    K = p.K
+    dx, du = r["dx"], r["du"]
+    delta = np.concatenate([dx[:, :-1], du[:, :-1], du[:, 1:], np.broadcast_to(r["ds"][:, None, None], (B, K, 1))], axis=-1)
+    lhs = np.einsum("bkji,bkj->bki", d, delta) + r["nu"] - dx[:, 1:] + (e - x[:, 1:])
+    assert np.abs(lhs).max() < 1e-9
+    assert np.abs((x + dx)[:, 0, 1:4] - ic[:, :3]).max() < 1e-12
+    un = np.linalg.norm(u + du, axis=-1)
+    assert (p.Tmax - un).min() > -1e-6
+
+
+def test_scvx_loop_reproduces_reference_logic():
+    """solve_step bookkeeping of rocketland.jl:292-320 on two iterations (first call grows the radius)."""
+    p = model.base_prob_scaled()
+    it = scvx.create_initial(p, 4)
+    assert it.rk == 100.0 and np.isinf(it.cost) and it.iter == 0
+    it1, cnu, cdel = scvx.solve_step(it)
+    assert it1.iter == 1 and it1.rk == pytest.approx(p.bet * 100.0) and np.isinf(cdel)
+    assert it1.sigma == pytest.approx(it.sigma + it1.last["dsr"])
+    assert cnu == pytest.approx(np.linalg.norm(it1.last["nur"]))
+    assert it1.cost == pytest.approx(it1.last["jK"])
