@@ -64,7 +64,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(npts, seed, budget_traj_per_core=16):
+def cpu_baseline(npts, seed, budget_traj_per_core=256):
     """The CPU twin (oracle/scvx_port.cpp + oracle/scvx_oracle.c, OpenMP over trajectories) running the
     same first solve_step on a bounded sample of the same workload, on this box's host cores."""
     from oracle import dynamics as od
