@@ -6,6 +6,7 @@
 // "C++ fp64 restatement of the same algorithm" BASELINE.md §4 asks to be timed on the host cores, and
 // the debug twin of the device kernel.  The independent check of the optimum is oracle/ipm.py.
 // The product never loads this library.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,6 +24,34 @@ struct HostEx {
     double min(double x) { return x; }
     bool all(bool b) { return b; }
     double* scratch() { return sc; }
+    // in-place Cholesky of a 14x14 SPD tile (row-major, lower triangle on output)
+    bool chol14(double* M) {
+        bool ok = true;
+        for (int j = 0; j < 14; j++) {
+            const double piv = M[15 * j];
+            if (!(piv > 0.0)) ok = false;
+            const double ip = 1.0 / std::sqrt(piv > 0.0 ? piv : 1.0);
+            for (int i = j; i < 14; i++) M[14 * i + j] *= ip;
+            for (int a = j + 1; a < 14; a++)
+                for (int b = j + 1; b <= a; b++) M[14 * a + b] -= M[14 * a + j] * M[14 * b + j];
+        }
+        return ok;
+    }
+    // out_k = z_k - N_k out_{k-1} (forward) or out_k = z_k - N_k out_{k+1} (reverse); 14-vectors, N row-major
+    void chain(int K, const double* z, const double* N, double* out, bool reverse) {
+        for (int step = 0; step < K; step++) {
+            const int k = reverse ? K - 1 - step : step;
+            const int prev = reverse ? k + 1 : k - 1;
+            for (int i = 0; i < 14; i++) {
+                double a = z[14 * k + i];
+                if (step > 0) {
+                    const double* row = N + (size_t)k * 196 + 14 * i;
+                    for (int j = 0; j < 14; j++) a -= row[j] * out[14 * prev + j];
+                }
+                out[14 * k + i] = a;
+            }
+        }
+    }
 };
 }  // namespace
 

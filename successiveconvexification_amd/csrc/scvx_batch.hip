@@ -43,6 +43,98 @@ struct WaveEx {
     }
     __device__ __forceinline__ bool all(bool b) { return __all(b) != 0; }
     __device__ __forceinline__ double* scratch() { return sc; }
+
+    // value of x in lane `src` (src wave-uniform) delivered to every lane: two v_readlane_b32, no LDS
+    static __device__ __forceinline__ double bcast(double x, int src) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+        return __hiloint2double(hi, lo);
+    }
+
+    // In-place Cholesky of the 14x14 SPD tile M (row-major, lower triangle on output): lane i keeps row i
+    // in VGPRs, pivots and column entries travel by readlane — 105 broadcasts, no barrier inside.
+    __device__ __forceinline__ bool chol14(double* M) {
+        const int i = lane();
+        const int r = i < 14 ? i : 13;
+        double m[14];
+#pragma unroll
+        for (int c = 0; c < 14; c++) m[c] = M[14 * r + c];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 14; j++) {
+            const double d = bcast(m[j], j);
+            ok = ok && (d > 0.0);
+            const double ip = 1.0 / sqrt(d > 0.0 ? d : 1.0);
+            if (i >= j) m[j] *= ip;
+#pragma unroll
+            for (int c = j + 1; c < 14; c++) {
+                const double lcj = bcast(m[j], c);
+                if (i >= c) m[c] = fma(-m[j], lcj, m[c]);
+            }
+        }
+        if (i < 14) {
+#pragma unroll
+            for (int c = 0; c < 14; c++) M[14 * i + c] = m[c];
+        }
+        return ok;
+    }
+
+    // out_k = z_k - N_k out_{k-1} (forward) / out_k = z_k - N_k out_{k+1} (reverse): the only sequential part
+    // of the block-tridiagonal solve.  The 196-double tile N_k is fetched COOPERATIVELY by all 64 lanes
+    // (coalesced, 3-4 doubles per lane) four steps ahead of its use, so four HBM/L2 round trips are always
+    // in flight; it is dropped into a two-slot LDS ring from which lane i reads its row (bank-conflict free:
+    // row stride 112 B) and the previous 14-vector is broadcast by readlane.  No barrier in the chain.
+    __device__ __forceinline__ void chain(int K, const double* __restrict__ z, const double* __restrict__ N,
+                                          double* __restrict__ out, bool reverse) {
+        constexpr int R = 4;  // tiles in flight
+        const int l = lane();
+        const bool live = l < 14;
+        const int i = live ? l : 13;
+        double* ring = sc + 32;  // 2 x 196 doubles (the factorisation tiles are idle during a solve)
+        const int k0 = reverse ? K - 1 : 0;
+        const int dk = reverse ? -1 : 1;
+        double t = z[14 * k0 + i];
+        if (live) out[14 * k0 + i] = t;
+        const int nsteps = K - 1;
+        double st[R][4];
+        double zs[R];
+        auto issue = [&](int step, double (&r)[4], double& zz) {
+            const int k = k0 + dk * (step + 1);
+            const double* base = N + (size_t)k * 196;
+            r[0] = base[l]; r[1] = base[l + 64]; r[2] = base[l + 128];
+            r[3] = (l < 4) ? base[l + 192] : 0.0;
+            zz = z[14 * k + i];
+        };
+#pragma unroll
+        for (int q = 0; q < R; q++)
+            if (q < nsteps) issue(q, st[q], zs[q]);
+        for (int s0 = 0; s0 < nsteps; s0 += R) {
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int step = s0 + q;
+                if (step < nsteps) {
+                    double* slot = ring + 196 * (q & 1);
+                    slot[l] = st[q][0]; slot[l + 64] = st[q][1]; slot[l + 128] = st[q][2];
+                    if (l < 4) slot[l + 192] = st[q][3];
+                    const double zc = zs[q];
+                    if (step + R < nsteps) issue(step + R, st[q], zs[q]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const double* row = slot + 14 * i;
+                    double a0 = zc, a1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 14; j += 2) {
+                        a0 = fma(-row[j], bcast(t, j), a0);
+                        a1 = fma(-row[j + 1], bcast(t, j + 1), a1);
+                    }
+                    t = a0 + a1;
+                    const int k = k0 + dk * (step + 1);
+                    if (live) out[14 * k + i] = t;
+                }
+            }
+        }
+    }
 };
 
 // info[b] = {status, iters, merit, pobj}
@@ -74,6 +166,9 @@ __global__ __launch_bounds__(64) void socp_kernel(ipm::Consts C, int B, size_t w
         info[4 * b + 1] = (double)r.iters;
         info[4 * b + 2] = r.merit;
         info[4 * b + 3] = r.pobj;
+#if defined(SCVX_IPM_PROF)
+        if (b == 0) for (int i = 0; i < 16; i++) work[i] = S.prof[i];  // diagnostic build: section cycles of trajectory 0
+#endif
     }
 }
 
@@ -551,6 +646,13 @@ int scvx_batch_get_solver_stats(scvx_batch* b, int32_t* status, int32_t* iters, 
     }
     return SCVX_OK;
 }
+
+#if defined(SCVX_IPM_PROF)
+int scvx_debug_ipm_prof(scvx_batch* b, double* out16) {
+    hipStreamSynchronize(b->ctx->stream);
+    return hipMemcpy(out16, b->work, 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int scvx_batch_set_profiling(scvx_batch* b, int enable) {
     if (!b) return SCVX_ERR_ARG;

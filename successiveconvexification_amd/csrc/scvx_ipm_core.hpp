@@ -18,9 +18,21 @@
 
 #if defined(__HIPCC__)
 #define SCVX_HD __host__ __device__ __forceinline__
+#define SCVX_HD_NI __host__ __device__ __attribute__((noinline))
 #else
 #define SCVX_HD inline
+#define SCVX_HD_NI inline
 #endif
+// optional in-kernel section timers (diagnostic builds only: -DSCVX_IPM_PROF)
+#if defined(SCVX_IPM_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define SCVX_TS(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define SCVX_TE(v, slot) prof[slot] += (double)(__builtin_amdgcn_s_memtime() - v)
+#else
+#define SCVX_TS(v)
+#define SCVX_TE(v, slot)
+#endif
+#define SCVX_T0() SCVX_TS(t0_)
+#define SCVX_T1(slot) SCVX_TE(t0_, slot)
 #if defined(SCVX_IPM_DEBUG) && !defined(__HIPCC__)
 #include <stdio.h>
 #define SCVX_DBG(...) fprintf(stderr, __VA_ARGS__)
@@ -77,7 +89,8 @@ struct Layout {
         n += (size_t)nc * 12;            // S, Z, rz, lam, Wv, t, Wibz, dS, dZ, sds, sdz, tmpc
         n += (size_t)ncones;             // Wbeta
         n += (size_t)(K + 1) * 25 + (size_t)(K + 1) * 9;  // hx, hu
-        n += (size_t)K * 196 * 3;        // Sd->Linv, So->Wb, (spare)
+        n += (size_t)K * 196 * 4;        // Sd, Linv, Nf, Nb (So staged in Nb)
+        n += (size_t)ny;                 // tchain
         n += (size_t)(nloc + ny) * 3;    // ls,ys, ltr,ytr, lnu,ynu
         n += (size_t)nloc * 2;           // tmpl, tmpl2
         n += (size_t)3 * (K + 1);        // uhat
@@ -239,15 +252,16 @@ struct Solver {
     double *S, *Z, *rz, *lam, *Wv, *tt, *Wibz, *dS, *dZ, *sds, *sdz, *tmpc;
     double* Wbeta;
     double *hx, *hu;
-    double *Linv, *Wb, *Sd;
+    double *Linv, *Nf, *Nb, *Sd, *tchain;
     double *ls, *ys, *ltr, *ytr, *lnu, *ynu;
     double *tmpl, *tmpl2;
     double *uhat, *lb0;
     // per-factorisation scalars
     double h_tr[4], h_nu[4], Msg[4], hrk, hnui;
     double css, cst, csn, cts, ctt, ctn, cns, cnt_, cnn;
+    double prof[16];
 
-    SCVX_HD Solver(Ex& e, const Consts& c) : ex(e), C(c) { L.init(c.K); }
+    SCVX_HD Solver(Ex& e, const Consts& c) : ex(e), C(c) { L.init(c.K); for (int i = 0; i < 16; i++) prof[i] = 0.0; }
 
     SCVX_HD void carve(double* w) {
         const int nv = L.nv, ny = L.ny, nc = L.nc, nloc = L.nloc, K = L.K;
@@ -259,7 +273,8 @@ struct Solver {
         Wibz = w; w += nc; dS = w; w += nc; dZ = w; w += nc; sds = w; w += nc; sdz = w; w += nc; tmpc = w; w += nc;
         Wbeta = w; w += L.ncones;
         hx = w; w += (size_t)(K + 1) * HX_SZ; hu = w; w += (size_t)(K + 1) * 9;
-        Linv = w; w += (size_t)K * 196; Wb = w; w += (size_t)K * 196; Sd = w; w += (size_t)K * 196;
+        Linv = w; w += (size_t)K * 196; Nf = w; w += (size_t)K * 196; Nb = w; w += (size_t)K * 196; Sd = w; w += (size_t)K * 196;
+        tchain = w; w += ny;
         ls = w; w += nloc; ys = w; w += ny; ltr = w; w += nloc; ytr = w; w += ny; lnu = w; w += nloc; ynu = w; w += ny;
         tmpl = w; w += nloc; tmpl2 = w; w += nloc;
         uhat = w; w += 3 * (K + 1); lb0 = w; w += (K + 1);
@@ -293,7 +308,8 @@ struct Solver {
 
     // ---- E (linearised dynamics rows, rocketland.jl:117-133) ----
     // out[k][i] = sum_j D_k[i][j] [dx_k; du_k; du_{k+1}; s]_j + nu_k[i] - dx_{k+1}[i]   (with_s: include the s column)
-    SCVX_HD void E_apply(const double* v, double* out, bool with_s) {
+    SCVX_HD_NI void E_apply(const double* v, double* out, bool with_s) {
+        SCVX_T0();
         const int K = L.K;
         const double s = with_s ? v[L.iS] : 0.0;
         for (int r = ex.lane(); r < 14 * K; r += ex.nlanes()) {
@@ -309,9 +325,10 @@ struct Solver {
             out[r] = a;
         }
         ex.sync();
+        SCVX_T1(1);
     }
     // g = E_loc' y on the local part (dx, du, nu); returns Sg . y (the s entry) to every lane
-    SCVX_HD double Et_apply(const double* yy, double* g) {
+    SCVX_HD_NI double Et_apply(const double* yy, double* g) {
         const int K = L.K;
         for (int t = ex.lane(); t < L.nx; t += ex.nlanes()) {
             const int k = t / 14, j = t - 14 * k;
@@ -351,7 +368,7 @@ struct Solver {
 
     // ---- cone maps: a(w), J dw, J' z ----
     // out = a(v) if affine else J v
-    SCVX_HD void cone_map(const double* v, double* out, bool affine) {
+    SCVX_HD_NI void cone_map(const double* v, double* out, bool affine) {
         const int K = L.K;
         const double af = affine ? 1.0 : 0.0;
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
@@ -387,7 +404,7 @@ struct Solver {
         ex.sync();
     }
     // g = J' z (var-shaped, all nv entries written)
-    SCVX_HD void cone_map_t(const double* z, double* g) {
+    SCVX_HD_NI void cone_map_t(const double* z, double* g) {
         const int K = L.K;
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
             double* gx_ = g + 14 * k;
@@ -489,7 +506,8 @@ struct Solver {
     }
 
     // ---- NT scalings for every cone, lam = W z ----
-    SCVX_HD void nt_all() {
+    SCVX_HD_NI void nt_all() {
+        SCVX_T0();
         for (int c = ex.lane(); c < L.nsmall; c += ex.nlanes()) {
             int off, d; L.small(c, off, d);
             if (d == 1) {
@@ -520,6 +538,7 @@ struct Solver {
             lam[L.o_rk] = sqrt(S[L.o_rk] * Z[L.o_rk]);
         }
         ex.sync();
+        SCVX_T1(11);
     }
     SCVX_HD void identity_scaling() {
         for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) Wv[i] = 0.0;
@@ -535,7 +554,8 @@ struct Solver {
         ex.sync();
     }
     // out = W in  /  W^-1 in   (cone vectors; in may alias out)
-    SCVX_HD void W_all(const double* in, double* out, bool inverse) {
+    SCVX_HD_NI void W_all(const double* in, double* out, bool inverse) {
+        SCVX_T0();
         for (int c = ex.lane(); c < L.nsmall; c += ex.nlanes()) {
             int off, d; L.small(c, off, d);
             if (d == 1) out[off] = inverse ? in[off] / Wbeta[c] : in[off] * Wbeta[c];
@@ -553,9 +573,10 @@ struct Solver {
             out[L.o_rk] = inverse ? in[L.o_rk] / Wbeta[L.c_rk] : in[L.o_rk] * Wbeta[L.c_rk];
         }
         ex.sync();
+        SCVX_T1(8);
     }
     // out = lam \ d
-    SCVX_HD void div_all(const double* d, double* out) {
+    SCVX_HD_NI void div_all(const double* d, double* out) {
         for (int c = ex.lane(); c < L.nsmall + 1; c += ex.nlanes()) {
             int off, dm;
             if (c < L.nsmall) L.small(c, off, dm); else { off = L.o_sg; dm = 2; }
@@ -576,7 +597,7 @@ struct Solver {
     }
     // out = base_sign * (lam o lam)  [mode 0: out = -lam o lam]
     //       mode 1: out = -lam o lam - sds o sdz + sigmu * e
-    SCVX_HD void centering_rhs(double* out, bool combined, double sigmu) {
+    SCVX_HD_NI void centering_rhs(double* out, bool combined, double sigmu) {
         for (int c = ex.lane(); c < L.nsmall + 1; c += ex.nlanes()) {
             int off, dm;
             if (c < L.nsmall) L.small(c, off, dm); else { off = L.o_sg; dm = 2; }
@@ -611,7 +632,7 @@ struct Solver {
         }
         ex.sync();
     }
-    SCVX_HD double maxstep_all(const double* d) {
+    SCVX_HD_NI double maxstep_all(const double* d) {
         double amax = INFINITY;
         for (int c = ex.lane(); c < L.nsmall + 1; c += ex.nlanes()) {
             int off, dm;
@@ -636,7 +657,8 @@ struct Solver {
     }
 
     // ---- Hb^-1 on a local vector (dx, du, nu); in may alias out ----
-    SCVX_HD void Hb_inv(const double* g, double* out) {
+    SCVX_HD_NI void Hb_inv(const double* g, double* out) {
+        SCVX_T0();
         const int K = L.K;
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
             double xin[14], yo[14];
@@ -649,55 +671,44 @@ struct Solver {
         }
         for (int i = ex.lane(); i < 14 * K; i += ex.nlanes()) out[L.nx + L.nu_ + i] = hnui * g[L.nx + L.nu_ + i];
         ex.sync();
+        SCVX_T1(3);
     }
 
-    // ---- block-tridiagonal solve S x = r  (r, x: [K][14]; x may alias r) using Linv, Wb ----
-    SCVX_HD void S_solve(const double* r, double* x) {
+    // ---- block-tridiagonal solve S x = r (r, x: [K][14], distinct buffers) ----
+    // With L the block Cholesky factor:  forward  t_k = Linv_k r_k - Nf_k t_{k-1},   Nf_k = Linv_k Wb_{k-1}
+    //                                    backward x_k = Linv_k' t_k - Nb_k x_{k+1},  Nb_k = Linv_k' Wb_k'
+    // The Linv products are chain-free (all k in parallel); only the 14x14 matrix-vector recurrences are
+    // sequential and run inside the executor (ex.chain: wave-synchronous on the device, no barriers).
+    SCVX_HD_NI void S_solve(const double* r, double* x) {
+        SCVX_T0();
         const int K = L.K;
-        double* sc = ex.scratch();  // [0..13] t_prev / x_next, [16..29] rr
-        for (int k = 0; k < K; k++) {
-            for (int i = ex.lane(); i < 14; i += ex.nlanes()) {
-                double a = r[14 * k + i];
-                if (k > 0) {
-                    const double* W = Wb + (size_t)(k - 1) * 196 + 14 * i;  // row i of Wb[k-1] (row-major)
-                    for (int j = 0; j < 14; j++) a -= W[j] * sc[j];
-                }
-                sc[16 + i] = a;
-            }
-            ex.sync();
-            for (int i = ex.lane(); i < 14; i += ex.nlanes()) {
-                const double* Li = Linv + (size_t)k * 196 + 14 * i;  // row i of Linv[k] (lower triangular)
-                double a = 0;
-                for (int j = 0; j <= i; j++) a += Li[j] * sc[16 + j];
-                sc[i] = a;
-                x[14 * k + i] = a;  // t[k]
-            }
-            ex.sync();
+        for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
+            const int k = t / 14, i = t - 14 * k;
+            const double* Li = Linv + (size_t)k * 196 + 14 * i;
+            const double* rk_ = r + 14 * k;
+            double a = 0;
+            for (int j = 0; j <= i; j++) a += Li[j] * rk_[j];
+            tchain[t] = a;
         }
-        // backward: x[k] = Linv[k]' (t[k] - Wb[k]' x[k+1])
-        for (int k = K - 1; k >= 0; k--) {
-            for (int i = ex.lane(); i < 14; i += ex.nlanes()) {
-                double a = x[14 * k + i];
-                if (k + 1 < K) {
-                    const double* W = Wb + (size_t)k * 196;  // Wb[k][j][i], column i
-                    for (int j = 0; j < 14; j++) a -= W[14 * j + i] * sc[j];
-                }
-                sc[16 + i] = a;
-            }
-            ex.sync();
-            for (int i = ex.lane(); i < 14; i += ex.nlanes()) {
-                const double* Lk = Linv + (size_t)k * 196;
-                double a = 0;
-                for (int j = i; j < 14; j++) a += Lk[14 * j + i] * sc[16 + j];
-                sc[i] = a;
-                x[14 * k + i] = a;
-            }
-            ex.sync();
+        ex.sync();
+        ex.chain(K, tchain, Nf, x, false);
+        ex.sync();
+        for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
+            const int k = t / 14, i = t - 14 * k;
+            const double* Lk = Linv + (size_t)k * 196;
+            const double* tk = x + 14 * k;
+            double a = 0;
+            for (int j = i; j < 14; j++) a += Lk[14 * j + i] * tk[j];
+            tchain[t] = a;
         }
+        ex.sync();
+        ex.chain(K, tchain, Nb, x, true);
+        ex.sync();
+        SCVX_T1(0);
     }
 
     // [Hb E'; E 0][dl; dyv] = [gl; ryv]   (gl: local part of a var vector; outputs may not alias inputs)
-    SCVX_HD void band_solve(const double* gl, const double* ryv, double* dl, double* dyv) {
+    SCVX_HD_NI void band_solve(const double* gl, const double* ryv, double* dl, double* dyv) {
         Hb_inv(gl, tmpl);
         E_apply(tmpl, tmpy, false);
         ex.sync();
@@ -712,7 +723,7 @@ struct Solver {
     }
 
     // ---- factorisation for the current scaling (Wv, Wbeta) ----
-    SCVX_HD bool build_kkt() {
+    SCVX_HD_NI bool build_kkt() {
         const int K = L.K;
         // big-cone scalars
         {
@@ -731,6 +742,7 @@ struct Solver {
             hrk = 1.0 / (Wbeta[L.c_rk] * Wbeta[L.c_rk]);
         }
         // node blocks -> compact inverses
+        SCVX_T0();
         const double dtr = h_tr[3];
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
             double* h = hx + (size_t)k * HX_SZ;
@@ -803,7 +815,9 @@ struct Solver {
             }
         }
         ex.sync();
-        // S blocks: Sd[k] (row-major 14x14), So[k] = block (k+1,k) -> stored in Wb[k] temporarily
+        SCVX_T1(4);
+        SCVX_TS(tS_);
+        // S blocks: Sd[k] (row-major 14x14), So[k] = block (k+1,k) -> staged in Nb[k]
         for (int e = ex.lane(); e < K * 196; e += ex.nlanes()) {
             const int k = e / 196, r = e - 196 * k, i = r / 14, j = r - 14 * i;
             const double* Dk = D + (size_t)k * 294;
@@ -820,15 +834,17 @@ struct Solver {
                 double t = 0;
                 for (int a = 0; a < 14; a++) { const double he = hxi_entry(hn, a, j); if (he != 0.0) t += Dn[14 * a + i] * he; }
                 double so = -t + hui_quad(hu + 9 * (k + 1), Dn + 14 * 14, i, Dk + 14 * 17, j);
-                Wb[e] = so;
+                Nb[e] = so;
             }
         }
         ex.sync();
-        // block Cholesky, sequential in k; tiles in scratch
+        SCVX_TE(tS_, 5);
+        SCVX_TS(tC_);
+        // block Cholesky, sequential in k; tiles in scratch (LDS on the device)
         double* sc = ex.scratch();
-        double* M = sc + 32;        // 196
-        double* Wp = sc + 32 + 196;  // previous Wb tile (196)
-        double* Li = sc + 32 + 392;  // Linv tile (196)
+        double* M = sc + 32;         // 196: pivot tile -> L (lower)
+        double* Wp = sc + 32 + 196;  // 196: Wb[k-1]
+        double* Li = sc + 32 + 392;  // 196: Linv[k]
         bool ok = true;
         for (int k = 0; k < K; k++) {
             for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
@@ -838,21 +854,8 @@ struct Solver {
                 M[e] = s;
             }
             ex.sync();
-            // right-looking Cholesky in place (lower triangle)
-            for (int j = 0; j < 14; j++) {
-                const double piv = M[15 * j];
-                if (!(piv > 0.0)) ok = false;
-                const double ip = 1.0 / sqrt(piv > 0.0 ? piv : 1.0);
-                ex.sync();
-                for (int i = j + ex.lane(); i < 14; i += ex.nlanes()) M[14 * i + j] *= ip;
-                ex.sync();
-                const int n = 13 - j;
-                for (int e = ex.lane(); e < n * n; e += ex.nlanes()) {
-                    const int a = j + 1 + e / n, b = j + 1 + (e - (e / n) * n);
-                    if (b <= a) M[14 * a + b] -= M[14 * a + j] * M[14 * b + j];
-                }
-                ex.sync();
-            }
+            ok = ex.chol14(M) && ok;   // in place, lower triangle; wave-synchronous on the device
+            ex.sync();
             // Linv: column c solved by lane c
             for (int c = ex.lane(); c < 14; c += ex.nlanes()) {
                 for (int i = 0; i < 14; i++) {
@@ -863,21 +866,40 @@ struct Solver {
                 }
             }
             ex.sync();
-            for (int e = ex.lane(); e < 196; e += ex.nlanes()) Linv[(size_t)k * 196 + e] = Li[e];
+            for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
+                const int i = e / 14, j = e - 14 * i;
+                Linv[(size_t)k * 196 + e] = Li[e];
+                if (k > 0) {  // Nf[k] = Linv_k Wb_{k-1}
+                    double s = 0;
+                    for (int c = 0; c <= i; c++) s += Li[14 * i + c] * Wp[14 * c + j];
+                    Nf[(size_t)k * 196 + e] = s;
+                }
+            }
+            ex.sync();
             if (k + 1 < K) {
-                // Wb[k] = So[k] Linv'
+                // Wb[k] = So[k] Linv'   (So staged in Nb[k])
                 for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
                     const int i = e / 14, j = e - 14 * i;
-                    const double* So = Wb + (size_t)k * 196 + 14 * i;
+                    const double* So = Nb + (size_t)k * 196 + 14 * i;
                     double s = 0;
                     for (int c = 0; c <= j; c++) s += So[c] * Li[14 * j + c];
                     M[e] = s;  // M is free now
                 }
                 ex.sync();
-                for (int e = ex.lane(); e < 196; e += ex.nlanes()) { Wp[e] = M[e]; Wb[(size_t)k * 196 + e] = M[e]; }
+                for (int e = ex.lane(); e < 196; e += ex.nlanes()) Wp[e] = M[e];
+                ex.sync();
+                // Nb[k] = (Wb_k Linv_k)' : Nb[k][j][i] = sum_{c>=j} Wb[i][c] Linv[c][j]
+                for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
+                    const int j = e / 14, i = e - 14 * j;
+                    double s = 0;
+                    for (int c = j; c < 14; c++) s += Wp[14 * i + c] * Li[14 * c + j];
+                    Nb[(size_t)k * 196 + e] = s;
+                }
             }
             ex.sync();
         }
+        SCVX_TE(tC_, 6);
+        SCVX_TS(tB_);
         // border solves
         zero(tmpv, L.nloc);
         ex.sync();
@@ -907,11 +929,12 @@ struct Solver {
             const double* Pnu = Wv + L.o_nu + 1; const int o = L.nx + L.nu_;
             cns = dot(Pnu, ls + o, L.ny); cnt_ = -dot(Pnu, ltr + o, L.ny); cnn = -dot(Pnu, lnu + o, L.ny);
         }
+        SCVX_TE(tB_, 7);
         return ex.all(ok);
     }
 
     // full reduced KKT: [H E'; E 0][dwv; dyv] = [g; ryv]  (g var-shaped incl. 4 globals)
-    SCVX_HD void kkt_solve(const double* g, const double* ryv, double* dwv, double* dyv) {
+    SCVX_HD_NI void kkt_solve(const double* g, const double* ryv, double* dwv, double* dyv) {
         band_solve(g, ryv, dwv, dyv);
         double a = 0;
         for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) {
@@ -960,7 +983,7 @@ struct Solver {
     }
 
     // H dwv (var-shaped, incl. globals) in operator form: J' W^-1 W^-1 J dwv
-    SCVX_HD void H_apply(const double* dwv, double* out) {
+    SCVX_HD_NI void H_apply(const double* dwv, double* out) {
         cone_map(dwv, tmpc, false);
         ex.sync();
         W_all(tmpc, tmpc, true);
@@ -970,7 +993,7 @@ struct Solver {
     }
 
     // Newton step for centering right-hand side ds_rhs (cone vector); results in dw, dy, dZ, dS
-    SCVX_HD void newton(const double* ds_rhs) {
+    SCVX_HD_NI void newton(const double* ds_rhs) {
         div_all(ds_rhs, tt);
         W_all(rz, tmpc, true);
         for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) Wibz[i] = -tmpc[i] - tt[i];
@@ -1031,7 +1054,7 @@ struct Solver {
         ex.sync();
     }
 
-    SCVX_HD void shift_into_cone(double* X) {
+    SCVX_HD_NI void shift_into_cone(double* X) {
         double t = -INFINITY;
         for (int c = ex.lane(); c < L.nsmall + 1; c += ex.nlanes()) {
             int off, dm;
@@ -1065,6 +1088,7 @@ struct Solver {
     SCVX_HD Result solve(const double* xbar_, const double* ubar_, const double* endpoint_, const double* D_,
                          double rk_, const double* ic, double* work) {
         xbar = xbar_; ubar = ubar_; endpoint = endpoint_; D = D_; rk = rk_;
+        SCVX_TS(tTot_);
         carve(work);
         const int K = L.K;
         // constants of this subproblem
@@ -1123,6 +1147,7 @@ struct Solver {
         for (int it = 1; it <= C.max_iter; it++) {
             res.iters = it;
             // residuals
+            SCVX_TS(tR_);
             cone_map(V, tmpc, true);
             ex.sync();
             for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) rz[i] = S[i] - tmpc[i];
@@ -1151,6 +1176,7 @@ struct Solver {
             const double pres = nry > nrz ? nry : nrz;
             const double dres = nrx / (C.wNu > 1.0 ? C.wNu : 1.0);
             const double relgap = gap / (fabs(pobj) > 1.0 ? fabs(pobj) : 1.0);
+            SCVX_TE(tR_, 9);
             double merit = pres > dres ? pres : dres;
             if (relgap > merit) merit = relgap;
             SCVX_DBG("%3d pobj %+.8e gap %.2e pres %.2e (ry %.2e rz %.2e) dres %.2e\n", it, pobj, gap, pres, nry, nrz, dres);
@@ -1167,7 +1193,7 @@ struct Solver {
             if (!build_kkt()) { res.status = best_merit < 100.0 * C.tol ? 0 : 2; break; }
             const double mu = gap / degree;
             centering_rhs(tt, false, 0.0);   // affine (predictor) right-hand side, consumed in place by newton
-            newton(tt);
+            { SCVX_TS(tN_); newton(tt); SCVX_TE(tN_, 10); }
             W_all(dS, sds, true);
             W_all(dZ, sdz, false);
             double a1 = maxstep_all(sds), a2 = maxstep_all(sdz);
@@ -1176,7 +1202,7 @@ struct Solver {
             const double sig = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
             SCVX_DBG("    aff alpha %.6e (a1 %.3e a2 %.3e) |dw|^2 %.6e ds %.6e dtnu %.6e dttr %.6e\n", alpha, a1, a2, dot(dw, dw, L.nv), dw[L.iS], dw[L.iTNU], dw[L.iTTR]);
             centering_rhs(tt, true, sig * mu);
-            newton(tt);
+            { SCVX_TS(tN_); newton(tt); SCVX_TE(tN_, 10); }
             W_all(dS, sds, true);
             W_all(dZ, sdz, false);
             a1 = maxstep_all(sds); a2 = maxstep_all(sdz);
@@ -1192,6 +1218,7 @@ struct Solver {
         }
         res.merit = best_merit;
         if (best_it > 0) { copy(V, Vbest, L.nv); ex.sync(); }
+        SCVX_TE(tTot_, 15);
         return res;
     }
 };

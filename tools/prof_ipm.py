@@ -1,0 +1,20 @@
+import ctypes as C, numpy as np, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from successiveconvexification_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "libscvx_hip_prof.so")
+from successiveconvexification_amd import sample_problems as sp
+from successiveconvexification_amd.batch import ScvxBatch
+from successiveconvexification_amd.dynamics import IntegratorCache
+import bench
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+c = IntegratorCache(sp.base_prob_scaled)
+b = ScvxBatch(c, B).init(bench.disperse_ics(sp.base_prob_scaled, 0, B, 20261004))
+b.socp_solve()
+out = np.zeros(16)
+_lib.lib().scvx_debug_ipm_prof.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+_lib.lib().scvx_debug_ipm_prof(b.handle, out.ctypes.data_as(C.POINTER(C.c_double)))
+st, its, merit, pobj = b.solver_stats()
+names = {0:"S_solve",1:"E_apply",3:"Hb_inv",4:"node blocks",5:"S assembly",6:"chol loop",7:"border solves",8:"W_all",9:"residuals",10:"newton(total)",11:"nt_all",15:"TOTAL"}
+tot = out[15]
+print("ipm iters traj0:", its[0], " total Mcycles(100MHz ticks?) %.1f" % (tot/1e6))
+for k,v in names.items(): print("%-14s %10.0f  %5.1f%%" % (v, out[k], 100*out[k]/tot))
