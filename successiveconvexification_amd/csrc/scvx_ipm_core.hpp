@@ -31,6 +31,13 @@
 #define SCVX_TS(v)
 #define SCVX_TE(v, slot)
 #endif
+// an iterate stuck at the numerical floor is accepted as optimal below this multiple of tol (MOI's ALMOST_OPTIMAL band)
+#ifndef SCVX_FLOOR_ACCEPT
+#define SCVX_FLOOR_ACCEPT 1000.0
+#endif
+#ifndef SCVX_REFINE_FROM
+#define SCVX_REFINE_FROM 1e-4
+#endif
 #define SCVX_T0() SCVX_TS(t0_)
 #define SCVX_T1(slot) SCVX_TE(t0_, slot)
 #if defined(SCVX_IPM_DEBUG) && !defined(__HIPCC__)
@@ -260,6 +267,7 @@ struct Solver {
     double h_tr[4], h_nu[4], Msg[4], hrk, hnui;
     double css, cst, csn, cts, ctt, ctn, cns, cnt_, cnn;
     double prof[16];
+    double cur_merit;  // merit of the current iterate: refinement only pays in the endgame
 
     SCVX_HD Solver(Ex& e, const Consts& c) : ex(e), C(c) { L.init(c.K); for (int i = 0; i < 16; i++) prof[i] = 0.0; }
 
@@ -1021,7 +1029,8 @@ struct Solver {
                      gx[L.iTNU] - r1[L.iTNU], gx[L.iTTR] - r1[L.iTTR], gx[L.iTS] - r1[L.iTS], sqrt(e3));
         }
 #endif
-        for (int it = 0; it < C.refine; it++) {
+        const int nref = (cur_merit < SCVX_REFINE_FROM) ? C.refine : 0;
+        for (int it = 0; it < nref; it++) {
             H_apply(dw, r1);
             const double sgy = Et_apply(dy, tmpl);
             ex.sync();
@@ -1114,30 +1123,36 @@ struct Solver {
         }
         ex.sync();
         Result res; res.status = 1; res.iters = 0; res.merit = INFINITY; res.pobj = 0;
-        // ---- initial point: least-squares slacks with identity scaling, then shift into the cone ----
+        cur_merit = INFINITY;
+        // ---- initial point (CVXOPT conelp style, W = I): two least-squares problems on one factorisation ----
+        //   primal:  min ||s||  s.t. E w = e, s = a(w)        -> w, s     (the cost does not enter)
+        //   dual:    min ||z||  s.t. -J'z + E'y + c = 0       -> y, z = -J w'
+        // then each of s, z is shifted into the cone interior if it is not already there.
         identity_scaling();
         if (!build_kkt()) { res.status = 2; return res; }
         cone_map(V, S, true);   // a0
-        ex.sync();
         cone_map_t(S, gx);
-        ex.sync();
         for (int i = ex.lane(); i < L.nv; i += ex.nlanes()) gx[i] = -gx[i];
-        ex.sync();
-        if (ex.lane() == 0) { gx[14 * K] += 1.0; gx[L.iTNU] -= C.wNu; gx[L.iTTR] -= 0.5; gx[L.iTS] -= 1.0; }  // -cost
         ex.sync();
         mask_fixed(gx);
         E_apply(V, ry, true);
-        ex.sync();
         for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) r2[i] = -(ry[i] + dk[i]);
         ex.sync();
-        kkt_solve(gx, r2, dw, y);
+        kkt_solve(gx, r2, dw, dy);
         for (int i = ex.lane(); i < L.nv; i += ex.nlanes()) V[i] += dw[i];
         ex.sync();
         cone_map(V, S, true);
+        // dual
+        zero(gx, L.nv);
+        if (ex.lane() == 0) { gx[14 * K] = 1.0; gx[L.iTNU] = -C.wNu; gx[L.iTTR] = -0.5; gx[L.iTS] = -1.0; }  // -cost
         ex.sync();
-        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) Z[i] = -S[i];
+        mask_fixed(gx);
+        zero(r2, L.ny);
+        kkt_solve(gx, r2, dw, y);
+        cone_map(dw, Z, false);  // J w'
+        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) Z[i] = -Z[i];
         ex.sync();
-        SCVX_DBG("init: |V|^2 %.12e s %.6e tnu %.6e ttr %.6e ts %.6e |y|^2 %.6e |S|^2 %.12e\n", dot(V, V, L.nv), V[L.iS], V[L.iTNU], V[L.iTTR], V[L.iTS], dot(y, y, L.ny), dot(S, S, L.nc));
+        SCVX_DBG("init: |V|^2 %.12e s %.6e tnu %.6e ttr %.6e ts %.6e |y|^2 %.6e |S|^2 %.12e |Z|^2 %.6e\n", dot(V, V, L.nv), V[L.iS], V[L.iTNU], V[L.iTTR], V[L.iTS], dot(y, y, L.ny), dot(S, S, L.nc), dot(Z, Z, L.nc));
         shift_into_cone(S);
         shift_into_cone(Z);
         SCVX_DBG("shifted: |S|^2 %.12e |Z|^2 %.12e\n", dot(S, S, L.nc), dot(Z, Z, L.nc));
@@ -1181,16 +1196,17 @@ struct Solver {
             if (relgap > merit) merit = relgap;
             SCVX_DBG("%3d pobj %+.8e gap %.2e pres %.2e (ry %.2e rz %.2e) dres %.2e\n", it, pobj, gap, pres, nry, nrz, dres);
             if (!(merit == merit) || !(gap == gap)) { res.status = 3; break; }
+            cur_merit = merit;
             if (merit < best_merit) {
                 best_merit = merit; best_it = it; res.pobj = pobj;
                 copy(Vbest, V, L.nv);
                 ex.sync();
             }
             if (pres < C.tol && dres < C.tol && relgap < C.tol) { res.status = 0; break; }
-            if (it - best_it >= 3 && best_merit < 1e-5) { res.status = best_merit < 100.0 * C.tol ? 0 : 2; break; }
-            if (it == C.max_iter) { res.status = best_merit < 100.0 * C.tol ? 0 : 1; break; }
+            if (it - best_it >= 3 && best_merit < 1e-5) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
+            if (it == C.max_iter) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 1; break; }
             nt_all();
-            if (!build_kkt()) { res.status = best_merit < 100.0 * C.tol ? 0 : 2; break; }
+            if (!build_kkt()) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
             const double mu = gap / degree;
             centering_rhs(tt, false, 0.0);   // affine (predictor) right-hand side, consumed in place by newton
             { SCVX_TS(tN_); newton(tt); SCVX_TE(tN_, 10); }
@@ -1209,8 +1225,8 @@ struct Solver {
             alpha = 0.99 * (a1 < a2 ? a1 : a2);
             if (alpha > 1.0) alpha = 1.0;
             SCVX_DBG("    cmb alpha %.6e |dw|^2 %.6e\n", alpha, dot(dw, dw, L.nv));
-            if (!(alpha == alpha)) { res.status = best_merit < 100.0 * C.tol ? 0 : 3; break; }
-            if (alpha < 1e-9) { res.status = best_merit < 100.0 * C.tol ? 0 : 2; break; }
+            if (!(alpha == alpha)) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 3; break; }
+            if (alpha < 1e-9) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
             for (int i = ex.lane(); i < L.nv; i += ex.nlanes()) V[i] += alpha * dw[i];
             for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) y[i] += alpha * dy[i];
             for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) { S[i] += alpha * dS[i]; Z[i] += alpha * dZ[i]; }
