@@ -16,7 +16,7 @@
 
 namespace {
 struct HostEx {
-    double sc[1024];
+    double sc[2048];
     int lane() const { return 0; }
     int nlanes() const { return 1; }
     void sync() {}
@@ -24,6 +24,19 @@ struct HostEx {
     double min(double x) { return x; }
     bool all(bool b) { return b; }
     double* scratch() { return sc; }
+    static constexpr int kPrefetchRegs = 0;
+    // L^-1 (row-major, lower) of the Cholesky factor of the SPD tile M
+    bool chol_inv14(double* M, double* Li) {
+        const bool ok = chol14(M);
+        for (int c = 0; c < 14; c++)
+            for (int i = 0; i < 14; i++) {
+                if (i < c) { Li[14 * i + c] = 0.0; continue; }
+                double s = (i == c) ? 1.0 : 0.0;
+                for (int t = c; t < i; t++) s -= M[14 * i + t] * Li[14 * t + c];
+                Li[14 * i + c] = s / M[15 * i];
+            }
+        return ok;
+    }
     // in-place Cholesky of a 14x14 SPD tile (row-major, lower triangle on output)
     bool chol14(double* M) {
         bool ok = true;

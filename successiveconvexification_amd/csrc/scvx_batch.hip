@@ -51,9 +51,12 @@ struct WaveEx {
         return __hiloint2double(hi, lo);
     }
 
-    // In-place Cholesky of the 14x14 SPD tile M (row-major, lower triangle on output): lane i keeps row i
-    // in VGPRs, pivots and column entries travel by readlane — 105 broadcasts, no barrier inside.
-    __device__ __forceinline__ bool chol14(double* M) {
+    static constexpr int kPrefetchRegs = 5;  // ceil(294 / 64): next D tile held in registers while segment k is processed
+
+    // Li = L^-1 (row-major, lower) where L L' = M, for the 14x14 SPD pivot tile in LDS.  Lane i keeps row i of
+    // M/L in VGPRs; pivots, column entries and the rows needed by the inversion travel by readlane:
+    // 105 broadcasts for the factorisation, 105 for the inverse, no barrier inside.
+    __device__ __forceinline__ bool chol_inv14(const double* M, double* Li) {
         const int i = lane();
         const int r = i < 14 ? i : 13;
         double m[14];
@@ -72,9 +75,22 @@ struct WaveEx {
                 if (i >= c) m[c] = fma(-m[j], lcj, m[c]);
             }
         }
+        // inverse: lane c owns column c of L^-1: x[i] = (delta_ic - sum_{t=c}^{i-1} L[i][t] x[t]) / L[i][i]
+        double x[14];
+#pragma unroll
+        for (int a = 0; a < 14; a++) {
+            double acc = (a == i) ? 1.0 : 0.0;
+#pragma unroll
+            for (int t = 0; t < a; t++) {
+                const double lat = bcast(m[t], a);  // L[a][t]
+                if (t >= i) acc = fma(-lat, x[t], acc);
+            }
+            const double laa = bcast(m[a], a);
+            x[a] = (a >= i) ? acc / laa : 0.0;
+        }
         if (i < 14) {
 #pragma unroll
-            for (int c = 0; c < 14; c++) M[14 * i + c] = m[c];
+            for (int a = 0; a < 14; a++) Li[14 * a + i] = x[a];
         }
         return ok;
     }
@@ -138,14 +154,14 @@ struct WaveEx {
 };
 
 // info[b] = {status, iters, merit, pobj}
-__global__ __launch_bounds__(64) void socp_kernel(ipm::Consts C, int B, size_t work_stride,
+__global__ __launch_bounds__(64, 2) void socp_kernel(ipm::Consts C, int B, size_t work_stride,
                                                   const double* __restrict__ x, const double* __restrict__ u,
                                                   const double* __restrict__ endpoint, const double* __restrict__ deriv,
                                                   const double* __restrict__ rk, const double* __restrict__ ic,
                                                   const int* __restrict__ active, double* __restrict__ work,
                                                   double* __restrict__ sol, double* __restrict__ nu,
                                                   double* __restrict__ info) {
-    __shared__ __attribute__((aligned(16))) double lds[640];
+    __shared__ __attribute__((aligned(16))) double lds[1536];
     const int b = blockIdx.x;
     if (b >= B) return;
     if (active && !active[b]) return;

@@ -690,12 +690,19 @@ struct Solver {
     SCVX_HD_NI void S_solve(const double* r, double* x) {
         SCVX_T0();
         const int K = L.K;
+        const double* const Linv = this->Linv;
+        const double* const Nf = this->Nf;
+        const double* const Nb = this->Nb;
+        double* const tchain = this->tchain;
         for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
             const int k = t / 14, i = t - 14 * k;
             const double* Li = Linv + (size_t)k * 196 + 14 * i;
             const double* rk_ = r + 14 * k;
             double a = 0;
-            for (int j = 0; j <= i; j++) a += Li[j] * rk_[j];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int j = 0; j < 14; j++) a += Li[j] * rk_[j];   // zeros above the diagonal: fixed trip count, loads batch
             tchain[t] = a;
         }
         ex.sync();
@@ -706,7 +713,10 @@ struct Solver {
             const double* Lk = Linv + (size_t)k * 196;
             const double* tk = x + 14 * k;
             double a = 0;
-            for (int j = i; j < 14; j++) a += Lk[14 * j + i] * tk[j];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int j = 0; j < 14; j++) a += Lk[14 * j + i] * tk[j];
             tchain[t] = a;
         }
         ex.sync();
@@ -824,87 +834,164 @@ struct Solver {
         }
         ex.sync();
         SCVX_T1(4);
-        SCVX_TS(tS_);
-        // S blocks: Sd[k] (row-major 14x14), So[k] = block (k+1,k) -> staged in Nb[k]
-        for (int e = ex.lane(); e < K * 196; e += ex.nlanes()) {
-            const int k = e / 196, r = e - 196 * k, i = r / 14, j = r - 14 * i;
-            const double* Dk = D + (size_t)k * 294;
-            double s = hxi_quad(hx + (size_t)k * HX_SZ, Dk, i, Dk, j);
-            s += hui_quad(hu + 9 * k, Dk + 14 * 14, i, Dk + 14 * 14, j);
-            s += hui_quad(hu + 9 * (k + 1), Dk + 14 * 17, i, Dk + 14 * 17, j);
-            s += hxi_entry(hx + (size_t)(k + 1) * HX_SZ, i, j);
-            if (i == j) s += hnui;
-            Sd[e] = s;
-            if (k + 1 < K) {
-                // So[k][i][j]: i row of segment k+1, j row of segment k
-                const double* Dn = D + (size_t)(k + 1) * 294;
-                const double* hn = hx + (size_t)(k + 1) * HX_SZ;
+        SCVX_TS(tC_);
+        // ---- fused Schur-complement assembly + block Cholesky, sequential in k, every tile in scratch (LDS) ----
+        //   Sd[k] = TA_k A_k' + TBm_k Bm_k' + TBp_k Bp_k' + Hxi_{k+1} + hnui I      TA_k  = A_k  Hxi_k   (14x14)
+        //   So[k] = -TA_{k+1} + TBm_{k+1} Bp_k'   (block (k+1,k))                    TBm_k = Bm_k Hui_k   (14x3)
+        //   pivot M_k = Sd[k] - Wb_{k-1} Wb_{k-1}',  Wb_k = So[k] L_k^-T             TBp_k = Bp_k Hui_{k+1}
+        // The D_{k+1} tile is fetched (coalesced, into registers on the device) while segment k is processed.
+        // members hoisted into locals: the Solver object sits in scratch memory on the device and would be
+        // re-read after every barrier
+        const double* const D_ = D;
+        const double* const hx_ = hx;
+        const double* const hu_ = hu;
+        double* const Linv_ = Linv;
+        double* const Nf_ = Nf;
+        double* const Nb_ = Nb;
+        const double hnui_ = hnui;
+        double* sc = ex.scratch();
+        double* M = sc + 32;            // 196  pivot tile, then Wb scratch
+        double* Wp = M + 196;           // 196  Wb[k-1]
+        double* Li = Wp + 196;          // 196  Linv[k]
+        double* Dt = Li + 196;          // 294  D_k tile (column-major 14x21)
+        double* TA = Dt + 294;          // 196  A_k Hxi_k
+        double* TB = TA + 196;          // 42+42 TBm_k (row-major 14x3), TBp_k
+        double* Bp = TB + 84;           // 42   copy of Bp_k (column-major 14x3) kept across the D tile swap
+        double* Hh = Bp + 42;           // 68   hx_k (25) hu_k (9) | hx_{k+1} (25) hu_{k+1} (9)
+        double* Hd = Hh + 68;           // 196  dense Hxi of the node being multiplied (fixed-trip inner products)
+        bool ok = true;
+#if defined(__HIPCC__)
+#define SCVX_UNROLL _Pragma("unroll")
+#else
+#define SCVX_UNROLL
+#endif
+        // prologue: D_0, hx_0/hu_0 -> LDS; TA_0, TBm_0
+        for (int e = ex.lane(); e < 294; e += ex.nlanes()) Dt[e] = D_[e];
+        for (int e = ex.lane(); e < 34; e += ex.nlanes()) Hh[34 + e] = e < 25 ? hx_[e] : hu_[e - 25];
+        ex.sync();
+        for (int e = ex.lane(); e < 196; e += ex.nlanes()) Hd[e] = hxi_entry(Hh + 34, e / 14, e % 14);
+        ex.sync();
+        for (int e = ex.lane(); e < 196 + 42; e += ex.nlanes()) {
+            if (e < 196) {
+                const int i = e / 14, j = e - 14 * i;
                 double t = 0;
-                for (int a = 0; a < 14; a++) { const double he = hxi_entry(hn, a, j); if (he != 0.0) t += Dn[14 * a + i] * he; }
-                double so = -t + hui_quad(hu + 9 * (k + 1), Dn + 14 * 14, i, Dk + 14 * 17, j);
-                Nb[e] = so;
+                SCVX_UNROLL
+                for (int a = 0; a < 14; a++) t += Dt[14 * a + i] * Hd[14 * a + j];
+                TA[e] = t;
+            } else {
+                const int q = e - 196, i = q / 3, c = q - 3 * i;
+                const double* h = Hh + 34 + 25;
+                TB[q] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
             }
         }
         ex.sync();
-        SCVX_TE(tS_, 5);
-        SCVX_TS(tC_);
-        // block Cholesky, sequential in k; tiles in scratch (LDS on the device)
-        double* sc = ex.scratch();
-        double* M = sc + 32;         // 196: pivot tile -> L (lower)
-        double* Wp = sc + 32 + 196;  // 196: Wb[k-1]
-        double* Li = sc + 32 + 392;  // 196: Linv[k]
-        bool ok = true;
         for (int k = 0; k < K; k++) {
-            for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
-                const int i = e / 14, j = e - 14 * i;
-                double s = Sd[(size_t)k * 196 + e];
-                if (k > 0) for (int c = 0; c < 14; c++) s -= Wp[14 * i + c] * Wp[14 * j + c];
-                M[e] = s;
+            SCVX_TS(ta_);
+            // prefetch the next segment's tile
+            constexpr int NPRE = Ex::kPrefetchRegs;
+            double pre[NPRE > 0 ? NPRE : 1];
+            const double* Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
+            if (NPRE > 0) {
+                SCVX_UNROLL
+                for (int q = 0; q < NPRE; q++) { const int e = ex.lane() + ex.nlanes() * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
+            }
+            // node inverses: slot 0 <- slot 1 (k), slot 1 <- k+1, dense tile of k+1
+            for (int e = ex.lane(); e < 34; e += ex.nlanes()) {
+                const double nk1 = e < 25 ? hx_[(size_t)(k + 1) * HX_SZ + e] : hu_[9 * (k + 1) + (e - 25)];
+                Hh[e] = Hh[34 + e];
+                Hh[34 + e] = nk1;
             }
             ex.sync();
-            ok = ex.chol14(M) && ok;   // in place, lower triangle; wave-synchronous on the device
-            ex.sync();
-            // Linv: column c solved by lane c
-            for (int c = ex.lane(); c < 14; c += ex.nlanes()) {
-                for (int i = 0; i < 14; i++) {
-                    if (i < c) { Li[14 * i + c] = 0.0; continue; }
-                    double s = (i == c) ? 1.0 : 0.0;
-                    for (int t = c; t < i; t++) s -= M[14 * i + t] * Li[14 * t + c];
-                    Li[14 * i + c] = s / M[15 * i];
+            for (int e = ex.lane(); e < 196 + 42; e += ex.nlanes()) {
+                if (e < 196) Hd[e] = hxi_entry(Hh + 34, e / 14, e % 14);
+                else {  // TBp_k = Bp_k Hui_{k+1}
+                    const int q = e - 196, i = q / 3, c = q - 3 * i;
+                    const double* h = Hh + 34 + 25;
+                    TB[42 + q] = Dt[14 * 17 + i] * h[c] + Dt[14 * 18 + i] * h[3 + c] + Dt[14 * 19 + i] * h[6 + c];
                 }
             }
             ex.sync();
+            SCVX_TE(ta_, 2);
+            SCVX_TS(tb_);
+            // pivot tile
             for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
                 const int i = e / 14, j = e - 14 * i;
-                Linv[(size_t)k * 196 + e] = Li[e];
-                if (k > 0) {  // Nf[k] = Linv_k Wb_{k-1}
-                    double s = 0;
-                    for (int c = 0; c <= i; c++) s += Li[14 * i + c] * Wp[14 * c + j];
-                    Nf[(size_t)k * 196 + e] = s;
-                }
+                double s = Hd[e] + (i == j ? hnui_ : 0.0);
+                double w = 0;
+                SCVX_UNROLL
+                for (int a = 0; a < 14; a++) { s += TA[14 * i + a] * Dt[14 * a + j]; w += Wp[14 * i + a] * Wp[14 * j + a]; }
+                SCVX_UNROLL
+                for (int c = 0; c < 3; c++) s += TB[3 * i + c] * Dt[14 * (14 + c) + j] + TB[42 + 3 * i + c] * Dt[14 * (17 + c) + j];
+                M[e] = (k > 0) ? s - w : s;
             }
             ex.sync();
+            SCVX_TE(tb_, 5);
+            SCVX_TS(tc_);
+            ok = ex.chol_inv14(M, Li) && ok;   // L^-1 of the pivot tile -> Li (row-major, lower, zeros above)
+            ex.sync();
+            SCVX_TE(tc_, 12);
+            SCVX_TS(td_);
+            for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
+                const int i = e / 14, j = e - 14 * i;
+                Linv_[(size_t)k * 196 + e] = Li[e];
+                double s = 0;   // Nf[k] = Linv_k Wb_{k-1}
+                SCVX_UNROLL
+                for (int c = 0; c < 14; c++) s += Li[14 * i + c] * Wp[14 * c + j];
+                if (k > 0) Nf_[(size_t)k * 196 + e] = s;
+            }
+            SCVX_TE(td_, 13);
+            SCVX_TS(te_);
             if (k + 1 < K) {
-                // Wb[k] = So[k] Linv'   (So staged in Nb[k])
+                // keep Bp_k, swap in D_{k+1}
+                for (int q = ex.lane(); q < 42; q += ex.nlanes()) Bp[q] = Dt[14 * 17 + q];
+                ex.sync();
+                if (NPRE > 0) {
+                    SCVX_UNROLL
+                    for (int q = 0; q < NPRE; q++) { const int e = ex.lane() + ex.nlanes() * q; if (e < 294) Dt[e] = pre[q]; }
+                } else {
+                    for (int e = ex.lane(); e < 294; e += ex.nlanes()) Dt[e] = Dn[e];
+                }
+                ex.sync();
+                // TA_{k+1}, TBm_{k+1}
+                for (int e = ex.lane(); e < 196 + 42; e += ex.nlanes()) {
+                    if (e < 196) {
+                        const int i = e / 14, j = e - 14 * i;
+                        double t = 0;
+                        SCVX_UNROLL
+                        for (int a = 0; a < 14; a++) t += Dt[14 * a + i] * Hd[14 * a + j];
+                        TA[e] = t;
+                    } else {
+                        const int q = e - 196, i = q / 3, c = q - 3 * i;
+                        const double* h = Hh + 34 + 25;
+                        TB[q] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
+                    }
+                }
+                ex.sync();
+                // So[k] = -TA_{k+1} + TBm_{k+1} Bp_k'  ->  Wb_k = So Linv'  (two passes through M)
                 for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
                     const int i = e / 14, j = e - 14 * i;
-                    const double* So = Nb + (size_t)k * 196 + 14 * i;
-                    double s = 0;
-                    for (int c = 0; c <= j; c++) s += So[c] * Li[14 * j + c];
-                    M[e] = s;  // M is free now
+                    M[e] = -TA[e] + TB[3 * i] * Bp[j] + TB[3 * i + 1] * Bp[14 + j] + TB[3 * i + 2] * Bp[28 + j];
                 }
                 ex.sync();
-                for (int e = ex.lane(); e < 196; e += ex.nlanes()) Wp[e] = M[e];
+                for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
+                    const int i = e / 14, j = e - 14 * i;
+                    double s = 0;
+                    SCVX_UNROLL
+                    for (int c = 0; c < 14; c++) s += M[14 * i + c] * Li[14 * j + c];
+                    Wp[e] = s;
+                }
                 ex.sync();
-                // Nb[k] = (Wb_k Linv_k)' : Nb[k][j][i] = sum_{c>=j} Wb[i][c] Linv[c][j]
+                // Nb[k] = (Wb_k Linv_k)' : Nb[k][j][i] = sum_c Wb[i][c] Linv[c][j]
                 for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
                     const int j = e / 14, i = e - 14 * j;
                     double s = 0;
-                    for (int c = j; c < 14; c++) s += Wp[14 * i + c] * Li[14 * c + j];
-                    Nb[(size_t)k * 196 + e] = s;
+                    SCVX_UNROLL
+                    for (int c = 0; c < 14; c++) s += Wp[14 * i + c] * Li[14 * c + j];
+                    Nb_[(size_t)k * 196 + e] = s;
                 }
             }
             ex.sync();
+            SCVX_TE(te_, 14);
         }
         SCVX_TE(tC_, 6);
         SCVX_TS(tB_);
