@@ -35,6 +35,22 @@ def k1_alg_bytes(K, n_u=3, s=8):
     return ((K + 1) * (14 + n_u) + 1 + K * (14 + 14 * (14 + 2 * n_u + 1))) * s
 
 
+def k1_measured_traffic(B):
+    """HBM bytes per K1 launch from the committed PMC passes (profiles/*_pmc_B<batch>.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc runs; FETCH doubled per the gfx950 half-count note of
+    MI355X_MICROARCH.md §HBM).  None when no pass at this batch size is on file."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_B%d.json" % B))):
+        try:
+            k = json.load(open(f))["kernels"]["scvx::linearize_kernel<false>"]
+            n = k["launches_in_fetch_pass"]
+            best = {"bytes": (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 / n, "source": os.path.basename(f)}
+        except Exception:
+            pass
+    return best
+
+
 def disperse_ics(p, lo, hi, seed, frac=0.1):
     """SURVEY.md §8d dispersion law; trajectory b draws from Philox stream b."""
     ic = np.zeros((hi - lo, 6))
@@ -116,12 +132,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("SCVX_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SCVX_DIST_BACKEND", "nccl")  # "gloo": dry-run of the N>1 logic with ranks sharing one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from successiveconvexification_amd import sample_problems as sp
     from successiveconvexification_amd.batch import ScvxBatch
@@ -166,13 +188,16 @@ def main():
             __cuda_array_interface__ = {"shape": (B, n // B), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
         mine = torch.as_tensor(_Dev(), device="cuda")
-        out = torch.empty((world,) + tuple(mine.shape), dtype=torch.float64, device="cuda")
-        dist.all_gather_into_tensor(out, mine)
+        dev = "cuda"
+        if dist.get_backend() != "nccl":
+            mine, dev = mine.cpu(), "cpu"
+        from successiveconvexification_amd.batch import gather_trajectories
+        out = gather_trajectories(mine)
         gathered = tuple(out.shape)
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([done], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([done], dtype=torch.float64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         done_all = int(tot.item())
     else:
@@ -183,6 +208,7 @@ def main():
         k1_ms = prof["linearize"] / max(nprof, 1)
         alg = k1_alg_bytes(K) * B
         achieved = alg / (k1_ms * 1e-3) if k1_ms > 0 else 0.0
+        traffic = k1_measured_traffic(B)
         line = {
             "metric": "6-DoF K=50 SCvx iterations/sec (batch)",
             "value": done_all / elapsed,
@@ -206,7 +232,8 @@ def main():
             "roofline": {
                 "kernel": "scvx::linearize_kernel (K1)", "bound": "hbm",
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": None,
+                "frac": achieved / HBM_PEAK, "traffic": traffic["bytes"] if traffic else None,
+                "traffic_source": traffic["source"] if traffic else None,
                 "alg_bytes_per_launch": alg, "avg_launch_ms": k1_ms,
                 "note": "K1 at rk4_npts=%d is FP64-FMA-bound, not HBM-bound (SURVEY 8d); traffic from PMC in profiles/" % args.npts,
             },

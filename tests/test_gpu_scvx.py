@@ -143,3 +143,44 @@ def test_solve_runs_to_imax_and_reports_status():
     assert np.isfinite(x).all() and np.isfinite(u).all()
     # the reference's sample problem keeps ||nu|| ~ 1e-2 (71 kg of propellant): it never meets nuTol
     assert np.all(st != 0)
+
+
+def test_rocketland_mirror_single_trajectory():
+    """The reference's recipe (rocketland.jl:26-32) through the host mirror: same names, same returns."""
+    from oracle import model, scvx as oscvx
+    from successiveconvexification_amd import rocketland as Rocketland, sample_problems as SampleProblems
+    from successiveconvexification_amd.defns import ProbInfo
+    from successiveconvexification_amd.dynamics import IntegratorCache, make_dynamics_module, linearize_dynamics, predict_state
+    prob = SampleProblems.base_prob_scaled
+    cache = IntegratorCache(prob, ProbInfo.from_problem(prob), make_dynamics_module(ProbInfo.from_problem(prob)))
+    pi = Rocketland.create_initial(prob, cache)
+    assert pi.iter == 0 and pi.rk == 100.0 and np.isinf(pi.cost) and len(pi.about) == prob.K + 1 and len(pi.dynam) == prob.K
+    assert pi.dynam[0].derivative.shape == (14, 21)
+    pi1, cnu, cdel = Rocketland.solve_step(pi, cache)
+    it = oscvx.create_initial(model.base_prob_scaled(), 10)
+    it1, onu, odel = oscvx.solve_step(it)
+    assert pi1.iter == 1 and pi1.rk == it1.rk and abs(pi1.sigma - it1.sigma) < 5e-4 and abs(cnu - onu) < 1e-5 and np.isinf(cdel)
+    assert np.abs(np.stack([p.state for p in pi1.about]) - it1.x).max() < 5e-4
+    # Dynamics entry points with the reference's signatures
+    lr = linearize_dynamics(pi1.about, pi1.sigma, 1 / (prob.K + 1), cache)
+    assert np.abs(lr[3].derivative - pi1.dynam[3].derivative).max() < 1e-13
+    xe = predict_state(pi1.about[3].state, pi1.about[3].control, pi1.about[4].control, pi1.sigma, 1 / (prob.K + 1), None, cache)
+    assert np.abs(xe - lr[3].endpoint).max() < 1e-13
+
+
+def test_checkpoint_restore_roundtrip():
+    """The batched iterate is the checkpoint: dump after one step, restore into a new batch, both continue identically."""
+    from oracle import model
+    po = model.base_prob_scaled()
+    ic = model.disperse_ics(po, 3, 20261004)
+    c, b = _setup(3, ic, npts=4)
+    b.solve_step()
+    x, u, s = b.trajectory()
+    rk, cost, it = b.scalars()
+    c2, b2 = _setup(3, ic, npts=4)
+    b2.set_trajectory(x, u, s)
+    b2.set_scalars(rk, cost, it)
+    st1, nu1, dj1 = b.solve_step()
+    st2, nu2, dj2 = b2.solve_step()
+    assert np.array_equal(st1, st2) and np.array_equal(nu1, nu2) and np.array_equal(dj1, dj2)  # bitwise: same kernels, same data
+    assert np.array_equal(b.trajectory()[0], b2.trajectory()[0])
