@@ -50,6 +50,12 @@ struct HostEx {
         }
         return ok;
     }
+    void chain3(int K, const double* z0, const double* z1, const double* z2, const double* N, double* o0, double* o1,
+                double* o2, bool reverse) {
+        chain(K, z0, N, o0, reverse);
+        chain(K, z1, N, o1, reverse);
+        chain(K, z2, N, o2, reverse);
+    }
     // out_k = z_k - N_k out_{k-1} (forward) or out_k = z_k - N_k out_{k+1} (reverse); 14-vectors, N row-major
     void chain(int K, const double* z, const double* N, double* out, bool reverse) {
         for (int step = 0; step < K; step++) {

@@ -151,6 +151,64 @@ struct WaveEx {
             }
         }
     }
+
+    // Three recurrences through the same tiles: the N_k tile is read once from HBM / LDS for the three
+    // right-hand sides of the border solves, and the three FMA chains interleave (ILP) instead of queueing.
+    __device__ __forceinline__ void chain3(int K, const double* __restrict__ z0, const double* __restrict__ z1,
+                                           const double* __restrict__ z2, const double* __restrict__ N,
+                                           double* __restrict__ o0, double* __restrict__ o1, double* __restrict__ o2,
+                                           bool reverse) {
+        constexpr int R = 4;
+        const int l = lane();
+        const bool live = l < 14;
+        const int i = live ? l : 13;
+        double* ring = sc + 32;
+        const int k0 = reverse ? K - 1 : 0;
+        const int dk = reverse ? -1 : 1;
+        double t0 = z0[14 * k0 + i], t1 = z1[14 * k0 + i], t2 = z2[14 * k0 + i];
+        if (live) { o0[14 * k0 + i] = t0; o1[14 * k0 + i] = t1; o2[14 * k0 + i] = t2; }
+        const int nsteps = K - 1;
+        double st[R][4];
+        double zs[R][3];
+        auto issue = [&](int step, double (&r)[4], double (&zz)[3]) {
+            const int k = k0 + dk * (step + 1);
+            const double* base = N + (size_t)k * 196;
+            r[0] = base[l]; r[1] = base[l + 64]; r[2] = base[l + 128];
+            r[3] = (l < 4) ? base[l + 192] : 0.0;
+            zz[0] = z0[14 * k + i]; zz[1] = z1[14 * k + i]; zz[2] = z2[14 * k + i];
+        };
+#pragma unroll
+        for (int q = 0; q < R; q++)
+            if (q < nsteps) issue(q, st[q], zs[q]);
+        for (int s0 = 0; s0 < nsteps; s0 += R) {
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int step = s0 + q;
+                if (step < nsteps) {
+                    double* slot = ring + 196 * (q & 1);
+                    slot[l] = st[q][0]; slot[l + 64] = st[q][1]; slot[l + 128] = st[q][2];
+                    if (l < 4) slot[l + 192] = st[q][3];
+                    const double c0 = zs[q][0], c1 = zs[q][1], c2 = zs[q][2];
+                    if (step + R < nsteps) issue(step + R, st[q], zs[q]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const double* row = slot + 14 * i;
+                    double a0 = c0, a1 = c1, a2 = c2;
+#pragma unroll
+                    for (int j = 0; j < 14; j++) {
+                        const double nij = row[j];
+                        a0 = fma(-nij, bcast(t0, j), a0);
+                        a1 = fma(-nij, bcast(t1, j), a1);
+                        a2 = fma(-nij, bcast(t2, j), a2);
+                    }
+                    t0 = a0; t1 = a1; t2 = a2;
+                    const int k = k0 + dk * (step + 1);
+                    if (live) { o0[14 * k + i] = t0; o1[14 * k + i] = t1; o2[14 * k + i] = t2; }
+                }
+            }
+        }
+    }
 };
 
 // info[b] = {status, iters, merit, pobj}

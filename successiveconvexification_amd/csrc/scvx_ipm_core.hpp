@@ -38,6 +38,11 @@
 #ifndef SCVX_REFINE_FROM
 #define SCVX_REFINE_FROM 1e-4
 #endif
+#if defined(__HIPCC__)
+#define SCVX_UNROLL _Pragma("unroll")
+#else
+#define SCVX_UNROLL
+#endif
 #define SCVX_T0() SCVX_TS(t0_)
 #define SCVX_T1(slot) SCVX_TE(t0_, slot)
 #if defined(SCVX_IPM_DEBUG) && !defined(__HIPCC__)
@@ -725,6 +730,70 @@ struct Solver {
         SCVX_T1(0);
     }
 
+    // Three right-hand sides through the block-tridiagonal solve with ONE pass over Linv / Nf / Nb.
+    // r*, x*: [K][14]; scratch t0,t1,t2: [K][14]; x may alias nothing.
+    SCVX_HD_NI void S_solve3(const double* r0, const double* r1, const double* r2_, double* x0, double* x1, double* x2,
+                             double* t0, double* t1, double* t2) {
+        const int K = L.K;
+        const double* const Linv = this->Linv;
+        const double* const Nf = this->Nf;
+        const double* const Nb = this->Nb;
+        for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
+            const int k = t / 14, i = t - 14 * k;
+            const double* Li = Linv + (size_t)k * 196 + 14 * i;
+            double a0 = 0, a1 = 0, a2 = 0;
+            SCVX_UNROLL
+            for (int j = 0; j < 14; j++) { const double l = Li[j]; a0 += l * r0[14 * k + j]; a1 += l * r1[14 * k + j]; a2 += l * r2_[14 * k + j]; }
+            t0[t] = a0; t1[t] = a1; t2[t] = a2;
+        }
+        ex.sync();
+        ex.chain3(K, t0, t1, t2, Nf, x0, x1, x2, false);
+        ex.sync();
+        for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
+            const int k = t / 14, i = t - 14 * k;
+            const double* Lk = Linv + (size_t)k * 196;
+            double a0 = 0, a1 = 0, a2 = 0;
+            SCVX_UNROLL
+            for (int j = 0; j < 14; j++) { const double l = Lk[14 * j + i]; a0 += l * x0[14 * k + j]; a1 += l * x1[14 * k + j]; a2 += l * x2[14 * k + j]; }
+            t0[t] = a0; t1[t] = a1; t2[t] = a2;
+        }
+        ex.sync();
+        ex.chain3(K, t0, t1, t2, Nb, x0, x1, x2, true);
+        ex.sync();
+    }
+    // g_r = E_loc' y_r on (dx, du) for three vectors with one pass over D; the nu block of E_loc' y is y itself
+    SCVX_HD_NI void Et_apply3(const double* y0, const double* y1, const double* y2, double* g0, double* g1, double* g2) {
+        const int K = L.K;
+        const double* const D = this->D;
+        for (int t = ex.lane(); t < L.nx; t += ex.nlanes()) {
+            const int k = t / 14, j = t - 14 * k;
+            double a0 = 0, a1 = 0, a2 = 0;
+            if (k < K) {
+                const double* col = D + (size_t)k * 294 + 14 * j;
+                SCVX_UNROLL
+                for (int i = 0; i < 14; i++) { const double c = col[i]; a0 += c * y0[14 * k + i]; a1 += c * y1[14 * k + i]; a2 += c * y2[14 * k + i]; }
+            }
+            if (k > 0) { a0 -= y0[14 * (k - 1) + j]; a1 -= y1[14 * (k - 1) + j]; a2 -= y2[14 * (k - 1) + j]; }
+            g0[t] = a0; g1[t] = a1; g2[t] = a2;
+        }
+        for (int t = ex.lane(); t < L.nu_; t += ex.nlanes()) {
+            const int k = t / 3, c = t - 3 * k;
+            double a0 = 0, a1 = 0, a2 = 0;
+            if (k < K) {
+                const double* col = D + (size_t)k * 294 + 14 * (14 + c);
+                SCVX_UNROLL
+                for (int i = 0; i < 14; i++) { const double cc = col[i]; a0 += cc * y0[14 * k + i]; a1 += cc * y1[14 * k + i]; a2 += cc * y2[14 * k + i]; }
+            }
+            if (k > 0) {
+                const double* col = D + (size_t)(k - 1) * 294 + 14 * (17 + c);
+                SCVX_UNROLL
+                for (int i = 0; i < 14; i++) { const double cc = col[i]; a0 += cc * y0[14 * (k - 1) + i]; a1 += cc * y1[14 * (k - 1) + i]; a2 += cc * y2[14 * (k - 1) + i]; }
+            }
+            g0[L.nx + t] = a0; g1[L.nx + t] = a1; g2[L.nx + t] = a2;
+        }
+        ex.sync();
+    }
+
     // [Hb E'; E 0][dl; dyv] = [gl; ryv]   (gl: local part of a var vector; outputs may not alias inputs)
     SCVX_HD_NI void band_solve(const double* gl, const double* ryv, double* dl, double* dyv) {
         Hb_inv(gl, tmpl);
@@ -860,11 +929,6 @@ struct Solver {
         double* Hh = Bp + 42;           // 68   hx_k (25) hu_k (9) | hx_{k+1} (25) hu_{k+1} (9)
         double* Hd = Hh + 68;           // 196  dense Hxi of the node being multiplied (fixed-trip inner products)
         bool ok = true;
-#if defined(__HIPCC__)
-#define SCVX_UNROLL _Pragma("unroll")
-#else
-#define SCVX_UNROLL
-#endif
         // prologue: D_0, hx_0/hu_0 -> LDS; TA_0, TBm_0
         for (int e = ex.lane(); e < 294; e += ex.nlanes()) Dt[e] = D_[e];
         for (int e = ex.lane(); e < 34; e += ex.nlanes()) Hh[34 + e] = e < 25 ? hx_[e] : hu_[e - 25];
@@ -995,21 +1059,40 @@ struct Solver {
         }
         SCVX_TE(tC_, 6);
         SCVX_TS(tB_);
-        // border solves
-        zero(tmpv, L.nloc);
-        ex.sync();
-        // sol_s = band(0, -Sg)
-        for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) { const int k = r / 14, i = r - 14 * k; r2[r] = -D[(size_t)k * 294 + 14 * 20 + i]; }
-        ex.sync();
-        band_solve(tmpv, r2, ls, ys);
-        // sol_tr = band(Ptr, 0): Ptr = Wv[o_tr+1 ..] on (dx,du), 0 on nu
-        for (int i = ex.lane(); i < L.nx + L.nu_; i += ex.nlanes()) tmpv[i] = Wv[L.o_tr + 1 + i];
-        ex.sync();
-        band_solve(tmpv, nullptr, ltr, ytr);
-        zero(tmpv, L.nx + L.nu_);
-        for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) tmpv[L.nx + L.nu_ + i] = Wv[L.o_nu + 1 + i];
-        ex.sync();
-        band_solve(tmpv, nullptr, lnu, ynu);
+        // border solves: three banded systems [Hb E'; E 0][l; y] = [g; r] sharing every matrix read
+        //   s  : g = 0,            r = -Sg   ->  S y = +Sg
+        //   tr : g = (Ptr, 0, 0),  r = 0     ->  S y = E_loc Hb^-1 g
+        //   nu : g = (0, 0, Pnu),  r = 0     ->  S y = hnui Pnu          (E_loc is the identity on the nu block)
+        {
+            const int nxu = L.nx + L.nu_;
+            double* g_tr = gx;     // nloc: Ptr on (dx,du), 0 on nu
+            for (int i = ex.lane(); i < L.nloc; i += ex.nlanes()) g_tr[i] = i < nxu ? Wv[L.o_tr + 1 + i] : 0.0;
+            ex.sync();
+            Hb_inv(g_tr, tmpl);
+            E_apply(tmpl, tmpy2, false);                       // r_tr
+            for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) {
+                const int k = r / 14, i = r - 14 * k;
+                tmpy[r] = D_[(size_t)k * 294 + 14 * 20 + i];  // r_s = +Sg
+                r2[r] = hnui_ * Wv[L.o_nu + 1 + r];           // r_nu
+            }
+            ex.sync();
+            S_solve3(tmpy, tmpy2, r2, ys, ytr, ynu, tchain, cy, dy);
+            Et_apply3(ys, ytr, ynu, tmpl, tmpl2, tmpv);
+            // l = Hb^-1 (g - E' y): assemble the three right-hand sides in place, then invert
+            for (int i = ex.lane(); i < L.nloc; i += ex.nlanes()) {
+                const bool isnu = i >= nxu;
+                const double e0 = isnu ? ys[i - nxu] : tmpl[i];
+                const double e1 = isnu ? ytr[i - nxu] : tmpl2[i];
+                const double e2 = isnu ? ynu[i - nxu] : tmpv[i];
+                tmpl[i] = -e0;
+                tmpl2[i] = g_tr[i] - e1;
+                tmpv[i] = (isnu ? Wv[L.o_nu + 1 + (i - nxu)] : 0.0) - e2;
+            }
+            ex.sync();
+            Hb_inv(tmpl, ls);
+            Hb_inv(tmpl2, ltr);
+            Hb_inv(tmpv, lnu);
+        }
         // border coefficients
         {
             double a = 0, b = 0, c = 0;
