@@ -25,6 +25,18 @@ struct HostEx {
     bool all(bool b) { return b; }
     double* scratch() { return sc; }
     static constexpr int kPrefetchRegs = 0;
+    // C(14x14) = (acc ? C : 0) + alpha * A(14 x Kd) B(Kd x 14); element strides: C(i,j) = C[i*sci + j*scj],
+    // A(i,k) = A[i*sai + k*sak], B(k,j) = B[k*sbk + j*sbj].  C must not alias A or B.
+    void tile_gemm(double* Cm, int sci, int scj, const double* A, int sai, int sak, const double* B, int sbk, int sbj,
+                   int Kd, double alpha, bool acc) {
+        for (int i = 0; i < 14; i++)
+            for (int j = 0; j < 14; j++) {
+                double s = 0;
+                for (int k = 0; k < Kd; k++) s += A[i * sai + k * sak] * B[k * sbk + j * sbj];
+                double* c = Cm + i * sci + j * scj;
+                *c = (acc ? *c : 0.0) + alpha * s;
+            }
+    }
     // L^-1 (row-major, lower) of the Cholesky factor of the SPD tile M
     bool chol_inv14(double* M, double* Li) {
         const bool ok = chol14(M);

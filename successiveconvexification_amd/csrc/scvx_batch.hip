@@ -53,6 +53,36 @@ struct WaveEx {
 
     static constexpr int kPrefetchRegs = 5;  // ceil(294 / 64): next D tile held in registers while segment k is processed
 
+    // C(14x14) = (acc ? C : 0) + alpha * A(14 x Kd) B(Kd x 14) on the FP64 matrix pipe: ceil(Kd/4) x
+    // v_mfma_f64_16x16x4_f64, tiles in LDS with arbitrary element strides (so transposes are free).
+    // Fragment maps (cdna guide §3, f64 form): A: lane l holds A[l&15][l>>4], B: lane l holds B[l>>4][l&15],
+    // C/D: register r of lane l is C[(l>>4) + 4r][l&15].  Rows/columns 14,15 and k >= Kd are fed zeros.
+    typedef double v4f64 __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ void tile_gemm(double* Cm, int sci, int scj, const double* A, int sai, int sak,
+                                              const double* B, int sbk, int sbj, int Kd, double alpha, bool acc) {
+        const int l = lane();
+        const int rc = l & 15, kq = l >> 4;
+        v4f64 c = {0.0, 0.0, 0.0, 0.0};
+        const bool in = rc < 14;
+        for (int k0 = 0; k0 < Kd; k0 += 4) {
+            const int k = k0 + kq;
+            const bool kin = in && (k < Kd);
+            const double a = kin ? A[rc * sai + k * sak] : 0.0;
+            const double b = kin ? B[k * sbk + rc * sbj] : 0.0;
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+        }
+        if (in) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = kq + 4 * r;
+                if (row < 14) {
+                    double* p = Cm + row * sci + rc * scj;
+                    *p = (acc ? *p : 0.0) + alpha * c[r];
+                }
+            }
+        }
+    }
+
     // Li = L^-1 (row-major, lower) where L L' = M, for the 14x14 SPD pivot tile in LDS.  Lane i keeps row i of
     // M/L in VGPRs; pivots, column entries and the rows needed by the inversion travel by readlane:
     // 105 broadcasts for the factorisation, 105 for the inverse, no barrier inside.

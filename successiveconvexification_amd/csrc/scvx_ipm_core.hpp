@@ -919,34 +919,29 @@ struct Solver {
         double* const Nb_ = Nb;
         const double hnui_ = hnui;
         double* sc = ex.scratch();
-        double* M = sc + 32;            // 196  pivot tile, then Wb scratch
+        double* M = sc + 32;            // 196  pivot tile / So / scratch product
         double* Wp = M + 196;           // 196  Wb[k-1]
         double* Li = Wp + 196;          // 196  Linv[k]
-        double* Dt = Li + 196;          // 294  D_k tile (column-major 14x21)
-        double* TA = Dt + 294;          // 196  A_k Hxi_k
-        double* TB = TA + 196;          // 42+42 TBm_k (row-major 14x3), TBp_k
-        double* Bp = TB + 84;           // 42   copy of Bp_k (column-major 14x3) kept across the D tile swap
+        double* Dt = Li + 196;          // 294  D_k tile (column-major 14x21: element (i,j) at 14 j + i)
+        double* T = Dt + 294;           // 308  [TA | TBm | TBp] = [A_k Hxi_k | Bm_k Hui_k | Bp_k Hui_{k+1}], 14 x 20, row stride 22
+        double* Bp = T + 308;           // 42   copy of Bp_k (column-major 14x3) kept across the D tile swap
         double* Hh = Bp + 42;           // 68   hx_k (25) hu_k (9) | hx_{k+1} (25) hu_{k+1} (9)
-        double* Hd = Hh + 68;           // 196  dense Hxi of the node being multiplied (fixed-trip inner products)
+        double* Hd = Hh + 68;           // 196  dense Hxi of the node being multiplied
+        constexpr int TS = 22;          // row stride of T (22: conflict-free fragment reads; 20 would be 2-way)
         bool ok = true;
+        // All 14x14xK products below go through ex.tile_gemm: FP64 MFMA (v_mfma_f64_16x16x4) on the device — one A and
+        // one B element per lane per instruction instead of 2 LDS reads per multiply-add — plain loops on the host.
         // prologue: D_0, hx_0/hu_0 -> LDS; TA_0, TBm_0
         for (int e = ex.lane(); e < 294; e += ex.nlanes()) Dt[e] = D_[e];
         for (int e = ex.lane(); e < 34; e += ex.nlanes()) Hh[34 + e] = e < 25 ? hx_[e] : hu_[e - 25];
         ex.sync();
         for (int e = ex.lane(); e < 196; e += ex.nlanes()) Hd[e] = hxi_entry(Hh + 34, e / 14, e % 14);
         ex.sync();
-        for (int e = ex.lane(); e < 196 + 42; e += ex.nlanes()) {
-            if (e < 196) {
-                const int i = e / 14, j = e - 14 * i;
-                double t = 0;
-                SCVX_UNROLL
-                for (int a = 0; a < 14; a++) t += Dt[14 * a + i] * Hd[14 * a + j];
-                TA[e] = t;
-            } else {
-                const int q = e - 196, i = q / 3, c = q - 3 * i;
-                const double* h = Hh + 34 + 25;
-                TB[q] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
-            }
+        ex.tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);          // TA_0 = A_0 Hxi_0
+        for (int q = ex.lane(); q < 42; q += ex.nlanes()) {
+            const int i = q / 3, c = q - 3 * i;
+            const double* h = Hh + 34 + 25;
+            T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
         }
         ex.sync();
         for (int k = 0; k < K; k++) {
@@ -967,27 +962,23 @@ struct Solver {
             }
             ex.sync();
             for (int e = ex.lane(); e < 196 + 42; e += ex.nlanes()) {
-                if (e < 196) Hd[e] = hxi_entry(Hh + 34, e / 14, e % 14);
-                else {  // TBp_k = Bp_k Hui_{k+1}
+                if (e < 196) {
+                    const int i = e / 14, j = e - 14 * i;
+                    const double h = hxi_entry(Hh + 34, i, j);
+                    Hd[e] = h;
+                    M[e] = h + (i == j ? hnui_ : 0.0);   // pivot tile starts from Hxi_{k+1} + hnui I
+                } else {  // TBp_k = Bp_k Hui_{k+1}
                     const int q = e - 196, i = q / 3, c = q - 3 * i;
                     const double* h = Hh + 34 + 25;
-                    TB[42 + q] = Dt[14 * 17 + i] * h[c] + Dt[14 * 18 + i] * h[3 + c] + Dt[14 * 19 + i] * h[6 + c];
+                    T[TS * i + 17 + c] = Dt[14 * 17 + i] * h[c] + Dt[14 * 18 + i] * h[3 + c] + Dt[14 * 19 + i] * h[6 + c];
                 }
             }
             ex.sync();
             SCVX_TE(ta_, 2);
             SCVX_TS(tb_);
-            // pivot tile
-            for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
-                const int i = e / 14, j = e - 14 * i;
-                double s = Hd[e] + (i == j ? hnui_ : 0.0);
-                double w = 0;
-                SCVX_UNROLL
-                for (int a = 0; a < 14; a++) { s += TA[14 * i + a] * Dt[14 * a + j]; w += Wp[14 * i + a] * Wp[14 * j + a]; }
-                SCVX_UNROLL
-                for (int c = 0; c < 3; c++) s += TB[3 * i + c] * Dt[14 * (14 + c) + j] + TB[42 + 3 * i + c] * Dt[14 * (17 + c) + j];
-                M[e] = (k > 0) ? s - w : s;
-            }
+            // pivot tile: M += [TA|TBm|TBp] [A|Bm|Bp]'  -  Wb_{k-1} Wb_{k-1}'
+            ex.tile_gemm(M, 14, 1, T, TS, 1, Dt, 14, 1, 20, 1.0, true);
+            if (k > 0) ex.tile_gemm(M, 14, 1, Wp, 14, 1, Wp, 1, 14, 14, -1.0, true);
             ex.sync();
             SCVX_TE(tb_, 5);
             SCVX_TS(tc_);
@@ -995,13 +986,11 @@ struct Solver {
             ex.sync();
             SCVX_TE(tc_, 12);
             SCVX_TS(td_);
-            for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
-                const int i = e / 14, j = e - 14 * i;
-                Linv_[(size_t)k * 196 + e] = Li[e];
-                double s = 0;   // Nf[k] = Linv_k Wb_{k-1}
-                SCVX_UNROLL
-                for (int c = 0; c < 14; c++) s += Li[14 * i + c] * Wp[14 * c + j];
-                if (k > 0) Nf_[(size_t)k * 196 + e] = s;
+            for (int e = ex.lane(); e < 196; e += ex.nlanes()) Linv_[(size_t)k * 196 + e] = Li[e];
+            if (k > 0) {  // Nf[k] = Linv_k Wb_{k-1}
+                ex.tile_gemm(M, 14, 1, Li, 14, 1, Wp, 14, 1, 14, 1.0, false);
+                ex.sync();
+                for (int e = ex.lane(); e < 196; e += ex.nlanes()) Nf_[(size_t)k * 196 + e] = M[e];
             }
             SCVX_TE(td_, 13);
             SCVX_TS(te_);
@@ -1016,43 +1005,25 @@ struct Solver {
                     for (int e = ex.lane(); e < 294; e += ex.nlanes()) Dt[e] = Dn[e];
                 }
                 ex.sync();
-                // TA_{k+1}, TBm_{k+1}
-                for (int e = ex.lane(); e < 196 + 42; e += ex.nlanes()) {
-                    if (e < 196) {
-                        const int i = e / 14, j = e - 14 * i;
-                        double t = 0;
-                        SCVX_UNROLL
-                        for (int a = 0; a < 14; a++) t += Dt[14 * a + i] * Hd[14 * a + j];
-                        TA[e] = t;
-                    } else {
-                        const int q = e - 196, i = q / 3, c = q - 3 * i;
-                        const double* h = Hh + 34 + 25;
-                        TB[q] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
-                    }
+                // TA_{k+1} = A_{k+1} Hxi_{k+1}, TBm_{k+1}
+                ex.tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
+                for (int q = ex.lane(); q < 42; q += ex.nlanes()) {
+                    const int i = q / 3, c = q - 3 * i;
+                    const double* h = Hh + 34 + 25;
+                    T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
                 }
                 ex.sync();
-                // So[k] = -TA_{k+1} + TBm_{k+1} Bp_k'  ->  Wb_k = So Linv'  (two passes through M)
+                // So[k] = -TA_{k+1} + TBm_{k+1} Bp_k'
                 for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
                     const int i = e / 14, j = e - 14 * i;
-                    M[e] = -TA[e] + TB[3 * i] * Bp[j] + TB[3 * i + 1] * Bp[14 + j] + TB[3 * i + 2] * Bp[28 + j];
+                    M[e] = -T[TS * i + j] + T[TS * i + 14] * Bp[j] + T[TS * i + 15] * Bp[14 + j] + T[TS * i + 16] * Bp[28 + j];
                 }
                 ex.sync();
-                for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
-                    const int i = e / 14, j = e - 14 * i;
-                    double s = 0;
-                    SCVX_UNROLL
-                    for (int c = 0; c < 14; c++) s += M[14 * i + c] * Li[14 * j + c];
-                    Wp[e] = s;
-                }
+                ex.tile_gemm(Wp, 14, 1, M, 14, 1, Li, 1, 14, 14, 1.0, false);      // Wb_k = So Linv'
                 ex.sync();
-                // Nb[k] = (Wb_k Linv_k)' : Nb[k][j][i] = sum_c Wb[i][c] Linv[c][j]
-                for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
-                    const int j = e / 14, i = e - 14 * j;
-                    double s = 0;
-                    SCVX_UNROLL
-                    for (int c = 0; c < 14; c++) s += Wp[14 * i + c] * Li[14 * c + j];
-                    Nb_[(size_t)k * 196 + e] = s;
-                }
+                ex.tile_gemm(M, 1, 14, Wp, 14, 1, Li, 14, 1, 14, 1.0, false);      // Nb[k] = (Wb_k Linv_k)' (stored transposed)
+                ex.sync();
+                for (int e = ex.lane(); e < 196; e += ex.nlanes()) Nb_[(size_t)k * 196 + e] = M[e];
             }
             ex.sync();
             SCVX_TE(te_, 14);
