@@ -15,6 +15,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #define SCVX_HD __host__ __device__ __forceinline__
@@ -518,22 +519,41 @@ struct Solver {
         return soc_maxstep_parts(l[0], d[off], l[0] * l[0] - ll, l[0] * d[off] - ld, d[off] * d[off] - dd);
     }
 
+    // ---- uniform iteration over the small cones: one strided loop per (dimension, block), dimension known at compile
+    // time so the per-cone code unrolls and its loads batch; f(std::integral_constant<int,D>, offset, cone index) ----
+    template <int D, class F>
+    SCVX_HD void each_small(int off0, int c0, int n, F&& f) {
+        for (int q = ex.lane(); q < n; q += ex.nlanes()) f(std::integral_constant<int, D>(), off0 + D * q, c0 + q);
+    }
+    template <class F>
+    SCVX_HD void all_small(F&& f, bool with_sg) {
+        const int K = L.K;
+        each_small<3>(L.o_gs, L.c_gs, 2 * K, f);            // gs, tilt are adjacent
+        each_small<4>(L.o_rate, L.c_rate, K, f);
+        each_small<1>(L.o_mass, L.c_mass, K, f);
+        each_small<4>(L.o_tb, L.c_tb, 2 * (K + 1), f);      // tb, tc are adjacent
+        each_small<1>(L.o_lb, L.c_lb, K + 1, f);
+        if (with_sg) { each_small<2>(L.o_sg, L.c_sg, 1, f); each_small<1>(L.o_rk, L.c_rk, 1, f); }
+    }
+
     // ---- NT scalings for every cone, lam = W z ----
     SCVX_HD_NI void nt_all() {
         SCVX_T0();
-        for (int c = ex.lane(); c < L.nsmall; c += ex.nlanes()) {
-            int off, d; L.small(c, off, d);
+        all_small([&](auto Dt_, int off, int c) {
+            constexpr int d = decltype(Dt_)::value;
             if (d == 1) {
                 Wbeta[c] = sqrt(S[off] / Z[off]);
                 lam[off] = sqrt(S[off] * Z[off]);
                 Wv[off] = 1.0;
             } else {
-                double beta;
-                soc_nt_small(S + off, Z + off, d, Wv + off, beta);
+                double beta, sv[d], zv[d], vv[d], lv[d];
+                for (int i = 0; i < d; i++) { sv[i] = S[off + i]; zv[i] = Z[off + i]; }
+                soc_nt_small(sv, zv, d, vv, beta);
+                soc_W_small(vv, beta, d, zv, lv, false);
                 Wbeta[c] = beta;
-                soc_W_small(Wv + off, beta, d, Z + off, lam + off, false);
+                for (int i = 0; i < d; i++) { Wv[off + i] = vv[i]; lam[off + i] = lv[i]; }
             }
-        }
+        }, false);
         big_nt(L.o_nu, 14 * L.K + 1, L.c_nu);
         big_nt(L.o_tr, 17 * (L.K + 1) + 1, L.c_tr);
         if (ex.lane() == 0) {
@@ -569,41 +589,38 @@ struct Solver {
     // out = W in  /  W^-1 in   (cone vectors; in may alias out)
     SCVX_HD_NI void W_all(const double* in, double* out, bool inverse) {
         SCVX_T0();
-        for (int c = ex.lane(); c < L.nsmall; c += ex.nlanes()) {
-            int off, d; L.small(c, off, d);
-            if (d == 1) out[off] = inverse ? in[off] / Wbeta[c] : in[off] * Wbeta[c];
+        all_small([&](auto Dt_, int off, int c) {
+            constexpr int d = decltype(Dt_)::value;
+            const double beta = Wbeta[c];
+            if (d == 1) out[off] = inverse ? in[off] / beta : in[off] * beta;
             else {
-                double tmp[4];
-                for (int i = 0; i < d; i++) tmp[i] = in[off + i];
-                soc_W_small(Wv + off, Wbeta[c], d, tmp, out + off, inverse);
+                double xv[d], vv[d], yv[d];
+                for (int i = 0; i < d; i++) { xv[i] = in[off + i]; vv[i] = Wv[off + i]; }
+                soc_W_small(vv, beta, d, xv, yv, inverse);
+                for (int i = 0; i < d; i++) out[off + i] = yv[i];
             }
-        }
+        }, true);
         big_W(L.o_nu, 14 * L.K + 1, L.c_nu, in, out, inverse);
         big_W(L.o_tr, 17 * (L.K + 1) + 1, L.c_tr, in, out, inverse);
-        if (ex.lane() == 0) {
-            double tmp[2] = {in[L.o_sg], in[L.o_sg + 1]};
-            soc_W_small(Wv + L.o_sg, Wbeta[L.c_sg], 2, tmp, out + L.o_sg, inverse);
-            out[L.o_rk] = inverse ? in[L.o_rk] / Wbeta[L.c_rk] : in[L.o_rk] * Wbeta[L.c_rk];
-        }
         ex.sync();
         SCVX_T1(8);
     }
     // out = lam \ d
     SCVX_HD_NI void div_all(const double* d, double* out) {
-        for (int c = ex.lane(); c < L.nsmall + 1; c += ex.nlanes()) {
-            int off, dm;
-            if (c < L.nsmall) L.small(c, off, dm); else { off = L.o_sg; dm = 2; }
+        all_small([&](auto Dt_, int off, int) {
+            constexpr int dm = decltype(Dt_)::value;
             if (dm == 1) out[off] = d[off] / lam[off];
             else {
-                const double* l = lam + off;
+                double l[dm], dv[dm];
+                for (int i = 0; i < dm; i++) { l[i] = lam[off + i]; dv[i] = d[off + i]; }
                 double ld = 0, ll = 0;
-                for (int i = 1; i < dm; i++) { ld += l[i] * d[off + i]; ll += l[i] * l[i]; }
-                const double x0 = (l[0] * d[off] - ld) / (l[0] * l[0] - ll);
-                for (int i = 1; i < dm; i++) out[off + i] = (d[off + i] - x0 * l[i]) / l[0];
+                for (int i = 1; i < dm; i++) { ld += l[i] * dv[i]; ll += l[i] * l[i]; }
+                const double x0 = (l[0] * dv[0] - ld) / (l[0] * l[0] - ll);
+                const double il0 = 1.0 / l[0];
+                for (int i = 1; i < dm; i++) out[off + i] = (dv[i] - x0 * l[i]) * il0;
                 out[off] = x0;
             }
-        }
-        if (ex.lane() == 0) out[L.o_rk] = d[L.o_rk] / lam[L.o_rk];
+        }, true);
         big_div(L.o_nu, 14 * L.K + 1, d, out);
         big_div(L.o_tr, 17 * (L.K + 1) + 1, d, out);
         ex.sync();
@@ -611,24 +628,19 @@ struct Solver {
     // out = base_sign * (lam o lam)  [mode 0: out = -lam o lam]
     //       mode 1: out = -lam o lam - sds o sdz + sigmu * e
     SCVX_HD_NI void centering_rhs(double* out, bool combined, double sigmu) {
-        for (int c = ex.lane(); c < L.nsmall + 1; c += ex.nlanes()) {
-            int off, dm;
-            if (c < L.nsmall) L.small(c, off, dm); else { off = L.o_sg; dm = 2; }
+        all_small([&](auto Dt_, int off, int) {
+            constexpr int dm = decltype(Dt_)::value;
             if (dm == 1) {
                 out[off] = -lam[off] * lam[off] + (combined ? (-sds[off] * sdz[off] + sigmu) : 0.0);
             } else {
-                const double* l = lam + off;
+                double l[dm], a[dm], b[dm];
+                for (int i = 0; i < dm; i++) { l[i] = lam[off + i]; a[i] = combined ? sds[off + i] : 0.0; b[i] = combined ? sdz[off + i] : 0.0; }
                 double ll = 0, ab = 0;
-                for (int i = 0; i < dm; i++) { ll += l[i] * l[i]; if (combined) ab += sds[off + i] * sdz[off + i]; }
-                for (int i = 1; i < dm; i++)
-                    out[off + i] = -2.0 * l[0] * l[i] - (combined ? (sds[off] * sdz[off + i] + sdz[off] * sds[off + i]) : 0.0);
+                for (int i = 0; i < dm; i++) { ll += l[i] * l[i]; ab += a[i] * b[i]; }
+                for (int i = 1; i < dm; i++) out[off + i] = -2.0 * l[0] * l[i] - (a[0] * b[i] + b[0] * a[i]);
                 out[off] = -ll + (combined ? (-ab + sigmu) : 0.0);
             }
-        }
-        if (ex.lane() == 0) {
-            const int off = L.o_rk;
-            out[off] = -lam[off] * lam[off] + (combined ? (-sds[off] * sdz[off] + sigmu) : 0.0);
-        }
+        }, true);
         const int offs[2] = {L.o_nu, L.o_tr};
         const int dims[2] = {14 * L.K + 1, 17 * (L.K + 1) + 1};
         for (int q = 0; q < 2; q++) {
@@ -647,20 +659,19 @@ struct Solver {
     }
     SCVX_HD_NI double maxstep_all(const double* d) {
         double amax = INFINITY;
-        for (int c = ex.lane(); c < L.nsmall + 1; c += ex.nlanes()) {
-            int off, dm;
-            if (c < L.nsmall) L.small(c, off, dm); else { off = L.o_sg; dm = 2; }
+        all_small([&](auto Dt_, int off, int) {
+            constexpr int dm = decltype(Dt_)::value;
             double a;
             if (dm == 1) a = d[off] < 0.0 ? -lam[off] / d[off] : INFINITY;
             else {
-                const double* l = lam + off;
+                double l[dm], dv[dm];
+                for (int i = 0; i < dm; i++) { l[i] = lam[off + i]; dv[i] = d[off + i]; }
                 double ll = 0, ld = 0, dd = 0;
-                for (int i = 1; i < dm; i++) { ll += l[i] * l[i]; ld += l[i] * d[off + i]; dd += d[off + i] * d[off + i]; }
-                a = soc_maxstep_parts(l[0], d[off], l[0] * l[0] - ll, l[0] * d[off] - ld, d[off] * d[off] - dd);
+                for (int i = 1; i < dm; i++) { ll += l[i] * l[i]; ld += l[i] * dv[i]; dd += dv[i] * dv[i]; }
+                a = soc_maxstep_parts(l[0], dv[0], l[0] * l[0] - ll, l[0] * dv[0] - ld, dv[0] * dv[0] - dd);
             }
             if (a < amax) amax = a;
-        }
-        if (d[L.o_rk] < 0.0) { const double a = -lam[L.o_rk] / d[L.o_rk]; if (a < amax) amax = a; }
+        }, true);
         amax = ex.min(amax);
         const double a1 = big_maxstep(L.o_nu, 14 * L.K + 1, d);
         const double a2 = big_maxstep(L.o_tr, 17 * (L.K + 1) + 1, d);
