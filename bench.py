@@ -51,6 +51,22 @@ def k1_measured_traffic(B):
     return best
 
 
+def k4_measured_traffic(B):
+    """HBM bytes per socp_kernel launch from the same committed PMC passes (lower bound: FETCH not doubled,
+    upper bound: FETCH doubled — the kernel mixes narrow strided and wide coalesced reads)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_B%d.json" % B))):
+        try:
+            k = json.load(open(f))["kernels"]["scvx::socp_kernel"]
+            n = k["launches_in_fetch_pass"]
+            best = {"lo": (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 / n,
+                    "hi": (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 / n, "source": os.path.basename(f)}
+        except Exception:
+            pass
+    return best
+
+
 def disperse_ics(p, lo, hi, seed, frac=0.1):
     """SURVEY.md §8d dispersion law; trajectory b draws from Philox stream b."""
     ic = np.zeros((hi - lo, 6))
@@ -238,6 +254,14 @@ def main():
                 "note": "K1 at rk4_npts=%d is FP64-FMA-bound, not HBM-bound (SURVEY 8d); traffic from PMC in profiles/" % args.npts,
             },
             "kernel_ms_per_step": {k: v / max(nprof, 1) for k, v in prof.items()},
+            "roofline_socp": (lambda t, ms: None if not t or ms <= 0 else {
+                "kernel": "scvx::socp_kernel (K4, 98 % of the step)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
+                "traffic_lo": t["lo"], "traffic_hi": t["hi"], "traffic_source": t["source"], "avg_launch_ms": ms,
+                "achieved_lo": t["lo"] / (ms * 1e-3) / 1e9, "achieved_hi": t["hi"] / (ms * 1e-3) / 1e9,
+                "frac_lo": t["lo"] / (ms * 1e-3) / HBM_PEAK, "frac_hi": t["hi"] / (ms * 1e-3) / HBM_PEAK,
+                "note": "measured HBM traffic of the per-trajectory working set (PMC), not an algorithmic minimum: the "
+                        "subproblem data (148 KB per trajectory) would fit on chip, the solver state (727 KB) does not",
+            })(k4_measured_traffic(B), prof["socp"] / max(nprof, 1)),
             "solver_stats_last_step": {"ipm_iters_mean": float(np.mean(its)), "ipm_iters_max": int(np.max(its)),
                                        "status_optimal_frac": float(np.mean(st == 0)), "merit_max": float(np.max(merit))},
         }
