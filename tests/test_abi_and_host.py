@@ -126,3 +126,15 @@ def test_shard_range_covers_everything():
         assert cuts[0][0] == 0 and cuts[-1][1] == total
         assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
         assert max(hi - lo for lo, hi in cuts) - min(hi - lo for lo, hi in cuts) <= 1
+
+
+def test_bench_roofline_byte_model_matches_survey():
+    """SURVEY.md §8d / BASELINE.md §3: algorithmic HBM bytes of K1 per trajectory."""
+    import bench
+    assert bench.k1_alg_bytes(50, 3, 8) == 130144
+    assert bench.k1_alg_bytes(50, 3, 4) == 65072
+    assert bench.k1_alg_bytes(100, 3, 4) == 130072
+    assert bench.k1_alg_bytes(100, 5, 4) == 153280
+    assert bench.HBM_PEAK == 8.0e12
+    t = bench.k1_measured_traffic(8192)
+    assert t is None or 0.9 < t["bytes"] / (bench.k1_alg_bytes(50) * 8192) < 1.2  # PMC: no wasted re-reads

@@ -116,3 +116,38 @@ def test_first_order_hold_and_zero_duration(exo):
     simpson = (g0 + 4 * gm + g1) / 6 / 51
     assert np.abs(d[1:, 20] - simpson[1:]).max() < 1e-12   # rows linear in u: one Simpson panel is exact
     assert abs(d[0, 20] - simpson[0]) < 1e-6               # mass row: -alpha*||u(t)|| is not linear in u
+
+
+def test_gap_to_the_reference_live_first_order_sensitivity(exo):
+    """the reference's live path declares jac = 0 (dynamics.jl:270) while paramjac carries the
+    true df/d(delta); if the sensitivity solver honours it, derivative = [I 0] + int F'(x(t)) dt — first order in dt.
+    The build integrates the exact variational equations; this test makes the deviation explicit: the gap is O(dt^2)
+    (ratio ~4 when dt halves) and ~1e-3 relative at the operating point, far above solver tolerances."""
+    p, par = exo
+    inp = _one_segment(p, 21)
+    inp[20] = 7.0
+
+    def first_order(dt, n=400):
+        # [I 0] + int_0^dt F'(x(t)) dt with F' = d(sigma g)/d[x,uk,up,sigma] along the exactly integrated state
+        acc = np.zeros((14, 21))
+        for s in range(n):
+            tm = (s + 0.5) / n
+            xm = od.segment(par, np.concatenate([inp[:14], inp[14:17], inp[14:17] * (1 - tm) + inp[17:20] * tm, [inp[20]]]),
+                            dt * tm, 8, with_deriv=False) if tm > 0 else inp[:14]
+            u = inp[14:17] * (1 - tm) + inp[17:20] * tm
+            A, Bu = od.jac(par, xm, u)
+            F = np.zeros((14, 21))
+            F[:, :14] = inp[20] * A
+            F[:, 14:17] = inp[20] * Bu * (1 - tm)
+            F[:, 17:20] = inp[20] * Bu * tm
+            F[:, 20] = od.rhs(par, xm, u)
+            acc += F * (dt / n)
+        acc[:, :14] += np.eye(14)
+        return acc
+
+    gaps = []
+    for dt in (1.0 / 51, 0.5 / 51):
+        _, d = od.segment(par, inp, dt, 10)
+        gaps.append(np.abs(d - first_order(dt)).max())
+    assert 3.0 < gaps[0] / gaps[1] < 5.0, gaps      # second order in dt
+    assert gaps[0] > 1e-4                            # not a rounding-level difference at the operating point
