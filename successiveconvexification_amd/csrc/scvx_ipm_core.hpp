@@ -99,7 +99,7 @@ struct Layout {
         n += (size_t)ny;                 // dk
         n += (size_t)nv * 8;             // V, rx, gx, dw, r1, cw, Vbest, tmpv
         n += (size_t)ny * 7;             // y, ry, dy, r2, cy, tmpy, tmpy2
-        n += (size_t)nc * 12;            // S, Z, rz, lam, Wv, t, Wibz, dS, dZ, sds, sdz, tmpc
+        n += (size_t)nc * 13;            // S, Z, rz, lam, Wv, t, Wibz, dS, dZ, sds, sdz, tmpc, Wirz
         n += (size_t)ncones;             // Wbeta
         n += (size_t)(K + 1) * 25 + (size_t)(K + 1) * 9;  // hx, hu
         n += (size_t)K * 196 * 4;        // Sd, Linv, Nf, Nb (So staged in Nb)
@@ -262,7 +262,7 @@ struct Solver {
     // workspace
     double *dk, *V, *rx, *gx, *dw, *r1, *cw, *Vbest, *tmpv;
     double *y, *ry, *dy, *r2, *cy, *tmpy, *tmpy2;
-    double *S, *Z, *rz, *lam, *Wv, *tt, *Wibz, *dS, *dZ, *sds, *sdz, *tmpc;
+    double *S, *Z, *rz, *lam, *Wv, *tt, *Wibz, *dS, *dZ, *sds, *sdz, *tmpc, *Wirz;
     double* Wbeta;
     double *hx, *hu;
     double *Linv, *Nf, *Nb, *Sd, *tchain;
@@ -285,6 +285,7 @@ struct Solver {
         y = w; w += ny; ry = w; w += ny; dy = w; w += ny; r2 = w; w += ny; cy = w; w += ny; tmpy = w; w += ny; tmpy2 = w; w += ny;
         S = w; w += nc; Z = w; w += nc; rz = w; w += nc; lam = w; w += nc; Wv = w; w += nc; tt = w; w += nc;
         Wibz = w; w += nc; dS = w; w += nc; dZ = w; w += nc; sds = w; w += nc; sdz = w; w += nc; tmpc = w; w += nc;
+        Wirz = w; w += nc;
         Wbeta = w; w += L.ncones;
         hx = w; w += (size_t)(K + 1) * HX_SZ; hu = w; w += (size_t)(K + 1) * 9;
         Linv = w; w += (size_t)K * 196; Nf = w; w += (size_t)K * 196; Nb = w; w += (size_t)K * 196; Sd = w; w += (size_t)K * 196;
@@ -1154,9 +1155,9 @@ struct Solver {
 
     // Newton step for centering right-hand side ds_rhs (cone vector); results in dw, dy, dZ, dS
     SCVX_HD_NI void newton(const double* ds_rhs) {
+        // Wirz = W^-1 rz is prepared once per iteration (shared by predictor and corrector)
         div_all(ds_rhs, tt);
-        W_all(rz, tmpc, true);
-        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) Wibz[i] = -tmpc[i] - tt[i];
+        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) Wibz[i] = -Wirz[i] - tt[i];
         ex.sync();
         W_all(Wibz, tmpc, true);
         cone_map_t(tmpc, gx);
@@ -1205,14 +1206,18 @@ struct Solver {
             for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) dy[i] += cy[i];
             ex.sync();
         }
+        // With wij = W^-1 J dw:   W^-1 ds = wij - W^-1 rz,   W dz = -(wij + W^-1 bz),   dz = W^-1 (W dz),   ds = J dw - rz
+        // so the scaled directions the step-length rule needs come for free (no further scaling passes).
         cone_map(dw, dS, false);  // J dw
+        W_all(dS, tmpc, true);    // wij
+        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) {
+            const double wij = tmpc[i];
+            sds[i] = wij - Wirz[i];
+            sdz[i] = -(wij + Wibz[i]);
+            dS[i] = dS[i] - rz[i];
+        }
         ex.sync();
-        W_all(dS, tmpc, true);
-        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) tmpc[i] += Wibz[i];
-        ex.sync();
-        W_all(tmpc, dZ, true);
-        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) { dZ[i] = -dZ[i]; dS[i] = dS[i] - rz[i]; }
-        ex.sync();
+        W_all(sdz, dZ, true);
     }
 
     SCVX_HD_NI void shift_into_cone(double* X) {
@@ -1360,10 +1365,9 @@ struct Solver {
             nt_all();
             if (!build_kkt()) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
             const double mu = gap / degree;
+            W_all(rz, Wirz, true);
             centering_rhs(tt, false, 0.0);   // affine (predictor) right-hand side, consumed in place by newton
             { SCVX_TS(tN_); newton(tt); SCVX_TE(tN_, 10); }
-            W_all(dS, sds, true);
-            W_all(dZ, sdz, false);
             double a1 = maxstep_all(sds), a2 = maxstep_all(sdz);
             double alpha = a1 < a2 ? a1 : a2;
             if (alpha > 1.0) alpha = 1.0;
@@ -1371,8 +1375,6 @@ struct Solver {
             SCVX_DBG("    aff alpha %.6e (a1 %.3e a2 %.3e) |dw|^2 %.6e ds %.6e dtnu %.6e dttr %.6e\n", alpha, a1, a2, dot(dw, dw, L.nv), dw[L.iS], dw[L.iTNU], dw[L.iTTR]);
             centering_rhs(tt, true, sig * mu);
             { SCVX_TS(tN_); newton(tt); SCVX_TE(tN_, 10); }
-            W_all(dS, sds, true);
-            W_all(dZ, sdz, false);
             a1 = maxstep_all(sds); a2 = maxstep_all(sdz);
             alpha = 0.99 * (a1 < a2 ? a1 : a2);
             if (alpha > 1.0) alpha = 1.0;
