@@ -5,7 +5,8 @@
 // fixed-step RK4 it names in Dynamics.rk4 (dynamics.jl:112-134, `npts` substeps, FOH control at
 // substep start / middle / end) without that routine's stage bug (:126-128 drop the step size).
 //
-// K1 work decomposition (wave64): the 21 columns of the 14x21 sensitivity
+// K1 work decomposition (wave64; aero instantiation — the exo one drops six closed-form columns, see K1Map):
+// the 21 columns of the 14x21 sensitivity
 //     d x(t) / d [x_k | u_k | u_{k+1} | sigma]
 // obey independent linear ODEs once the state trajectory is known, so ONE LANE OWNS ONE COLUMN and
 // keeps it, its RK4 accumulator and its stage value in VGPRs (no LDS traffic, no cross-lane
@@ -20,23 +21,35 @@
 namespace scvx {
 
 constexpr int WAVES_PER_BLOCK = 4;
-constexpr int SEG_PER_WAVE = 3;
-constexpr int TILE = SEG_PER_WAVE * 21 * 14;  // 882 doubles per wavefront
+
+// Lanes per segment and segments per wavefront.
+//   aero : 21 lanes, one per column, 3 segments per wave (63 lanes).
+//   exo  : 15 lanes, 4 segments per wave (60 lanes).  Without aerodynamics nothing depends on position or velocity
+//          except r' = sigma v, so six columns are closed form under RK4 (exact for polynomials in t):
+//            d x(dt)/d r_k = [0; I; 0; 0; 0],   d x(dt)/d v_k = [0; sigma dt I; I; 0; 0]
+//          and only the columns of m, q(4), w(3), u_k(3), u_{k+1}(3), sigma are integrated.
+template <bool AERO> struct K1Map { static constexpr int LPS = 21, SPW = 3; };
+template <> struct K1Map<false> { static constexpr int LPS = 15, SPW = 4; };
+__device__ __forceinline__ int exo_slot_to_col(int slot) {  // 0 -> m, 1..7 -> q,w, 8..14 -> u_k,u_{k+1},sigma
+    return slot == 0 ? 0 : slot + 6;
+}
 
 template <bool AERO>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void linearize_kernel(
     DynParams p, long nseg, int K, const double* __restrict__ x, const double* __restrict__ u,
     const double* __restrict__ sigma, double dt, int nsub, double* __restrict__ endpoint,
     double* __restrict__ deriv) {
-    __shared__ __attribute__((aligned(16))) double tile[WAVES_PER_BLOCK][64 * 14];
+    constexpr int LPS = K1Map<AERO>::LPS, SPW = K1Map<AERO>::SPW;
+    __shared__ __attribute__((aligned(16))) double tile[WAVES_PER_BLOCK][SPW * 294];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const long gwave = (long)blockIdx.x * WAVES_PER_BLOCK + wave;
-    const int sl = lane / 21;
-    const int col = lane - sl * 21;
-    const long seg0 = gwave * SEG_PER_WAVE;
+    const int sl = lane / LPS;
+    const int slot = lane - sl * LPS;
+    const int col = AERO ? slot : exo_slot_to_col(slot);
+    const long seg0 = gwave * SPW;
     long seg = seg0 + sl;
-    const bool active = (sl < SEG_PER_WAVE) && (seg < nseg);
+    const bool active = (sl < SPW) && (seg < nseg);
     if (!active) seg = (seg0 < nseg) ? seg0 : nseg - 1;  // idle lanes shadow a valid segment, never store
     const long b = seg / K;
     const int k = (int)(seg - b * K);
@@ -100,23 +113,33 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void linearize_kernel(
         }
     }
 
-    // ---- epilogue: LDS transpose -> coalesced 16-byte stores of the wave's contiguous tile ----
+    // ---- epilogue: columns into the LDS tile -> coalesced 16-byte stores of the wave's contiguous tile ----
     double* t = tile[wave];
+    if (sl < SPW) {
 #pragma unroll
-    for (int i = 0; i < 14; i++) t[lane * 14 + i] = c[i];
+        for (int i = 0; i < 14; i++) t[sl * 294 + col * 14 + i] = c[i];
+        if (!AERO && slot < 6) {  // closed-form columns: slots 0..2 write d/dr_k, slots 3..5 write d/dv_k
+            const int j = slot < 3 ? slot : slot - 3;
+            double* cc = t + sl * 294 + (slot < 3 ? 1 + j : 4 + j) * 14;
+#pragma unroll
+            for (int i = 0; i < 14; i++) cc[i] = 0.0;
+            if (slot < 3) cc[1 + j] = 1.0;
+            else { cc[1 + j] = sig * dt; cc[4 + j] = 1.0; }
+        }
+    }
     __syncthreads();
     if (seg0 < nseg) {
         const long rem = nseg - seg0;
-        const int nvalid = rem < SEG_PER_WAVE ? (int)rem : SEG_PER_WAVE;
+        const int nvalid = rem < SPW ? (int)rem : SPW;
         const int n2 = nvalid * 147;  // double2 elements in the tile (294 / 2 per segment)
         double2* out = reinterpret_cast<double2*>(deriv + (size_t)seg0 * 294);
         const double2* src = reinterpret_cast<const double2*>(t);
 #pragma unroll
-        for (int r = 0; r < 7; r++) {
+        for (int r = 0; r < (SPW * 147 + 63) / 64; r++) {
             const int e = lane + 64 * r;
             if (e < n2) out[e] = src[e];
         }
-        if (active && col == 0) {
+        if (active && slot == 0) {
             double* ep = endpoint + (size_t)seg * 14;
 #pragma unroll
             for (int i = 0; i < 14; i++) ep[i] = xs[i];
@@ -178,7 +201,8 @@ hipError_t launch_linearize(const scvx_ctx* ctx, int B, int K, const double* x, 
                             double dt, double* endpoint, double* deriv, hipStream_t st) {
     const long nseg = (long)B * K;
     if (nseg == 0) return hipSuccess;
-    const long nwave = (nseg + SEG_PER_WAVE - 1) / SEG_PER_WAVE;
+    const int spw = ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW;
+    const long nwave = (nseg + spw - 1) / spw;
     const unsigned grid = (unsigned)((nwave + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
     if (ctx->dyn.aero)
         hipLaunchKernelGGL(linearize_kernel<true>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, st, ctx->dyn, nseg, K, x,
