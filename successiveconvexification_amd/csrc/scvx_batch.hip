@@ -242,7 +242,7 @@ struct WaveEx {
 };
 
 // info[b] = {status, iters, merit, pobj}
-__global__ __launch_bounds__(64, 2) void socp_kernel(ipm::Consts C, int B, size_t work_stride,
+__global__ __launch_bounds__(64, 3) void socp_kernel(ipm::Consts C, int B, size_t work_stride,
                                                   const double* __restrict__ x, const double* __restrict__ u,
                                                   const double* __restrict__ endpoint, const double* __restrict__ deriv,
                                                   const double* __restrict__ rk, const double* __restrict__ ic,
