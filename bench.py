@@ -265,7 +265,7 @@ def main():
             "solver_stats_last_step": {"ipm_iters_mean": float(np.mean(its)), "ipm_iters_max": int(np.max(its)),
                                        "status_optimal_frac": float(np.mean(st == 0)), "merit_max": float(np.max(merit))},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.npts, args.seed)
         print(json.dumps(line), flush=True)
     if dist is not None:
