@@ -1,5 +1,6 @@
 // C ABI of libscvx_hip.so: context management and the discretisation entry points (include/scvx.h).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "scvx_internal.hpp"
@@ -124,6 +125,7 @@ int scvx_ctx_create(const scvx_problem* p, int device, scvx_ctx** out) {
         return SCVX_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (const char* v = std::getenv("SCVX_K1_VARIANT")) ctx->k1_variant = std::atoi(v) ? 1 : 0;
     *out = ctx;
     return SCVX_OK;
 }

@@ -348,4 +348,91 @@ __device__ __forceinline__ void column_deriv(const DynParams& p, const Stage<AER
     for (int i = 0; i < 14; i++) dc[i] = fma(sigma, a[i], gsel * s.g[i]);
 }
 
+// ---- producer / consumer form of the stage: what a column needs to know about the state trajectory ----
+// Coefficient record of one RK stage of one segment (NCOEF doubles, stored [field][segment] in LDS):
+//   g[14] | C[9] | invm | am[3] | Dq[12] | Mw[9] | q[4] | w[3] | ku[3] = -alpha u/|u| | (aero) Dv[9]
+template <bool AERO> struct StageRec { static constexpr int N = AERO ? 67 : 58; };
+
+template <bool AERO>
+__device__ __forceinline__ void stage_publish(const DynParams& p, const Stage<AERO>& s, const double* x, const double* u,
+                                              double* rec, int stride) {
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) rec[(o++) * stride] = s.g[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) rec[(o++) * stride] = s.C[i];
+    rec[(o++) * stride] = s.invm;
+#pragma unroll
+    for (int i = 0; i < 3; i++) rec[(o++) * stride] = s.am[i];
+#pragma unroll
+    for (int i = 0; i < 12; i++) rec[(o++) * stride] = s.Dq[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) rec[(o++) * stride] = s.Mw[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) rec[(o++) * stride] = x[7 + i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) rec[(o++) * stride] = x[11 + i];
+    const double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    const double k = un > 0.0 ? -p.alpha / un : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) rec[(o++) * stride] = k * u[i];
+    if (AERO) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) rec[(o++) * stride] = s.Dv[i];
+    }
+}
+
+// d/dt of one sensitivity column from a published stage record (same arithmetic as column_deriv)
+template <bool AERO>
+__device__ __forceinline__ void column_deriv_rec(const DynParams& p, const double* rec, int stride, const double* c,
+                                                 const double* wc, double gsel, double sigma, double* dc) {
+    // the whole record into registers first: 58 (67) independent LDS reads in flight, one wait — read one at a
+    // time each multiply-add would expose a full LDS latency with only two waves per SIMD to hide it
+    constexpr int NR = StageRec<AERO>::N;
+    double rr[NR];
+#pragma unroll
+    for (int i = 0; i < NR; i++) rr[i] = rec[i * stride];
+    auto R = [&](int i) { return rr[i]; };
+    const int oC = 14, oInvm = 23, oAm = 24, oDq = 27, oMw = 39, oQ = 48, oW = 52, oKu = 55, oDv = 58;
+    double a[14];
+    a[0] = R(oKu) * wc[0] + R(oKu + 1) * wc[1] + R(oKu + 2) * wc[2];
+    a[1] = c[4]; a[2] = c[5]; a[3] = c[6];
+    const double invm = R(oInvm);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double t = R(oAm + i) * c[0];
+        t = fma(R(oDq + 4 * i), c[7], t);
+        t = fma(R(oDq + 4 * i + 1), c[8], t);
+        t = fma(R(oDq + 4 * i + 2), c[9], t);
+        t = fma(R(oDq + 4 * i + 3), c[10], t);
+        if (AERO) {
+            t = fma(R(oDv + 3 * i), c[4], t);
+            t = fma(R(oDv + 3 * i + 1), c[5], t);
+            t = fma(R(oDv + 3 * i + 2), c[6], t);
+        }
+        t = fma((R(oC + 3 * i) * wc[0] + R(oC + 3 * i + 1) * wc[1] + R(oC + 3 * i + 2) * wc[2]), invm, t);
+        a[4 + i] = t;
+    }
+    const double q0 = R(oQ), q1 = R(oQ + 1), q2 = R(oQ + 2), q3 = R(oQ + 3);
+    const double w0 = R(oW), w1 = R(oW + 1), w2 = R(oW + 2);
+    const double cq0 = c[7], cq1 = c[8], cq2 = c[9], cq3 = c[10];
+    const double cw0 = c[11], cw1 = c[12], cw2 = c[13];
+    a[7] = 0.5 * (-w0 * cq1 - w1 * cq2 - w2 * cq3 - q1 * cw0 - q2 * cw1 - q3 * cw2);
+    a[8] = 0.5 * (w0 * cq0 + w2 * cq2 - w1 * cq3 + q0 * cw0 - q3 * cw1 + q2 * cw2);
+    a[9] = 0.5 * (w1 * cq0 - w2 * cq1 + w0 * cq3 + q3 * cw0 + q0 * cw1 - q1 * cw2);
+    a[10] = 0.5 * (w2 * cq0 + w1 * cq1 - w0 * cq2 - q2 * cw0 + q1 * cw1 + q0 * cw2);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double t = R(oMw + 3 * i) * cw0;
+        t = fma(R(oMw + 3 * i + 1), cw1, t);
+        t = fma(R(oMw + 3 * i + 2), cw2, t);
+        t = fma(p.JrT[3 * i], wc[0], t);
+        t = fma(p.JrT[3 * i + 1], wc[1], t);
+        t = fma(p.JrT[3 * i + 2], wc[2], t);
+        a[11 + i] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) dc[i] = fma(sigma, a[i], gsel * R(i));
+}
+
 }  // namespace scvx

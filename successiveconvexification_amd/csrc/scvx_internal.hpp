@@ -12,6 +12,7 @@ struct scvx_ctx {
     scvx_problem prob{};
     scvx::DynParams dyn{};
     int nsub = 10;
+    int k1_variant = 1;  // 0: one-lane-per-column kernel, 1: producer/consumer kernel (SCVX_K1_VARIANT overrides)
     double* d_cdrag = nullptr;
     double* d_clift = nullptr;
     std::string err;
