@@ -20,6 +20,7 @@ struct HostEx {
     int lane() const { return 0; }
     int nlanes() const { return 1; }
     void sync() {}
+    void sync_lds() {}
     double sum(double x) { return x; }
     double min(double x) { return x; }
     bool all(bool b) { return b; }

@@ -31,6 +31,14 @@ struct WaveEx {
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int nlanes() const { return 64; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
+    // LDS-only ordering inside the single wavefront of the block: a release/acquire pair restricted to the local
+    // address space compiles to `s_waitcnt lgkmcnt(0)` — global loads (prefetches) and stores stay in flight,
+    // whereas __syncthreads() / an unrestricted workgroup fence drains vmcnt(0) at every phase boundary.
+    __device__ __forceinline__ void sync_lds() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
     __device__ __forceinline__ double sum(double x) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -164,9 +172,7 @@ struct WaveEx {
                     if (l < 4) slot[l + 192] = st[q][3];
                     const double zc = zs[q];
                     if (step + R < nsteps) issue(step + R, st[q], zs[q]);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    sync_lds();
                     const double* row = slot + 14 * i;
                     double a0 = zc, a1 = 0.0;
 #pragma unroll
@@ -220,9 +226,7 @@ struct WaveEx {
                     if (l < 4) slot[l + 192] = st[q][3];
                     const double c0 = zs[q][0], c1 = zs[q][1], c2 = zs[q][2];
                     if (step + R < nsteps) issue(step + R, st[q], zs[q]);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    sync_lds();
                     const double* row = slot + 14 * i;
                     double a0 = c0, a1 = c1, a2 = c2;
 #pragma unroll

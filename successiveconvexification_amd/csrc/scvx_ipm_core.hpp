@@ -946,16 +946,16 @@ struct Solver {
         // prologue: D_0, hx_0/hu_0 -> LDS; TA_0, TBm_0
         for (int e = ex.lane(); e < 294; e += ex.nlanes()) Dt[e] = D_[e];
         for (int e = ex.lane(); e < 34; e += ex.nlanes()) Hh[34 + e] = e < 25 ? hx_[e] : hu_[e - 25];
-        ex.sync();
+        ex.sync_lds();
         for (int e = ex.lane(); e < 196; e += ex.nlanes()) Hd[e] = hxi_entry(Hh + 34, e / 14, e % 14);
-        ex.sync();
+        ex.sync_lds();
         ex.tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);          // TA_0 = A_0 Hxi_0
         for (int q = ex.lane(); q < 42; q += ex.nlanes()) {
             const int i = q / 3, c = q - 3 * i;
             const double* h = Hh + 34 + 25;
             T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
         }
-        ex.sync();
+        ex.sync_lds();
         for (int k = 0; k < K; k++) {
             SCVX_TS(ta_);
             // prefetch the next segment's tile
@@ -972,7 +972,7 @@ struct Solver {
                 Hh[e] = Hh[34 + e];
                 Hh[34 + e] = nk1;
             }
-            ex.sync();
+            ex.sync_lds();
             for (int e = ex.lane(); e < 196 + 42; e += ex.nlanes()) {
                 if (e < 196) {
                     const int i = e / 14, j = e - 14 * i;
@@ -985,23 +985,23 @@ struct Solver {
                     T[TS * i + 17 + c] = Dt[14 * 17 + i] * h[c] + Dt[14 * 18 + i] * h[3 + c] + Dt[14 * 19 + i] * h[6 + c];
                 }
             }
-            ex.sync();
+            ex.sync_lds();
             SCVX_TE(ta_, 2);
             SCVX_TS(tb_);
             // pivot tile: M += [TA|TBm|TBp] [A|Bm|Bp]'  -  Wb_{k-1} Wb_{k-1}'
             ex.tile_gemm(M, 14, 1, T, TS, 1, Dt, 14, 1, 20, 1.0, true);
             if (k > 0) ex.tile_gemm(M, 14, 1, Wp, 14, 1, Wp, 1, 14, 14, -1.0, true);
-            ex.sync();
+            ex.sync_lds();
             SCVX_TE(tb_, 5);
             SCVX_TS(tc_);
             ok = ex.chol_inv14(M, Li) && ok;   // L^-1 of the pivot tile -> Li (row-major, lower, zeros above)
-            ex.sync();
+            ex.sync_lds();
             SCVX_TE(tc_, 12);
             SCVX_TS(td_);
             for (int e = ex.lane(); e < 196; e += ex.nlanes()) Linv_[(size_t)k * 196 + e] = Li[e];
             if (k > 0) {  // Nf[k] = Linv_k Wb_{k-1}
                 ex.tile_gemm(M, 14, 1, Li, 14, 1, Wp, 14, 1, 14, 1.0, false);
-                ex.sync();
+                ex.sync_lds();
                 for (int e = ex.lane(); e < 196; e += ex.nlanes()) Nf_[(size_t)k * 196 + e] = M[e];
             }
             SCVX_TE(td_, 13);
@@ -1009,14 +1009,14 @@ struct Solver {
             if (k + 1 < K) {
                 // keep Bp_k, swap in D_{k+1}
                 for (int q = ex.lane(); q < 42; q += ex.nlanes()) Bp[q] = Dt[14 * 17 + q];
-                ex.sync();
+                ex.sync_lds();
                 if (NPRE > 0) {
                     SCVX_UNROLL
                     for (int q = 0; q < NPRE; q++) { const int e = ex.lane() + ex.nlanes() * q; if (e < 294) Dt[e] = pre[q]; }
                 } else {
                     for (int e = ex.lane(); e < 294; e += ex.nlanes()) Dt[e] = Dn[e];
                 }
-                ex.sync();
+                ex.sync_lds();
                 // TA_{k+1} = A_{k+1} Hxi_{k+1}, TBm_{k+1}
                 ex.tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
                 for (int q = ex.lane(); q < 42; q += ex.nlanes()) {
@@ -1024,22 +1024,23 @@ struct Solver {
                     const double* h = Hh + 34 + 25;
                     T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
                 }
-                ex.sync();
+                ex.sync_lds();
                 // So[k] = -TA_{k+1} + TBm_{k+1} Bp_k'
                 for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
                     const int i = e / 14, j = e - 14 * i;
                     M[e] = -T[TS * i + j] + T[TS * i + 14] * Bp[j] + T[TS * i + 15] * Bp[14 + j] + T[TS * i + 16] * Bp[28 + j];
                 }
-                ex.sync();
+                ex.sync_lds();
                 ex.tile_gemm(Wp, 14, 1, M, 14, 1, Li, 1, 14, 14, 1.0, false);      // Wb_k = So Linv'
-                ex.sync();
+                ex.sync_lds();
                 ex.tile_gemm(M, 1, 14, Wp, 14, 1, Li, 14, 1, 14, 1.0, false);      // Nb[k] = (Wb_k Linv_k)' (stored transposed)
-                ex.sync();
+                ex.sync_lds();
                 for (int e = ex.lane(); e < 196; e += ex.nlanes()) Nb_[(size_t)k * 196 + e] = M[e];
             }
-            ex.sync();
+            ex.sync_lds();
             SCVX_TE(te_, 14);
         }
+        ex.sync();   // the factors written above are read back (by other lanes) in the border solves
         SCVX_TE(tC_, 6);
         SCVX_TS(tB_);
         // border solves: three banded systems [Hb E'; E 0][l; y] = [g; r] sharing every matrix read
