@@ -51,12 +51,20 @@ struct HostEx {
         return ok;
     }
     // in-place Cholesky of a 14x14 SPD tile (row-major, lower triangle on output)
+    // Dynamic regularisation (as in ECOS / QDLDL-style KKT solvers): a pivot below 1e-13 * max diagonal — the Schur
+    // complement is numerically semidefinite in the IPM endgame — is clamped to that value; the perturbation is
+    // absorbed by the iterative refinement of the Newton solve.  Only a non-finite pivot is a failure.
     bool chol14(double* M) {
         bool ok = true;
+        double dmax = 0.0;
+        for (int j = 0; j < 14; j++) dmax = M[15 * j] > dmax ? M[15 * j] : dmax;
+        const double floor_ = 1e-13 * dmax;
         for (int j = 0; j < 14; j++) {
-            const double piv = M[15 * j];
-            if (!(piv > 0.0)) ok = false;
-            const double ip = 1.0 / std::sqrt(piv > 0.0 ? piv : 1.0);
+            double piv = M[15 * j];
+            if (!(piv == piv) || !(dmax > 0.0)) ok = false;
+            if (!(piv > floor_)) piv = floor_ > 0.0 ? floor_ : 1.0;
+            const double ip = 1.0 / std::sqrt(piv);
+            M[15 * j] = piv;
             for (int i = j; i < 14; i++) M[14 * i + j] *= ip;
             for (int a = j + 1; a < 14; a++)
                 for (int b = j + 1; b <= a; b++) M[14 * a + b] -= M[14 * a + j] * M[14 * b + j];

@@ -100,13 +100,19 @@ struct WaveEx {
         double m[14];
 #pragma unroll
         for (int c = 0; c < 14; c++) m[c] = M[14 * r + c];
-        bool ok = true;
+        // dynamic regularisation (same rule as the host executor): pivots below 1e-13 * max diagonal are clamped
+        double dmax = 0.0;
+#pragma unroll
+        for (int j = 0; j < 14; j++) dmax = fmax(dmax, M[15 * j]);   // same address in every lane: LDS broadcast reads
+        const double floor_ = fmax(1e-13 * dmax, 1e-300);
+        bool ok = dmax > 0.0;
 #pragma unroll
         for (int j = 0; j < 14; j++) {
-            const double d = bcast(m[j], j);
-            ok = ok && (d > 0.0);
-            const double ip = 1.0 / sqrt(d > 0.0 ? d : 1.0);
-            if (i >= j) m[j] *= ip;
+            const double d0 = bcast(m[j], j);
+            ok = ok && (d0 == d0);
+            const double d = fmax(d0, floor_);          // NaN-safe: fmax returns the non-NaN operand
+            const double ip = 1.0 / sqrt(d);
+            m[j] = (i == j) ? d * ip : m[j] * ip;       // rows above j hold junk in column j, never read
 #pragma unroll
             for (int c = j + 1; c < 14; c++) {
                 const double lcj = bcast(m[j], c);

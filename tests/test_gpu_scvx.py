@@ -285,3 +285,35 @@ def test_other_horizons_match_cpu_twin(K):
     assert np.abs(x - (xb + tw["dx"])).max() < 5e-4 and np.abs(u - (ub + tw["du"])).max() < 5e-4
     st2, nun, dj = b.solve_step()
     assert np.all(st2 == 1)
+
+
+def test_flyable_problem_converges_and_freezes():
+    """A variant of the sample problem with enough propellant (the reference's own sample never converges: 71 kg):
+    every trajectory reaches SCVX_ST_CONVERGED (||nu|| <= nuTol and dJ <= delTol, rocketland.jl:436) with nu driven to
+    zero, converged trajectories are frozen, and the conic solver never fails in the harder endgame where the nu-cone
+    collapses to its vertex (dynamic pivot regularisation)."""
+    from dataclasses import replace
+    import bench
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    p = replace(sp.base_prob_scaled, mdry=0.55, nuTol=1e-6, delTol=1e-3, imax=40, tf_guess=8.0)
+    B = 8
+    c = IntegratorCache(p, npts=10)
+    b = ScvxBatch(c, B).init(bench.disperse_ics(p, 0, B, 7))
+    st, it, nu, dj = b.solve()
+    assert np.all(st == 0), (st, it)
+    assert np.all(it < p.imax - 1) and nu.max() < 1e-6 and np.all(dj <= p.delTol)
+    x, u, s = b.trajectory()
+    K = p.K
+    # the converged trajectories are dynamically feasible: nonlinear re-propagation closes the defects
+    from successiveconvexification_amd.dynamics import propagate_batch
+    xp = propagate_batch(c, x, u, s, 1.0 / (K + 1))
+    assert np.abs(xp - x[:, 1:]).max() < 1e-5
+    assert (x[:, -1, 0] > p.mdry).all() and (s > 5).all()
+    un = np.linalg.norm(u, axis=-1)
+    assert (un <= p.Tmax + 1e-6).all() and (un >= p.Tmin - 1e-4).all()
+    # frozen: another solve_step changes nothing for converged trajectories
+    before = b.trajectory_record().copy()
+    st2, _, _ = b.solve_step()
+    assert np.array_equal(b.trajectory_record(), before) and np.all(st2 == 0)
