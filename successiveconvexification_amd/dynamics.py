@@ -126,3 +126,11 @@ def predict_state(initial_state, uk, up, sigma, dt, pinfo, cache: IntegratorCach
     u[0, 0] = uk
     u[0, 1] = up
     return propagate_batch(cache, x, u, np.array([float(sigma)]), dt)[0, 0]
+
+
+def next_step(dynam, ab, abn, state, control_k, control_kp, sigma, sigHat, relax):
+    """autodiff_dynamics.jl:104-107 / old_dynamics.jl:150-153: the affine prediction of the next node from a LinRes,
+    derivative * [dx; du_k; du_{k+1}; dsigma] + endpoint + relax (host-side helper, a 14x21 product)."""
+    ctrl = np.concatenate([np.asarray(state) - ab.state, np.asarray(control_k) - ab.control,
+                           np.asarray(control_kp) - abn.control, [sigma - sigHat]])
+    return dynam.derivative @ ctrl + dynam.endpoint + relax

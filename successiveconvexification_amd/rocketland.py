@@ -1,6 +1,7 @@
 """Rocketland — the reference's SCvx driver API (rocketland.jl), one trajectory at a time, over the HIP path.
 
     create_initial(problem, cache) -> ProblemIteration            rocketland.jl:34-39
+    run_iters(iprob, niters, cache) -> (trajectories, tfs)        rocketland.jl:420-430
     solve_step(iteration, cache) -> (ProblemIteration, |nu|, dJ)  rocketland.jl:226-321
     solve_problem(iprob, cache) -> (ProblemIteration, cnu, cdel)  rocketland.jl:432-443
 The recipe of rocketland.jl:26-32 reads the same here:
@@ -48,3 +49,17 @@ def solve_problem(iprob: DescentProblem, cache: IntegratorCache):
         prob, cnu, cdel = solve_step(prob, cache)
         it += 1
     return prob, cnu, cdel
+
+
+def run_iters(iprob: DescentProblem, niters: int, cache: IntegratorCache = None):
+    """rocketland.jl:420-430: niters solve_steps, keeping the position history r[3][K+1] and sigma of every iterate
+    (the reference's version calls 1-argument create_initial/solve_step that do not exist at HEAD; the cache is
+    explicit here)."""
+    cache = cache if cache is not None else IntegratorCache(iprob)
+    ip = create_initial(iprob, cache)
+    trjs, tfs = [], []
+    for _ in range(niters):
+        ip, _, _ = solve_step(ip, cache)
+        tfs.append(ip.sigma)
+        trjs.append(np.stack([pt.state[1:4] for pt in ip.about], axis=1))
+    return trjs, tfs

@@ -175,6 +175,15 @@ def test_rocketland_mirror_single_trajectory():
     assert np.abs(lr[3].derivative - pi1.dynam[3].derivative).max() < 1e-13
     xe = predict_state(pi1.about[3].state, pi1.about[3].control, pi1.about[4].control, pi1.sigma, 1 / (prob.K + 1), None, cache)
     assert np.abs(xe - lr[3].endpoint).max() < 1e-13
+    # next_step (autodiff_dynamics.jl:104-107): the affine model reproduces the nonlinear map to second order
+    from successiveconvexification_amd.dynamics import next_step
+    a, an = pi1.about[3], pi1.about[4]
+    pert = 1e-5
+    pred = next_step(lr[3], a, an, a.state + pert, a.control, an.control, pi1.sigma, pi1.sigma, 0.0)
+    true = predict_state(a.state + pert, a.control, an.control, pi1.sigma, 1 / (prob.K + 1), None, cache)
+    assert np.abs(pred - true).max() < 1e-7
+    trjs, tfs = Rocketland.run_iters(prob, 2, cache)
+    assert len(trjs) == 2 and trjs[0].shape == (3, prob.K + 1) and abs(tfs[0] - it1.sigma) < 5e-4
 
 
 def test_checkpoint_restore_roundtrip():
