@@ -8,6 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscvx_hip.so")
+_DEFAULT_LIB_PATH = LIB_PATH
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -85,6 +86,13 @@ def lib() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
+    if not os.path.exists(LIB_PATH) and LIB_PATH == _DEFAULT_LIB_PATH:
+        # a source checkout without the built artefact: build the HIP extension (hipcc, gfx950) — never a CPU path
+        try:
+            from . import build as _build
+            _build.build()
+        except Exception as e:  # noqa: BLE001
+            raise ScvxError(f"{LIB_PATH} is missing and building it with hipcc failed: {e}") from e
     if not os.path.exists(LIB_PATH):
         raise ScvxError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
