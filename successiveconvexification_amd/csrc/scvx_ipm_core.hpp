@@ -83,16 +83,6 @@ struct Layout {
         nsmall = c_lb + K + 1;
         c_nu = nsmall; c_tr = nsmall + 1; c_sg = nsmall + 2; c_rk = nsmall + 3; ncones = nsmall + 4;
     }
-    // small cone c in [0, nsmall): offset into the cone vector and dimension
-    SCVX_HD void small(int c, int& off, int& dim) const {
-        if (c < c_tilt) { off = o_gs + 3 * c; dim = 3; }
-        else if (c < c_rate) { off = o_tilt + 3 * (c - c_tilt); dim = 3; }
-        else if (c < c_mass) { off = o_rate + 4 * (c - c_rate); dim = 4; }
-        else if (c < c_tb) { off = o_mass + (c - c_mass); dim = 1; }
-        else if (c < c_tc) { off = o_tb + 4 * (c - c_tb); dim = 4; }
-        else if (c < c_lb) { off = o_tc + 4 * (c - c_tc); dim = 4; }
-        else { off = o_lb + (c - c_lb); dim = 1; }
-    }
     // doubles of per-trajectory workspace
     SCVX_HD size_t work_doubles() const {
         size_t n = 0;
@@ -102,7 +92,7 @@ struct Layout {
         n += (size_t)nc * 13;            // S, Z, rz, lam, Wv, t, Wibz, dS, dZ, sds, sdz, tmpc, Wirz
         n += (size_t)ncones;             // Wbeta
         n += (size_t)(K + 1) * 25 + (size_t)(K + 1) * 9;  // hx, hu
-        n += (size_t)K * 196 * 4;        // Sd, Linv, Nf, Nb (So staged in Nb)
+        n += (size_t)K * 196 * 3;        // Linv, Nf, Nb
         n += (size_t)ny;                 // tchain
         n += (size_t)(nloc + ny) * 3;    // ls,ys, ltr,ytr, lnu,ynu
         n += (size_t)nloc * 2;           // tmpl, tmpl2
@@ -210,37 +200,6 @@ SCVX_HD void hxi_apply(const double* h, const double* x, double* y) {
     y[10] = h[HX_Q34 + 2] * x[9] + h[HX_Q34 + 3] * x[10];
     for (int i = 0; i < 3; i++) y[11 + i] = h[HX_W + 3 * i] * x[11] + h[HX_W + 3 * i + 1] * x[12] + h[HX_W + 3 * i + 2] * x[13];
 }
-// a' Hxi b where a, b are rows i, j of a 14x14 column-major (stride 14) matrix: a[c] = A[c*14 + i]
-SCVX_HD double hxi_quad(const double* h, const double* A, int i, const double* Bm, int j) {
-    double s = h[HX_M] * A[i] * Bm[j];
-    for (int a = 0; a < 3; a++) {
-        const double ai = A[(1 + a) * 14 + i];
-        s += ai * (h[HX_R + 3 * a] * Bm[14 + j] + h[HX_R + 3 * a + 1] * Bm[28 + j] + h[HX_R + 3 * a + 2] * Bm[42 + j]);
-    }
-    double t = 0;
-    for (int a = 4; a < 7; a++) t += A[a * 14 + i] * Bm[a * 14 + j];
-    s += h[HX_V] * t;
-    s += h[HX_Q] * (A[7 * 14 + i] * Bm[7 * 14 + j] + A[8 * 14 + i] * Bm[8 * 14 + j]);
-    {
-        const double a9 = A[9 * 14 + i], a10 = A[10 * 14 + i], b9 = Bm[9 * 14 + j], b10 = Bm[10 * 14 + j];
-        s += a9 * (h[HX_Q34] * b9 + h[HX_Q34 + 1] * b10) + a10 * (h[HX_Q34 + 2] * b9 + h[HX_Q34 + 3] * b10);
-    }
-    for (int a = 0; a < 3; a++) {
-        const double ai = A[(11 + a) * 14 + i];
-        s += ai * (h[HX_W + 3 * a] * Bm[11 * 14 + j] + h[HX_W + 3 * a + 1] * Bm[12 * 14 + j] + h[HX_W + 3 * a + 2] * Bm[13 * 14 + j]);
-    }
-    return s;
-}
-// a' Hui b with a = row i of a 14x3 col-major block (stride 14), b = row j of another
-SCVX_HD double hui_quad(const double* hu, const double* Ba, int i, const double* Bb, int j) {
-    double s = 0;
-    for (int c = 0; c < 3; c++) {
-        const double t = hu[3 * c] * Bb[j] + hu[3 * c + 1] * Bb[14 + j] + hu[3 * c + 2] * Bb[28 + j];
-        s += Ba[c * 14 + i] * t;
-    }
-    return s;
-}
-
 // ------------------------------------------------------------------------------------------------
 // the solver
 // ------------------------------------------------------------------------------------------------
@@ -265,7 +224,7 @@ struct Solver {
     double *S, *Z, *rz, *lam, *Wv, *tt, *Wibz, *dS, *dZ, *sds, *sdz, *tmpc, *Wirz;
     double* Wbeta;
     double *hx, *hu;
-    double *Linv, *Nf, *Nb, *Sd, *tchain;
+    double *Linv, *Nf, *Nb, *tchain;
     double *ls, *ys, *ltr, *ytr, *lnu, *ynu;
     double *tmpl, *tmpl2;
     double *uhat, *lb0;
@@ -288,7 +247,7 @@ struct Solver {
         Wirz = w; w += nc;
         Wbeta = w; w += L.ncones;
         hx = w; w += (size_t)(K + 1) * HX_SZ; hu = w; w += (size_t)(K + 1) * 9;
-        Linv = w; w += (size_t)K * 196; Nf = w; w += (size_t)K * 196; Nb = w; w += (size_t)K * 196; Sd = w; w += (size_t)K * 196;
+        Linv = w; w += (size_t)K * 196; Nf = w; w += (size_t)K * 196; Nb = w; w += (size_t)K * 196;
         tchain = w; w += ny;
         ls = w; w += nloc; ys = w; w += ny; ltr = w; w += nloc; ytr = w; w += ny; lnu = w; w += nloc; ynu = w; w += ny;
         tmpl = w; w += nloc; tmpl2 = w; w += nloc;
@@ -577,10 +536,7 @@ struct Solver {
     SCVX_HD void identity_scaling() {
         for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) Wv[i] = 0.0;
         ex.sync();
-        for (int c = ex.lane(); c < L.nsmall; c += ex.nlanes()) {
-            int off, d; L.small(c, off, d);
-            Wv[off] = 1.0; Wbeta[c] = 1.0;
-        }
+        all_small([&](auto, int off, int c) { Wv[off] = 1.0; Wbeta[c] = 1.0; }, false);
         if (ex.lane() == 0) {
             Wv[L.o_nu] = 1.0; Wv[L.o_tr] = 1.0; Wv[L.o_sg] = 1.0; Wv[L.o_rk] = 1.0;
             Wbeta[L.c_nu] = Wbeta[L.c_tr] = Wbeta[L.c_sg] = Wbeta[L.c_rk] = 1.0;
@@ -1223,15 +1179,13 @@ struct Solver {
 
     SCVX_HD_NI void shift_into_cone(double* X) {
         double t = -INFINITY;
-        for (int c = ex.lane(); c < L.nsmall + 1; c += ex.nlanes()) {
-            int off, dm;
-            if (c < L.nsmall) L.small(c, off, dm); else { off = L.o_sg; dm = 2; }
+        all_small([&](auto Dt_, int off, int) {
+            constexpr int dm = decltype(Dt_)::value;
             double n = 0;
             for (int i = 1; i < dm; i++) n += X[off + i] * X[off + i];
             const double m = sqrt(n) - X[off];
             if (m > t) t = m;
-        }
-        { const double m = -X[L.o_rk]; if (m > t) t = m; }
+        }, true);
         t = -ex.min(-t);
         const int offs[2] = {L.o_nu, L.o_tr};
         const int dims[2] = {14 * L.K + 1, 17 * (L.K + 1) + 1};
@@ -1245,8 +1199,8 @@ struct Solver {
         ex.sync();
         if (t >= -1e-8) {
             const double sh = 1.0 + t;
-            for (int c = ex.lane(); c < L.nsmall; c += ex.nlanes()) { int off, dm; L.small(c, off, dm); X[off] += sh; }
-            if (ex.lane() == 0) { X[L.o_nu] += sh; X[L.o_tr] += sh; X[L.o_sg] += sh; X[L.o_rk] += sh; }
+            all_small([&](auto, int off, int) { X[off] += sh; }, true);
+            if (ex.lane() == 0) { X[L.o_nu] += sh; X[L.o_tr] += sh; }
         }
         ex.sync();
     }
