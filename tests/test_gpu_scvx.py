@@ -103,12 +103,13 @@ def test_solve_step_matches_oracle_scvx_two_iterations():
 
 
 def test_returned_iterate_is_feasible_full_batch():
-    """Size-independent properties at B = 512: what the solver returns satisfies every constraint of
+    """Size-independent properties at the full batch B = 8192: what the solver returns satisfies every constraint of
     Rocketland.build_model to the solver tolerance, and the linearised dynamics hold exactly with nu."""
     from oracle import model
     po = model.base_prob_scaled()
-    B = 512
-    ic = model.disperse_ics(po, B, 20261004)
+    B = 8192
+    import bench
+    ic = bench.disperse_ics(po, 0, B, 20261004)
     c, b = _setup(B, ic, npts=4)
     xb, ub, sg = b.trajectory()
     e, d = b.linearization()
