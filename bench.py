@@ -247,7 +247,7 @@ def main():
                 "traj_iters_timed": done_all, "all_gather_shape": gathered,
             },
             "roofline": {
-                "kernel": "scvx::linearize_kernel (K1)", "bound": "hbm",
+                "kernel": "scvx::linearize_pc_kernel (K1)", "bound": "hbm",
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
