@@ -130,6 +130,31 @@ def cpu_baseline(npts, seed, budget_traj_per_core=256):
                       f"{t:.1f} s wall; same algorithm as the device path (scvx_ipm_core.hpp + RK4 npts={npts})"}
 
 
+def traj_linf_vs_oracle(cache_cls, batch_cls, prob, npts):
+    """Second half of the headline metric ("traj L-inf vs ref"): a complete Rocketland.solve_problem of the sample
+    problem (B = 1, imax-1 = 14 solve_steps) on the device against the oracle's recorded run, a committed fixture
+    (tests/golden/oracle_scvx_full.npz — data; generated by tests/golden/make_oracle_full_run.py).  Outside the timed region."""
+    f = os.path.join(ROOT, "tests", "golden", "oracle_scvx_full.npz")
+    if not os.path.exists(f) or npts != 10:
+        return None
+    g = np.load(f)
+    c = cache_cls(prob, npts=npts)
+    b = batch_cls(c, 1).init(None)
+    wx = wu = ws = 0.0
+    same = True
+    for n in range(len(g["log"])):
+        b.solve_step()
+        x, u, s = b.trajectory()
+        rk, _, _ = b.scalars()
+        same = same and rk[0] == g["log"][n][3]
+        wx = max(wx, float(np.abs(x[0] - g["xs"][n]).max()))
+        wu = max(wu, float(np.abs(u[0] - g["us"][n]).max()))
+        ws = max(ws, abs(float(s[0]) - float(g["log"][n][5])))
+    b.close(); c.close()
+    return {"x": wx, "u": wu, "sigma": ws, "solve_steps": int(len(g["log"])), "same_accept_reject_sequence": bool(same),
+            "ref": "oracle (IPM on the exact build_model rows + RK4 npts=10); parity with the Julia reference itself is unpinned"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,6 +291,8 @@ def main():
             "solver_stats_last_step": {"ipm_iters_mean": float(np.mean(its)), "ipm_iters_max": int(np.max(its)),
                                        "status_optimal_frac": float(np.mean(st == 0)), "merit_max": float(np.max(merit))},
         }
+        if world == 1:
+            line["traj_linf_vs_oracle"] = traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts)
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.npts, args.seed)
         print(json.dumps(line), flush=True)
