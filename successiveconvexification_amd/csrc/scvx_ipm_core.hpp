@@ -36,6 +36,9 @@
 #ifndef SCVX_FLOOR_ACCEPT
 #define SCVX_FLOOR_ACCEPT 1000.0
 #endif
+#ifndef SCVX_STREAM_U
+#define SCVX_STREAM_U 4   // elements in flight per lane in the streaming loops (Solver::stream)
+#endif
 #ifndef SCVX_REFINE_FROM
 #define SCVX_REFINE_FROM 1e-4
 #endif
@@ -263,20 +266,45 @@ struct Solver {
     SCVX_HD bool fixed_u(int k, int c) const { return k == L.K && c > 0; }
 
     // ---- parallel vector helpers ----
+    // Streaming loop over [i0, n) with U independent elements in flight per lane: ld(i) gathers the inputs of element
+    // i (returned by value), st(i, v) computes and stores.  All loads of a batch are issued before its first store, so
+    // the memory latency is paid once per U elements instead of once per element (the solver state streams from HBM;
+    // a plain `for` makes the compiler wait on every element because the stores may alias the next loads).
+    // Element order per lane is ascending, so reductions accumulated in st() keep their summation order.
+    template <int U = SCVX_STREAM_U, class LD, class ST>
+    SCVX_HD void stream(int i0, int n, LD&& ld, ST&& st) {
+        const int nl = ex.nlanes();
+        int i = i0 + ex.lane();
+        for (; i + (U - 1) * nl < n; i += U * nl) {
+            decltype(ld(0)) v[U];
+            SCVX_UNROLL
+            for (int q = 0; q < U; q++) v[q] = ld(i + q * nl);
+            SCVX_UNROLL
+            for (int q = 0; q < U; q++) st(i + q * nl, v[q]);
+        }
+        for (; i < n; i += nl) st(i, ld(i));
+    }
+    struct D2 { double a, b; };
+    struct D3 { double a, b, c; };
+    struct D4 { double a, b, c, d; };
+    struct D5 { double a, b, c, d, e; };
+
     SCVX_HD double dot(const double* a, const double* b, int n) {
         double s = 0;
-        for (int i = ex.lane(); i < n; i += ex.nlanes()) s += a[i] * b[i];
+        stream(0, n, [&](int i) { return D2{a[i], b[i]}; }, [&](int, const D2& v) { s += v.a * v.b; });
         return ex.sum(s);
     }
-    SCVX_HD void axpy_set(double* o, const double* a, double al, const double* b, int n) {  // o = a + al b
-        for (int i = ex.lane(); i < n; i += ex.nlanes()) o[i] = a[i] + al * b[i];
+    SCVX_HD double sumsq(const double* a, int n) {
+        double s = 0;
+        stream<8>(0, n, [&](int i) { return a[i]; }, [&](int, double v) { s += v * v; });
+        return ex.sum(s);
     }
     SCVX_HD void zero(double* o, int n) {
         for (int i = ex.lane(); i < n; i += ex.nlanes()) o[i] = 0.0;
         ex.sync();
     }
     SCVX_HD void copy(double* o, const double* a, int n) {
-        for (int i = ex.lane(); i < n; i += ex.nlanes()) o[i] = a[i];
+        stream<8>(0, n, [&](int i) { return a[i]; }, [&](int i, double v) { o[i] = v; });
         ex.sync();
     }
 
@@ -366,8 +394,11 @@ struct Solver {
             tc[0] = u[0] * C.icos; tc[1] = u[0]; tc[2] = u[1]; tc[3] = u[2];
             out[L.o_lb + k] = uhat[3 * k] * du[0] + uhat[3 * k + 1] * du[1] + uhat[3 * k + 2] * du[2] - af * lb0[k];
         }
-        for (int i = ex.lane(); i < 14 * K; i += ex.nlanes()) out[L.o_nu + 1 + i] = v[L.nx + L.nu_ + i];
-        for (int i = ex.lane(); i < L.nx + L.nu_; i += ex.nlanes()) out[L.o_tr + 1 + i] = v[i];
+        {
+            const double* vn = v + L.nx + L.nu_; double* on = out + L.o_nu + 1; double* ot = out + L.o_tr + 1;
+            stream<8>(0, 14 * K, [&](int i) { return vn[i]; }, [&](int i, double x) { on[i] = x; });
+            stream<8>(0, L.nx + L.nu_, [&](int i) { return v[i]; }, [&](int i, double x) { ot[i] = x; });
+        }
         if (ex.lane() == 0) {
             out[L.o_nu] = v[L.iTNU];
             out[L.o_tr] = v[L.iTTR];
@@ -401,7 +432,10 @@ struct Solver {
             for (int c = 0; c < 3; c++) gu[c] = tru[c] + tb[1 + c] + tc[1 + c] + zl * uhat[3 * k + c];
             gu[0] += tc[0] * C.icos;
         }
-        for (int i = ex.lane(); i < 14 * K; i += ex.nlanes()) g[L.nx + L.nu_ + i] = z[L.o_nu + 1 + i];
+        {
+            const double* zn = z + L.o_nu + 1; double* gn = g + L.nx + L.nu_;
+            stream<8>(0, 14 * K, [&](int i) { return zn[i]; }, [&](int i, double x) { gn[i] = x; });
+        }
         if (ex.lane() == 0) {
             g[L.iTNU] = z[L.o_nu];
             g[L.iTTR] = z[L.o_tr] - z[L.o_rk];
@@ -423,7 +457,8 @@ struct Solver {
     SCVX_HD void big_nt(int off, int dim, int cidx) {
         const double* s = S + off; const double* z = Z + off;
         double a = 0, b = 0, c = 0;
-        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) { a += s[i] * s[i]; b += z[i] * z[i]; c += s[i] * z[i]; }
+        stream(1, dim, [&](int i) { return D2{s[i], z[i]}; },
+               [&](int, const D2& v) { a += v.a * v.a; b += v.b * v.b; c += v.a * v.b; });
         a = ex.sum(a); b = ex.sum(b); c = ex.sum(c);
         const double sj = sqrt(s[0] * s[0] - a), zj = sqrt(z[0] * z[0] - b);
         const double isj = 1.0 / sj, izj = 1.0 / zj;
@@ -432,51 +467,60 @@ struct Solver {
         const double wb0 = (s[0] * isj + z[0] * izj) * ig;
         const double den = 1.0 / sqrt(2.0 * (wb0 + 1.0));
         double* v = Wv + off;
-        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) v[i] = (s[i] * isj - z[i] * izj) * ig * den;
+        stream(1, dim, [&](int i) { return D2{s[i], z[i]}; },
+               [&](int i, const D2& q) { v[i] = (q.a * isj - q.b * izj) * ig * den; });
         if (ex.lane() == 0) { v[0] = (wb0 + 1.0) * den; Wbeta[cidx] = sqrt(sj * izj); }
     }
     SCVX_HD void big_W(int off, int dim, int cidx, const double* x, double* yv, bool inverse) {
         const double* v = Wv + off;
+        const double* xo = x + off; double* yo = yv + off;
         double vx = 0;
-        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) vx += v[i] * x[off + i];
+        stream(1, dim, [&](int i) { return D2{v[i], xo[i]}; }, [&](int, const D2& q) { vx += q.a * q.b; });
         vx = ex.sum(vx);
         vx = v[0] * x[off] + (inverse ? -vx : vx);
         const double beta = Wbeta[cidx];
         const double sc = inverse ? 1.0 / beta : beta;
         const double x0 = x[off];
+        const double tw = (inverse ? -2.0 : 2.0) * vx;
         ex.sync();  // x may alias yv: every lane has read x[off] before lane 0 overwrites it
-        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) yv[off + i] = ((inverse ? -2.0 : 2.0) * vx * v[i] + x[off + i]) * sc;
+        stream(1, dim, [&](int i) { return D2{v[i], xo[i]}; }, [&](int i, const D2& q) { yo[i] = (tw * q.a + q.b) * sc; });
         if (ex.lane() == 0) yv[off] = (2.0 * vx * v[0] - x0) * sc;
     }
     // t = lam \ d on a big cone
     SCVX_HD void big_div(int off, int dim, const double* d, double* out) {
         const double* l = lam + off;
+        const double* dd = d + off; double* oo = out + off;
         double ld = 0, ll = 0;
-        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) { ld += l[i] * d[off + i]; ll += l[i] * l[i]; }
+        stream(1, dim, [&](int i) { return D2{l[i], dd[i]}; }, [&](int, const D2& q) { ld += q.a * q.b; ll += q.a * q.a; });
         ld = ex.sum(ld); ll = ex.sum(ll);
         const double det = l[0] * l[0] - ll;
         const double x0 = (l[0] * d[off] - ld) / det;
         const double il0 = 1.0 / l[0];
         ex.sync();
-        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) out[off + i] = (d[off + i] - x0 * l[i]) * il0;
+        stream(1, dim, [&](int i) { return D2{l[i], dd[i]}; }, [&](int i, const D2& q) { oo[i] = (q.b - x0 * q.a) * il0; });
         if (ex.lane() == 0) out[off] = x0;
     }
     // out = a o b on a big cone
     SCVX_HD void big_prod(int off, int dim, const double* a, const double* b, double* out) {
+        const double* ao = a + off; const double* bo = b + off; double* oo = out + off;
         double ab = 0;
-        for (int i = ex.lane(); i < dim; i += ex.nlanes()) ab += a[off + i] * b[off + i];
+        stream(0, dim, [&](int i) { return D2{ao[i], bo[i]}; }, [&](int, const D2& q) { ab += q.a * q.b; });
         ab = ex.sum(ab);
         const double a0 = a[off], b0 = b[off];
         ex.sync();
-        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) out[off + i] = a0 * b[off + i] + b0 * a[off + i];
+        stream(1, dim, [&](int i) { return D2{ao[i], bo[i]}; }, [&](int i, const D2& q) { oo[i] = a0 * q.b + b0 * q.a; });
         if (ex.lane() == 0) out[off] = ab;
     }
-    SCVX_HD double big_maxstep(int off, int dim, const double* d) {
+    // step lengths for two directions with one pass over lam
+    SCVX_HD void big_maxstep2(int off, int dim, const double* d1, const double* d2, double& s1, double& s2) {
         const double* l = lam + off;
-        double ll = 0, ld = 0, dd = 0;
-        for (int i = 1 + ex.lane(); i < dim; i += ex.nlanes()) { ll += l[i] * l[i]; ld += l[i] * d[off + i]; dd += d[off + i] * d[off + i]; }
-        ll = ex.sum(ll); ld = ex.sum(ld); dd = ex.sum(dd);
-        return soc_maxstep_parts(l[0], d[off], l[0] * l[0] - ll, l[0] * d[off] - ld, d[off] * d[off] - dd);
+        const double* p = d1 + off; const double* q = d2 + off;
+        double ll = 0, ld = 0, dd = 0, le = 0, ee = 0;
+        stream(1, dim, [&](int i) { return D3{l[i], p[i], q[i]}; },
+               [&](int, const D3& v) { ll += v.a * v.a; ld += v.a * v.b; dd += v.b * v.b; le += v.a * v.c; ee += v.c * v.c; });
+        ll = ex.sum(ll); ld = ex.sum(ld); dd = ex.sum(dd); le = ex.sum(le); ee = ex.sum(ee);
+        s1 = soc_maxstep_parts(l[0], p[0], l[0] * l[0] - ll, l[0] * p[0] - ld, p[0] * p[0] - dd);
+        s2 = soc_maxstep_parts(l[0], q[0], l[0] * l[0] - ll, l[0] * q[0] - le, q[0] * q[0] - ee);
     }
 
     // ---- uniform iteration over the small cones: one strided loop per (dimension, block), dimension known at compile
@@ -606,34 +650,47 @@ struct Solver {
             if (combined) {
                 big_prod(offs[q], dims[q], sds, sdz, tmpc);
                 ex.sync();
-                for (int i = ex.lane(); i < dims[q]; i += ex.nlanes()) out[offs[q] + i] = -out[offs[q] + i] - tmpc[offs[q] + i];
+                double* oo = out + offs[q]; const double* tc = tmpc + offs[q];
+                stream(0, dims[q], [&](int i) { return D2{oo[i], tc[i]}; }, [&](int i, const D2& v) { oo[i] = -v.a - v.b; });
                 if (ex.lane() == 0) out[offs[q]] += sigmu;
             } else {
-                for (int i = ex.lane(); i < dims[q]; i += ex.nlanes()) out[offs[q] + i] = -out[offs[q] + i];
+                double* oo = out + offs[q];
+                stream<8>(0, dims[q], [&](int i) { return oo[i]; }, [&](int i, double v) { oo[i] = -v; });
             }
         }
         ex.sync();
     }
-    SCVX_HD_NI double maxstep_all(const double* d) {
+    // largest step keeping lam + a*d1 and lam + a*d2 in the cone (one pass over lam for both scaled directions)
+    SCVX_HD_NI double maxstep_all(const double* d1, const double* d2) {
         double amax = INFINITY;
         all_small([&](auto Dt_, int off, int) {
             constexpr int dm = decltype(Dt_)::value;
-            double a;
-            if (dm == 1) a = d[off] < 0.0 ? -lam[off] / d[off] : INFINITY;
-            else {
-                double l[dm], dv[dm];
-                for (int i = 0; i < dm; i++) { l[i] = lam[off + i]; dv[i] = d[off + i]; }
-                double ll = 0, ld = 0, dd = 0;
-                for (int i = 1; i < dm; i++) { ll += l[i] * l[i]; ld += l[i] * dv[i]; dd += dv[i] * dv[i]; }
+            double a, b;
+            if (dm == 1) {
+                const double l0 = lam[off], p = d1[off], q = d2[off];
+                a = p < 0.0 ? -l0 / p : INFINITY;
+                b = q < 0.0 ? -l0 / q : INFINITY;
+            } else {
+                double l[dm], dv[dm], ev[dm];
+                for (int i = 0; i < dm; i++) { l[i] = lam[off + i]; dv[i] = d1[off + i]; ev[i] = d2[off + i]; }
+                double ll = 0, ld = 0, dd = 0, le = 0, ee = 0;
+                for (int i = 1; i < dm; i++) {
+                    ll += l[i] * l[i]; ld += l[i] * dv[i]; dd += dv[i] * dv[i]; le += l[i] * ev[i]; ee += ev[i] * ev[i];
+                }
                 a = soc_maxstep_parts(l[0], dv[0], l[0] * l[0] - ll, l[0] * dv[0] - ld, dv[0] * dv[0] - dd);
+                b = soc_maxstep_parts(l[0], ev[0], l[0] * l[0] - ll, l[0] * ev[0] - le, ev[0] * ev[0] - ee);
             }
             if (a < amax) amax = a;
+            if (b < amax) amax = b;
         }, true);
         amax = ex.min(amax);
-        const double a1 = big_maxstep(L.o_nu, 14 * L.K + 1, d);
-        const double a2 = big_maxstep(L.o_tr, 17 * (L.K + 1) + 1, d);
+        double a1, b1, a2, b2;
+        big_maxstep2(L.o_nu, 14 * L.K + 1, d1, d2, a1, b1);
+        big_maxstep2(L.o_tr, 17 * (L.K + 1) + 1, d1, d2, a2, b2);
         if (a1 < amax) amax = a1;
+        if (b1 < amax) amax = b1;
         if (a2 < amax) amax = a2;
+        if (b2 < amax) amax = b2;
         return amax;
     }
 
@@ -650,7 +707,11 @@ struct Solver {
             const double u0 = g[L.nx + 3 * k], u1 = g[L.nx + 3 * k + 1], u2 = g[L.nx + 3 * k + 2];
             for (int c = 0; c < 3; c++) out[L.nx + 3 * k + c] = h[3 * c] * u0 + h[3 * c + 1] * u1 + h[3 * c + 2] * u2;
         }
-        for (int i = ex.lane(); i < 14 * K; i += ex.nlanes()) out[L.nx + L.nu_ + i] = hnui * g[L.nx + L.nu_ + i];
+        {
+            const double* gn = g + L.nx + L.nu_; double* on = out + L.nx + L.nu_;
+            const double hn = hnui;
+            stream<8>(0, 14 * K, [&](int i) { return gn[i]; }, [&](int i, double v) { on[i] = hn * v; });
+        }
         ex.sync();
         SCVX_T1(3);
     }
@@ -767,12 +828,18 @@ struct Solver {
         Hb_inv(gl, tmpl);
         E_apply(tmpl, tmpy, false);
         ex.sync();
-        if (ryv) for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) tmpy[i] -= ryv[i];
+        if (ryv) {
+            double* ty = tmpy;
+            stream(0, L.ny, [&](int i) { return D2{ty[i], ryv[i]}; }, [&](int i, const D2& v) { ty[i] = v.a - v.b; });
+        }
         ex.sync();
         S_solve(tmpy, dyv);
         (void)Et_apply(dyv, tmpl2);
         ex.sync();
-        for (int i = ex.lane(); i < L.nloc; i += ex.nlanes()) tmpl2[i] = gl[i] - tmpl2[i];
+        {
+            double* t2 = tmpl2;
+            stream(0, L.nloc, [&](int i) { return D2{gl[i], t2[i]}; }, [&](int i, const D2& v) { t2[i] = v.a - v.b; });
+        }
         ex.sync();
         Hb_inv(tmpl2, dl);
     }
@@ -784,8 +851,11 @@ struct Solver {
         {
             const int dn = 14 * K + 1, dt = 17 * (K + 1) + 1;
             double n1 = 0, n2 = 0;
-            for (int i = 1 + ex.lane(); i < dn; i += ex.nlanes()) n1 += Wv[L.o_nu + i] * Wv[L.o_nu + i];
-            for (int i = 1 + ex.lane(); i < dt; i += ex.nlanes()) n2 += Wv[L.o_tr + i] * Wv[L.o_tr + i];
+            {
+                const double* wn = Wv + L.o_nu; const double* wt = Wv + L.o_tr;
+                stream<8>(1, dn, [&](int i) { return wn[i]; }, [&](int, double v) { n1 += v * v; });
+                stream<8>(1, dt, [&](int i) { return wt[i]; }, [&](int, double v) { n2 += v * v; });
+            }
             n1 = ex.sum(n1); n2 = ex.sum(n2);
             soc_w2(Wv[L.o_nu], n1, Wbeta[L.c_nu], h_nu[0], h_nu[1], h_nu[2], h_nu[3]);
             soc_w2(Wv[L.o_tr], n2, Wbeta[L.c_tr], h_tr[0], h_tr[1], h_tr[2], h_tr[3]);
@@ -1006,27 +1076,31 @@ struct Solver {
         {
             const int nxu = L.nx + L.nu_;
             double* g_tr = gx;     // nloc: Ptr on (dx,du), 0 on nu
-            for (int i = ex.lane(); i < L.nloc; i += ex.nlanes()) g_tr[i] = i < nxu ? Wv[L.o_tr + 1 + i] : 0.0;
+            {
+                const double* wt = Wv + L.o_tr + 1;
+                stream<8>(0, L.nloc, [&](int i) { return i < nxu ? wt[i] : 0.0; }, [&](int i, double v) { g_tr[i] = v; });
+            }
             ex.sync();
             Hb_inv(g_tr, tmpl);
             E_apply(tmpl, tmpy2, false);                       // r_tr
-            for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) {
-                const int k = r / 14, i = r - 14 * k;
-                tmpy[r] = D_[(size_t)k * 294 + 14 * 20 + i];  // r_s = +Sg
-                r2[r] = hnui_ * Wv[L.o_nu + 1 + r];           // r_nu
+            {
+                double* ty = tmpy; double* r2_ = r2; const double* wn = Wv + L.o_nu + 1;
+                stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D2{D_[(size_t)k * 294 + 14 * 20 + i], wn[r]}; },
+                       [&](int r, const D2& v) { ty[r] = v.a; r2_[r] = hnui_ * v.b; });   // r_s = +Sg, r_nu
             }
             ex.sync();
             S_solve3(tmpy, tmpy2, r2, ys, ytr, ynu, tchain, cy, dy);
             Et_apply3(ys, ytr, ynu, tmpl, tmpl2, tmpv);
             // l = Hb^-1 (g - E' y): assemble the three right-hand sides in place, then invert
-            for (int i = ex.lane(); i < L.nloc; i += ex.nlanes()) {
-                const bool isnu = i >= nxu;
-                const double e0 = isnu ? ys[i - nxu] : tmpl[i];
-                const double e1 = isnu ? ytr[i - nxu] : tmpl2[i];
-                const double e2 = isnu ? ynu[i - nxu] : tmpv[i];
-                tmpl[i] = -e0;
-                tmpl2[i] = g_tr[i] - e1;
-                tmpv[i] = (isnu ? Wv[L.o_nu + 1 + (i - nxu)] : 0.0) - e2;
+            {
+                double* t0 = tmpl; double* t1 = tmpl2; double* t2 = tmpv;
+                const double* y0 = ys; const double* y1 = ytr; const double* y2 = ynu; const double* wn = Wv + L.o_nu + 1;
+                stream(0, L.nloc, [&](int i) {
+                           const bool isnu = i >= nxu;
+                           return D5{isnu ? y0[i - nxu] : t0[i], isnu ? y1[i - nxu] : t1[i], isnu ? y2[i - nxu] : t2[i],
+                                     g_tr[i], isnu ? wn[i - nxu] : 0.0};
+                       },
+                       [&](int i, const D5& v) { t0[i] = -v.a; t1[i] = v.d - v.b; t2[i] = v.e - v.c; });
             }
             ex.sync();
             Hb_inv(tmpl, ls);
@@ -1036,10 +1110,10 @@ struct Solver {
         // border coefficients
         {
             double a = 0, b = 0, c = 0;
-            for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) {
-                const int k = r / 14, i = r - 14 * k;
-                const double sg = D[(size_t)k * 294 + 14 * 20 + i];
-                a += sg * ys[r]; b += sg * ytr[r]; c += sg * ynu[r];
+            {
+                const double* y0 = ys; const double* y1 = ytr; const double* y2 = ynu;
+                stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D4{D_[(size_t)k * 294 + 14 * 20 + i], y0[r], y1[r], y2[r]}; },
+                       [&](int, const D4& v) { a += v.a * v.b; b += v.a * v.c; c += v.a * v.d; });
             }
             css = ex.sum(a); cst = -ex.sum(b); csn = -ex.sum(c);
             const double* Ptr = Wv + L.o_tr + 1; const int nt = L.nx + L.nu_;
@@ -1055,9 +1129,10 @@ struct Solver {
     SCVX_HD_NI void kkt_solve(const double* g, const double* ryv, double* dwv, double* dyv) {
         band_solve(g, ryv, dwv, dyv);
         double a = 0;
-        for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) {
-            const int k = r / 14, i = r - 14 * k;
-            a += D[(size_t)k * 294 + 14 * 20 + i] * dyv[r];
+        {
+            const double* const D_ = D;
+            stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D2{D_[(size_t)k * 294 + 14 * 20 + i], dyv[r]}; },
+                   [&](int, const D2& v) { a += v.a * v.b; });
         }
         const double c0s = ex.sum(a);
         const double c0t = dot(Wv + L.o_tr + 1, dwv, L.nx + L.nu_);
@@ -1094,8 +1169,14 @@ struct Solver {
         const double s_ = b[0], ts_ = b[1], tnu_ = b[2], ttr_ = b[3];
         const double ctr = h01t * ttr_ + b[4], cnu = h01n * tnu_ + b[5];
         ex.sync();
-        for (int i = ex.lane(); i < L.nloc; i += ex.nlanes()) dwv[i] = dwv[i] + ls[i] * s_ - ltr[i] * ctr - lnu[i] * cnu;
-        for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) dyv[i] = dyv[i] + ys[i] * s_ - ytr[i] * ctr - ynu[i] * cnu;
+        {
+            const double* a0 = ls; const double* a1 = ltr; const double* a2 = lnu;
+            stream(0, L.nloc, [&](int i) { return D4{dwv[i], a0[i], a1[i], a2[i]}; },
+                   [&](int i, const D4& v) { dwv[i] = v.a + v.b * s_ - v.c * ctr - v.d * cnu; });
+            const double* b0 = ys; const double* b1 = ytr; const double* b2 = ynu;
+            stream(0, L.ny, [&](int i) { return D4{dyv[i], b0[i], b1[i], b2[i]}; },
+                   [&](int i, const D4& v) { dyv[i] = v.a + v.b * s_ - v.c * ctr - v.d * cnu; });
+        }
         if (ex.lane() == 0) { dwv[L.iS] = s_; dwv[L.iTS] = ts_; dwv[L.iTNU] = tnu_; dwv[L.iTTR] = ttr_; }
         ex.sync();
     }
@@ -1110,20 +1191,26 @@ struct Solver {
         ex.sync();
     }
 
-    // Newton step for centering right-hand side ds_rhs (cone vector); results in dw, dy, dZ, dS
-    SCVX_HD_NI void newton(const double* ds_rhs) {
+    // Newton step for centering right-hand side ds_rhs (cone vector); results in dw, dy, sds, sdz and -- when `full` --
+    // dS, dZ (the predictor only needs the scaled directions for its step length and the Mehrotra correction).
+    SCVX_HD_NI void newton(const double* ds_rhs, bool full) {
         // Wirz = W^-1 rz is prepared once per iteration (shared by predictor and corrector)
         div_all(ds_rhs, tt);
-        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) Wibz[i] = -Wirz[i] - tt[i];
+        {
+            double* wb = Wibz; const double* wr = Wirz; const double* t_ = tt;
+            stream(0, L.nc, [&](int i) { return D2{wr[i], t_[i]}; }, [&](int i, const D2& v) { wb[i] = -v.a - v.b; });
+        }
         ex.sync();
         W_all(Wibz, tmpc, true);
         cone_map_t(tmpc, gx);
         ex.sync();
-        for (int i = ex.lane(); i < L.nv; i += ex.nlanes()) gx[i] = -rx[i] - gx[i];
+        {
+            double* g_ = gx; const double* rx_ = rx; double* r2_ = r2; const double* ry_ = ry;
+            stream(0, L.nv, [&](int i) { return D2{rx_[i], g_[i]}; }, [&](int i, const D2& v) { g_[i] = -v.a - v.b; });
+            stream<8>(0, L.ny, [&](int i) { return ry_[i]; }, [&](int i, double v) { r2_[i] = -v; });
+        }
         ex.sync();
         mask_fixed(gx);
-        for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) r2[i] = -ry[i];
-        ex.sync();
         kkt_solve(gx, r2, dw, dy);
 #if defined(SCVX_IPM_DEBUG) && !defined(__HIPCC__)
         {
@@ -1144,7 +1231,10 @@ struct Solver {
             H_apply(dw, r1);
             const double sgy = Et_apply(dy, tmpl);
             ex.sync();
-            for (int i = ex.lane(); i < L.nloc; i += ex.nlanes()) r1[i] = gx[i] - r1[i] - tmpl[i];
+            {
+                double* r1_ = r1; const double* g_ = gx; const double* tl = tmpl;
+                stream(0, L.nloc, [&](int i) { return D3{g_[i], r1_[i], tl[i]}; }, [&](int i, const D3& v) { r1_[i] = v.a - v.b - v.c; });
+            }
             ex.sync();
             if (ex.lane() == 0) {
                 r1[L.iS] = gx[L.iS] - r1[L.iS] - sgy;
@@ -1156,25 +1246,35 @@ struct Solver {
             mask_fixed(r1);
             E_apply(dw, tmpy2, true);
             ex.sync();
-            for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) tmpy2[i] = -ry[i] - tmpy2[i];
+            {
+                double* t2 = tmpy2; const double* ry_ = ry;
+                stream(0, L.ny, [&](int i) { return D2{ry_[i], t2[i]}; }, [&](int i, const D2& v) { t2[i] = -v.a - v.b; });
+            }
             ex.sync();
             kkt_solve(r1, tmpy2, cw, cy);
-            for (int i = ex.lane(); i < L.nv; i += ex.nlanes()) dw[i] += cw[i];
-            for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) dy[i] += cy[i];
+            {
+                double* dw_ = dw; const double* cw_ = cw; double* dy_ = dy; const double* cy_ = cy;
+                stream(0, L.nv, [&](int i) { return D2{dw_[i], cw_[i]}; }, [&](int i, const D2& v) { dw_[i] = v.a + v.b; });
+                stream(0, L.ny, [&](int i) { return D2{dy_[i], cy_[i]}; }, [&](int i, const D2& v) { dy_[i] = v.a + v.b; });
+            }
             ex.sync();
         }
         // With wij = W^-1 J dw:   W^-1 ds = wij - W^-1 rz,   W dz = -(wij + W^-1 bz),   dz = W^-1 (W dz),   ds = J dw - rz
         // so the scaled directions the step-length rule needs come for free (no further scaling passes).
         cone_map(dw, dS, false);  // J dw
         W_all(dS, tmpc, true);    // wij
-        for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) {
-            const double wij = tmpc[i];
-            sds[i] = wij - Wirz[i];
-            sdz[i] = -(wij + Wibz[i]);
-            dS[i] = dS[i] - rz[i];
+        {
+            const double* tc = tmpc; const double* wr = Wirz; const double* wb = Wibz; const double* rz_ = rz;
+            double* sds_ = sds; double* sdz_ = sdz; double* dS_ = dS;
+            if (full)
+                stream(0, L.nc, [&](int i) { return D5{tc[i], wr[i], wb[i], dS_[i], rz_[i]}; },
+                       [&](int i, const D5& v) { sds_[i] = v.a - v.b; sdz_[i] = -(v.a + v.c); dS_[i] = v.d - v.e; });
+            else
+                stream(0, L.nc, [&](int i) { return D3{tc[i], wr[i], wb[i]}; },
+                       [&](int i, const D3& v) { sds_[i] = v.a - v.b; sdz_[i] = -(v.a + v.c); });
         }
         ex.sync();
-        W_all(sdz, dZ, true);
+        if (full) W_all(sdz, dZ, true);
     }
 
     SCVX_HD_NI void shift_into_cone(double* X) {
@@ -1277,12 +1377,21 @@ struct Solver {
             SCVX_TS(tR_);
             cone_map(V, tmpc, true);
             ex.sync();
-            for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) rz[i] = S[i] - tmpc[i];
+            // rz = S - a(V); the complementarity gap S'Z and |rz|^2 ride along on the same pass
+            double gap_ = 0, nrz2 = 0;
+            {
+                double* rz_ = rz; const double* S_ = S; const double* Z_ = Z; const double* tc = tmpc;
+                stream(0, L.nc, [&](int i) { return D3{S_[i], tc[i], Z_[i]}; },
+                       [&](int i, const D3& v) { const double r = v.a - v.b; rz_[i] = r; gap_ += v.a * v.c; nrz2 += r * r; });
+            }
             ex.sync();
             cone_map_t(Z, rx);
             const double sgy = Et_apply(y, tmpl);
             ex.sync();
-            for (int i = ex.lane(); i < L.nloc; i += ex.nlanes()) rx[i] = -rx[i] + tmpl[i];
+            {
+                double* rx_ = rx; const double* tl = tmpl;
+                stream(0, L.nloc, [&](int i) { return D2{rx_[i], tl[i]}; }, [&](int i, const D2& v) { rx_[i] = -v.a + v.b; });
+            }
             ex.sync();
             if (ex.lane() == 0) {
                 rx[14 * K] += -1.0;
@@ -1295,11 +1404,16 @@ struct Solver {
             mask_fixed(rx);
             E_apply(V, ry, true);
             ex.sync();
-            for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) ry[i] += dk[i];
+            double nry2 = 0;
+            {
+                double* ry_ = ry; const double* dk_ = dk;
+                stream(0, L.ny, [&](int i) { return D2{ry_[i], dk_[i]}; },
+                       [&](int i, const D2& v) { const double r = v.a + v.b; ry_[i] = r; nry2 += r * r; });
+            }
             ex.sync();
-            const double gap = dot(S, Z, L.nc);
+            const double gap = ex.sum(gap_);
             const double pobj = -V[14 * K] + C.wNu * V[L.iTNU] + 0.5 * V[L.iTTR] + V[L.iTS];
-            const double nrx = sqrt(dot(rx, rx, L.nv)), nry = sqrt(dot(ry, ry, L.ny)), nrz = sqrt(dot(rz, rz, L.nc));
+            const double nrx = sqrt(sumsq(rx, L.nv)), nry = sqrt(ex.sum(nry2)), nrz = sqrt(ex.sum(nrz2));
             const double pres = nry > nrz ? nry : nrz;
             const double dres = nrx / (C.wNu > 1.0 ? C.wNu : 1.0);
             const double relgap = gap / (fabs(pobj) > 1.0 ? fabs(pobj) : 1.0);
@@ -1322,23 +1436,26 @@ struct Solver {
             const double mu = gap / degree;
             W_all(rz, Wirz, true);
             centering_rhs(tt, false, 0.0);   // affine (predictor) right-hand side, consumed in place by newton
-            { SCVX_TS(tN_); newton(tt); SCVX_TE(tN_, 10); }
-            double a1 = maxstep_all(sds), a2 = maxstep_all(sdz);
-            double alpha = a1 < a2 ? a1 : a2;
+            { SCVX_TS(tN_); newton(tt, false); SCVX_TE(tN_, 10); }
+            double alpha = maxstep_all(sds, sdz);
             if (alpha > 1.0) alpha = 1.0;
             const double sig = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
-            SCVX_DBG("    aff alpha %.6e (a1 %.3e a2 %.3e) |dw|^2 %.6e ds %.6e dtnu %.6e dttr %.6e\n", alpha, a1, a2, dot(dw, dw, L.nv), dw[L.iS], dw[L.iTNU], dw[L.iTTR]);
+            SCVX_DBG("    aff alpha %.6e |dw|^2 %.6e ds %.6e dtnu %.6e dttr %.6e\n", alpha, dot(dw, dw, L.nv), dw[L.iS], dw[L.iTNU], dw[L.iTTR]);
             centering_rhs(tt, true, sig * mu);
-            { SCVX_TS(tN_); newton(tt); SCVX_TE(tN_, 10); }
-            a1 = maxstep_all(sds); a2 = maxstep_all(sdz);
-            alpha = 0.99 * (a1 < a2 ? a1 : a2);
+            { SCVX_TS(tN_); newton(tt, true); SCVX_TE(tN_, 10); }
+            alpha = 0.99 * maxstep_all(sds, sdz);
             if (alpha > 1.0) alpha = 1.0;
             SCVX_DBG("    cmb alpha %.6e |dw|^2 %.6e\n", alpha, dot(dw, dw, L.nv));
             if (!(alpha == alpha)) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 3; break; }
             if (alpha < 1e-9) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
-            for (int i = ex.lane(); i < L.nv; i += ex.nlanes()) V[i] += alpha * dw[i];
-            for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) y[i] += alpha * dy[i];
-            for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) { S[i] += alpha * dS[i]; Z[i] += alpha * dZ[i]; }
+            {
+                double* V_ = V; const double* dw_ = dw; double* y_ = y; const double* dy_ = dy;
+                double* S_ = S; const double* dS_ = dS; double* Z_ = Z; const double* dZ_ = dZ;
+                stream(0, L.nv, [&](int i) { return D2{V_[i], dw_[i]}; }, [&](int i, const D2& v) { V_[i] = v.a + alpha * v.b; });
+                stream(0, L.ny, [&](int i) { return D2{y_[i], dy_[i]}; }, [&](int i, const D2& v) { y_[i] = v.a + alpha * v.b; });
+                stream(0, L.nc, [&](int i) { return D4{S_[i], dS_[i], Z_[i], dZ_[i]}; },
+                       [&](int i, const D4& v) { S_[i] = v.a + alpha * v.b; Z_[i] = v.c + alpha * v.d; });
+            }
             ex.sync();
         }
         res.merit = best_merit;
