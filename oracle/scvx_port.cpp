@@ -77,7 +77,8 @@ struct HostEx {
         chain(K, z1, N, o1, reverse);
         chain(K, z2, N, o2, reverse);
     }
-    // out_k = z_k - N_k out_{k-1} (forward) or out_k = z_k - N_k out_{k+1} (reverse); 14-vectors, N row-major
+    // out_k = z_k + N_k out_{k-1} (forward) or out_k = z_k + N_{k+1}' out_{k+1} (reverse); 14-vectors; N_k is the negated
+    // coupling tile stored transposed (element (i, j) at 14 j + i), as Solver::build_kkt writes it
     void chain(int K, const double* z, const double* N, double* out, bool reverse) {
         for (int step = 0; step < K; step++) {
             const int k = reverse ? K - 1 - step : step;
@@ -85,8 +86,13 @@ struct HostEx {
             for (int i = 0; i < 14; i++) {
                 double a = z[14 * k + i];
                 if (step > 0) {
-                    const double* row = N + (size_t)k * 196 + 14 * i;
-                    for (int j = 0; j < 14; j++) a -= row[j] * out[14 * prev + j];
+                    if (!reverse) {
+                        const double* col = N + (size_t)k * 196 + i;
+                        for (int j = 0; j < 14; j++) a += col[14 * j] * out[14 * prev + j];
+                    } else {
+                        const double* row = N + (size_t)(k + 1) * 196 + 14 * i;
+                        for (int j = 0; j < 14; j++) a += row[j] * out[14 * prev + j];
+                    }
                 }
                 out[14 * k + i] = a;
             }

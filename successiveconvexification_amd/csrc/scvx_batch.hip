@@ -26,8 +26,14 @@ using scvx::fail;
 
 namespace scvx {
 
+// The tile scratch of socp_kernel (one wavefront per block).  File scope on purpose: every routine of the solver
+// reaches it through WaveEx::scratch() as a known LDS symbol, so tile accesses compile to ds_read/ds_write (lgkmcnt
+// only).  A pointer carried in the executor object is reloaded from memory in each non-inlined routine, loses its
+// address space, and every LDS access becomes a flat_load/flat_store that also waits on the global loads and
+// stores in flight (vmcnt) — which serialises the tile arithmetic behind the HBM traffic it is meant to overlap.
+__shared__ __attribute__((aligned(16))) double g_socp_lds[1536];
+
 struct WaveEx {
-    double* sc;
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int nlanes() const { return 64; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
@@ -50,7 +56,7 @@ struct WaveEx {
         return x;
     }
     __device__ __forceinline__ bool all(bool b) { return __all(b) != 0; }
-    __device__ __forceinline__ double* scratch() { return sc; }
+    __device__ __forceinline__ double* scratch() { return g_socp_lds; }
 
     // value of x in lane `src` (src wave-uniform) delivered to every lane: two v_readlane_b32, no LDS
     static __device__ __forceinline__ double bcast(double x, int src) {
@@ -139,115 +145,100 @@ struct WaveEx {
         return ok;
     }
 
-    // out_k = z_k - N_k out_{k-1} (forward) / out_k = z_k - N_k out_{k+1} (reverse): the only sequential part
-    // of the block-tridiagonal solve.  The 196-double tile N_k is fetched COOPERATIVELY by all 64 lanes
-    // (coalesced, 3-4 doubles per lane) four steps ahead of its use, so four HBM/L2 round trips are always
-    // in flight; it is dropped into a two-slot LDS ring from which lane i reads its row (bank-conflict free:
-    // row stride 112 B) and the previous 14-vector is broadcast by readlane.  No barrier in the chain.
-    __device__ __forceinline__ void chain(int K, const double* __restrict__ z, const double* __restrict__ N,
-                                          double* __restrict__ out, bool reverse) {
-        constexpr int R = 4;  // tiles in flight
-        const int l = lane();
-        const bool live = l < 14;
-        const int i = live ? l : 13;
-        double* ring = sc + 32;  // 2 x 196 doubles (the factorisation tiles are idle during a solve)
+    // out_k = z_k + N_k out_{k-1} (forward) / out_k = z_k + N_{k+1}' out_{k+1} (reverse) for NR right-hand sides at
+    // once: the only sequential part of the block-tridiagonal solve, run entirely on the FP64 matrix pipe.
+    // (N_k is the NEGATED coupling tile, stored TRANSPOSED: element (i, j) at 14 j + i — see Solver::S_solve.)
+    //
+    // One step is  D = Z_k E + N_k T_{k-1}  as five v_mfma_f64_16x16x4:  T holds the NR running 14-vectors as columns
+    // 0..NR-1.  With the fragment maps of tile_gemm, register r of lane (g = l>>4, n = l&15) of the result is
+    // D[g + 4r][n]; feeding MFMA c the k-slots {g + 4c} makes its B operand B[g + 4c][n] = register c of the SAME lane
+    // of the previous result — the recurrence never leaves the accumulator registers: no LDS, no cross-lane traffic,
+    // no barrier.  The A operands are plain loads from the tile (forward, lane (g, row): element (g + 4c) * 14 + row,
+    // 4 runs of 14 consecutive doubles per instruction; reverse: the transposed element 14 row + g + 4c), and z rides in a fifth MFMA against a constant selector
+    // (A[row][16 + g] = z_g[row], B[16 + g][n] = delta(g, n)), issued ahead of the dependent four.  Operands for step
+    // s + R are requested while step s runs (R x 10 VGPRs in flight).
+    template <int NR>
+    __device__ __forceinline__ void chain_mfma(int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
+                                               bool reverse) {
+        static_assert(NR >= 1 && NR <= 4, "right-hand sides ride in k-slots 16..19");
+        constexpr int R = 8;
+        const int l = lane(), n = l & 15, g = l >> 4;
+        const bool rin = n < 14;   // for the A operands n is the tile row
+        // every lane loads from a valid (clamped) address and masks the value afterwards: a predicated load would
+        // compile to a branch around each of the five loads of a step
+        int offA[4];
+        double mA[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int kk = g + 4 * c;
+            const bool in = rin && kk < 14;
+            offA[c] = in ? (reverse ? 14 * n + kk : kk * 14 + n) : 0;
+            mA[c] = in ? 1.0 : 0.0;
+        }
+        const bool zin = rin && g < NR;
+        const int offZ = zin ? n : 0;
+        ipm::cgptr zp = z[0];
+        ipm::gptr op = o[0];
+#pragma unroll
+        for (int q = 1; q < NR; q++) {
+            if (g == q) zp = z[q];
+            if (n == q) op = o[q];
+        }
+        const double bsel = (g == n) ? 1.0 : 0.0;
+        const bool oin = n < NR;
+        const bool oin3 = oin && g < 2;   // register 3 holds row g + 12
         const int k0 = reverse ? K - 1 : 0;
         const int dk = reverse ? -1 : 1;
-        double t = z[14 * k0 + i];
-        if (live) out[14 * k0 + i] = t;
-        const int nsteps = K - 1;
-        double st[R][4];
-        double zs[R];
-        auto issue = [&](int step, double (&r)[4], double& zz) {
-            const int k = k0 + dk * (step + 1);
-            const double* base = N + (size_t)k * 196;
-            r[0] = base[l]; r[1] = base[l + 64]; r[2] = base[l + 128];
-            r[3] = (l < 4) ? base[l + 192] : 0.0;
-            zz = z[14 * k + i];
+        double st[R][5];
+        auto issue = [&](int s, double (&f)[5]) {
+            const int k = k0 + dk * s;
+            ipm::cgptr base = N + (size_t)(reverse ? (k + 1 < K ? k + 1 : k) : k) * 196;   // reverse: the tile of node k + 1
+#pragma unroll
+            for (int c = 0; c < 4; c++) f[c] = base[offA[c]];
+            f[4] = zp[14 * k + offZ];
         };
 #pragma unroll
         for (int q = 0; q < R; q++)
-            if (q < nsteps) issue(q, st[q], zs[q]);
-        for (int s0 = 0; s0 < nsteps; s0 += R) {
+            if (q < K) issue(q, st[q]);
+        v4f64 d = {0.0, 0.0, 0.0, 0.0};
+        for (int s0 = 0; s0 < K; s0 += R) {
 #pragma unroll
             for (int q = 0; q < R; q++) {
-                const int step = s0 + q;
-                if (step < nsteps) {
-                    double* slot = ring + 196 * (q & 1);
-                    slot[l] = st[q][0]; slot[l + 64] = st[q][1]; slot[l + 128] = st[q][2];
-                    if (l < 4) slot[l + 192] = st[q][3];
-                    const double zc = zs[q];
-                    if (step + R < nsteps) issue(step + R, st[q], zs[q]);
-                    sync_lds();
-                    const double* row = slot + 14 * i;
-                    double a0 = zc, a1 = 0.0;
+                const int s = s0 + q;
+                if (s < K) {
+                    // the first node has no coupling term (its tile is never written: mask, don't multiply)
+                    const double m0 = s > 0 ? 1.0 : 0.0;
+                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(zin ? st[q][4] : 0.0, bsel, acc, 0, 0, 0);
 #pragma unroll
-                    for (int j = 0; j < 14; j += 2) {
-                        a0 = fma(-row[j], bcast(t, j), a0);
-                        a1 = fma(-row[j + 1], bcast(t, j + 1), a1);
+                    for (int c = 0; c < 4; c++) {
+                        const double a = (mA[c] * m0 != 0.0) ? st[q][c] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, d[c], acc, 0, 0, 0);
                     }
-                    t = a0 + a1;
-                    const int k = k0 + dk * (step + 1);
-                    if (live) out[14 * k + i] = t;
+                    d = acc;
+                    // operands of step s + R go into the registers this step has just consumed
+                    if (s + R < K) issue(s + R, st[q]);
+                    const int k = k0 + dk * s;
+                    if (oin) {
+                        op[14 * k + g] = d[0];
+                        op[14 * k + g + 4] = d[1];
+                        op[14 * k + g + 8] = d[2];
+                    }
+                    if (oin3) op[14 * k + g + 12] = d[3];
                 }
             }
         }
     }
-
-    // Three recurrences through the same tiles: the N_k tile is read once from HBM / LDS for the three
-    // right-hand sides of the border solves, and the three FMA chains interleave (ILP) instead of queueing.
-    __device__ __forceinline__ void chain3(int K, const double* __restrict__ z0, const double* __restrict__ z1,
-                                           const double* __restrict__ z2, const double* __restrict__ N,
-                                           double* __restrict__ o0, double* __restrict__ o1, double* __restrict__ o2,
-                                           bool reverse) {
-        constexpr int R = 4;
-        const int l = lane();
-        const bool live = l < 14;
-        const int i = live ? l : 13;
-        double* ring = sc + 32;
-        const int k0 = reverse ? K - 1 : 0;
-        const int dk = reverse ? -1 : 1;
-        double t0 = z0[14 * k0 + i], t1 = z1[14 * k0 + i], t2 = z2[14 * k0 + i];
-        if (live) { o0[14 * k0 + i] = t0; o1[14 * k0 + i] = t1; o2[14 * k0 + i] = t2; }
-        const int nsteps = K - 1;
-        double st[R][4];
-        double zs[R][3];
-        auto issue = [&](int step, double (&r)[4], double (&zz)[3]) {
-            const int k = k0 + dk * (step + 1);
-            const double* base = N + (size_t)k * 196;
-            r[0] = base[l]; r[1] = base[l + 64]; r[2] = base[l + 128];
-            r[3] = (l < 4) ? base[l + 192] : 0.0;
-            zz[0] = z0[14 * k + i]; zz[1] = z1[14 * k + i]; zz[2] = z2[14 * k + i];
-        };
-#pragma unroll
-        for (int q = 0; q < R; q++)
-            if (q < nsteps) issue(q, st[q], zs[q]);
-        for (int s0 = 0; s0 < nsteps; s0 += R) {
-#pragma unroll
-            for (int q = 0; q < R; q++) {
-                const int step = s0 + q;
-                if (step < nsteps) {
-                    double* slot = ring + 196 * (q & 1);
-                    slot[l] = st[q][0]; slot[l + 64] = st[q][1]; slot[l + 128] = st[q][2];
-                    if (l < 4) slot[l + 192] = st[q][3];
-                    const double c0 = zs[q][0], c1 = zs[q][1], c2 = zs[q][2];
-                    if (step + R < nsteps) issue(step + R, st[q], zs[q]);
-                    sync_lds();
-                    const double* row = slot + 14 * i;
-                    double a0 = c0, a1 = c1, a2 = c2;
-#pragma unroll
-                    for (int j = 0; j < 14; j++) {
-                        const double nij = row[j];
-                        a0 = fma(-nij, bcast(t0, j), a0);
-                        a1 = fma(-nij, bcast(t1, j), a1);
-                        a2 = fma(-nij, bcast(t2, j), a2);
-                    }
-                    t0 = a0; t1 = a1; t2 = a2;
-                    const int k = k0 + dk * (step + 1);
-                    if (live) { o0[14 * k + i] = t0; o1[14 * k + i] = t1; o2[14 * k + i] = t2; }
-                }
-            }
-        }
+    __device__ __forceinline__ void chain(int K, ipm::cgptr z, ipm::cgptr N, ipm::gptr out, bool reverse) {
+        const ipm::cgptr zs[1] = {z};
+        const ipm::gptr os[1] = {out};
+        chain_mfma<1>(K, zs, N, os, reverse);
+    }
+    __device__ __forceinline__ void chain3(int K, ipm::cgptr z0, ipm::cgptr z1, ipm::cgptr z2, ipm::cgptr N, ipm::gptr o0,
+                                           ipm::gptr o1, ipm::gptr o2, bool reverse) {
+        const ipm::cgptr zs[3] = {z0, z1, z2};
+        const ipm::gptr os[3] = {o0, o1, o2};
+        chain_mfma<3>(K, zs, N, os, reverse);
     }
 };
 
@@ -259,16 +250,16 @@ __global__ __launch_bounds__(64, 3) void socp_kernel(ipm::Consts C, int B, size_
                                                   const int* __restrict__ active, double* __restrict__ work,
                                                   double* __restrict__ sol, double* __restrict__ nu,
                                                   double* __restrict__ info) {
-    __shared__ __attribute__((aligned(16))) double lds[1536];
     const int b = blockIdx.x;
     if (b >= B) return;
     if (active && !active[b]) return;
     const int K = C.K;
-    WaveEx ex{lds};
+    WaveEx ex;
     ipm::Solver<WaveEx> S(ex, C);
-    const ipm::Result r = S.solve(x + (size_t)b * (K + 1) * 14, u + (size_t)b * (K + 1) * 3,
-                                  endpoint + (size_t)b * K * 14, deriv + (size_t)b * K * 294, rk[b], ic + (size_t)b * 6,
-                                  work + (size_t)b * work_stride);
+    // kernel arguments are HBM pointers: hand them to the solver typed as such (see ipm::gptr)
+    const ipm::Result r = S.solve((ipm::cgptr)(x + (size_t)b * (K + 1) * 14), (ipm::cgptr)(u + (size_t)b * (K + 1) * 3),
+                                  (ipm::cgptr)(endpoint + (size_t)b * K * 14), (ipm::cgptr)(deriv + (size_t)b * K * 294), rk[b],
+                                  (ipm::cgptr)(ic + (size_t)b * 6), (ipm::gptr)(work + (size_t)b * work_stride));
     const int nxu = S.L.nx + S.L.nu_;
     double* so = sol + (size_t)b * (nxu + 1);
     for (int i = threadIdx.x; i < nxu; i += 64) so[i] = S.V[i];
@@ -281,7 +272,7 @@ __global__ __launch_bounds__(64, 3) void socp_kernel(ipm::Consts C, int B, size_
         info[4 * b + 2] = r.merit;
         info[4 * b + 3] = r.pobj;
 #if defined(SCVX_IPM_PROF)
-        if (b == 0) for (int i = 0; i < 16; i++) work[i] = S.prof[i];  // diagnostic build: section cycles of trajectory 0
+        if (b == 0) for (int i = 0; i < 32; i++) work[i] = S.prof[i];  // diagnostic build: section cycles of trajectory 0
 #endif
     }
 }
@@ -762,9 +753,9 @@ int scvx_batch_get_solver_stats(scvx_batch* b, int32_t* status, int32_t* iters, 
 }
 
 #if defined(SCVX_IPM_PROF)
-int scvx_debug_ipm_prof(scvx_batch* b, double* out16) {
-    hipStreamSynchronize(b->ctx->stream);
-    return hipMemcpy(out16, b->work, 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+int scvx_debug_ipm_prof(scvx_batch* b, double* out32) {
+    (void)hipStreamSynchronize(b->ctx->stream);
+    return hipMemcpy(out32, b->work, 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
 #endif
 

@@ -59,6 +59,18 @@
 namespace scvx {
 namespace ipm {
 
+// Pointers into the solver's HBM-resident state are typed with the global address space on the device, so every
+// access compiles to global_load/global_store (vmcnt only).  A plain `double*` kept in the solver object is
+// reloaded from memory in each non-inlined routine, loses its address space and becomes a flat access, which counts
+// against lgkmcnt as well -- and every wait for an LDS tile then also waits for the HBM traffic in flight.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) double gdouble;
+#else
+typedef double gdouble;
+#endif
+typedef gdouble* gptr;
+typedef const gdouble* cgptr;
+
 struct Consts {
     int K, max_iter, refine, pad;
     double tol;
@@ -95,7 +107,7 @@ struct Layout {
         n += (size_t)nc * 13;            // S, Z, rz, lam, Wv, t, Wibz, dS, dZ, sds, sdz, tmpc, Wirz
         n += (size_t)ncones;             // Wbeta
         n += (size_t)(K + 1) * 25 + (size_t)(K + 1) * 9;  // hx, hu
-        n += (size_t)K * 196 * 3;        // Linv, Nf, Nb
+        n += (size_t)K * 196 * 2;        // Linv, Nf
         n += (size_t)ny;                 // tchain
         n += (size_t)(nloc + ny) * 3;    // ls,ys, ltr,ytr, lnu,ynu
         n += (size_t)nloc * 2;           // tmpl, tmpl2
@@ -109,7 +121,8 @@ struct Layout {
 // ------------------------------------------------------------------------------------------------
 // scalar helpers for small second-order cones (dim <= 4), W = beta (2 v v' - J)
 // ------------------------------------------------------------------------------------------------
-SCVX_HD void soc_nt_small(const double* s, const double* z, int d, double* v, double& beta) {
+template <class PS, class PZ, class PV>
+SCVX_HD void soc_nt_small(PS s, PZ z, int d, PV v, double& beta) {
     double s1 = 0, z1 = 0, sz = 0;
     for (int i = 1; i < d; i++) { s1 += s[i] * s[i]; z1 += z[i] * z[i]; sz += s[i] * z[i]; }
     const double sj = sqrt(s[0] * s[0] - s1), zj = sqrt(z[0] * z[0] - z1);
@@ -123,7 +136,8 @@ SCVX_HD void soc_nt_small(const double* s, const double* z, int d, double* v, do
     beta = sqrt(sj * izj);
 }
 // y = W x (inverse=false) or W^-1 x
-SCVX_HD void soc_W_small(const double* v, double beta, int d, const double* x, double* y, bool inverse) {
+template <class PV, class PX, class PY>
+SCVX_HD void soc_W_small(PV v, double beta, int d, PX x, PY y, bool inverse) {
     double vx = v[0] * x[0];
     if (!inverse) { for (int i = 1; i < d; i++) vx += v[i] * x[i]; }
     else { for (int i = 1; i < d; i++) vx -= v[i] * x[i]; }
@@ -158,7 +172,8 @@ SCVX_HD double soc_maxstep_parts(double l0, double d0, double ll, double ld, dou
 }
 // inverse of a symmetric positive definite 3x3 (row-major in/out) through its Cholesky factor: backward
 // stable for the nearly rank-one blocks d I + kappa v v' an active cone produces (the cofactor formula is not)
-SCVX_HD void inv3(const double* M, double* Mi) {
+template <class PO>
+SCVX_HD void inv3(const double* M, PO Mi) {
     const double l00 = sqrt(M[0]);
     const double l10 = M[3] / l00, l20 = M[6] / l00;
     const double l11 = sqrt(M[4] - l10 * l10);
@@ -177,7 +192,8 @@ SCVX_HD void inv3(const double* M, double* Mi) {
     Mi[5] = Mi[7] = i21 * i22;
     Mi[8] = i22 * i22;
 }
-SCVX_HD void inv2(double a, double b, double d, double* Mi) {  // [[a b],[b d]] SPD
+template <class PO>
+SCVX_HD void inv2(double a, double b, double d, PO Mi) {  // [[a b],[b d]] SPD
     const double l00 = sqrt(a), l10 = b / l00, l11 = sqrt(d - l10 * l10);
     const double i00 = 1.0 / l00, i11 = 1.0 / l11, i10 = -l10 * i00 * i11;
     Mi[0] = i00 * i00 + i10 * i10; Mi[1] = Mi[2] = i10 * i11; Mi[3] = i11 * i11;
@@ -185,7 +201,8 @@ SCVX_HD void inv2(double a, double b, double d, double* Mi) {  // [[a b],[b d]] 
 
 // compact per-node inverse of the x-block of Hb: [hm | Hr 3x3 | hv | hq | Hq34 2x2 | Hw 3x3] = 25 doubles
 enum { HX_M = 0, HX_R = 1, HX_V = 10, HX_Q = 11, HX_Q34 = 12, HX_W = 16, HX_SZ = 25 };
-SCVX_HD double hxi_entry(const double* h, int a, int b) {
+template <class PH>
+SCVX_HD double hxi_entry(PH h, int a, int b) {
     if (a == 0) return b == 0 ? h[HX_M] : 0.0;
     if (a < 4) return (b >= 1 && b < 4) ? h[HX_R + 3 * (a - 1) + (b - 1)] : 0.0;
     if (a < 7) return a == b ? h[HX_V] : 0.0;
@@ -194,7 +211,8 @@ SCVX_HD double hxi_entry(const double* h, int a, int b) {
     return (b >= 11) ? h[HX_W + 3 * (a - 11) + (b - 11)] : 0.0;
 }
 // y = Hxi * x for one node (14-vectors)
-SCVX_HD void hxi_apply(const double* h, const double* x, double* y) {
+template <class PH>
+SCVX_HD void hxi_apply(PH h, const double* x, double* y) {
     y[0] = h[HX_M] * x[0];
     for (int i = 0; i < 3; i++) y[1 + i] = h[HX_R + 3 * i] * x[1] + h[HX_R + 3 * i + 1] * x[2] + h[HX_R + 3 * i + 2] * x[3];
     for (int i = 4; i < 7; i++) y[i] = h[HX_V] * x[i];
@@ -218,28 +236,28 @@ struct Solver {
     const Consts& C;
     Layout L;
     // inputs
-    const double *xbar, *ubar, *D, *endpoint;
+    cgptr xbar, ubar, D, endpoint;
     double x0fix[10];  // mwet, rIi(3), vIi(3), wBi(3)
     double rk;
     // workspace
-    double *dk, *V, *rx, *gx, *dw, *r1, *cw, *Vbest, *tmpv;
-    double *y, *ry, *dy, *r2, *cy, *tmpy, *tmpy2;
-    double *S, *Z, *rz, *lam, *Wv, *tt, *Wibz, *dS, *dZ, *sds, *sdz, *tmpc, *Wirz;
-    double* Wbeta;
-    double *hx, *hu;
-    double *Linv, *Nf, *Nb, *tchain;
-    double *ls, *ys, *ltr, *ytr, *lnu, *ynu;
-    double *tmpl, *tmpl2;
-    double *uhat, *lb0;
+    gptr dk, V, rx, gx, dw, r1, cw, Vbest, tmpv;
+    gptr y, ry, dy, r2, cy, tmpy, tmpy2;
+    gptr S, Z, rz, lam, Wv, tt, Wibz, dS, dZ, sds, sdz, tmpc, Wirz;
+    gptr Wbeta;
+    gptr hx, hu;
+    gptr Linv, Nf, tchain;
+    gptr ls, ys, ltr, ytr, lnu, ynu;
+    gptr tmpl, tmpl2;
+    gptr uhat, lb0;
     // per-factorisation scalars
     double h_tr[4], h_nu[4], Msg[4], hrk, hnui;
     double css, cst, csn, cts, ctt, ctn, cns, cnt_, cnn;
-    double prof[16];
+    double prof[32];
     double cur_merit;  // merit of the current iterate: refinement only pays in the endgame
 
-    SCVX_HD Solver(Ex& e, const Consts& c) : ex(e), C(c) { L.init(c.K); for (int i = 0; i < 16; i++) prof[i] = 0.0; }
+    SCVX_HD Solver(Ex& e, const Consts& c) : ex(e), C(c) { L.init(c.K); for (int i = 0; i < 32; i++) prof[i] = 0.0; }
 
-    SCVX_HD void carve(double* w) {
+    SCVX_HD void carve(gptr w) {
         const int nv = L.nv, ny = L.ny, nc = L.nc, nloc = L.nloc, K = L.K;
         dk = w; w += ny;
         V = w; w += nv; rx = w; w += nv; gx = w; w += nv; dw = w; w += nv; r1 = w; w += nv; cw = w; w += nv;
@@ -250,7 +268,7 @@ struct Solver {
         Wirz = w; w += nc;
         Wbeta = w; w += L.ncones;
         hx = w; w += (size_t)(K + 1) * HX_SZ; hu = w; w += (size_t)(K + 1) * 9;
-        Linv = w; w += (size_t)K * 196; Nf = w; w += (size_t)K * 196; Nb = w; w += (size_t)K * 196;
+        Linv = w; w += (size_t)K * 196; Nf = w; w += (size_t)K * 196;
         tchain = w; w += ny;
         ls = w; w += nloc; ys = w; w += ny; ltr = w; w += nloc; ytr = w; w += ny; lnu = w; w += nloc; ynu = w; w += ny;
         tmpl = w; w += nloc; tmpl2 = w; w += nloc;
@@ -289,36 +307,36 @@ struct Solver {
     struct D4 { double a, b, c, d; };
     struct D5 { double a, b, c, d, e; };
 
-    SCVX_HD double dot(const double* a, const double* b, int n) {
+    SCVX_HD double dot(cgptr a, cgptr b, int n) {
         double s = 0;
         stream(0, n, [&](int i) { return D2{a[i], b[i]}; }, [&](int, const D2& v) { s += v.a * v.b; });
         return ex.sum(s);
     }
-    SCVX_HD double sumsq(const double* a, int n) {
+    SCVX_HD double sumsq(cgptr a, int n) {
         double s = 0;
         stream<8>(0, n, [&](int i) { return a[i]; }, [&](int, double v) { s += v * v; });
         return ex.sum(s);
     }
-    SCVX_HD void zero(double* o, int n) {
+    SCVX_HD void zero(gptr o, int n) {
         for (int i = ex.lane(); i < n; i += ex.nlanes()) o[i] = 0.0;
         ex.sync();
     }
-    SCVX_HD void copy(double* o, const double* a, int n) {
+    SCVX_HD void copy(gptr o, cgptr a, int n) {
         stream<8>(0, n, [&](int i) { return a[i]; }, [&](int i, double v) { o[i] = v; });
         ex.sync();
     }
 
     // ---- E (linearised dynamics rows, rocketland.jl:117-133) ----
     // out[k][i] = sum_j D_k[i][j] [dx_k; du_k; du_{k+1}; s]_j + nu_k[i] - dx_{k+1}[i]   (with_s: include the s column)
-    SCVX_HD_NI void E_apply(const double* v, double* out, bool with_s) {
+    SCVX_HD_NI void E_apply(cgptr v, gptr out, bool with_s) {
         SCVX_T0();
         const int K = L.K;
         const double s = with_s ? v[L.iS] : 0.0;
         for (int r = ex.lane(); r < 14 * K; r += ex.nlanes()) {
             const int k = r / 14, i = r - 14 * k;
-            const double* Dk = D + (size_t)k * 294 + i;
-            const double* dx = v + 14 * k;
-            const double* du = v + L.nx + 3 * k;
+            cgptr Dk = D + (size_t)k * 294 + i;
+            cgptr dx = v + 14 * k;
+            cgptr du = v + L.nx + 3 * k;
             double a = 0;
             for (int j = 0; j < 14; j++) a += Dk[14 * j] * dx[j];
             for (int j = 0; j < 6; j++) a += Dk[14 * (14 + j)] * du[j];  // du_k then du_{k+1} are adjacent
@@ -330,14 +348,15 @@ struct Solver {
         SCVX_T1(1);
     }
     // g = E_loc' y on the local part (dx, du, nu); returns Sg . y (the s entry) to every lane
-    SCVX_HD_NI double Et_apply(const double* yy, double* g) {
+    SCVX_HD_NI double Et_apply(cgptr yy, gptr g) {
+        SCVX_T0();
         const int K = L.K;
         for (int t = ex.lane(); t < L.nx; t += ex.nlanes()) {
             const int k = t / 14, j = t - 14 * k;
             double a = 0;
             if (k < K) {
-                const double* col = D + (size_t)k * 294 + 14 * j;
-                const double* yk = yy + 14 * k;
+                cgptr col = D + (size_t)k * 294 + 14 * j;
+                cgptr yk = yy + 14 * k;
                 for (int i = 0; i < 14; i++) a += col[i] * yk[i];
             }
             if (k > 0) a -= yy[14 * (k - 1) + j];
@@ -347,13 +366,13 @@ struct Solver {
             const int k = t / 3, c = t - 3 * k;
             double a = 0;
             if (k < K) {
-                const double* col = D + (size_t)k * 294 + 14 * (14 + c);
-                const double* yk = yy + 14 * k;
+                cgptr col = D + (size_t)k * 294 + 14 * (14 + c);
+                cgptr yk = yy + 14 * k;
                 for (int i = 0; i < 14; i++) a += col[i] * yk[i];
             }
             if (k > 0) {
-                const double* col = D + (size_t)(k - 1) * 294 + 14 * (17 + c);
-                const double* yk = yy + 14 * (k - 1);
+                cgptr col = D + (size_t)(k - 1) * 294 + 14 * (17 + c);
+                cgptr yk = yy + 14 * (k - 1);
                 for (int i = 0; i < 14; i++) a += col[i] * yk[i];
             }
             g[L.nx + t] = a;
@@ -365,37 +384,39 @@ struct Solver {
             sg += D[(size_t)k * 294 + 14 * 20 + i] * yy[r];
         }
         ex.sync();
+        SCVX_T1(20);
         return ex.sum(sg);
     }
 
     // ---- cone maps: a(w), J dw, J' z ----
     // out = a(v) if affine else J v
-    SCVX_HD_NI void cone_map(const double* v, double* out, bool affine) {
+    SCVX_HD_NI void cone_map(cgptr v, gptr out, bool affine) {
+        SCVX_T0();
         const int K = L.K;
         const double af = affine ? 1.0 : 0.0;
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
-            const double* dx = v + 14 * k;
-            const double* du = v + L.nx + 3 * k;
+            cgptr dx = v + 14 * k;
+            cgptr du = v + L.nx + 3 * k;
             double x[14], u[3];
             for (int j = 0; j < 14; j++) x[j] = af * xbar[14 * k + j] + dx[j];
             for (int c = 0; c < 3; c++) u[c] = af * ubar[3 * k + c] + du[c];
             if (k < K) {
-                double* g = out + L.o_gs + 3 * k;
+                gptr g = out + L.o_gs + 3 * k;
                 g[0] = x[1] * C.itan; g[1] = x[2]; g[2] = x[3];
-                double* t = out + L.o_tilt + 3 * k;
+                gptr t = out + L.o_tilt + 3 * k;
                 t[0] = af * C.sqcm; t[1] = x[9]; t[2] = x[10];
-                double* r = out + L.o_rate + 4 * k;
+                gptr r = out + L.o_rate + 4 * k;
                 r[0] = af * C.omMax; r[1] = x[11]; r[2] = x[12]; r[3] = x[13];
             }
             if (k >= 1) out[L.o_mass + (k - 1)] = x[0] - af * C.mdry;
-            double* tb = out + L.o_tb + 4 * k;
+            gptr tb = out + L.o_tb + 4 * k;
             tb[0] = af * C.Tmax; tb[1] = u[0]; tb[2] = u[1]; tb[3] = u[2];
-            double* tc = out + L.o_tc + 4 * k;
+            gptr tc = out + L.o_tc + 4 * k;
             tc[0] = u[0] * C.icos; tc[1] = u[0]; tc[2] = u[1]; tc[3] = u[2];
             out[L.o_lb + k] = uhat[3 * k] * du[0] + uhat[3 * k + 1] * du[1] + uhat[3 * k + 2] * du[2] - af * lb0[k];
         }
         {
-            const double* vn = v + L.nx + L.nu_; double* on = out + L.o_nu + 1; double* ot = out + L.o_tr + 1;
+            cgptr vn = v + L.nx + L.nu_; gptr on = out + L.o_nu + 1; gptr ot = out + L.o_tr + 1;
             stream<8>(0, 14 * K, [&](int i) { return vn[i]; }, [&](int i, double x) { on[i] = x; });
             stream<8>(0, L.nx + L.nu_, [&](int i) { return v[i]; }, [&](int i, double x) { ot[i] = x; });
         }
@@ -407,33 +428,35 @@ struct Solver {
             out[L.o_rk] = af * rk - v[L.iTTR];
         }
         ex.sync();
+        SCVX_T1(21);
     }
     // g = J' z (var-shaped, all nv entries written)
-    SCVX_HD_NI void cone_map_t(const double* z, double* g) {
+    SCVX_HD_NI void cone_map_t(cgptr z, gptr g) {
+        SCVX_T0();
         const int K = L.K;
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
-            double* gx_ = g + 14 * k;
-            const double* trx = z + L.o_tr + 1 + 14 * k;
+            gptr gx_ = g + 14 * k;
+            cgptr trx = z + L.o_tr + 1 + 14 * k;
             for (int j = 0; j < 14; j++) gx_[j] = trx[j];
             if (k >= 1) gx_[0] += z[L.o_mass + (k - 1)];
             if (k < K) {
-                const double* gs = z + L.o_gs + 3 * k;
+                cgptr gs = z + L.o_gs + 3 * k;
                 gx_[1] += gs[0] * C.itan; gx_[2] += gs[1]; gx_[3] += gs[2];
-                const double* t = z + L.o_tilt + 3 * k;
+                cgptr t = z + L.o_tilt + 3 * k;
                 gx_[9] += t[1]; gx_[10] += t[2];
-                const double* r = z + L.o_rate + 4 * k;
+                cgptr r = z + L.o_rate + 4 * k;
                 gx_[11] += r[1]; gx_[12] += r[2]; gx_[13] += r[3];
             }
-            double* gu = g + L.nx + 3 * k;
-            const double* tru = z + L.o_tr + 1 + L.nx + 3 * k;
-            const double* tb = z + L.o_tb + 4 * k;
-            const double* tc = z + L.o_tc + 4 * k;
+            gptr gu = g + L.nx + 3 * k;
+            cgptr tru = z + L.o_tr + 1 + L.nx + 3 * k;
+            cgptr tb = z + L.o_tb + 4 * k;
+            cgptr tc = z + L.o_tc + 4 * k;
             const double zl = z[L.o_lb + k];
             for (int c = 0; c < 3; c++) gu[c] = tru[c] + tb[1 + c] + tc[1 + c] + zl * uhat[3 * k + c];
             gu[0] += tc[0] * C.icos;
         }
         {
-            const double* zn = z + L.o_nu + 1; double* gn = g + L.nx + L.nu_;
+            cgptr zn = z + L.o_nu + 1; gptr gn = g + L.nx + L.nu_;
             stream<8>(0, 14 * K, [&](int i) { return zn[i]; }, [&](int i, double x) { gn[i] = x; });
         }
         if (ex.lane() == 0) {
@@ -443,8 +466,9 @@ struct Solver {
             g[L.iS] = z[L.o_sg + 1];
         }
         ex.sync();
+        SCVX_T1(21);
     }
-    SCVX_HD void mask_fixed(double* g) {
+    SCVX_HD void mask_fixed(gptr g) {
         for (int j = ex.lane(); j < 14; j += ex.nlanes()) {
             if (fixed_x(0, j)) g[j] = 0.0;
             if (fixed_x(L.K, j)) g[14 * L.K + j] = 0.0;
@@ -455,7 +479,7 @@ struct Solver {
 
     // ---- big-cone helpers (all lanes cooperate) ----
     SCVX_HD void big_nt(int off, int dim, int cidx) {
-        const double* s = S + off; const double* z = Z + off;
+        cgptr s = S + off; cgptr z = Z + off;
         double a = 0, b = 0, c = 0;
         stream(1, dim, [&](int i) { return D2{s[i], z[i]}; },
                [&](int, const D2& v) { a += v.a * v.a; b += v.b * v.b; c += v.a * v.b; });
@@ -466,14 +490,14 @@ struct Solver {
         const double ig = 0.5 / gam;
         const double wb0 = (s[0] * isj + z[0] * izj) * ig;
         const double den = 1.0 / sqrt(2.0 * (wb0 + 1.0));
-        double* v = Wv + off;
+        gptr v = Wv + off;
         stream(1, dim, [&](int i) { return D2{s[i], z[i]}; },
                [&](int i, const D2& q) { v[i] = (q.a * isj - q.b * izj) * ig * den; });
         if (ex.lane() == 0) { v[0] = (wb0 + 1.0) * den; Wbeta[cidx] = sqrt(sj * izj); }
     }
-    SCVX_HD void big_W(int off, int dim, int cidx, const double* x, double* yv, bool inverse) {
-        const double* v = Wv + off;
-        const double* xo = x + off; double* yo = yv + off;
+    SCVX_HD void big_W(int off, int dim, int cidx, cgptr x, gptr yv, bool inverse) {
+        cgptr v = Wv + off;
+        cgptr xo = x + off; gptr yo = yv + off;
         double vx = 0;
         stream(1, dim, [&](int i) { return D2{v[i], xo[i]}; }, [&](int, const D2& q) { vx += q.a * q.b; });
         vx = ex.sum(vx);
@@ -487,9 +511,9 @@ struct Solver {
         if (ex.lane() == 0) yv[off] = (2.0 * vx * v[0] - x0) * sc;
     }
     // t = lam \ d on a big cone
-    SCVX_HD void big_div(int off, int dim, const double* d, double* out) {
-        const double* l = lam + off;
-        const double* dd = d + off; double* oo = out + off;
+    SCVX_HD void big_div(int off, int dim, cgptr d, gptr out) {
+        cgptr l = lam + off;
+        cgptr dd = d + off; gptr oo = out + off;
         double ld = 0, ll = 0;
         stream(1, dim, [&](int i) { return D2{l[i], dd[i]}; }, [&](int, const D2& q) { ld += q.a * q.b; ll += q.a * q.a; });
         ld = ex.sum(ld); ll = ex.sum(ll);
@@ -501,8 +525,8 @@ struct Solver {
         if (ex.lane() == 0) out[off] = x0;
     }
     // out = a o b on a big cone
-    SCVX_HD void big_prod(int off, int dim, const double* a, const double* b, double* out) {
-        const double* ao = a + off; const double* bo = b + off; double* oo = out + off;
+    SCVX_HD void big_prod(int off, int dim, cgptr a, cgptr b, gptr out) {
+        cgptr ao = a + off; cgptr bo = b + off; gptr oo = out + off;
         double ab = 0;
         stream(0, dim, [&](int i) { return D2{ao[i], bo[i]}; }, [&](int, const D2& q) { ab += q.a * q.b; });
         ab = ex.sum(ab);
@@ -512,9 +536,9 @@ struct Solver {
         if (ex.lane() == 0) out[off] = ab;
     }
     // step lengths for two directions with one pass over lam
-    SCVX_HD void big_maxstep2(int off, int dim, const double* d1, const double* d2, double& s1, double& s2) {
-        const double* l = lam + off;
-        const double* p = d1 + off; const double* q = d2 + off;
+    SCVX_HD void big_maxstep2(int off, int dim, cgptr d1, cgptr d2, double& s1, double& s2) {
+        cgptr l = lam + off;
+        cgptr p = d1 + off; cgptr q = d2 + off;
         double ll = 0, ld = 0, dd = 0, le = 0, ee = 0;
         stream(1, dim, [&](int i) { return D3{l[i], p[i], q[i]}; },
                [&](int, const D3& v) { ll += v.a * v.a; ld += v.a * v.b; dd += v.b * v.b; le += v.a * v.c; ee += v.c * v.c; });
@@ -588,7 +612,7 @@ struct Solver {
         ex.sync();
     }
     // out = W in  /  W^-1 in   (cone vectors; in may alias out)
-    SCVX_HD_NI void W_all(const double* in, double* out, bool inverse) {
+    SCVX_HD_NI void W_all(cgptr in, gptr out, bool inverse) {
         SCVX_T0();
         all_small([&](auto Dt_, int off, int c) {
             constexpr int d = decltype(Dt_)::value;
@@ -607,7 +631,8 @@ struct Solver {
         SCVX_T1(8);
     }
     // out = lam \ d
-    SCVX_HD_NI void div_all(const double* d, double* out) {
+    SCVX_HD_NI void div_all(cgptr d, gptr out) {
+        SCVX_T0();
         all_small([&](auto Dt_, int off, int) {
             constexpr int dm = decltype(Dt_)::value;
             if (dm == 1) out[off] = d[off] / lam[off];
@@ -625,10 +650,12 @@ struct Solver {
         big_div(L.o_nu, 14 * L.K + 1, d, out);
         big_div(L.o_tr, 17 * (L.K + 1) + 1, d, out);
         ex.sync();
+        SCVX_T1(22);
     }
     // out = base_sign * (lam o lam)  [mode 0: out = -lam o lam]
     //       mode 1: out = -lam o lam - sds o sdz + sigmu * e
-    SCVX_HD_NI void centering_rhs(double* out, bool combined, double sigmu) {
+    SCVX_HD_NI void centering_rhs(gptr out, bool combined, double sigmu) {
+        SCVX_T0();
         all_small([&](auto Dt_, int off, int) {
             constexpr int dm = decltype(Dt_)::value;
             if (dm == 1) {
@@ -650,18 +677,20 @@ struct Solver {
             if (combined) {
                 big_prod(offs[q], dims[q], sds, sdz, tmpc);
                 ex.sync();
-                double* oo = out + offs[q]; const double* tc = tmpc + offs[q];
+                gptr oo = out + offs[q]; cgptr tc = tmpc + offs[q];
                 stream(0, dims[q], [&](int i) { return D2{oo[i], tc[i]}; }, [&](int i, const D2& v) { oo[i] = -v.a - v.b; });
                 if (ex.lane() == 0) out[offs[q]] += sigmu;
             } else {
-                double* oo = out + offs[q];
+                gptr oo = out + offs[q];
                 stream<8>(0, dims[q], [&](int i) { return oo[i]; }, [&](int i, double v) { oo[i] = -v; });
             }
         }
         ex.sync();
+        SCVX_T1(22);
     }
     // largest step keeping lam + a*d1 and lam + a*d2 in the cone (one pass over lam for both scaled directions)
-    SCVX_HD_NI double maxstep_all(const double* d1, const double* d2) {
+    SCVX_HD_NI double maxstep_all(cgptr d1, cgptr d2) {
+        SCVX_T0();
         double amax = INFINITY;
         all_small([&](auto Dt_, int off, int) {
             constexpr int dm = decltype(Dt_)::value;
@@ -691,11 +720,12 @@ struct Solver {
         if (b1 < amax) amax = b1;
         if (a2 < amax) amax = a2;
         if (b2 < amax) amax = b2;
+        SCVX_T1(22);
         return amax;
     }
 
     // ---- Hb^-1 on a local vector (dx, du, nu); in may alias out ----
-    SCVX_HD_NI void Hb_inv(const double* g, double* out) {
+    SCVX_HD_NI void Hb_inv(cgptr g, gptr out) {
         SCVX_T0();
         const int K = L.K;
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
@@ -703,12 +733,12 @@ struct Solver {
             for (int j = 0; j < 14; j++) xin[j] = g[14 * k + j];
             hxi_apply(hx + (size_t)k * HX_SZ, xin, yo);
             for (int j = 0; j < 14; j++) out[14 * k + j] = yo[j];
-            const double* h = hu + 9 * k;
+            cgptr h = hu + 9 * k;
             const double u0 = g[L.nx + 3 * k], u1 = g[L.nx + 3 * k + 1], u2 = g[L.nx + 3 * k + 2];
             for (int c = 0; c < 3; c++) out[L.nx + 3 * k + c] = h[3 * c] * u0 + h[3 * c + 1] * u1 + h[3 * c + 2] * u2;
         }
         {
-            const double* gn = g + L.nx + L.nu_; double* on = out + L.nx + L.nu_;
+            cgptr gn = g + L.nx + L.nu_; gptr on = out + L.nx + L.nu_;
             const double hn = hnui;
             stream<8>(0, 14 * K, [&](int i) { return gn[i]; }, [&](int i, double v) { on[i] = hn * v; });
         }
@@ -717,21 +747,24 @@ struct Solver {
     }
 
     // ---- block-tridiagonal solve S x = r (r, x: [K][14], distinct buffers) ----
-    // With L the block Cholesky factor:  forward  t_k = Linv_k r_k - Nf_k t_{k-1},   Nf_k = Linv_k Wb_{k-1}
-    //                                    backward x_k = Linv_k' t_k - Nb_k x_{k+1},  Nb_k = Linv_k' Wb_k'
-    // The Linv products are chain-free (all k in parallel); only the 14x14 matrix-vector recurrences are
-    // sequential and run inside the executor (ex.chain: wave-synchronous on the device, no barriers).
-    SCVX_HD_NI void S_solve(const double* r, double* x) {
+    // S = L L' with L block lower bidiagonal (diagonal blocks L_k, sub-diagonal blocks Wb_k).  Stored per segment:
+    // Linv_k = L_k^-1 and the coupling tile Nf_k = -Linv_k Wb_{k-1} (negated, transposed: element (i,j) at 14 j + i).
+    //     forward   t_k = Linv_k r_k + Nf_k t_{k-1}
+    //     backward  w_k = t_k + Nf_{k+1}' w_{k+1},   x_k = Linv_k' w_k
+    // (L'^-1 in terms of w = L_k' x_k: Wb_k' x_{k+1} = Wb_k' Linv_{k+1}' w_{k+1} = -Nf_{k+1}' w_{k+1}, so the SAME tile
+    // serves both sweeps and no second coupling matrix is formed, stored or read.)
+    // The Linv products are chain-free (all k in parallel); only the 14x14 matrix-vector recurrences are sequential
+    // and run inside the executor (ex.chain: FP64 matrix pipe on the device, no barriers).
+    SCVX_HD_NI void S_solve(cgptr r, gptr x) {
         SCVX_T0();
         const int K = L.K;
-        const double* const Linv = this->Linv;
-        const double* const Nf = this->Nf;
-        const double* const Nb = this->Nb;
-        double* const tchain = this->tchain;
+        const cgptr Linv = this->Linv;
+        const cgptr Nf = this->Nf;
+        const gptr tchain = this->tchain;
         for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
             const int k = t / 14, i = t - 14 * k;
-            const double* Li = Linv + (size_t)k * 196 + 14 * i;
-            const double* rk_ = r + 14 * k;
+            cgptr Li = Linv + (size_t)k * 196 + 14 * i;
+            cgptr rk_ = r + 14 * k;
             double a = 0;
 #if defined(__HIPCC__)
 #pragma unroll
@@ -740,36 +773,42 @@ struct Solver {
             tchain[t] = a;
         }
         ex.sync();
-        ex.chain(K, tchain, Nf, x, false);
+        SCVX_TE(t0_, 16);
+        SCVX_TS(tc1_);
+        ex.chain(K, tchain, Nf, x, false);       // t -> x
         ex.sync();
+        SCVX_TE(tc1_, 17);
+        SCVX_TS(tc2_);
+        ex.chain(K, x, Nf, tchain, true);        // w -> tchain
+        ex.sync();
+        SCVX_TE(tc2_, 19);
+        SCVX_TS(tp2_);
         for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
             const int k = t / 14, i = t - 14 * k;
-            const double* Lk = Linv + (size_t)k * 196;
-            const double* tk = x + 14 * k;
+            cgptr Lk = Linv + (size_t)k * 196;
+            cgptr wk = tchain + 14 * k;
             double a = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-            for (int j = 0; j < 14; j++) a += Lk[14 * j + i] * tk[j];
-            tchain[t] = a;
+            for (int j = 0; j < 14; j++) a += Lk[14 * j + i] * wk[j];
+            x[t] = a;
         }
         ex.sync();
-        ex.chain(K, tchain, Nb, x, true);
-        ex.sync();
+        SCVX_TE(tp2_, 18);
         SCVX_T1(0);
     }
 
-    // Three right-hand sides through the block-tridiagonal solve with ONE pass over Linv / Nf / Nb.
-    // r*, x*: [K][14]; scratch t0,t1,t2: [K][14]; x may alias nothing.
-    SCVX_HD_NI void S_solve3(const double* r0, const double* r1, const double* r2_, double* x0, double* x1, double* x2,
-                             double* t0, double* t1, double* t2) {
+    // Three right-hand sides through the block-tridiagonal solve with ONE pass over Linv / Nf per sweep.
+    // r*, x*: [K][14]; scratch t0,t1,t2: [K][14]; nothing may alias.
+    SCVX_HD_NI void S_solve3(cgptr r0, cgptr r1, cgptr r2_, gptr x0, gptr x1, gptr x2,
+                             gptr t0, gptr t1, gptr t2) {
         const int K = L.K;
-        const double* const Linv = this->Linv;
-        const double* const Nf = this->Nf;
-        const double* const Nb = this->Nb;
+        const cgptr Linv = this->Linv;
+        const cgptr Nf = this->Nf;
         for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
             const int k = t / 14, i = t - 14 * k;
-            const double* Li = Linv + (size_t)k * 196 + 14 * i;
+            cgptr Li = Linv + (size_t)k * 196 + 14 * i;
             double a0 = 0, a1 = 0, a2 = 0;
             SCVX_UNROLL
             for (int j = 0; j < 14; j++) { const double l = Li[j]; a0 += l * r0[14 * k + j]; a1 += l * r1[14 * k + j]; a2 += l * r2_[14 * k + j]; }
@@ -778,27 +817,27 @@ struct Solver {
         ex.sync();
         ex.chain3(K, t0, t1, t2, Nf, x0, x1, x2, false);
         ex.sync();
+        ex.chain3(K, x0, x1, x2, Nf, t0, t1, t2, true);
+        ex.sync();
         for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
             const int k = t / 14, i = t - 14 * k;
-            const double* Lk = Linv + (size_t)k * 196;
+            cgptr Lk = Linv + (size_t)k * 196;
             double a0 = 0, a1 = 0, a2 = 0;
             SCVX_UNROLL
-            for (int j = 0; j < 14; j++) { const double l = Lk[14 * j + i]; a0 += l * x0[14 * k + j]; a1 += l * x1[14 * k + j]; a2 += l * x2[14 * k + j]; }
-            t0[t] = a0; t1[t] = a1; t2[t] = a2;
+            for (int j = 0; j < 14; j++) { const double l = Lk[14 * j + i]; a0 += l * t0[14 * k + j]; a1 += l * t1[14 * k + j]; a2 += l * t2[14 * k + j]; }
+            x0[t] = a0; x1[t] = a1; x2[t] = a2;
         }
-        ex.sync();
-        ex.chain3(K, t0, t1, t2, Nb, x0, x1, x2, true);
         ex.sync();
     }
     // g_r = E_loc' y_r on (dx, du) for three vectors with one pass over D; the nu block of E_loc' y is y itself
-    SCVX_HD_NI void Et_apply3(const double* y0, const double* y1, const double* y2, double* g0, double* g1, double* g2) {
+    SCVX_HD_NI void Et_apply3(cgptr y0, cgptr y1, cgptr y2, gptr g0, gptr g1, gptr g2) {
         const int K = L.K;
-        const double* const D = this->D;
+        const cgptr D = this->D;
         for (int t = ex.lane(); t < L.nx; t += ex.nlanes()) {
             const int k = t / 14, j = t - 14 * k;
             double a0 = 0, a1 = 0, a2 = 0;
             if (k < K) {
-                const double* col = D + (size_t)k * 294 + 14 * j;
+                cgptr col = D + (size_t)k * 294 + 14 * j;
                 SCVX_UNROLL
                 for (int i = 0; i < 14; i++) { const double c = col[i]; a0 += c * y0[14 * k + i]; a1 += c * y1[14 * k + i]; a2 += c * y2[14 * k + i]; }
             }
@@ -809,12 +848,12 @@ struct Solver {
             const int k = t / 3, c = t - 3 * k;
             double a0 = 0, a1 = 0, a2 = 0;
             if (k < K) {
-                const double* col = D + (size_t)k * 294 + 14 * (14 + c);
+                cgptr col = D + (size_t)k * 294 + 14 * (14 + c);
                 SCVX_UNROLL
                 for (int i = 0; i < 14; i++) { const double cc = col[i]; a0 += cc * y0[14 * k + i]; a1 += cc * y1[14 * k + i]; a2 += cc * y2[14 * k + i]; }
             }
             if (k > 0) {
-                const double* col = D + (size_t)(k - 1) * 294 + 14 * (17 + c);
+                cgptr col = D + (size_t)(k - 1) * 294 + 14 * (17 + c);
                 SCVX_UNROLL
                 for (int i = 0; i < 14; i++) { const double cc = col[i]; a0 += cc * y0[14 * (k - 1) + i]; a1 += cc * y1[14 * (k - 1) + i]; a2 += cc * y2[14 * (k - 1) + i]; }
             }
@@ -824,12 +863,12 @@ struct Solver {
     }
 
     // [Hb E'; E 0][dl; dyv] = [gl; ryv]   (gl: local part of a var vector; outputs may not alias inputs)
-    SCVX_HD_NI void band_solve(const double* gl, const double* ryv, double* dl, double* dyv) {
+    SCVX_HD_NI void band_solve(cgptr gl, cgptr ryv, gptr dl, gptr dyv) {
         Hb_inv(gl, tmpl);
         E_apply(tmpl, tmpy, false);
         ex.sync();
         if (ryv) {
-            double* ty = tmpy;
+            gptr ty = tmpy;
             stream(0, L.ny, [&](int i) { return D2{ty[i], ryv[i]}; }, [&](int i, const D2& v) { ty[i] = v.a - v.b; });
         }
         ex.sync();
@@ -837,7 +876,7 @@ struct Solver {
         (void)Et_apply(dyv, tmpl2);
         ex.sync();
         {
-            double* t2 = tmpl2;
+            gptr t2 = tmpl2;
             stream(0, L.nloc, [&](int i) { return D2{gl[i], t2[i]}; }, [&](int i, const D2& v) { t2[i] = v.a - v.b; });
         }
         ex.sync();
@@ -852,7 +891,7 @@ struct Solver {
             const int dn = 14 * K + 1, dt = 17 * (K + 1) + 1;
             double n1 = 0, n2 = 0;
             {
-                const double* wn = Wv + L.o_nu; const double* wt = Wv + L.o_tr;
+                cgptr wn = Wv + L.o_nu; cgptr wt = Wv + L.o_tr;
                 stream<8>(1, dn, [&](int i) { return wn[i]; }, [&](int, double v) { n1 += v * v; });
                 stream<8>(1, dt, [&](int i) { return wt[i]; }, [&](int, double v) { n2 += v * v; });
             }
@@ -870,7 +909,7 @@ struct Solver {
         SCVX_T0();
         const double dtr = h_tr[3];
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
-            double* h = hx + (size_t)k * HX_SZ;
+            gptr h = hx + (size_t)k * HX_SZ;
             for (int i = 0; i < HX_SZ; i++) h[i] = 0.0;
             const bool first = (k == 0), last = (k == K);
             // mass
@@ -882,7 +921,7 @@ struct Solver {
             }
             if (!first && !last) {
                 // r block with glideslope cone
-                const double* v = Wv + L.o_gs + 3 * k;
+                cgptr v = Wv + L.o_gs + 3 * k;
                 double h00, h01, h11, b2;
                 soc_w2(v[0], v[1] * v[1] + v[2] * v[2], Wbeta[L.c_gs + k], h00, h01, h11, b2);
                 double M[9];
@@ -897,13 +936,13 @@ struct Solver {
             }
             if (!last) {
                 h[HX_Q] = 1.0 / dtr;
-                const double* v = Wv + L.o_tilt + 3 * k;
+                cgptr v = Wv + L.o_tilt + 3 * k;
                 double h00, h01, h11, b2;
                 soc_w2(v[0], v[1] * v[1] + v[2] * v[2], Wbeta[L.c_tilt + k], h00, h01, h11, b2);
                 inv2(dtr + b2 + h11 * v[1] * v[1], h11 * v[1] * v[2], dtr + b2 + h11 * v[2] * v[2], h + HX_Q34);
             }
             if (!first && !last) {
-                const double* v = Wv + L.o_rate + 4 * k;
+                cgptr v = Wv + L.o_rate + 4 * k;
                 double h00, h01, h11, b2;
                 soc_w2(v[0], v[1] * v[1] + v[2] * v[2] + v[3] * v[3], Wbeta[L.c_rate + k], h00, h01, h11, b2);
                 double M[9];
@@ -916,7 +955,7 @@ struct Solver {
                 double M[9];
                 for (int i = 0; i < 9; i++) M[i] = 0.0;
                 M[0] = M[4] = M[8] = dtr;
-                const double* v = Wv + L.o_tb + 4 * k;
+                cgptr v = Wv + L.o_tb + 4 * k;
                 double h00, h01, h11, b2;
                 soc_w2(v[0], v[1] * v[1] + v[2] * v[2] + v[3] * v[3], Wbeta[L.c_tb + k], h00, h01, h11, b2);
                 for (int a = 0; a < 3; a++)
@@ -932,7 +971,7 @@ struct Solver {
                 const double il2 = 1.0 / (wl * wl);
                 for (int a = 0; a < 3; a++)
                     for (int b = 0; b < 3; b++) M[3 * a + b] += il2 * uhat[3 * k + a] * uhat[3 * k + b];
-                double* hi = hu + 9 * k;
+                gptr hi = hu + 9 * k;
                 if (last) {
                     for (int i = 0; i < 9; i++) hi[i] = 0.0;
                     hi[0] = 1.0 / M[0];
@@ -949,12 +988,11 @@ struct Solver {
         // The D_{k+1} tile is fetched (coalesced, into registers on the device) while segment k is processed.
         // members hoisted into locals: the Solver object sits in scratch memory on the device and would be
         // re-read after every barrier
-        const double* const D_ = D;
-        const double* const hx_ = hx;
-        const double* const hu_ = hu;
-        double* const Linv_ = Linv;
-        double* const Nf_ = Nf;
-        double* const Nb_ = Nb;
+        const cgptr D_ = D;
+        const cgptr hx_ = hx;
+        const cgptr hu_ = hu;
+        const gptr Linv_ = Linv;
+        const gptr Nf_ = Nf;
         const double hnui_ = hnui;
         double* sc = ex.scratch();
         double* M = sc + 32;            // 196  pivot tile / So / scratch product
@@ -987,7 +1025,7 @@ struct Solver {
             // prefetch the next segment's tile
             constexpr int NPRE = Ex::kPrefetchRegs;
             double pre[NPRE > 0 ? NPRE : 1];
-            const double* Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
+            cgptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
             if (NPRE > 0) {
                 SCVX_UNROLL
                 for (int q = 0; q < NPRE; q++) { const int e = ex.lane() + ex.nlanes() * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
@@ -1025,8 +1063,8 @@ struct Solver {
             SCVX_TE(tc_, 12);
             SCVX_TS(td_);
             for (int e = ex.lane(); e < 196; e += ex.nlanes()) Linv_[(size_t)k * 196 + e] = Li[e];
-            if (k > 0) {  // Nf[k] = Linv_k Wb_{k-1}
-                ex.tile_gemm(M, 14, 1, Li, 14, 1, Wp, 14, 1, 14, 1.0, false);
+            if (k > 0) {  // Nf[k] = -Linv_k Wb_{k-1}, stored transposed (the layout the executor's chain consumes)
+                ex.tile_gemm(M, 1, 14, Li, 14, 1, Wp, 14, 1, 14, -1.0, false);
                 ex.sync_lds();
                 for (int e = ex.lane(); e < 196; e += ex.nlanes()) Nf_[(size_t)k * 196 + e] = M[e];
             }
@@ -1058,10 +1096,6 @@ struct Solver {
                 }
                 ex.sync_lds();
                 ex.tile_gemm(Wp, 14, 1, M, 14, 1, Li, 1, 14, 14, 1.0, false);      // Wb_k = So Linv'
-                ex.sync_lds();
-                ex.tile_gemm(M, 1, 14, Wp, 14, 1, Li, 14, 1, 14, 1.0, false);      // Nb[k] = (Wb_k Linv_k)' (stored transposed)
-                ex.sync_lds();
-                for (int e = ex.lane(); e < 196; e += ex.nlanes()) Nb_[(size_t)k * 196 + e] = M[e];
             }
             ex.sync_lds();
             SCVX_TE(te_, 14);
@@ -1075,16 +1109,16 @@ struct Solver {
         //   nu : g = (0, 0, Pnu),  r = 0     ->  S y = hnui Pnu          (E_loc is the identity on the nu block)
         {
             const int nxu = L.nx + L.nu_;
-            double* g_tr = gx;     // nloc: Ptr on (dx,du), 0 on nu
+            gptr g_tr = gx;     // nloc: Ptr on (dx,du), 0 on nu
             {
-                const double* wt = Wv + L.o_tr + 1;
+                cgptr wt = Wv + L.o_tr + 1;
                 stream<8>(0, L.nloc, [&](int i) { return i < nxu ? wt[i] : 0.0; }, [&](int i, double v) { g_tr[i] = v; });
             }
             ex.sync();
             Hb_inv(g_tr, tmpl);
             E_apply(tmpl, tmpy2, false);                       // r_tr
             {
-                double* ty = tmpy; double* r2_ = r2; const double* wn = Wv + L.o_nu + 1;
+                gptr ty = tmpy; gptr r2_ = r2; cgptr wn = Wv + L.o_nu + 1;
                 stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D2{D_[(size_t)k * 294 + 14 * 20 + i], wn[r]}; },
                        [&](int r, const D2& v) { ty[r] = v.a; r2_[r] = hnui_ * v.b; });   // r_s = +Sg, r_nu
             }
@@ -1093,8 +1127,8 @@ struct Solver {
             Et_apply3(ys, ytr, ynu, tmpl, tmpl2, tmpv);
             // l = Hb^-1 (g - E' y): assemble the three right-hand sides in place, then invert
             {
-                double* t0 = tmpl; double* t1 = tmpl2; double* t2 = tmpv;
-                const double* y0 = ys; const double* y1 = ytr; const double* y2 = ynu; const double* wn = Wv + L.o_nu + 1;
+                gptr t0 = tmpl; gptr t1 = tmpl2; gptr t2 = tmpv;
+                cgptr y0 = ys; cgptr y1 = ytr; cgptr y2 = ynu; cgptr wn = Wv + L.o_nu + 1;
                 stream(0, L.nloc, [&](int i) {
                            const bool isnu = i >= nxu;
                            return D5{isnu ? y0[i - nxu] : t0[i], isnu ? y1[i - nxu] : t1[i], isnu ? y2[i - nxu] : t2[i],
@@ -1111,14 +1145,14 @@ struct Solver {
         {
             double a = 0, b = 0, c = 0;
             {
-                const double* y0 = ys; const double* y1 = ytr; const double* y2 = ynu;
+                cgptr y0 = ys; cgptr y1 = ytr; cgptr y2 = ynu;
                 stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D4{D_[(size_t)k * 294 + 14 * 20 + i], y0[r], y1[r], y2[r]}; },
                        [&](int, const D4& v) { a += v.a * v.b; b += v.a * v.c; c += v.a * v.d; });
             }
             css = ex.sum(a); cst = -ex.sum(b); csn = -ex.sum(c);
-            const double* Ptr = Wv + L.o_tr + 1; const int nt = L.nx + L.nu_;
+            cgptr Ptr = Wv + L.o_tr + 1; const int nt = L.nx + L.nu_;
             cts = dot(Ptr, ls, nt); ctt = -dot(Ptr, ltr, nt); ctn = -dot(Ptr, lnu, nt);
-            const double* Pnu = Wv + L.o_nu + 1; const int o = L.nx + L.nu_;
+            cgptr Pnu = Wv + L.o_nu + 1; const int o = L.nx + L.nu_;
             cns = dot(Pnu, ls + o, L.ny); cnt_ = -dot(Pnu, ltr + o, L.ny); cnn = -dot(Pnu, lnu + o, L.ny);
         }
         SCVX_TE(tB_, 7);
@@ -1126,11 +1160,11 @@ struct Solver {
     }
 
     // full reduced KKT: [H E'; E 0][dwv; dyv] = [g; ryv]  (g var-shaped incl. 4 globals)
-    SCVX_HD_NI void kkt_solve(const double* g, const double* ryv, double* dwv, double* dyv) {
+    SCVX_HD_NI void kkt_solve(cgptr g, cgptr ryv, gptr dwv, gptr dyv) {
         band_solve(g, ryv, dwv, dyv);
         double a = 0;
         {
-            const double* const D_ = D;
+            const cgptr D_ = D;
             stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D2{D_[(size_t)k * 294 + 14 * 20 + i], dyv[r]}; },
                    [&](int, const D2& v) { a += v.a * v.b; });
         }
@@ -1170,10 +1204,10 @@ struct Solver {
         const double ctr = h01t * ttr_ + b[4], cnu = h01n * tnu_ + b[5];
         ex.sync();
         {
-            const double* a0 = ls; const double* a1 = ltr; const double* a2 = lnu;
+            cgptr a0 = ls; cgptr a1 = ltr; cgptr a2 = lnu;
             stream(0, L.nloc, [&](int i) { return D4{dwv[i], a0[i], a1[i], a2[i]}; },
                    [&](int i, const D4& v) { dwv[i] = v.a + v.b * s_ - v.c * ctr - v.d * cnu; });
-            const double* b0 = ys; const double* b1 = ytr; const double* b2 = ynu;
+            cgptr b0 = ys; cgptr b1 = ytr; cgptr b2 = ynu;
             stream(0, L.ny, [&](int i) { return D4{dyv[i], b0[i], b1[i], b2[i]}; },
                    [&](int i, const D4& v) { dyv[i] = v.a + v.b * s_ - v.c * ctr - v.d * cnu; });
         }
@@ -1182,7 +1216,7 @@ struct Solver {
     }
 
     // H dwv (var-shaped, incl. globals) in operator form: J' W^-1 W^-1 J dwv
-    SCVX_HD_NI void H_apply(const double* dwv, double* out) {
+    SCVX_HD_NI void H_apply(cgptr dwv, gptr out) {
         cone_map(dwv, tmpc, false);
         ex.sync();
         W_all(tmpc, tmpc, true);
@@ -1193,11 +1227,11 @@ struct Solver {
 
     // Newton step for centering right-hand side ds_rhs (cone vector); results in dw, dy, sds, sdz and -- when `full` --
     // dS, dZ (the predictor only needs the scaled directions for its step length and the Mehrotra correction).
-    SCVX_HD_NI void newton(const double* ds_rhs, bool full) {
+    SCVX_HD_NI void newton(cgptr ds_rhs, bool full) {
         // Wirz = W^-1 rz is prepared once per iteration (shared by predictor and corrector)
         div_all(ds_rhs, tt);
         {
-            double* wb = Wibz; const double* wr = Wirz; const double* t_ = tt;
+            gptr wb = Wibz; cgptr wr = Wirz; cgptr t_ = tt;
             stream(0, L.nc, [&](int i) { return D2{wr[i], t_[i]}; }, [&](int i, const D2& v) { wb[i] = -v.a - v.b; });
         }
         ex.sync();
@@ -1205,7 +1239,7 @@ struct Solver {
         cone_map_t(tmpc, gx);
         ex.sync();
         {
-            double* g_ = gx; const double* rx_ = rx; double* r2_ = r2; const double* ry_ = ry;
+            gptr g_ = gx; cgptr rx_ = rx; gptr r2_ = r2; cgptr ry_ = ry;
             stream(0, L.nv, [&](int i) { return D2{rx_[i], g_[i]}; }, [&](int i, const D2& v) { g_[i] = -v.a - v.b; });
             stream<8>(0, L.ny, [&](int i) { return ry_[i]; }, [&](int i, double v) { r2_[i] = -v; });
         }
@@ -1232,7 +1266,7 @@ struct Solver {
             const double sgy = Et_apply(dy, tmpl);
             ex.sync();
             {
-                double* r1_ = r1; const double* g_ = gx; const double* tl = tmpl;
+                gptr r1_ = r1; cgptr g_ = gx; cgptr tl = tmpl;
                 stream(0, L.nloc, [&](int i) { return D3{g_[i], r1_[i], tl[i]}; }, [&](int i, const D3& v) { r1_[i] = v.a - v.b - v.c; });
             }
             ex.sync();
@@ -1247,13 +1281,13 @@ struct Solver {
             E_apply(dw, tmpy2, true);
             ex.sync();
             {
-                double* t2 = tmpy2; const double* ry_ = ry;
+                gptr t2 = tmpy2; cgptr ry_ = ry;
                 stream(0, L.ny, [&](int i) { return D2{ry_[i], t2[i]}; }, [&](int i, const D2& v) { t2[i] = -v.a - v.b; });
             }
             ex.sync();
             kkt_solve(r1, tmpy2, cw, cy);
             {
-                double* dw_ = dw; const double* cw_ = cw; double* dy_ = dy; const double* cy_ = cy;
+                gptr dw_ = dw; cgptr cw_ = cw; gptr dy_ = dy; cgptr cy_ = cy;
                 stream(0, L.nv, [&](int i) { return D2{dw_[i], cw_[i]}; }, [&](int i, const D2& v) { dw_[i] = v.a + v.b; });
                 stream(0, L.ny, [&](int i) { return D2{dy_[i], cy_[i]}; }, [&](int i, const D2& v) { dy_[i] = v.a + v.b; });
             }
@@ -1264,8 +1298,8 @@ struct Solver {
         cone_map(dw, dS, false);  // J dw
         W_all(dS, tmpc, true);    // wij
         {
-            const double* tc = tmpc; const double* wr = Wirz; const double* wb = Wibz; const double* rz_ = rz;
-            double* sds_ = sds; double* sdz_ = sdz; double* dS_ = dS;
+            cgptr tc = tmpc; cgptr wr = Wirz; cgptr wb = Wibz; cgptr rz_ = rz;
+            gptr sds_ = sds; gptr sdz_ = sdz; gptr dS_ = dS;
             if (full)
                 stream(0, L.nc, [&](int i) { return D5{tc[i], wr[i], wb[i], dS_[i], rz_[i]}; },
                        [&](int i, const D5& v) { sds_[i] = v.a - v.b; sdz_[i] = -(v.a + v.c); dS_[i] = v.d - v.e; });
@@ -1277,7 +1311,7 @@ struct Solver {
         if (full) W_all(sdz, dZ, true);
     }
 
-    SCVX_HD_NI void shift_into_cone(double* X) {
+    SCVX_HD_NI void shift_into_cone(gptr X) {
         double t = -INFINITY;
         all_small([&](auto Dt_, int off, int) {
             constexpr int dm = decltype(Dt_)::value;
@@ -1306,8 +1340,8 @@ struct Solver {
     }
 
     // ---- the solve.  ic: (rIi, vIi) of this trajectory.  Outputs in V (dx, du, nu, s, ...). ----
-    SCVX_HD Result solve(const double* xbar_, const double* ubar_, const double* endpoint_, const double* D_,
-                         double rk_, const double* ic, double* work) {
+    SCVX_HD Result solve(cgptr xbar_, cgptr ubar_, cgptr endpoint_, cgptr D_,
+                         double rk_, cgptr ic, gptr work) {
         xbar = xbar_; ubar = ubar_; endpoint = endpoint_; D = D_; rk = rk_;
         SCVX_TS(tTot_);
         carve(work);
@@ -1315,7 +1349,7 @@ struct Solver {
         // constants of this subproblem
         for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) dk[r] = endpoint[r] - xbar[14 + r];
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
-            const double* u = ubar + 3 * k;
+            cgptr u = ubar + 3 * k;
             const double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
             for (int c = 0; c < 3; c++) uhat[3 * k + c] = u[c] / un;  // rocketland.jl:199 (un = 0 -> NaN, as in the reference)
             lb0[k] = C.Tmin - un;
@@ -1326,8 +1360,8 @@ struct Solver {
             // fixed components: w = bc - xbar (rocketland.jl:109-115)
             V[0] = C.mwet - xbar[0];
             for (int i = 0; i < 3; i++) { V[1 + i] = ic[i] - xbar[1 + i]; V[4 + i] = ic[3 + i] - xbar[4 + i]; V[11 + i] = C.wBi[i] - xbar[11 + i]; }
-            const double* xK = xbar + 14 * K;
-            double* vK = V + 14 * K;
+            cgptr xK = xbar + 14 * K;
+            gptr vK = V + 14 * K;
             for (int i = 0; i < 3; i++) { vK[1 + i] = C.rIf[i] - xK[1 + i]; vK[4 + i] = C.vIf[i] - xK[4 + i]; vK[11 + i] = C.wBf[i] - xK[11 + i]; }
             for (int i = 0; i < 4; i++) vK[7 + i] = C.qBIf[i] - xK[7 + i];
             V[L.nx + 3 * K + 1] = 0.0 - ubar[3 * K + 1];
@@ -1380,7 +1414,7 @@ struct Solver {
             // rz = S - a(V); the complementarity gap S'Z and |rz|^2 ride along on the same pass
             double gap_ = 0, nrz2 = 0;
             {
-                double* rz_ = rz; const double* S_ = S; const double* Z_ = Z; const double* tc = tmpc;
+                gptr rz_ = rz; cgptr S_ = S; cgptr Z_ = Z; cgptr tc = tmpc;
                 stream(0, L.nc, [&](int i) { return D3{S_[i], tc[i], Z_[i]}; },
                        [&](int i, const D3& v) { const double r = v.a - v.b; rz_[i] = r; gap_ += v.a * v.c; nrz2 += r * r; });
             }
@@ -1389,7 +1423,7 @@ struct Solver {
             const double sgy = Et_apply(y, tmpl);
             ex.sync();
             {
-                double* rx_ = rx; const double* tl = tmpl;
+                gptr rx_ = rx; cgptr tl = tmpl;
                 stream(0, L.nloc, [&](int i) { return D2{rx_[i], tl[i]}; }, [&](int i, const D2& v) { rx_[i] = -v.a + v.b; });
             }
             ex.sync();
@@ -1406,7 +1440,7 @@ struct Solver {
             ex.sync();
             double nry2 = 0;
             {
-                double* ry_ = ry; const double* dk_ = dk;
+                gptr ry_ = ry; cgptr dk_ = dk;
                 stream(0, L.ny, [&](int i) { return D2{ry_[i], dk_[i]}; },
                        [&](int i, const D2& v) { const double r = v.a + v.b; ry_[i] = r; nry2 += r * r; });
             }
@@ -1449,8 +1483,8 @@ struct Solver {
             if (!(alpha == alpha)) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 3; break; }
             if (alpha < 1e-9) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
             {
-                double* V_ = V; const double* dw_ = dw; double* y_ = y; const double* dy_ = dy;
-                double* S_ = S; const double* dS_ = dS; double* Z_ = Z; const double* dZ_ = dZ;
+                gptr V_ = V; cgptr dw_ = dw; gptr y_ = y; cgptr dy_ = dy;
+                gptr S_ = S; cgptr dS_ = dS; gptr Z_ = Z; cgptr dZ_ = dZ;
                 stream(0, L.nv, [&](int i) { return D2{V_[i], dw_[i]}; }, [&](int i, const D2& v) { V_[i] = v.a + alpha * v.b; });
                 stream(0, L.ny, [&](int i) { return D2{y_[i], dy_[i]}; }, [&](int i, const D2& v) { y_[i] = v.a + alpha * v.b; });
                 stream(0, L.nc, [&](int i) { return D4{S_[i], dS_[i], Z_[i], dZ_[i]}; },
