@@ -164,6 +164,7 @@ def main():
     ap.add_argument("--npts", type=int, default=10, help="RK4 substeps per segment (Dynamics.rk4 npts)")
     ap.add_argument("--seed", type=int, default=20261004)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traj-check", action="store_true", help="skip the B=1 full-solve parity figure (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -291,7 +292,7 @@ def main():
             "solver_stats_last_step": {"ipm_iters_mean": float(np.mean(its)), "ipm_iters_max": int(np.max(its)),
                                        "status_optimal_frac": float(np.mean(st == 0)), "merit_max": float(np.max(merit))},
         }
-        if world == 1:
+        if world == 1 and not args.no_traj_check:
             line["traj_linf_vs_oracle"] = traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts)
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.npts, args.seed)

@@ -78,6 +78,12 @@ struct Consts {
     double rIf[3], vIf[3], qBIf[4], wBi[3], wBf[3];
 };
 
+// Packed storage of the lower-triangular 14x14 inverse factor L_k^-1 (105 doubles instead of 196: the factor is read
+// four times per solve from HBM).  Row i (i + 1 entries) shares a 15-slot line with row 13 - i (14 - i entries):
+//     entry (i, j), j <= i, lives at  linv_row(i) + j.
+enum { LINV_SZ = 105 };
+SCVX_HD int linv_row(int i) { return i < 7 ? 15 * i : 15 * (13 - i) + (14 - i); }
+
 struct Layout {
     int K, nx, nu_, nloc, nv, iS, iTNU, iTTR, iTS;
     int o_gs, o_tilt, o_rate, o_mass, o_tb, o_tc, o_lb, o_nu, o_tr, o_sg, o_rk, nc;
@@ -107,7 +113,7 @@ struct Layout {
         n += (size_t)nc * 13;            // S, Z, rz, lam, Wv, t, Wibz, dS, dZ, sds, sdz, tmpc, Wirz
         n += (size_t)ncones;             // Wbeta
         n += (size_t)(K + 1) * 25 + (size_t)(K + 1) * 9;  // hx, hu
-        n += (size_t)K * 196 * 2;        // Linv, Nf
+        n += (size_t)K * (LINV_SZ + 196);  // Linv (packed lower triangle), Nf
         n += (size_t)ny;                 // tchain
         n += (size_t)(nloc + ny) * 3;    // ls,ys, ltr,ytr, lnu,ynu
         n += (size_t)nloc * 2;           // tmpl, tmpl2
@@ -268,7 +274,7 @@ struct Solver {
         Wirz = w; w += nc;
         Wbeta = w; w += L.ncones;
         hx = w; w += (size_t)(K + 1) * HX_SZ; hu = w; w += (size_t)(K + 1) * 9;
-        Linv = w; w += (size_t)K * 196; Nf = w; w += (size_t)K * 196;
+        Linv = w; w += (size_t)K * LINV_SZ; Nf = w; w += (size_t)K * 196;
         tchain = w; w += ny;
         ls = w; w += nloc; ys = w; w += ny; ltr = w; w += nloc; ytr = w; w += ny; lnu = w; w += nloc; ynu = w; w += ny;
         tmpl = w; w += nloc; tmpl2 = w; w += nloc;
@@ -763,13 +769,13 @@ struct Solver {
         const gptr tchain = this->tchain;
         for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
             const int k = t / 14, i = t - 14 * k;
-            cgptr Li = Linv + (size_t)k * 196 + 14 * i;
+            cgptr Li = Linv + (size_t)k * LINV_SZ + linv_row(i);
             cgptr rk_ = r + 14 * k;
             double a = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-            for (int j = 0; j < 14; j++) a += Li[j] * rk_[j];   // zeros above the diagonal: fixed trip count, loads batch
+            for (int j = 0; j < 14; j++) a += (j <= i ? Li[j <= i ? j : i] : 0.0) * rk_[j];   // fixed trip count: the loads batch
             tchain[t] = a;
         }
         ex.sync();
@@ -785,13 +791,13 @@ struct Solver {
         SCVX_TS(tp2_);
         for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
             const int k = t / 14, i = t - 14 * k;
-            cgptr Lk = Linv + (size_t)k * 196;
+            cgptr Lk = Linv + (size_t)k * LINV_SZ;
             cgptr wk = tchain + 14 * k;
             double a = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-            for (int j = 0; j < 14; j++) a += Lk[14 * j + i] * wk[j];
+            for (int j = 0; j < 14; j++) a += (j >= i ? Lk[linv_row(j) + (j >= i ? i : j)] : 0.0) * wk[j];   // column i of L^-1
             x[t] = a;
         }
         ex.sync();
@@ -808,10 +814,10 @@ struct Solver {
         const cgptr Nf = this->Nf;
         for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
             const int k = t / 14, i = t - 14 * k;
-            cgptr Li = Linv + (size_t)k * 196 + 14 * i;
+            cgptr Li = Linv + (size_t)k * LINV_SZ + linv_row(i);
             double a0 = 0, a1 = 0, a2 = 0;
             SCVX_UNROLL
-            for (int j = 0; j < 14; j++) { const double l = Li[j]; a0 += l * r0[14 * k + j]; a1 += l * r1[14 * k + j]; a2 += l * r2_[14 * k + j]; }
+            for (int j = 0; j < 14; j++) { const double l = j <= i ? Li[j <= i ? j : i] : 0.0; a0 += l * r0[14 * k + j]; a1 += l * r1[14 * k + j]; a2 += l * r2_[14 * k + j]; }
             t0[t] = a0; t1[t] = a1; t2[t] = a2;
         }
         ex.sync();
@@ -821,10 +827,10 @@ struct Solver {
         ex.sync();
         for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
             const int k = t / 14, i = t - 14 * k;
-            cgptr Lk = Linv + (size_t)k * 196;
+            cgptr Lk = Linv + (size_t)k * LINV_SZ;
             double a0 = 0, a1 = 0, a2 = 0;
             SCVX_UNROLL
-            for (int j = 0; j < 14; j++) { const double l = Lk[14 * j + i]; a0 += l * t0[14 * k + j]; a1 += l * t1[14 * k + j]; a2 += l * t2[14 * k + j]; }
+            for (int j = 0; j < 14; j++) { const double l = j >= i ? Lk[linv_row(j) + (j >= i ? i : j)] : 0.0; a0 += l * t0[14 * k + j]; a1 += l * t1[14 * k + j]; a2 += l * t2[14 * k + j]; }
             x0[t] = a0; x1[t] = a1; x2[t] = a2;
         }
         ex.sync();
@@ -1062,7 +1068,11 @@ struct Solver {
             ex.sync_lds();
             SCVX_TE(tc_, 12);
             SCVX_TS(td_);
-            for (int e = ex.lane(); e < 196; e += ex.nlanes()) Linv_[(size_t)k * 196 + e] = Li[e];
+            for (int e = ex.lane(); e < LINV_SZ; e += ex.nlanes()) {   // packed lower triangle (see linv_row)
+                const int p = e / 15, q = e - 15 * p;
+                const int i = q <= p ? p : 13 - p, j = q <= p ? q : q - (p + 1);
+                Linv_[(size_t)k * LINV_SZ + e] = Li[14 * i + j];
+            }
             if (k > 0) {  // Nf[k] = -Linv_k Wb_{k-1}, stored transposed (the layout the executor's chain consumes)
                 ex.tile_gemm(M, 1, 14, Li, 14, 1, Wp, 14, 1, 14, -1.0, false);
                 ex.sync_lds();
@@ -1228,11 +1238,16 @@ struct Solver {
     // Newton step for centering right-hand side ds_rhs (cone vector); results in dw, dy, sds, sdz and -- when `full` --
     // dS, dZ (the predictor only needs the scaled directions for its step length and the Mehrotra correction).
     SCVX_HD_NI void newton(cgptr ds_rhs, bool full) {
-        // Wirz = W^-1 rz is prepared once per iteration (shared by predictor and corrector)
-        div_all(ds_rhs, tt);
-        {
+        // Wirz = W^-1 rz is prepared once per iteration (shared by predictor and corrector).
+        // Wibz = -Wirz - lam \ ds_rhs.  The predictor's right-hand side is -lam o lam, for which lam \ ds_rhs = -lam
+        // exactly (ds_rhs == nullptr): neither the cone product nor the cone division is formed.
+        if (ds_rhs) {
+            div_all(ds_rhs, tt);
             gptr wb = Wibz; cgptr wr = Wirz; cgptr t_ = tt;
             stream(0, L.nc, [&](int i) { return D2{wr[i], t_[i]}; }, [&](int i, const D2& v) { wb[i] = -v.a - v.b; });
+        } else {
+            gptr wb = Wibz; cgptr wr = Wirz; cgptr l_ = lam;
+            stream(0, L.nc, [&](int i) { return D2{wr[i], l_[i]}; }, [&](int i, const D2& v) { wb[i] = v.b - v.a; });
         }
         ex.sync();
         W_all(Wibz, tmpc, true);
@@ -1469,8 +1484,7 @@ struct Solver {
             if (!build_kkt()) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
             const double mu = gap / degree;
             W_all(rz, Wirz, true);
-            centering_rhs(tt, false, 0.0);   // affine (predictor) right-hand side, consumed in place by newton
-            { SCVX_TS(tN_); newton(tt, false); SCVX_TE(tN_, 10); }
+            { SCVX_TS(tN_); newton(nullptr, false); SCVX_TE(tN_, 10); }   // predictor: affine right-hand side -lam o lam
             double alpha = maxstep_all(sds, sdz);
             if (alpha > 1.0) alpha = 1.0;
             const double sig = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
