@@ -110,7 +110,7 @@ struct Layout {
         n += (size_t)ny;                 // dk
         n += (size_t)nv * 8;             // V, rx, gx, dw, r1, cw, Vbest, tmpv
         n += (size_t)ny * 7;             // y, ry, dy, r2, cy, tmpy, tmpy2
-        n += (size_t)nc * 13;            // S, Z, rz, lam, Wv, t, Wibz, dS, dZ, sds, sdz, tmpc, Wirz
+        n += (size_t)nc * 8;             // S, Z, lam, Wv, Wibz, tmpc, Wirz, sd
         n += (size_t)ncones;             // Wbeta
         n += (size_t)(K + 1) * 25 + (size_t)(K + 1) * 9;  // hx, hu
         n += (size_t)K * (LINV_SZ + 196);  // Linv (packed lower triangle), Nf
@@ -248,7 +248,7 @@ struct Solver {
     // workspace
     gptr dk, V, rx, gx, dw, r1, cw, Vbest, tmpv;
     gptr y, ry, dy, r2, cy, tmpy, tmpy2;
-    gptr S, Z, rz, lam, Wv, tt, Wibz, dS, dZ, sds, sdz, tmpc, Wirz;
+    gptr S, Z, lam, Wv, Wibz, tmpc, Wirz, sd;
     gptr Wbeta;
     gptr hx, hu;
     gptr Linv, Nf, tchain;
@@ -258,6 +258,7 @@ struct Solver {
     // per-factorisation scalars
     double h_tr[4], h_nu[4], Msg[4], hrk, hnui;
     double css, cst, csn, cts, ctt, ctn, cns, cnt_, cnn;
+    double bigvz[2];  // <v, W dz>_1 of the two big cones (corr_dir_pass -> update_pass)
     double prof[32];
     double cur_merit;  // merit of the current iterate: refinement only pays in the endgame
 
@@ -269,9 +270,8 @@ struct Solver {
         V = w; w += nv; rx = w; w += nv; gx = w; w += nv; dw = w; w += nv; r1 = w; w += nv; cw = w; w += nv;
         Vbest = w; w += nv; tmpv = w; w += nv;
         y = w; w += ny; ry = w; w += ny; dy = w; w += ny; r2 = w; w += ny; cy = w; w += ny; tmpy = w; w += ny; tmpy2 = w; w += ny;
-        S = w; w += nc; Z = w; w += nc; rz = w; w += nc; lam = w; w += nc; Wv = w; w += nc; tt = w; w += nc;
-        Wibz = w; w += nc; dS = w; w += nc; dZ = w; w += nc; sds = w; w += nc; sdz = w; w += nc; tmpc = w; w += nc;
-        Wirz = w; w += nc;
+        S = w; w += nc; Z = w; w += nc; lam = w; w += nc; Wv = w; w += nc;
+        Wibz = w; w += nc; tmpc = w; w += nc; Wirz = w; w += nc; sd = w; w += nc;
         Wbeta = w; w += L.ncones;
         hx = w; w += (size_t)(K + 1) * HX_SZ; hu = w; w += (size_t)(K + 1) * 9;
         Linv = w; w += (size_t)K * LINV_SZ; Nf = w; w += (size_t)K * 196;
@@ -484,23 +484,6 @@ struct Solver {
     }
 
     // ---- big-cone helpers (all lanes cooperate) ----
-    SCVX_HD void big_nt(int off, int dim, int cidx) {
-        cgptr s = S + off; cgptr z = Z + off;
-        double a = 0, b = 0, c = 0;
-        stream(1, dim, [&](int i) { return D2{s[i], z[i]}; },
-               [&](int, const D2& v) { a += v.a * v.a; b += v.b * v.b; c += v.a * v.b; });
-        a = ex.sum(a); b = ex.sum(b); c = ex.sum(c);
-        const double sj = sqrt(s[0] * s[0] - a), zj = sqrt(z[0] * z[0] - b);
-        const double isj = 1.0 / sj, izj = 1.0 / zj;
-        const double gam = sqrt(0.5 * (1.0 + (s[0] * z[0] + c) * isj * izj));
-        const double ig = 0.5 / gam;
-        const double wb0 = (s[0] * isj + z[0] * izj) * ig;
-        const double den = 1.0 / sqrt(2.0 * (wb0 + 1.0));
-        gptr v = Wv + off;
-        stream(1, dim, [&](int i) { return D2{s[i], z[i]}; },
-               [&](int i, const D2& q) { v[i] = (q.a * isj - q.b * izj) * ig * den; });
-        if (ex.lane() == 0) { v[0] = (wb0 + 1.0) * den; Wbeta[cidx] = sqrt(sj * izj); }
-    }
     SCVX_HD void big_W(int off, int dim, int cidx, cgptr x, gptr yv, bool inverse) {
         cgptr v = Wv + off;
         cgptr xo = x + off; gptr yo = yv + off;
@@ -516,43 +499,6 @@ struct Solver {
         stream(1, dim, [&](int i) { return D2{v[i], xo[i]}; }, [&](int i, const D2& q) { yo[i] = (tw * q.a + q.b) * sc; });
         if (ex.lane() == 0) yv[off] = (2.0 * vx * v[0] - x0) * sc;
     }
-    // t = lam \ d on a big cone
-    SCVX_HD void big_div(int off, int dim, cgptr d, gptr out) {
-        cgptr l = lam + off;
-        cgptr dd = d + off; gptr oo = out + off;
-        double ld = 0, ll = 0;
-        stream(1, dim, [&](int i) { return D2{l[i], dd[i]}; }, [&](int, const D2& q) { ld += q.a * q.b; ll += q.a * q.a; });
-        ld = ex.sum(ld); ll = ex.sum(ll);
-        const double det = l[0] * l[0] - ll;
-        const double x0 = (l[0] * d[off] - ld) / det;
-        const double il0 = 1.0 / l[0];
-        ex.sync();
-        stream(1, dim, [&](int i) { return D2{l[i], dd[i]}; }, [&](int i, const D2& q) { oo[i] = (q.b - x0 * q.a) * il0; });
-        if (ex.lane() == 0) out[off] = x0;
-    }
-    // out = a o b on a big cone
-    SCVX_HD void big_prod(int off, int dim, cgptr a, cgptr b, gptr out) {
-        cgptr ao = a + off; cgptr bo = b + off; gptr oo = out + off;
-        double ab = 0;
-        stream(0, dim, [&](int i) { return D2{ao[i], bo[i]}; }, [&](int, const D2& q) { ab += q.a * q.b; });
-        ab = ex.sum(ab);
-        const double a0 = a[off], b0 = b[off];
-        ex.sync();
-        stream(1, dim, [&](int i) { return D2{ao[i], bo[i]}; }, [&](int i, const D2& q) { oo[i] = a0 * q.b + b0 * q.a; });
-        if (ex.lane() == 0) out[off] = ab;
-    }
-    // step lengths for two directions with one pass over lam
-    SCVX_HD void big_maxstep2(int off, int dim, cgptr d1, cgptr d2, double& s1, double& s2) {
-        cgptr l = lam + off;
-        cgptr p = d1 + off; cgptr q = d2 + off;
-        double ll = 0, ld = 0, dd = 0, le = 0, ee = 0;
-        stream(1, dim, [&](int i) { return D3{l[i], p[i], q[i]}; },
-               [&](int, const D3& v) { ll += v.a * v.a; ld += v.a * v.b; dd += v.b * v.b; le += v.a * v.c; ee += v.c * v.c; });
-        ll = ex.sum(ll); ld = ex.sum(ld); dd = ex.sum(dd); le = ex.sum(le); ee = ex.sum(ee);
-        s1 = soc_maxstep_parts(l[0], p[0], l[0] * l[0] - ll, l[0] * p[0] - ld, p[0] * p[0] - dd);
-        s2 = soc_maxstep_parts(l[0], q[0], l[0] * l[0] - ll, l[0] * q[0] - le, q[0] * q[0] - ee);
-    }
-
     // ---- uniform iteration over the small cones: one strided loop per (dimension, block), dimension known at compile
     // time so the per-cone code unrolls and its loads batch; f(std::integral_constant<int,D>, offset, cone index) ----
     template <int D, class F>
@@ -570,43 +516,6 @@ struct Solver {
         if (with_sg) { each_small<2>(L.o_sg, L.c_sg, 1, f); each_small<1>(L.o_rk, L.c_rk, 1, f); }
     }
 
-    // ---- NT scalings for every cone, lam = W z ----
-    SCVX_HD_NI void nt_all() {
-        SCVX_T0();
-        all_small([&](auto Dt_, int off, int c) {
-            constexpr int d = decltype(Dt_)::value;
-            if (d == 1) {
-                Wbeta[c] = sqrt(S[off] / Z[off]);
-                lam[off] = sqrt(S[off] * Z[off]);
-                Wv[off] = 1.0;
-            } else {
-                double beta, sv[d], zv[d], vv[d], lv[d];
-                for (int i = 0; i < d; i++) { sv[i] = S[off + i]; zv[i] = Z[off + i]; }
-                soc_nt_small(sv, zv, d, vv, beta);
-                soc_W_small(vv, beta, d, zv, lv, false);
-                Wbeta[c] = beta;
-                for (int i = 0; i < d; i++) { Wv[off + i] = vv[i]; lam[off + i] = lv[i]; }
-            }
-        }, false);
-        big_nt(L.o_nu, 14 * L.K + 1, L.c_nu);
-        big_nt(L.o_tr, 17 * (L.K + 1) + 1, L.c_tr);
-        if (ex.lane() == 0) {
-            double beta;
-            soc_nt_small(S + L.o_sg, Z + L.o_sg, 2, Wv + L.o_sg, beta);
-            Wbeta[L.c_sg] = beta;
-            Wbeta[L.c_rk] = sqrt(S[L.o_rk] / Z[L.o_rk]);
-            Wv[L.o_rk] = 1.0;
-        }
-        ex.sync();
-        big_W(L.o_nu, 14 * L.K + 1, L.c_nu, Z, lam, false);
-        big_W(L.o_tr, 17 * (L.K + 1) + 1, L.c_tr, Z, lam, false);
-        if (ex.lane() == 0) {
-            soc_W_small(Wv + L.o_sg, Wbeta[L.c_sg], 2, Z + L.o_sg, lam + L.o_sg, false);
-            lam[L.o_rk] = sqrt(S[L.o_rk] * Z[L.o_rk]);
-        }
-        ex.sync();
-        SCVX_T1(11);
-    }
     SCVX_HD void identity_scaling() {
         for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) Wv[i] = 0.0;
         ex.sync();
@@ -636,98 +545,349 @@ struct Solver {
         ex.sync();
         SCVX_T1(8);
     }
-    // out = lam \ d
-    SCVX_HD_NI void div_all(cgptr d, gptr out) {
+    // ------------------------------------------------------------------------------------------------
+    // Fused cone passes.  The solver state streams from HBM, so one interior-point iteration is organised as five
+    // sweeps over the cones, each reading what it needs once and writing only what a later sweep consumes:
+    //     scale_pass      S, Z, V        -> Wv, Wbeta, lam, Wirz = W^-1 (S - a(V)), tmpc = W^-1 (lam - Wirz), S'Z, |rz|^2
+    //     pred_dir_pass   dw             -> sd = W^-1 ds_aff (W dz_aff = -lam - sd is implied), affine step length
+    //     corr_rhs_pass   lam, sd, sigmu -> Wibz, tmpc = W^-1 Wibz
+    //     corr_dir_pass   dw             -> sd = W dz, step length, <v, W dz> of the big cones
+    //     update_pass     alpha          -> Z += alpha W^-1 sd,  S += alpha (J dw - (S - a(V)))
+    // A small cone (dimension <= 4) lives in the registers of one lane for the whole sweep; the two big trust-region
+    // cones are swept cooperatively: reductions first (their scalars enter every element), then one apply sweep.
+    // a(v) / J v of a small cone are gathered straight from the variable vector (no cone-shaped temporary).
+    // ------------------------------------------------------------------------------------------------
+    enum { G_GS3 = 0, G_RATE = 1, G_MASS = 2, G_T4 = 3, G_LB = 4, G_SG = 5, G_RK = 6 };
+    template <int GRP, int D, class F>
+    SCVX_HD void each_small_g(int off0, int c0, int n, F&& f) {
+        for (int q = ex.lane(); q < n; q += ex.nlanes())
+            f(std::integral_constant<int, GRP>(), std::integral_constant<int, D>(), off0 + D * q, c0 + q, q);
+    }
+    // f(group tag, dimension tag, offset in the cone vector, cone index, index inside the group)
+    template <class F>
+    SCVX_HD void for_small(F&& f) {
+        const int K = L.K;
+        each_small_g<G_GS3, 3>(L.o_gs, L.c_gs, 2 * K, f);            // gs, tilt are adjacent
+        each_small_g<G_RATE, 4>(L.o_rate, L.c_rate, K, f);
+        each_small_g<G_MASS, 1>(L.o_mass, L.c_mass, K, f);
+        each_small_g<G_T4, 4>(L.o_tb, L.c_tb, 2 * (K + 1), f);       // tb, tc are adjacent
+        each_small_g<G_LB, 1>(L.o_lb, L.c_lb, K + 1, f);
+        each_small_g<G_SG, 2>(L.o_sg, L.c_sg, 1, f);
+        each_small_g<G_RK, 1>(L.o_rk, L.c_rk, 1, f);
+    }
+    // one small cone of a(v) (af = 1) or J v (af = 0): the rows cone_map writes for it
+    template <int GRP, int D>
+    SCVX_HD void small_gather(int q, cgptr v, double af, double (&o)[D]) const {
+        const int K = L.K;
+        if constexpr (GRP == G_GS3) {
+            const bool gs = q < K;
+            const int k = gs ? q : q - K;
+            cgptr dx = v + 14 * k; cgptr xb = xbar + 14 * k;
+            const int i1 = gs ? 2 : 9, i2 = gs ? 3 : 10;
+            const double x1 = af * xb[1] + dx[1];
+            o[0] = gs ? x1 * C.itan : af * C.sqcm;
+            o[1] = af * xb[i1] + dx[i1];
+            o[2] = af * xb[i2] + dx[i2];
+        } else if constexpr (GRP == G_RATE) {
+            cgptr dx = v + 14 * q; cgptr xb = xbar + 14 * q;
+            o[0] = af * C.omMax;
+            for (int j = 0; j < 3; j++) o[1 + j] = af * xb[11 + j] + dx[11 + j];
+        } else if constexpr (GRP == G_MASS) {
+            const int k = q + 1;
+            o[0] = (af * xbar[14 * k] + v[14 * k]) - af * C.mdry;
+        } else if constexpr (GRP == G_T4) {
+            const bool tb = q <= K;
+            const int k = tb ? q : q - (K + 1);
+            cgptr du = v + L.nx + 3 * k; cgptr ub = ubar + 3 * k;
+            double u[3];
+            for (int c = 0; c < 3; c++) u[c] = af * ub[c] + du[c];
+            o[0] = tb ? af * C.Tmax : u[0] * C.icos;
+            o[1] = u[0]; o[2] = u[1]; o[3] = u[2];
+        } else if constexpr (GRP == G_LB) {
+            cgptr du = v + L.nx + 3 * q;
+            o[0] = uhat[3 * q] * du[0] + uhat[3 * q + 1] * du[1] + uhat[3 * q + 2] * du[2] - af * lb0[q];
+        } else if constexpr (GRP == G_SG) {
+            o[0] = v[L.iTS]; o[1] = v[L.iS];
+        } else {
+            o[0] = af * rk - v[L.iTTR];
+        }
+    }
+    // the two big cones: offset / dimension / cone index in the cone vector; head and body of a(v) = J v in a var vector
+    struct BigCone { int off, dim, cidx, head, body; };
+    SCVX_HD BigCone big_cone(int q) const {
+        return q == 0 ? BigCone{L.o_nu, 14 * L.K + 1, L.c_nu, L.iTNU, L.nx + L.nu_}
+                      : BigCone{L.o_tr, 17 * (L.K + 1) + 1, L.c_tr, L.iTTR, 0};
+    }
+    struct D6 { double a, b, c, d, e, f; };
+
+    // ---- sweep 1: scaling, residual, predictor right-hand side ----
+    SCVX_HD_NI void scale_pass(double& gap_out, double& nrz2_out) {
         SCVX_T0();
-        all_small([&](auto Dt_, int off, int) {
-            constexpr int dm = decltype(Dt_)::value;
-            if (dm == 1) out[off] = d[off] / lam[off];
-            else {
-                double l[dm], dv[dm];
-                for (int i = 0; i < dm; i++) { l[i] = lam[off + i]; dv[i] = d[off + i]; }
-                double ld = 0, ll = 0;
-                for (int i = 1; i < dm; i++) { ld += l[i] * dv[i]; ll += l[i] * l[i]; }
-                const double x0 = (l[0] * dv[0] - ld) / (l[0] * l[0] - ll);
-                const double il0 = 1.0 / l[0];
-                for (int i = 1; i < dm; i++) out[off + i] = (dv[i] - x0 * l[i]) * il0;
-                out[off] = x0;
+        double gap = 0, nrz2 = 0;
+        const cgptr S_ = S; const cgptr Z_ = Z; const cgptr V_ = V;
+        const gptr Wv_ = Wv; const gptr lam_ = lam; const gptr Wirz_ = Wirz; const gptr tmpc_ = tmpc; const gptr Wbeta_ = Wbeta;
+        for_small([&](auto G_, auto Dt_, int off, int c, int q) {
+            constexpr int GRP = decltype(G_)::value, D = decltype(Dt_)::value;
+            double s[D], z[D], a[D], r[D];
+            for (int i = 0; i < D; i++) { s[i] = S_[off + i]; z[i] = Z_[off + i]; }
+            small_gather<GRP, D>(q, V_, 1.0, a);
+            for (int i = 0; i < D; i++) { r[i] = s[i] - a[i]; gap += s[i] * z[i]; nrz2 += r[i] * r[i]; }
+            if constexpr (D == 1) {
+                const double beta = sqrt(s[0] / z[0]), l = sqrt(s[0] * z[0]);
+                const double wr = r[0] / beta;
+                Wbeta_[c] = beta; Wv_[off] = 1.0; lam_[off] = l; Wirz_[off] = wr; tmpc_[off] = (l - wr) / beta;
+            } else {
+                double beta, v[D], l[D], wr[D], m[D], t[D];
+                soc_nt_small(s, z, D, v, beta);
+                soc_W_small(v, beta, D, z, l, false);
+                soc_W_small(v, beta, D, r, wr, true);
+                for (int i = 0; i < D; i++) m[i] = l[i] - wr[i];
+                soc_W_small(v, beta, D, m, t, true);
+                Wbeta_[c] = beta;
+                for (int i = 0; i < D; i++) { Wv_[off + i] = v[i]; lam_[off + i] = l[i]; Wirz_[off + i] = wr[i]; tmpc_[off + i] = t[i]; }
             }
-        }, true);
-        big_div(L.o_nu, 14 * L.K + 1, d, out);
-        big_div(L.o_tr, 17 * (L.K + 1) + 1, d, out);
+        });
+        for (int q = 0; q < 2; q++) {
+            const BigCone bc = big_cone(q);
+            const cgptr s = S_ + bc.off; const cgptr z = Z_ + bc.off; const cgptr ab = V_ + bc.body - 1;   // ab[i] = a_i, i >= 1
+            double a = 0, b = 0, c = 0;
+            stream(1, bc.dim, [&](int i) { return D2{s[i], z[i]}; },
+                   [&](int, const D2& v) { a += v.a * v.a; b += v.b * v.b; c += v.a * v.b; });
+            a = ex.sum(a); b = ex.sum(b); c = ex.sum(c);
+            const double s0 = s[0], z0 = z[0], r0 = s0 - V_[bc.head];
+            const double sj = sqrt(s0 * s0 - a), zj = sqrt(z0 * z0 - b);
+            const double isj = 1.0 / sj, izj = 1.0 / zj;
+            const double gam = sqrt(0.5 * (1.0 + (s0 * z0 + c) * isj * izj));
+            const double ig = 0.5 / gam;
+            const double wb0 = (s0 * isj + z0 * izj) * ig;
+            const double den = 1.0 / sqrt(2.0 * (wb0 + 1.0));
+            const double v0 = (wb0 + 1.0) * den, beta = sqrt(sj * izj), ibeta = 1.0 / beta;
+            const double igd = ig * den;
+            // second reduction: products with v (v_i = (s_i / sj - z_i / zj) ig den needs the scalars above)
+            double vz = 0, vr = 0, vv = 0, g1 = 0, n1 = 0;
+            stream(1, bc.dim, [&](int i) { return D3{s[i], z[i], ab[i]}; },
+                   [&](int, const D3& w) {
+                       const double vi = (w.a * isj - w.b * izj) * igd, ri = w.a - w.c;
+                       vz += vi * w.b; vr += vi * ri; vv += vi * vi; g1 += w.a * w.b; n1 += ri * ri;
+                   });
+            vz = ex.sum(vz); vr = ex.sum(vr); vv = ex.sum(vv);
+            gap += g1; nrz2 += n1;
+            if (ex.lane() == 0) { gap += s0 * z0; nrz2 += r0 * r0; }
+            const double vxz = v0 * z0 + vz;                       // lam = W z
+            const double l0 = (2.0 * vxz * v0 - z0) * beta;
+            const double vxr = v0 * r0 - vr;                       // Wirz = W^-1 rz
+            const double wr0 = (2.0 * vxr * v0 - r0) * ibeta;
+            const double m0 = l0 - wr0;                            // tmpc = W^-1 (lam - Wirz)
+            const double vl = beta * (2.0 * vxz * vv + vz);        // <v, lam>_1
+            const double vw = (-2.0 * vxr * vv + vr) * ibeta;      // <v, Wirz>_1
+            const double vxm = v0 * m0 - (vl - vw);
+            const double t0 = (2.0 * vxm * v0 - m0) * ibeta;
+            const gptr vo = Wv_ + bc.off; const gptr lo = lam_ + bc.off; const gptr wo = Wirz_ + bc.off; const gptr to = tmpc_ + bc.off;
+            stream(1, bc.dim, [&](int i) { return D3{s[i], z[i], ab[i]}; },
+                   [&](int i, const D3& w) {
+                       const double vi = (w.a * isj - w.b * izj) * igd, ri = w.a - w.c;
+                       const double li = (2.0 * vxz * vi + w.b) * beta;
+                       const double wi = (-2.0 * vxr * vi + ri) * ibeta;
+                       vo[i] = vi; lo[i] = li; wo[i] = wi;
+                       to[i] = (-2.0 * vxm * vi + (li - wi)) * ibeta;
+                   });
+            if (ex.lane() == 0) { vo[0] = v0; lo[0] = l0; wo[0] = wr0; to[0] = t0; Wbeta_[bc.cidx] = beta; }
+        }
+        ex.sync();
+        gap_out = ex.sum(gap);
+        nrz2_out = ex.sum(nrz2);
+        SCVX_T1(11);
+    }
+
+    // ---- sweeps 2 and 4: scaled directions from the Newton step dw, step length to the cone boundary ----
+    // wij = W^-1 J dw,  W^-1 ds = wij - Wirz,  W dz = -(wij + Wibz)   (predictor: Wibz = lam - Wirz, so W dz = -lam - W^-1 ds).
+    // PRED: stores sd = W^-1 ds (the corrector's right-hand side needs it).  Otherwise stores sd = W dz (update_pass needs
+    // it) and, for the big cones, <v, W dz>_1 in bigvz[].
+    template <bool PRED>
+    SCVX_HD_NI double dir_pass() {
+        SCVX_T0();
+        double amax = INFINITY;
+        const cgptr dw_ = dw; const cgptr Wv_ = Wv; const cgptr lam_ = lam; const cgptr Wirz_ = Wirz; const cgptr Wibz_ = Wibz;
+        const cgptr Wbeta_ = Wbeta; const gptr sd_ = sd;
+        for_small([&](auto G_, auto Dt_, int off, int c, int q) {
+            constexpr int GRP = decltype(G_)::value, D = decltype(Dt_)::value;
+            double ds[D], l[D], wr[D], a[D], b[D];
+            small_gather<GRP, D>(q, dw_, 0.0, ds);
+            const double beta = Wbeta_[c];
+            for (int i = 0; i < D; i++) { l[i] = lam_[off + i]; wr[i] = Wirz_[off + i]; }
+            if constexpr (D == 1) {
+                const double wij = ds[0] / beta;
+                a[0] = wij - wr[0];
+                b[0] = PRED ? -l[0] - a[0] : -(wij + Wibz_[off]);
+                const double sa = a[0] < 0.0 ? -l[0] / a[0] : INFINITY, sb = b[0] < 0.0 ? -l[0] / b[0] : INFINITY;
+                if (sa < amax) amax = sa;
+                if (sb < amax) amax = sb;
+            } else {
+                double v[D], wij[D];
+                for (int i = 0; i < D; i++) v[i] = Wv_[off + i];
+                soc_W_small(v, beta, D, ds, wij, true);
+                for (int i = 0; i < D; i++) { a[i] = wij[i] - wr[i]; b[i] = PRED ? -l[i] - a[i] : -(wij[i] + Wibz_[off + i]); }
+                double ll = 0, la = 0, aa = 0, lb = 0, bb = 0;
+                for (int i = 1; i < D; i++) { ll += l[i] * l[i]; la += l[i] * a[i]; aa += a[i] * a[i]; lb += l[i] * b[i]; bb += b[i] * b[i]; }
+                const double sa = soc_maxstep_parts(l[0], a[0], l[0] * l[0] - ll, l[0] * a[0] - la, a[0] * a[0] - aa);
+                const double sb = soc_maxstep_parts(l[0], b[0], l[0] * l[0] - ll, l[0] * b[0] - lb, b[0] * b[0] - bb);
+                if (sa < amax) amax = sa;
+                if (sb < amax) amax = sb;
+            }
+            for (int i = 0; i < D; i++) sd_[off + i] = PRED ? a[i] : b[i];
+        });
+        amax = ex.min(amax);
+        for (int q = 0; q < 2; q++) {
+            const BigCone bc = big_cone(q);
+            const cgptr v = Wv_ + bc.off; const cgptr l = lam_ + bc.off; const cgptr wr = Wirz_ + bc.off; const cgptr wb = Wibz_ + bc.off;
+            const cgptr db = dw_ + bc.body - 1;   // db[i] = (J dw)_i, i >= 1
+            const gptr so = sd_ + bc.off;
+            double vd = 0;
+            stream(1, bc.dim, [&](int i) { return D2{v[i], db[i]}; }, [&](int, const D2& w) { vd += w.a * w.b; });
+            vd = ex.sum(vd);
+            const double beta = Wbeta_[bc.cidx], ibeta = 1.0 / beta, v0 = v[0], d0 = dw_[bc.head], l0 = l[0];
+            const double vx = v0 * d0 - vd;
+            const double wij0 = (2.0 * vx * v0 - d0) * ibeta;
+            const double a0 = wij0 - wr[0];
+            const double b0 = PRED ? -l0 - a0 : -(wij0 + wb[0]);
+            double ll = 0, la = 0, aa = 0, lb = 0, bb = 0, vb = 0;
+            if (PRED) {
+                stream(1, bc.dim, [&](int i) { return D4{v[i], db[i], wr[i], l[i]}; },
+                       [&](int i, const D4& w) {
+                           const double ai = (-2.0 * vx * w.a + w.b) * ibeta - w.c, bi = -w.d - ai;
+                           so[i] = ai;
+                           ll += w.d * w.d; la += w.d * ai; aa += ai * ai; lb += w.d * bi; bb += bi * bi;
+                       });
+            } else {
+                stream(1, bc.dim, [&](int i) { return D5{v[i], db[i], wr[i], l[i], wb[i]}; },
+                       [&](int i, const D5& w) {
+                           const double wij = (-2.0 * vx * w.a + w.b) * ibeta;
+                           const double ai = wij - w.c, bi = -(wij + w.e);
+                           so[i] = bi;
+                           ll += w.d * w.d; la += w.d * ai; aa += ai * ai; lb += w.d * bi; bb += bi * bi; vb += w.a * bi;
+                       });
+            }
+            ll = ex.sum(ll); la = ex.sum(la); aa = ex.sum(aa); lb = ex.sum(lb); bb = ex.sum(bb);
+            if (!PRED) bigvz[q] = ex.sum(vb);
+            if (ex.lane() == 0) so[0] = PRED ? a0 : b0;
+            const double sa = soc_maxstep_parts(l0, a0, l0 * l0 - ll, l0 * a0 - la, a0 * a0 - aa);
+            const double sb = soc_maxstep_parts(l0, b0, l0 * l0 - ll, l0 * b0 - lb, b0 * b0 - bb);
+            if (sa < amax) amax = sa;
+            if (sb < amax) amax = sb;
+        }
         ex.sync();
         SCVX_T1(22);
+        return amax;
     }
-    // out = base_sign * (lam o lam)  [mode 0: out = -lam o lam]
-    //       mode 1: out = -lam o lam - sds o sdz + sigmu * e
-    SCVX_HD_NI void centering_rhs(gptr out, bool combined, double sigmu) {
+
+    // ---- sweep 3: the corrector's cone right-hand side ----
+    // With a = W^-1 ds_aff (in sd) and b = W dz_aff = -lam - a:   t = lam \ (-lam o lam - a o b + sigmu e),
+    // Wibz = -Wirz - t,  tmpc = W^-1 Wibz.
+    SCVX_HD_NI void corr_rhs_pass(double sigmu) {
         SCVX_T0();
-        all_small([&](auto Dt_, int off, int) {
-            constexpr int dm = decltype(Dt_)::value;
-            if (dm == 1) {
-                out[off] = -lam[off] * lam[off] + (combined ? (-sds[off] * sdz[off] + sigmu) : 0.0);
+        const cgptr Wv_ = Wv; const cgptr lam_ = lam; const cgptr Wirz_ = Wirz; const cgptr sd_ = sd; const cgptr Wbeta_ = Wbeta;
+        const gptr Wibz_ = Wibz; const gptr tmpc_ = tmpc;
+        for_small([&](auto, auto Dt_, int off, int c, int) {
+            constexpr int D = decltype(Dt_)::value;
+            double l[D], a[D], b[D], wr[D];
+            for (int i = 0; i < D; i++) { l[i] = lam_[off + i]; a[i] = sd_[off + i]; wr[i] = Wirz_[off + i]; b[i] = -l[i] - a[i]; }
+            const double beta = Wbeta_[c];
+            if constexpr (D == 1) {
+                const double rhs = -l[0] * l[0] + (-a[0] * b[0] + sigmu);
+                const double wb = -wr[0] - rhs / l[0];
+                Wibz_[off] = wb; tmpc_[off] = wb / beta;
             } else {
-                double l[dm], a[dm], b[dm];
-                for (int i = 0; i < dm; i++) { l[i] = lam[off + i]; a[i] = combined ? sds[off + i] : 0.0; b[i] = combined ? sdz[off + i] : 0.0; }
+                double rhs[D], t[D], wb[D], v[D], o[D];
                 double ll = 0, ab = 0;
-                for (int i = 0; i < dm; i++) { ll += l[i] * l[i]; ab += a[i] * b[i]; }
-                for (int i = 1; i < dm; i++) out[off + i] = -2.0 * l[0] * l[i] - (a[0] * b[i] + b[0] * a[i]);
-                out[off] = -ll + (combined ? (-ab + sigmu) : 0.0);
+                for (int i = 0; i < D; i++) { ll += l[i] * l[i]; ab += a[i] * b[i]; }
+                for (int i = 1; i < D; i++) rhs[i] = -2.0 * l[0] * l[i] - (a[0] * b[i] + b[0] * a[i]);
+                rhs[0] = -ll + (-ab + sigmu);
+                double ld = 0, l1 = 0;
+                for (int i = 1; i < D; i++) { ld += l[i] * rhs[i]; l1 += l[i] * l[i]; }
+                const double x0 = (l[0] * rhs[0] - ld) / (l[0] * l[0] - l1);
+                const double il0 = 1.0 / l[0];
+                t[0] = x0;
+                for (int i = 1; i < D; i++) t[i] = (rhs[i] - x0 * l[i]) * il0;
+                for (int i = 0; i < D; i++) { wb[i] = -wr[i] - t[i]; v[i] = Wv_[off + i]; }
+                soc_W_small(v, beta, D, wb, o, true);
+                for (int i = 0; i < D; i++) { Wibz_[off + i] = wb[i]; tmpc_[off + i] = o[i]; }
             }
-        }, true);
-        const int offs[2] = {L.o_nu, L.o_tr};
-        const int dims[2] = {14 * L.K + 1, 17 * (L.K + 1) + 1};
+        });
         for (int q = 0; q < 2; q++) {
-            big_prod(offs[q], dims[q], lam, lam, out);
-            ex.sync();
-            if (combined) {
-                big_prod(offs[q], dims[q], sds, sdz, tmpc);
-                ex.sync();
-                gptr oo = out + offs[q]; cgptr tc = tmpc + offs[q];
-                stream(0, dims[q], [&](int i) { return D2{oo[i], tc[i]}; }, [&](int i, const D2& v) { oo[i] = -v.a - v.b; });
-                if (ex.lane() == 0) out[offs[q]] += sigmu;
-            } else {
-                gptr oo = out + offs[q];
-                stream<8>(0, dims[q], [&](int i) { return oo[i]; }, [&](int i, double v) { oo[i] = -v; });
-            }
+            const BigCone bc = big_cone(q);
+            const cgptr v = Wv_ + bc.off; const cgptr l = lam_ + bc.off; const cgptr wr = Wirz_ + bc.off; const cgptr a = sd_ + bc.off;
+            const gptr wbo = Wibz_ + bc.off; const gptr to = tmpc_ + bc.off;
+            const double l0 = l[0], a0 = a[0], b0 = -l0 - a0, v0 = v[0], wr0 = wr[0];
+            const double beta = Wbeta_[bc.cidx], ibeta = 1.0 / beta;
+            // one reduction sweep: the heads are known, so rhs_i = -2 l0 l_i - (a0 b_i + b0 a_i) is available per element
+            double ll = 0, ab = 0, lr = 0, vr = 0, vl = 0, vw = 0;
+            stream(1, bc.dim, [&](int i) { return D4{l[i], a[i], v[i], wr[i]}; },
+                   [&](int, const D4& w) {
+                       const double bi = -w.a - w.b, ri = -2.0 * l0 * w.a - (a0 * bi + b0 * w.b);
+                       ll += w.a * w.a; ab += w.b * bi; lr += w.a * ri; vr += w.c * ri; vl += w.c * w.a; vw += w.c * w.d;
+                   });
+            ll = ex.sum(ll); ab = ex.sum(ab); lr = ex.sum(lr); vr = ex.sum(vr); vl = ex.sum(vl); vw = ex.sum(vw);
+            const double rhs0 = -(ll + l0 * l0) + (-(ab + a0 * b0) + sigmu);
+            const double x0 = (l0 * rhs0 - lr) / (l0 * l0 - ll);
+            const double il0 = 1.0 / l0;
+            const double wb0 = -wr0 - x0;
+            const double vt = (vr - x0 * vl) * il0;                 // <v, t>_1
+            const double vx = v0 * wb0 - (-vw - vt);                // inverse scaling of Wibz
+            stream(1, bc.dim, [&](int i) { return D4{l[i], a[i], v[i], wr[i]}; },
+                   [&](int i, const D4& w) {
+                       const double bi = -w.a - w.b, ri = -2.0 * l0 * w.a - (a0 * bi + b0 * w.b);
+                       const double wbi = -w.d - (ri - x0 * w.a) * il0;
+                       wbo[i] = wbi;
+                       to[i] = (-2.0 * vx * w.c + wbi) * ibeta;
+                   });
+            if (ex.lane() == 0) { wbo[0] = wb0; to[0] = (2.0 * vx * v0 - wb0) * ibeta; }
         }
         ex.sync();
         SCVX_T1(22);
     }
-    // largest step keeping lam + a*d1 and lam + a*d2 in the cone (one pass over lam for both scaled directions)
-    SCVX_HD_NI double maxstep_all(cgptr d1, cgptr d2) {
+
+    // ---- sweep 5: S += alpha (J dw - rz) with rz = S - a(V) recomputed from the old V,  Z += alpha W^-1 (W dz) ----
+    SCVX_HD_NI void update_pass(double alpha) {
         SCVX_T0();
-        double amax = INFINITY;
-        all_small([&](auto Dt_, int off, int) {
-            constexpr int dm = decltype(Dt_)::value;
-            double a, b;
-            if (dm == 1) {
-                const double l0 = lam[off], p = d1[off], q = d2[off];
-                a = p < 0.0 ? -l0 / p : INFINITY;
-                b = q < 0.0 ? -l0 / q : INFINITY;
+        const gptr S_ = S; const gptr Z_ = Z; const cgptr V_ = V; const cgptr dw_ = dw; const cgptr Wv_ = Wv; const cgptr sd_ = sd;
+        const cgptr Wbeta_ = Wbeta;
+        for_small([&](auto G_, auto Dt_, int off, int c, int q) {
+            constexpr int GRP = decltype(G_)::value, D = decltype(Dt_)::value;
+            double s[D], z[D], a[D], jd[D], b[D];
+            for (int i = 0; i < D; i++) { s[i] = S_[off + i]; z[i] = Z_[off + i]; b[i] = sd_[off + i]; }
+            small_gather<GRP, D>(q, V_, 1.0, a);
+            small_gather<GRP, D>(q, dw_, 0.0, jd);
+            const double beta = Wbeta_[c];
+            if constexpr (D == 1) {
+                S_[off] = s[0] + alpha * (jd[0] - (s[0] - a[0]));
+                Z_[off] = z[0] + alpha * (b[0] / beta);
             } else {
-                double l[dm], dv[dm], ev[dm];
-                for (int i = 0; i < dm; i++) { l[i] = lam[off + i]; dv[i] = d1[off + i]; ev[i] = d2[off + i]; }
-                double ll = 0, ld = 0, dd = 0, le = 0, ee = 0;
-                for (int i = 1; i < dm; i++) {
-                    ll += l[i] * l[i]; ld += l[i] * dv[i]; dd += dv[i] * dv[i]; le += l[i] * ev[i]; ee += ev[i] * ev[i];
-                }
-                a = soc_maxstep_parts(l[0], dv[0], l[0] * l[0] - ll, l[0] * dv[0] - ld, dv[0] * dv[0] - dd);
-                b = soc_maxstep_parts(l[0], ev[0], l[0] * l[0] - ll, l[0] * ev[0] - le, ev[0] * ev[0] - ee);
+                double v[D], dz[D];
+                for (int i = 0; i < D; i++) v[i] = Wv_[off + i];
+                soc_W_small(v, beta, D, b, dz, true);
+                for (int i = 0; i < D; i++) { S_[off + i] = s[i] + alpha * (jd[i] - (s[i] - a[i])); Z_[off + i] = z[i] + alpha * dz[i]; }
             }
-            if (a < amax) amax = a;
-            if (b < amax) amax = b;
-        }, true);
-        amax = ex.min(amax);
-        double a1, b1, a2, b2;
-        big_maxstep2(L.o_nu, 14 * L.K + 1, d1, d2, a1, b1);
-        big_maxstep2(L.o_tr, 17 * (L.K + 1) + 1, d1, d2, a2, b2);
-        if (a1 < amax) amax = a1;
-        if (b1 < amax) amax = b1;
-        if (a2 < amax) amax = a2;
-        if (b2 < amax) amax = b2;
-        SCVX_T1(22);
-        return amax;
+        });
+        for (int q = 0; q < 2; q++) {
+            const BigCone bc = big_cone(q);
+            const gptr s = S_ + bc.off; const gptr z = Z_ + bc.off; const cgptr v = Wv_ + bc.off; const cgptr b = sd_ + bc.off;
+            const cgptr ab = V_ + bc.body - 1; const cgptr db = dw_ + bc.body - 1;
+            const double beta = Wbeta_[bc.cidx], ibeta = 1.0 / beta, v0 = v[0], b0 = b[0];
+            const double vx = v0 * b0 - bigvz[q];
+            const double s0 = s[0], z0 = z[0], a0 = V_[bc.head], d0 = dw_[bc.head];
+            ex.sync();   // every lane holds the heads before lane 0 overwrites them
+            stream(1, bc.dim, [&](int i) { return D6{s[i], z[i], v[i], b[i], ab[i], db[i]}; },
+                   [&](int i, const D6& w) {
+                       s[i] = w.a + alpha * (w.f - (w.a - w.e));
+                       z[i] = w.b + alpha * ((-2.0 * vx * w.c + w.d) * ibeta);
+                   });
+            if (ex.lane() == 0) {
+                s[0] = s0 + alpha * (d0 - (s0 - a0));
+                z[0] = z0 + alpha * ((2.0 * vx * v0 - b0) * ibeta);
+            }
+        }
+        ex.sync();
+        SCVX_T1(23);
     }
 
     // ---- Hb^-1 on a local vector (dx, du, nu); in may alias out ----
@@ -1235,22 +1395,8 @@ struct Solver {
         ex.sync();
     }
 
-    // Newton step for centering right-hand side ds_rhs (cone vector); results in dw, dy, sds, sdz and -- when `full` --
-    // dS, dZ (the predictor only needs the scaled directions for its step length and the Mehrotra correction).
-    SCVX_HD_NI void newton(cgptr ds_rhs, bool full) {
-        // Wirz = W^-1 rz is prepared once per iteration (shared by predictor and corrector).
-        // Wibz = -Wirz - lam \ ds_rhs.  The predictor's right-hand side is -lam o lam, for which lam \ ds_rhs = -lam
-        // exactly (ds_rhs == nullptr): neither the cone product nor the cone division is formed.
-        if (ds_rhs) {
-            div_all(ds_rhs, tt);
-            gptr wb = Wibz; cgptr wr = Wirz; cgptr t_ = tt;
-            stream(0, L.nc, [&](int i) { return D2{wr[i], t_[i]}; }, [&](int i, const D2& v) { wb[i] = -v.a - v.b; });
-        } else {
-            gptr wb = Wibz; cgptr wr = Wirz; cgptr l_ = lam;
-            stream(0, L.nc, [&](int i) { return D2{wr[i], l_[i]}; }, [&](int i, const D2& v) { wb[i] = v.b - v.a; });
-        }
-        ex.sync();
-        W_all(Wibz, tmpc, true);
+    // Newton step for the cone right-hand side held in tmpc = W^-1 Wibz (scale_pass / corr_rhs_pass): results in dw, dy
+    SCVX_HD_NI void newton_solve() {
         cone_map_t(tmpc, gx);
         ex.sync();
         {
@@ -1308,22 +1454,6 @@ struct Solver {
             }
             ex.sync();
         }
-        // With wij = W^-1 J dw:   W^-1 ds = wij - W^-1 rz,   W dz = -(wij + W^-1 bz),   dz = W^-1 (W dz),   ds = J dw - rz
-        // so the scaled directions the step-length rule needs come for free (no further scaling passes).
-        cone_map(dw, dS, false);  // J dw
-        W_all(dS, tmpc, true);    // wij
-        {
-            cgptr tc = tmpc; cgptr wr = Wirz; cgptr wb = Wibz; cgptr rz_ = rz;
-            gptr sds_ = sds; gptr sdz_ = sdz; gptr dS_ = dS;
-            if (full)
-                stream(0, L.nc, [&](int i) { return D5{tc[i], wr[i], wb[i], dS_[i], rz_[i]}; },
-                       [&](int i, const D5& v) { sds_[i] = v.a - v.b; sdz_[i] = -(v.a + v.c); dS_[i] = v.d - v.e; });
-            else
-                stream(0, L.nc, [&](int i) { return D3{tc[i], wr[i], wb[i]}; },
-                       [&](int i, const D3& v) { sds_[i] = v.a - v.b; sdz_[i] = -(v.a + v.c); });
-        }
-        ex.sync();
-        if (full) W_all(sdz, dZ, true);
     }
 
     SCVX_HD_NI void shift_into_cone(gptr X) {
@@ -1422,18 +1552,11 @@ struct Solver {
         const int degree = L.ncones;
         for (int it = 1; it <= C.max_iter; it++) {
             res.iters = it;
-            // residuals
+            // cone residual rz = S - a(V), S'Z, and -- on the same sweep -- the scaling of this iterate
+            double gap, nrz2;
+            scale_pass(gap, nrz2);
+            // dual and equality residuals
             SCVX_TS(tR_);
-            cone_map(V, tmpc, true);
-            ex.sync();
-            // rz = S - a(V); the complementarity gap S'Z and |rz|^2 ride along on the same pass
-            double gap_ = 0, nrz2 = 0;
-            {
-                gptr rz_ = rz; cgptr S_ = S; cgptr Z_ = Z; cgptr tc = tmpc;
-                stream(0, L.nc, [&](int i) { return D3{S_[i], tc[i], Z_[i]}; },
-                       [&](int i, const D3& v) { const double r = v.a - v.b; rz_[i] = r; gap_ += v.a * v.c; nrz2 += r * r; });
-            }
-            ex.sync();
             cone_map_t(Z, rx);
             const double sgy = Et_apply(y, tmpl);
             ex.sync();
@@ -1460,9 +1583,8 @@ struct Solver {
                        [&](int i, const D2& v) { const double r = v.a + v.b; ry_[i] = r; nry2 += r * r; });
             }
             ex.sync();
-            const double gap = ex.sum(gap_);
             const double pobj = -V[14 * K] + C.wNu * V[L.iTNU] + 0.5 * V[L.iTTR] + V[L.iTS];
-            const double nrx = sqrt(sumsq(rx, L.nv)), nry = sqrt(ex.sum(nry2)), nrz = sqrt(ex.sum(nrz2));
+            const double nrx = sqrt(sumsq(rx, L.nv)), nry = sqrt(ex.sum(nry2)), nrz = sqrt(nrz2);
             const double pres = nry > nrz ? nry : nrz;
             const double dres = nrx / (C.wNu > 1.0 ? C.wNu : 1.0);
             const double relgap = gap / (fabs(pobj) > 1.0 ? fabs(pobj) : 1.0);
@@ -1480,29 +1602,25 @@ struct Solver {
             if (pres < C.tol && dres < C.tol && relgap < C.tol) { res.status = 0; break; }
             if (it - best_it >= 3 && best_merit < 1e-5) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
             if (it == C.max_iter) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 1; break; }
-            nt_all();
             if (!build_kkt()) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
             const double mu = gap / degree;
-            W_all(rz, Wirz, true);
-            { SCVX_TS(tN_); newton(nullptr, false); SCVX_TE(tN_, 10); }   // predictor: affine right-hand side -lam o lam
-            double alpha = maxstep_all(sds, sdz);
+            { SCVX_TS(tN_); newton_solve(); SCVX_TE(tN_, 10); }   // predictor: affine right-hand side -lam o lam
+            double alpha = dir_pass<true>();
             if (alpha > 1.0) alpha = 1.0;
             const double sig = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
             SCVX_DBG("    aff alpha %.6e |dw|^2 %.6e ds %.6e dtnu %.6e dttr %.6e\n", alpha, dot(dw, dw, L.nv), dw[L.iS], dw[L.iTNU], dw[L.iTTR]);
-            centering_rhs(tt, true, sig * mu);
-            { SCVX_TS(tN_); newton(tt, true); SCVX_TE(tN_, 10); }
-            alpha = 0.99 * maxstep_all(sds, sdz);
+            corr_rhs_pass(sig * mu);
+            { SCVX_TS(tN_); newton_solve(); SCVX_TE(tN_, 10); }
+            alpha = 0.99 * dir_pass<false>();
             if (alpha > 1.0) alpha = 1.0;
             SCVX_DBG("    cmb alpha %.6e |dw|^2 %.6e\n", alpha, dot(dw, dw, L.nv));
             if (!(alpha == alpha)) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 3; break; }
             if (alpha < 1e-9) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
+            update_pass(alpha);   // S, Z (reads the old V)
             {
                 gptr V_ = V; cgptr dw_ = dw; gptr y_ = y; cgptr dy_ = dy;
-                gptr S_ = S; cgptr dS_ = dS; gptr Z_ = Z; cgptr dZ_ = dZ;
                 stream(0, L.nv, [&](int i) { return D2{V_[i], dw_[i]}; }, [&](int i, const D2& v) { V_[i] = v.a + alpha * v.b; });
                 stream(0, L.ny, [&](int i) { return D2{y_[i], dy_[i]}; }, [&](int i, const D2& v) { y_[i] = v.a + alpha * v.b; });
-                stream(0, L.nc, [&](int i) { return D4{S_[i], dS_[i], Z_[i], dZ_[i]}; },
-                       [&](int i, const D4& v) { S_[i] = v.a + alpha * v.b; Z_[i] = v.c + alpha * v.d; });
             }
             ex.sync();
         }
