@@ -112,12 +112,19 @@ struct WaveEx {
         for (int j = 0; j < 14; j++) dmax = fmax(dmax, M[15 * j]);   // same address in every lane: LDS broadcast reads
         const double floor_ = fmax(1e-13 * dmax, 1e-300);
         bool ok = dmax > 0.0;
+        double ipv[14];   // 1 / L[j][j], identical in every lane: the inverse below multiplies instead of dividing
 #pragma unroll
         for (int j = 0; j < 14; j++) {
             const double d0 = bcast(m[j], j);
             ok = ok && (d0 == d0);
             const double d = fmax(d0, floor_);          // NaN-safe: fmax returns the non-NaN operand
-            const double ip = 1.0 / sqrt(d);
+            // 1/sqrt(d) from v_rsq_f64 and two Newton steps (d is a clamped positive pivot: no special cases) — the
+            // library sqrt + division pair is ~50 dependent instructions on this critical path, this is 9
+            double ip = __builtin_amdgcn_rsq(d);
+            const double hd = 0.5 * d;
+            ip = fma(ip, fma(-hd * ip, ip, 0.5), ip);
+            ip = fma(ip, fma(-hd * ip, ip, 0.5), ip);
+            ipv[j] = ip;
             m[j] = (i == j) ? d * ip : m[j] * ip;       // rows above j hold junk in column j, never read
 #pragma unroll
             for (int c = j + 1; c < 14; c++) {
@@ -135,8 +142,7 @@ struct WaveEx {
                 const double lat = bcast(m[t], a);  // L[a][t]
                 if (t >= i) acc = fma(-lat, x[t], acc);
             }
-            const double laa = bcast(m[a], a);
-            x[a] = (a >= i) ? acc / laa : 0.0;
+            x[a] = (a >= i) ? acc * ipv[a] : 0.0;
         }
         if (i < 14) {
 #pragma unroll

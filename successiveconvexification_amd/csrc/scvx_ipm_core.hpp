@@ -114,6 +114,7 @@ struct Layout {
         n += (size_t)ncones;             // Wbeta
         n += (size_t)(K + 1) * 25 + (size_t)(K + 1) * 9;  // hx, hu
         n += (size_t)K * (LINV_SZ + 196);  // Linv (packed lower triangle), Nf
+        n += (size_t)K * 196;            // At: the state blocks A_k of D transposed (coalesced E' products)
         n += (size_t)ny;                 // tchain
         n += (size_t)(nloc + ny) * 3;    // ls,ys, ltr,ytr, lnu,ynu
         n += (size_t)nloc * 2;           // tmpl, tmpl2
@@ -251,7 +252,7 @@ struct Solver {
     gptr S, Z, lam, Wv, Wibz, tmpc, Wirz, sd;
     gptr Wbeta;
     gptr hx, hu;
-    gptr Linv, Nf, tchain;
+    gptr Linv, Nf, tchain, At;
     gptr ls, ys, ltr, ytr, lnu, ynu;
     gptr tmpl, tmpl2;
     gptr uhat, lb0;
@@ -274,7 +275,7 @@ struct Solver {
         Wibz = w; w += nc; tmpc = w; w += nc; Wirz = w; w += nc; sd = w; w += nc;
         Wbeta = w; w += L.ncones;
         hx = w; w += (size_t)(K + 1) * HX_SZ; hu = w; w += (size_t)(K + 1) * 9;
-        Linv = w; w += (size_t)K * LINV_SZ; Nf = w; w += (size_t)K * 196;
+        Linv = w; w += (size_t)K * LINV_SZ; Nf = w; w += (size_t)K * 196; At = w; w += (size_t)K * 196;
         tchain = w; w += ny;
         ls = w; w += nloc; ys = w; w += ny; ltr = w; w += nloc; ytr = w; w += ny; lnu = w; w += nloc; ynu = w; w += ny;
         tmpl = w; w += nloc; tmpl2 = w; w += nloc;
@@ -334,42 +335,53 @@ struct Solver {
 
     // ---- E (linearised dynamics rows, rocketland.jl:117-133) ----
     // out[k][i] = sum_j D_k[i][j] [dx_k; du_k; du_{k+1}; s]_j + nu_k[i] - dx_{k+1}[i]   (with_s: include the s column)
-    SCVX_HD_NI void E_apply(cgptr v, gptr out, bool with_s) {
+    //             + sa * add[k][i]  (add may be null);  returns |out|^2
+    SCVX_HD_NI double E_apply(cgptr v, gptr out, bool with_s, cgptr add = nullptr, double sa = 1.0) {
         SCVX_T0();
         const int K = L.K;
         const double s = with_s ? v[L.iS] : 0.0;
+        double n2 = 0;
         for (int r = ex.lane(); r < 14 * K; r += ex.nlanes()) {
             const int k = r / 14, i = r - 14 * k;
             cgptr Dk = D + (size_t)k * 294 + i;
             cgptr dx = v + 14 * k;
             cgptr du = v + L.nx + 3 * k;
+            const double ad = add ? add[r] : 0.0;   // issued with the batch of loads below, not after it
             double a = 0;
             for (int j = 0; j < 14; j++) a += Dk[14 * j] * dx[j];
             for (int j = 0; j < 6; j++) a += Dk[14 * (14 + j)] * du[j];  // du_k then du_{k+1} are adjacent
             a += Dk[14 * 20] * s;
             a += v[L.nx + L.nu_ + r] - v[14 * (k + 1) + i];
+            a += sa * ad;
             out[r] = a;
+            n2 += a * a;
         }
         ex.sync();
         SCVX_T1(1);
+        return ex.sum(n2);
     }
-    // g = E_loc' y on the local part (dx, du, nu); returns Sg . y (the s entry) to every lane
-    SCVX_HD_NI double Et_apply(cgptr yy, gptr g) {
+    // g = E_loc' y on the local part (dx, du, nu); returns Sg . y (the s entry) to every lane.
+    // mode 1: g = base - E_loc' y;  mode 2: g = E_loc' y - base  (base may be g itself: each entry is read and written by
+    // the same lane)
+    SCVX_HD_NI double Et_apply(cgptr yy, gptr g, cgptr base = nullptr, int mode = 0) {
         SCVX_T0();
         const int K = L.K;
         for (int t = ex.lane(); t < L.nx; t += ex.nlanes()) {
             const int k = t / 14, j = t - 14 * k;
+            const double b0 = mode ? base[t] : 0.0;   // loaded with the batch below
             double a = 0;
             if (k < K) {
-                cgptr col = D + (size_t)k * 294 + 14 * j;
+                cgptr col = At + (size_t)k * 196 + j;   // A_k' row-major: lanes j read consecutive doubles
                 cgptr yk = yy + 14 * k;
-                for (int i = 0; i < 14; i++) a += col[i] * yk[i];
+                for (int i = 0; i < 14; i++) a += col[14 * i] * yk[i];
             }
             if (k > 0) a -= yy[14 * (k - 1) + j];
+            if (mode) a = mode == 1 ? b0 - a : a - b0;
             g[t] = a;
         }
         for (int t = ex.lane(); t < L.nu_; t += ex.nlanes()) {
             const int k = t / 3, c = t - 3 * k;
+            const double b0 = mode ? base[L.nx + t] : 0.0;
             double a = 0;
             if (k < K) {
                 cgptr col = D + (size_t)k * 294 + 14 * (14 + c);
@@ -381,13 +393,14 @@ struct Solver {
                 cgptr yk = yy + 14 * (k - 1);
                 for (int i = 0; i < 14; i++) a += col[i] * yk[i];
             }
+            if (mode) a = mode == 1 ? b0 - a : a - b0;
             g[L.nx + t] = a;
         }
         double sg = 0;
-        for (int r = ex.lane(); r < 14 * K; r += ex.nlanes()) {
-            const int k = r / 14, i = r - 14 * k;
-            g[L.nx + L.nu_ + r] = yy[r];
-            sg += D[(size_t)k * 294 + 14 * 20 + i] * yy[r];
+        {
+            const cgptr D_ = D; cgptr bn = mode ? base + L.nx + L.nu_ : yy; const gptr gn = g + L.nx + L.nu_;
+            stream(0, 14 * K, [&](int r) { const int k = r / 14, i = r - 14 * k; return D3{yy[r], bn[r], D_[(size_t)k * 294 + 14 * 20 + i]}; },
+                   [&](int r, const D3& w) { gn[r] = mode == 0 ? w.a : (mode == 1 ? w.b - w.a : w.a - w.b); sg += w.c * w.a; });
         }
         ex.sync();
         SCVX_T1(20);
@@ -436,40 +449,56 @@ struct Solver {
         ex.sync();
         SCVX_T1(21);
     }
-    // g = J' z (var-shaped, all nv entries written)
-    SCVX_HD_NI void cone_map_t(cgptr z, gptr g) {
+    // g = J' z (var-shaped, all nv entries written), or g = -sub - J' z when sub is given (the Newton right-hand side)
+    SCVX_HD_NI void cone_map_t(cgptr z, gptr g, cgptr sub = nullptr) {
         SCVX_T0();
         const int K = L.K;
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
-            gptr gx_ = g + 14 * k;
+            double gl[17];   // the node's rows are assembled in registers and stored once
             cgptr trx = z + L.o_tr + 1 + 14 * k;
-            for (int j = 0; j < 14; j++) gx_[j] = trx[j];
-            if (k >= 1) gx_[0] += z[L.o_mass + (k - 1)];
+            for (int j = 0; j < 14; j++) gl[j] = trx[j];
+            if (k >= 1) gl[0] += z[L.o_mass + (k - 1)];
             if (k < K) {
                 cgptr gs = z + L.o_gs + 3 * k;
-                gx_[1] += gs[0] * C.itan; gx_[2] += gs[1]; gx_[3] += gs[2];
+                gl[1] += gs[0] * C.itan; gl[2] += gs[1]; gl[3] += gs[2];
                 cgptr t = z + L.o_tilt + 3 * k;
-                gx_[9] += t[1]; gx_[10] += t[2];
+                gl[9] += t[1]; gl[10] += t[2];
                 cgptr r = z + L.o_rate + 4 * k;
-                gx_[11] += r[1]; gx_[12] += r[2]; gx_[13] += r[3];
+                gl[11] += r[1]; gl[12] += r[2]; gl[13] += r[3];
             }
-            gptr gu = g + L.nx + 3 * k;
             cgptr tru = z + L.o_tr + 1 + L.nx + 3 * k;
             cgptr tb = z + L.o_tb + 4 * k;
             cgptr tc = z + L.o_tc + 4 * k;
             const double zl = z[L.o_lb + k];
-            for (int c = 0; c < 3; c++) gu[c] = tru[c] + tb[1 + c] + tc[1 + c] + zl * uhat[3 * k + c];
-            gu[0] += tc[0] * C.icos;
+            for (int c = 0; c < 3; c++) gl[14 + c] = tru[c] + tb[1 + c] + tc[1 + c] + zl * uhat[3 * k + c];
+            gl[14] += tc[0] * C.icos;
+            gptr gx_ = g + 14 * k; gptr gu = g + L.nx + 3 * k;
+            if (sub) {
+                double sb[17];
+                for (int j = 0; j < 14; j++) sb[j] = sub[14 * k + j];
+                for (int c = 0; c < 3; c++) sb[14 + c] = sub[L.nx + 3 * k + c];
+                for (int j = 0; j < 14; j++) gx_[j] = -sb[j] - gl[j];
+                for (int c = 0; c < 3; c++) gu[c] = -sb[14 + c] - gl[14 + c];
+            } else {
+                for (int j = 0; j < 14; j++) gx_[j] = gl[j];
+                for (int c = 0; c < 3; c++) gu[c] = gl[14 + c];
+            }
         }
         {
             cgptr zn = z + L.o_nu + 1; gptr gn = g + L.nx + L.nu_;
-            stream<8>(0, 14 * K, [&](int i) { return zn[i]; }, [&](int i, double x) { gn[i] = x; });
+            if (sub) {
+                cgptr sn = sub + L.nx + L.nu_;
+                stream(0, 14 * K, [&](int i) { return D2{zn[i], sn[i]}; }, [&](int i, const D2& x) { gn[i] = -x.b - x.a; });
+            } else {
+                stream<8>(0, 14 * K, [&](int i) { return zn[i]; }, [&](int i, double x) { gn[i] = x; });
+            }
         }
         if (ex.lane() == 0) {
-            g[L.iTNU] = z[L.o_nu];
-            g[L.iTTR] = z[L.o_tr] - z[L.o_rk];
-            g[L.iTS] = z[L.o_sg];
-            g[L.iS] = z[L.o_sg + 1];
+            const double g0 = z[L.o_nu], g1 = z[L.o_tr] - z[L.o_rk], g2 = z[L.o_sg], g3 = z[L.o_sg + 1];
+            g[L.iTNU] = sub ? -sub[L.iTNU] - g0 : g0;
+            g[L.iTTR] = sub ? -sub[L.iTTR] - g1 : g1;
+            g[L.iTS] = sub ? -sub[L.iTS] - g2 : g2;
+            g[L.iS] = sub ? -sub[L.iS] - g3 : g3;
         }
         ex.sync();
         SCVX_T1(21);
@@ -999,13 +1028,14 @@ struct Solver {
     SCVX_HD_NI void Et_apply3(cgptr y0, cgptr y1, cgptr y2, gptr g0, gptr g1, gptr g2) {
         const int K = L.K;
         const cgptr D = this->D;
+        const cgptr At = this->At;
         for (int t = ex.lane(); t < L.nx; t += ex.nlanes()) {
             const int k = t / 14, j = t - 14 * k;
             double a0 = 0, a1 = 0, a2 = 0;
             if (k < K) {
-                cgptr col = D + (size_t)k * 294 + 14 * j;
+                cgptr col = At + (size_t)k * 196 + j;
                 SCVX_UNROLL
-                for (int i = 0; i < 14; i++) { const double c = col[i]; a0 += c * y0[14 * k + i]; a1 += c * y1[14 * k + i]; a2 += c * y2[14 * k + i]; }
+                for (int i = 0; i < 14; i++) { const double c = col[14 * i]; a0 += c * y0[14 * k + i]; a1 += c * y1[14 * k + i]; a2 += c * y2[14 * k + i]; }
             }
             if (k > 0) { a0 -= y0[14 * (k - 1) + j]; a1 -= y1[14 * (k - 1) + j]; a2 -= y2[14 * (k - 1) + j]; }
             g0[t] = a0; g1[t] = a1; g2[t] = a2;
@@ -1029,23 +1059,12 @@ struct Solver {
     }
 
     // [Hb E'; E 0][dl; dyv] = [gl; ryv]   (gl: local part of a var vector; outputs may not alias inputs)
-    SCVX_HD_NI void band_solve(cgptr gl, cgptr ryv, gptr dl, gptr dyv) {
+    // The equality right-hand side is rsign * ryv (ryv may be null).
+    SCVX_HD_NI void band_solve(cgptr gl, cgptr ryv, double rsign, gptr dl, gptr dyv) {
         Hb_inv(gl, tmpl);
-        E_apply(tmpl, tmpy, false);
-        ex.sync();
-        if (ryv) {
-            gptr ty = tmpy;
-            stream(0, L.ny, [&](int i) { return D2{ty[i], ryv[i]}; }, [&](int i, const D2& v) { ty[i] = v.a - v.b; });
-        }
-        ex.sync();
+        (void)E_apply(tmpl, tmpy, false, ryv, -rsign);      // E Hb^-1 g - r
         S_solve(tmpy, dyv);
-        (void)Et_apply(dyv, tmpl2);
-        ex.sync();
-        {
-            gptr t2 = tmpl2;
-            stream(0, L.nloc, [&](int i) { return D2{gl[i], t2[i]}; }, [&](int i, const D2& v) { t2[i] = v.a - v.b; });
-        }
-        ex.sync();
+        (void)Et_apply(dyv, tmpl2, gl, 1);                  // g - E' y
         Hb_inv(tmpl2, dl);
     }
 
@@ -1186,10 +1205,19 @@ struct Solver {
             T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
         }
         ex.sync_lds();
+        // the compact node inverses (34 doubles) are requested one segment ahead as well: lane e holds element e of node
+        // k + 1 while segment k - 1 is processed (register-prefetching executors have at least 34 lanes)
+        auto node_elem = [&](int node, int e) -> double {
+            return e < 25 ? hx_[(size_t)node * HX_SZ + e] : hu_[9 * node + (e - 25)];
+        };
+        double hn = 0.0;
+        if (Ex::kPrefetchRegs > 0 && ex.lane() < 34) hn = node_elem(1, ex.lane());
         for (int k = 0; k < K; k++) {
             SCVX_TS(ta_);
             // prefetch the next segment's tile
             constexpr int NPRE = Ex::kPrefetchRegs;
+            double hn2 = 0.0;
+            if (NPRE > 0 && ex.lane() < 34) hn2 = node_elem(k + 2 <= K ? k + 2 : K, ex.lane());
             double pre[NPRE > 0 ? NPRE : 1];
             cgptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
             if (NPRE > 0) {
@@ -1198,10 +1226,11 @@ struct Solver {
             }
             // node inverses: slot 0 <- slot 1 (k), slot 1 <- k+1, dense tile of k+1
             for (int e = ex.lane(); e < 34; e += ex.nlanes()) {
-                const double nk1 = e < 25 ? hx_[(size_t)(k + 1) * HX_SZ + e] : hu_[9 * (k + 1) + (e - 25)];
+                const double nk1 = NPRE > 0 ? hn : node_elem(k + 1, e);
                 Hh[e] = Hh[34 + e];
                 Hh[34 + e] = nk1;
             }
+            hn = hn2;
             ex.sync_lds();
             for (int e = ex.lane(); e < 196 + 42; e += ex.nlanes()) {
                 if (e < 196) {
@@ -1330,8 +1359,8 @@ struct Solver {
     }
 
     // full reduced KKT: [H E'; E 0][dwv; dyv] = [g; ryv]  (g var-shaped incl. 4 globals)
-    SCVX_HD_NI void kkt_solve(cgptr g, cgptr ryv, gptr dwv, gptr dyv) {
-        band_solve(g, ryv, dwv, dyv);
+    SCVX_HD_NI void kkt_solve(cgptr g, cgptr ryv, gptr dwv, gptr dyv, double rsign = 1.0) {
+        band_solve(g, ryv, rsign, dwv, dyv);
         double a = 0;
         {
             const cgptr D_ = D;
@@ -1397,16 +1426,9 @@ struct Solver {
 
     // Newton step for the cone right-hand side held in tmpc = W^-1 Wibz (scale_pass / corr_rhs_pass): results in dw, dy
     SCVX_HD_NI void newton_solve() {
-        cone_map_t(tmpc, gx);
-        ex.sync();
-        {
-            gptr g_ = gx; cgptr rx_ = rx; gptr r2_ = r2; cgptr ry_ = ry;
-            stream(0, L.nv, [&](int i) { return D2{rx_[i], g_[i]}; }, [&](int i, const D2& v) { g_[i] = -v.a - v.b; });
-            stream<8>(0, L.ny, [&](int i) { return ry_[i]; }, [&](int i, double v) { r2_[i] = -v; });
-        }
-        ex.sync();
+        cone_map_t(tmpc, gx, rx);      // gx = -rx - J' W^-1 Wibz
         mask_fixed(gx);
-        kkt_solve(gx, r2, dw, dy);
+        kkt_solve(gx, ry, dw, dy, -1.0);   // equality right-hand side -ry
 #if defined(SCVX_IPM_DEBUG) && !defined(__HIPCC__)
         {
             H_apply(dw, r1);
@@ -1416,7 +1438,7 @@ struct Solver {
                 if (i < 14) fx = fixed_x(0, i); else if (i >= 14 * L.K && i < L.nx) fx = fixed_x(L.K, i - 14 * L.K); else if (i == L.nx + 3 * L.K + 1 || i == L.nx + 3 * L.K + 2) fx = true;
                 if (!fx) { if (i < L.nx + L.nu_) e1 += r * r; else e2 += r * r; } }
             E_apply(dw, tmpy2, true);
-            for (int i = 0; i < L.ny; i++) { double r = r2[i] - tmpy2[i]; e3 += r * r; }
+            for (int i = 0; i < L.ny; i++) { double r = -ry[i] - tmpy2[i]; e3 += r * r; }
             SCVX_DBG("      kkt res: xu %.2e nu %.2e s %.2e tnu %.2e ttr %.2e ts %.2e | E %.2e\n", sqrt(e1), sqrt(e2), gx[L.iS] - r1[L.iS] - sgy,
                      gx[L.iTNU] - r1[L.iTNU], gx[L.iTTR] - r1[L.iTTR], gx[L.iTS] - r1[L.iTS], sqrt(e3));
         }
@@ -1493,6 +1515,11 @@ struct Solver {
         const int K = L.K;
         // constants of this subproblem
         for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) dk[r] = endpoint[r] - xbar[14 + r];
+        {   // A_k' once per subproblem: element (i, j) of A_k sits at 14 j + i in D (column-major), at 14 i + j here
+            const cgptr D_ = D; const gptr At_ = At;
+            stream(0, 196 * K, [&](int e) { const int k = e / 196, r = e - 196 * k, i = r / 14, j = r - 14 * i; return D_[(size_t)k * 294 + 14 * j + i]; },
+                   [&](int e, double v) { At_[e] = v; });
+        }
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
             cgptr u = ubar + 3 * k;
             const double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
@@ -1558,13 +1585,7 @@ struct Solver {
             // dual and equality residuals
             SCVX_TS(tR_);
             cone_map_t(Z, rx);
-            const double sgy = Et_apply(y, tmpl);
-            ex.sync();
-            {
-                gptr rx_ = rx; cgptr tl = tmpl;
-                stream(0, L.nloc, [&](int i) { return D2{rx_[i], tl[i]}; }, [&](int i, const D2& v) { rx_[i] = -v.a + v.b; });
-            }
-            ex.sync();
+            const double sgy = Et_apply(y, rx, rx, 2);     // rx = E'y - J'Z on the local part
             if (ex.lane() == 0) {
                 rx[14 * K] += -1.0;
                 rx[L.iS] = -rx[L.iS] + sgy;
@@ -1574,17 +1595,9 @@ struct Solver {
             }
             ex.sync();
             mask_fixed(rx);
-            E_apply(V, ry, true);
-            ex.sync();
-            double nry2 = 0;
-            {
-                gptr ry_ = ry; cgptr dk_ = dk;
-                stream(0, L.ny, [&](int i) { return D2{ry_[i], dk_[i]}; },
-                       [&](int i, const D2& v) { const double r = v.a + v.b; ry_[i] = r; nry2 += r * r; });
-            }
-            ex.sync();
+            const double nry2 = E_apply(V, ry, true, dk, 1.0);   // ry = E V + dk
             const double pobj = -V[14 * K] + C.wNu * V[L.iTNU] + 0.5 * V[L.iTTR] + V[L.iTS];
-            const double nrx = sqrt(sumsq(rx, L.nv)), nry = sqrt(ex.sum(nry2)), nrz = sqrt(nrz2);
+            const double nrx = sqrt(sumsq(rx, L.nv)), nry = sqrt(nry2), nrz = sqrt(nrz2);
             const double pres = nry > nrz ? nry : nrz;
             const double dres = nrx / (C.wNu > 1.0 ? C.wNu : 1.0);
             const double relgap = gap / (fabs(pobj) > 1.0 ? fabs(pobj) : 1.0);
