@@ -287,7 +287,7 @@ def main():
                 "achieved_lo": t["lo"] / (ms * 1e-3) / 1e9, "achieved_hi": t["hi"] / (ms * 1e-3) / 1e9,
                 "frac_lo": t["lo"] / (ms * 1e-3) / HBM_PEAK, "frac_hi": t["hi"] / (ms * 1e-3) / HBM_PEAK,
                 "note": "measured HBM traffic of the per-trajectory working set (PMC), not an algorithmic minimum: the "
-                        "subproblem data (148 KB per trajectory) would fit on chip, the solver state (727 KB) does not",
+                        "subproblem data (148 KB per trajectory) would fit on chip, the solver state (613 KB) does not",
             })(k4_measured_traffic(B), prof["socp"] / max(nprof, 1)),
             "solver_stats_last_step": {"ipm_iters_mean": float(np.mean(its)), "ipm_iters_max": int(np.max(its)),
                                        "status_optimal_frac": float(np.mean(st == 0)), "merit_max": float(np.max(merit))},
