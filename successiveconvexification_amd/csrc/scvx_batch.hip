@@ -15,6 +15,7 @@
 // are cross-lane shuffles; the 14x14 pivot tiles of the block Cholesky live in LDS.  Each trajectory's
 // working set is one contiguous slab of HBM so every strided lane loop is a coalesced access.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -248,29 +249,84 @@ struct WaveEx {
     }
 };
 
+// Small batches: NW wavefronts cooperate on ONE trajectory (a lone wavefront per trajectory leaves most of the chip idle
+// below a few hundred trajectories and each solve is latency-bound: 26 ms per subproblem).  The streaming sweeps, the
+// E / E' products and the node loops of the solver are written against lane()/nlanes(), so they simply spread over
+// 64 NW lanes; the 14x14 tile arithmetic and the block recurrences stay on wavefront 0 (they are sequential in k), with
+// workgroup barriers where the single-wavefront executor needs none.  Reductions go through LDS in a fixed order, so
+// every lane of the workgroup sees bit-identical scalars (uniform control flow, as in WaveEx).
+template <int NW>
+struct BlockEx {
+    WaveEx w0;
+    static constexpr int kPrefetchRegs = (294 + 64 * NW - 1) / (64 * NW);
+    __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
+    __device__ __forceinline__ int nlanes() const { return 64 * NW; }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    __device__ __forceinline__ void sync_lds() { __syncthreads(); }
+    __device__ __forceinline__ double* scratch() { return g_socp_lds; }
+    __device__ __forceinline__ bool first() const { return threadIdx.x < 64; }
+    // slots 0..NW-1 of the scratch header hold the per-wavefront partials, slot 16 a flag
+    template <class OP>
+    __device__ __forceinline__ double reduce(double x, OP op) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x = op(x, __shfl_xor(x, o, 64));
+        double* red = g_socp_lds;
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+        __syncthreads();
+        double r = red[0];
+#pragma unroll
+        for (int q = 1; q < NW; q++) r = op(r, red[q]);
+        __syncthreads();   // the partials may be overwritten by the next reduction
+        return r;
+    }
+    __device__ __forceinline__ double sum(double x) { return reduce(x, [](double a, double b) { return a + b; }); }
+    __device__ __forceinline__ double min(double x) { return reduce(x, [](double a, double b) { return fmin(a, b); }); }
+    __device__ __forceinline__ bool all(bool b) { return __syncthreads_and(b ? 1 : 0) != 0; }
+    __device__ __forceinline__ void tile_gemm(double* Cm, int sci, int scj, const double* A, int sai, int sak, const double* B,
+                                              int sbk, int sbj, int Kd, double alpha, bool acc) {
+        if (first()) w0.tile_gemm(Cm, sci, scj, A, sai, sak, B, sbk, sbj, Kd, alpha, acc);
+    }
+    __device__ __forceinline__ bool chol_inv14(const double* M, double* Li) {
+        double* flag = g_socp_lds + 16;
+        if (first()) {
+            const bool ok = w0.chol_inv14(M, Li);
+            if (threadIdx.x == 0) *flag = ok ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        const bool ok = *flag != 0.0;
+        __syncthreads();
+        return ok;
+    }
+    __device__ __forceinline__ void chain(int K, ipm::cgptr z, ipm::cgptr N, ipm::gptr out, bool reverse) {
+        if (first()) w0.chain(K, z, N, out, reverse);
+    }
+    __device__ __forceinline__ void chain3(int K, ipm::cgptr z0, ipm::cgptr z1, ipm::cgptr z2, ipm::cgptr N, ipm::gptr o0,
+                                           ipm::gptr o1, ipm::gptr o2, bool reverse) {
+        if (first()) w0.chain3(K, z0, z1, z2, N, o0, o1, o2, reverse);
+    }
+};
+
 // info[b] = {status, iters, merit, pobj}
-__global__ __launch_bounds__(64, 3) void socp_kernel(ipm::Consts C, int B, size_t work_stride,
-                                                  const double* __restrict__ x, const double* __restrict__ u,
-                                                  const double* __restrict__ endpoint, const double* __restrict__ deriv,
-                                                  const double* __restrict__ rk, const double* __restrict__ ic,
-                                                  const int* __restrict__ active, double* __restrict__ work,
-                                                  double* __restrict__ sol, double* __restrict__ nu,
-                                                  double* __restrict__ info) {
+template <class Ex>
+__device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t work_stride, const double* x, const double* u,
+                                          const double* endpoint, const double* deriv, const double* rk, const double* ic,
+                                          const int* active, double* work, double* sol, double* nu, double* info) {
     const int b = blockIdx.x;
     if (b >= B) return;
     if (active && !active[b]) return;
     const int K = C.K;
-    WaveEx ex;
-    ipm::Solver<WaveEx> S(ex, C);
+    Ex ex;
+    ipm::Solver<Ex> S(ex, C);
     // kernel arguments are HBM pointers: hand them to the solver typed as such (see ipm::gptr)
     const ipm::Result r = S.solve((ipm::cgptr)(x + (size_t)b * (K + 1) * 14), (ipm::cgptr)(u + (size_t)b * (K + 1) * 3),
                                   (ipm::cgptr)(endpoint + (size_t)b * K * 14), (ipm::cgptr)(deriv + (size_t)b * K * 294), rk[b],
                                   (ipm::cgptr)(ic + (size_t)b * 6), (ipm::gptr)(work + (size_t)b * work_stride));
     const int nxu = S.L.nx + S.L.nu_;
+    const int nl = ex.nlanes();
     double* so = sol + (size_t)b * (nxu + 1);
-    for (int i = threadIdx.x; i < nxu; i += 64) so[i] = S.V[i];
+    for (int i = threadIdx.x; i < nxu; i += nl) so[i] = S.V[i];
     double* no = nu + (size_t)b * S.L.ny;
-    for (int i = threadIdx.x; i < S.L.ny; i += 64) no[i] = S.V[nxu + i];
+    for (int i = threadIdx.x; i < S.L.ny; i += nl) no[i] = S.V[nxu + i];
     if (threadIdx.x == 0) {
         so[nxu] = S.V[S.L.iS];
         info[4 * b + 0] = (double)r.status;
@@ -281,6 +337,29 @@ __global__ __launch_bounds__(64, 3) void socp_kernel(ipm::Consts C, int B, size_
         if (b == 0) for (int i = 0; i < 32; i++) work[i] = S.prof[i];  // diagnostic build: section cycles of trajectory 0
 #endif
     }
+}
+
+// one wavefront per trajectory (large batches: the chip is filled by trajectories)
+__global__ __launch_bounds__(64, 3) void socp_kernel(ipm::Consts C, int B, size_t work_stride,
+                                                  const double* __restrict__ x, const double* __restrict__ u,
+                                                  const double* __restrict__ endpoint, const double* __restrict__ deriv,
+                                                  const double* __restrict__ rk, const double* __restrict__ ic,
+                                                  const int* __restrict__ active, double* __restrict__ work,
+                                                  double* __restrict__ sol, double* __restrict__ nu,
+                                                  double* __restrict__ info) {
+    socp_body<WaveEx>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info);
+}
+
+// SOCP_BLOCK_WAVES wavefronts per trajectory (small batches)
+constexpr int SOCP_BLOCK_WAVES = 4;
+__global__ __launch_bounds__(64 * SOCP_BLOCK_WAVES) void socp_block_kernel(ipm::Consts C, int B, size_t work_stride,
+                                                  const double* __restrict__ x, const double* __restrict__ u,
+                                                  const double* __restrict__ endpoint, const double* __restrict__ deriv,
+                                                  const double* __restrict__ rk, const double* __restrict__ ic,
+                                                  const int* __restrict__ active, double* __restrict__ work,
+                                                  double* __restrict__ sol, double* __restrict__ nu,
+                                                  double* __restrict__ info) {
+    socp_body<BlockEx<SOCP_BLOCK_WAVES>>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info);
 }
 
 // cand = about + step (x, u in one contiguous [B][(K+1)*17+1] trajectory record, sigma last)
@@ -403,6 +482,8 @@ struct scvx_batch {
 
 namespace {
 
+constexpr int SOCP_BLOCK_MAX_B = 512;
+
 void rotation_between_e1(const double* b, double* q) {
     // Rotations.rotation_between([1,0,0], b) as [w,x,y,z] (initial_solve.jl:121-122)
     const double nb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
@@ -433,8 +514,17 @@ int split_views(scvx_batch* b, const double* rec, double* x, double* u, double* 
 }
 
 int enqueue_socp(scvx_batch* b) {
-    hipLaunchKernelGGL(scvx::socp_kernel, dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
-                       b->endpoint, b->deriv, b->rk, b->ic, b->active, b->work, b->sol, b->nu, b->info);
+    // below SOCP_BLOCK_MAX_B trajectories a wavefront per trajectory cannot fill the chip: several wavefronts share one
+    // (SCVX_K4_WAVES=1 / 4 forces either form)
+    bool block = b->B <= SOCP_BLOCK_MAX_B;
+    if (const char* v = std::getenv("SCVX_K4_WAVES")) block = std::atoi(v) > 1;
+    if (block)
+        hipLaunchKernelGGL(scvx::socp_block_kernel, dim3(b->B), dim3(64 * scvx::SOCP_BLOCK_WAVES), 0, b->ctx->stream, b->C, b->B,
+                           b->work_stride, b->x, b->u, b->endpoint, b->deriv, b->rk, b->ic, b->active, b->work, b->sol, b->nu,
+                           b->info);
+    else
+        hipLaunchKernelGGL(scvx::socp_kernel, dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
+                           b->endpoint, b->deriv, b->rk, b->ic, b->active, b->work, b->sol, b->nu, b->info);
     SCVX_HIP(b->ctx, hipGetLastError());
     return SCVX_OK;
 }

@@ -78,6 +78,31 @@ def test_socp_matches_cpu_twin_and_oracle_ipm():
     assert abs(obj - sol.pobj) < 1e-5 * abs(sol.pobj)
 
 
+def test_both_socp_executors_agree(monkeypatch):
+    """socp_kernel (one wavefront per trajectory, the large-batch form) and socp_block_kernel (four wavefronts per
+    trajectory, chosen below 512 trajectories) run the same portable solver core: same iteration paths, objectives to
+    1e-7 relative (the tolerance of the twin comparison above), minimisers to the flatness of the optimum.  SCVX_K4_WAVES forces either form."""
+    from oracle import model
+    po = model.base_prob_scaled()
+    B = 6
+    ic = model.disperse_ics(po, B, 20261004)
+    res = {}
+    for waves in ("1", "4"):
+        monkeypatch.setenv("SCVX_K4_WAVES", waves)
+        c, b = _setup(B, ic)
+        xb, ub, sg = b.trajectory()
+        x, u, snew, nu = b.socp_solve()
+        st, its, merit, pobj = b.solver_stats()
+        assert np.all(st == 0), (waves, st, merit)
+        res[waves] = (x, u, snew, nu, its, pobj)
+        b.close(); c.close()
+    a, bq = res["1"], res["4"]
+    assert np.abs(a[4] - bq[4]).max() <= 3          # iteration counts: the floor-acceptance rule looks 3 iterations back
+    assert np.abs(a[5] - bq[5]).max() < 1e-7 * np.abs(a[5]).max()
+    for i in range(4):
+        assert np.abs(a[i] - bq[i]).max() < 1e-4
+
+
 def test_solve_step_matches_oracle_scvx_two_iterations():
     """Two full solve_step calls against oracle.scvx (IPM + exact discretisation) on one trajectory."""
     from oracle import model, scvx as oscvx
