@@ -155,6 +155,42 @@ def traj_linf_vs_oracle(cache_cls, batch_cls, prob, npts):
             "ref": "oracle (IPM on the exact build_model rows + RK4 npts=10); parity with the Julia reference itself is unpinned"}
 
 
+def k1_by_npts(cache, batch, torch, K, B, default_npts):
+    """K1 alone on the batch's current trajectories for rk4 npts in (1, 2, 4, 10): the HBM fraction of the discretisation
+    kernel depends on how much FP64 work a segment carries (SURVEY.md 8d), so the bench states it per npts.  Device
+    pointers through the C ABI (scvx_linearize_f64), HIP events on the stream the kernel runs on; outside the timed region."""
+    import ctypes as C
+    x, u, s = batch.trajectory()
+    xd, ud, sd = (torch.tensor(np.ascontiguousarray(a), device="cuda") for a in (x, u, s))
+    e = torch.empty((B, K, 14), dtype=torch.float64, device="cuda")
+    d = torch.empty((B, K, 21, 14), dtype=torch.float64, device="cuda")
+    L, out = cache._L, {}
+    ts = torch.cuda.Stream()            # a real stream handle: torch's default stream is handle 0, which the library
+    cache.set_stream(ts.cuda_stream)    # replaces by its own stream, where torch's events would not see the kernel
+    torch.cuda.synchronize()
+    for npts in (1, 2, 4, 10):
+        cache.set_npts(npts)
+
+        def call():
+            return L.scvx_linearize_f64(cache.handle, B, K, C.c_void_p(xd.data_ptr()), C.c_void_p(ud.data_ptr()),
+                                        C.c_void_p(sd.data_ptr()), C.c_double(1.0 / (K + 1)), C.c_void_p(e.data_ptr()),
+                                        C.c_void_p(d.data_ptr()))
+        for _ in range(2):
+            assert call() == 0
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record(ts)
+        for _ in range(5):
+            call()
+        t1.record(ts)
+        torch.cuda.synchronize()
+        ms = t0.elapsed_time(t1) / 5
+        out[str(npts)] = {"ms": ms, "achieved_GBps": k1_alg_bytes(K) * B / (ms * 1e-3) / 1e9,
+                          "frac": k1_alg_bytes(K) * B / (ms * 1e-3) / HBM_PEAK}
+    cache.set_npts(default_npts)
+    cache.set_stream(torch.cuda.current_stream().cuda_stream)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -292,6 +328,8 @@ def main():
             "solver_stats_last_step": {"ipm_iters_mean": float(np.mean(its)), "ipm_iters_max": int(np.max(its)),
                                        "status_optimal_frac": float(np.mean(st == 0)), "merit_max": float(np.max(merit))},
         }
+        if world == 1:
+            line["roofline_k1_by_npts"] = k1_by_npts(cache, batch, torch, K, B, args.npts)
         if world == 1 and not args.no_traj_check:
             line["traj_linf_vs_oracle"] = traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts)
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
