@@ -126,6 +126,7 @@ int scvx_ctx_create(const scvx_problem* p, int device, scvx_ctx** out) {
     }
     ctx->stream = ctx->own_stream;
     if (const char* v = std::getenv("SCVX_K1_VARIANT")) ctx->k1_variant = std::atoi(v) ? 1 : 0;
+    if (const char* v = std::getenv("SCVX_K1_SG")) ctx->k1_sg = std::atoi(v) ? 1 : 0;
     *out = ctx;
     return SCVX_OK;
 }

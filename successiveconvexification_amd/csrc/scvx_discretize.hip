@@ -155,13 +155,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void linearize_kernel(
 //                        stage, the coefficient record a column needs (StageRec) into a double-buffered LDS slab;
 //   waves 1-7 (consumers) one lane per sensitivity column (15 per segment exo, 4 segments per wave; 21 x 3 aero):
 //                        read their segment's record (LDS broadcast), advance the column.
-// One barrier per RK4 substep; the producer works one substep (4 stage records) ahead through an 8-slot ring.  The stage evaluation is executed once per 28 (21)
+// One barrier per RK stage, the producer one stage ahead through a 2-slot ring (SG; or per substep, one substep ahead,
+// 8 slots).  The stage evaluation is executed once per 28 (21)
 // segments instead of once per 4 (3): ~1.8x fewer instructions per segment.  Output tiles leave through LDS as
 // coalesced 16-byte stores, exactly as in linearize_kernel.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int PC_WAVES = 8;
 constexpr int PC_GROUP = 4;              // stages published per barrier (one RK4 substep)
-template <bool AERO>
+// SG (stage-granular, the default): one barrier per RK stage and the producer one STAGE ahead (2-slot ring) instead of
+// one barrier per substep and the producer one substep ahead: the pipeline fills after one stage instead of four (at
+// npts = 1 the substep-granular form does not overlap at all), which outweighs the 4x barrier count at every npts.
+template <bool AERO, bool SG>
 __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
     DynParams p, long nseg, int K, const double* __restrict__ x, const double* __restrict__ u,
     const double* __restrict__ sigma, double dt, int nsub, double* __restrict__ endpoint,
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
     constexpr int NC = PC_WAVES - 1;
     constexpr int NS = NC * SPW;               // segments per block
     constexpr int NR = StageRec<AERO>::N;
-    constexpr int RING = 2 * PC_GROUP;         // stage records in flight: the producer runs one substep ahead
+    constexpr int RING = SG ? 2 : 2 * PC_GROUP;   // stage records in flight: the producer runs one stage / one substep ahead
     constexpr int RING_D = RING * NR * NS, TILE_D = NC * SPW * 294;
     // one LDS slab: the coefficient ring during the integration, the output tiles afterwards
     __shared__ __attribute__((aligned(16))) double lds[RING_D > TILE_D ? RING_D : TILE_D];
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
                     double uu[3] = {fma(uk0, lkm, up0 * lkp), fma(uk1, lkm, up1 * lkp), fma(uk2, lkm, up2 * lkp)};
                     Stage<AERO> st;
                     stage_eval<AERO>(p, xt, uu, st);
-                    if (live) stage_publish<AERO>(p, st, xt, uu, lds + ((s & 1) * PC_GROUP + stg) * NR * NS + l, NS);
+                    if (live) stage_publish<AERO>(p, st, xt, uu, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + l, NS);
                     const double wacc = h * ((stg == 0 || stg == 3) ? (1.0 / 6.0) : (1.0 / 3.0));
                     const double wnext = h * (stg == 2 ? 1.0 : 0.5);
 #pragma unroll
@@ -214,11 +218,12 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
                         xa[i] = fma(wacc, dx, xa[i]);
                         xt[i] = (stg < 3) ? fma(wnext, dx, xs[i]) : xa[i];
                     }
+                    if (SG) __syncthreads();   // stage 4 s + stg is published
                 }
 #pragma unroll
                 for (int i = 0; i < 14; i++) xs[i] = xa[i];
             }
-            __syncthreads();
+            if (!SG || s == nsub) __syncthreads();
         }
         if (valid) {
             double* ep = endpoint + (size_t)seg * 14;
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
             const double wk = is_uk ? lkm : (is_up ? lkp : 0.0);
             const double wc[3] = {e0 * wk, e1 * wk, e2 * wk};
             double dc[14];
-            column_deriv_rec<AERO>(p, lds + ((s & 1) * PC_GROUP + stg) * NR * NS + ls, NS, ct, wc, gsel, sig, dc);
+            column_deriv_rec<AERO>(p, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + ls, NS, ct, wc, gsel, sig, dc);
             const double wacc = h * ((stg == 0 || stg == 3) ? (1.0 / 6.0) : (1.0 / 3.0));
             const double wnext = h * (stg == 2 ? 1.0 : 0.5);
 #pragma unroll
@@ -264,10 +269,11 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
                 ca[i] = fma(wacc, dc[i], ca[i]);
                 ct[i] = (stg < 3) ? fma(wnext, dc[i], c[i]) : ca[i];
             }
+            if (SG) __syncthreads();   // this slot is free again / the next stage is published
         }
 #pragma unroll
         for (int i = 0; i < 14; i++) c[i] = ca[i];
-        __syncthreads();
+        if (!SG) __syncthreads();
     }
     // ---- epilogue: columns into the LDS tile (the ring is dead now) -> coalesced 16-byte stores ----
     double* t = lds + cw * SPW * 294;
@@ -366,12 +372,17 @@ hipError_t launch_linearize(const scvx_ctx* ctx, int B, int K, const double* x, 
     } else {
         const int ns = (PC_WAVES - 1) * (ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW);
         const unsigned grid = (unsigned)((nseg + ns - 1) / ns);
-        if (ctx->dyn.aero)
-            hipLaunchKernelGGL(linearize_pc_kernel<true>, dim3(grid), dim3(64 * PC_WAVES), 0, st, ctx->dyn, nseg, K, x, u,
-                               sigma, dt, ctx->nsub, endpoint, deriv);
-        else
-            hipLaunchKernelGGL(linearize_pc_kernel<false>, dim3(grid), dim3(64 * PC_WAVES), 0, st, ctx->dyn, nseg, K, x, u,
-                               sigma, dt, ctx->nsub, endpoint, deriv);
+        // stage-granular pipeline by default (faster at every npts measured: 0.70 -> 0.60 ms at npts 1, 3.05 -> 2.96 ms
+        // at npts 10, B = 8192); SCVX_K1_SG=0 selects the substep-granular form
+        const bool sg = ctx->k1_sg != 0;
+        const dim3 g(grid), blk(64 * PC_WAVES);
+        if (ctx->dyn.aero) {
+            if (sg) hipLaunchKernelGGL((linearize_pc_kernel<true, true>), g, blk, 0, st, ctx->dyn, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
+            else hipLaunchKernelGGL((linearize_pc_kernel<true, false>), g, blk, 0, st, ctx->dyn, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
+        } else {
+            if (sg) hipLaunchKernelGGL((linearize_pc_kernel<false, true>), g, blk, 0, st, ctx->dyn, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
+            else hipLaunchKernelGGL((linearize_pc_kernel<false, false>), g, blk, 0, st, ctx->dyn, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
+        }
     }
     return hipGetLastError();
 }

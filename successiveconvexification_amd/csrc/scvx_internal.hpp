@@ -13,6 +13,7 @@ struct scvx_ctx {
     scvx::DynParams dyn{};
     int nsub = 10;
     int k1_variant = 1;  // 0: one-lane-per-column kernel, 1: producer/consumer kernel (SCVX_K1_VARIANT overrides)
+    int k1_sg = 1;       // producer/consumer pipeline per RK stage (1, default) or per substep (0); SCVX_K1_SG overrides
     double* d_cdrag = nullptr;
     double* d_clift = nullptr;
     std::string err;

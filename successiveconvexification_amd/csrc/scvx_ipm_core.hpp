@@ -3,8 +3,8 @@
 // Replaces MOI.optimize!(model) (rocketland.jl:271; Mosek / ECOS interior-point solvers) for the model
 // Rocketland.build_model assembles (rocketland.jl:53-219).  One *executor* solves one trajectory's
 // subproblem; the executor abstraction `Ex` supplies lane(), nlanes(), sync(), sum(), min(), scratch():
-//     device  : one 64-lane wavefront per trajectory (scvx_socp.hip), reductions by cross-lane shuffles,
-//               scratch tiles in LDS
+//     device  : one 64-lane wavefront per trajectory (WaveEx, scvx_batch.hip) or four per trajectory for small
+//               batches (BlockEx), reductions by cross-lane shuffles, scratch tiles in LDS
 //     host    : one thread per trajectory (the CPU twin timed as bench.py's cpu_baseline)
 // The algorithm (Mehrotra predictor-corrector, Nesterov-Todd scaling, CVXOPT-style initial point) and
 // every formula follow the validated numpy twin oracle/ipm_struct.py; see DESIGN.md §SOCP for the maths.
@@ -244,7 +244,6 @@ struct Solver {
     Layout L;
     // inputs
     cgptr xbar, ubar, D, endpoint;
-    double x0fix[10];  // mwet, rIi(3), vIi(3), wBi(3)
     double rk;
     // workspace
     gptr dk, V, rx, gx, dw, r1, cw, Vbest, tmpv;
