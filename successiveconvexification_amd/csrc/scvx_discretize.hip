@@ -160,7 +160,18 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void linearize_kernel(
 // segments instead of once per 4 (3): ~1.8x fewer instructions per segment.  Output tiles leave through LDS as
 // coalesced 16-byte stores, exactly as in linearize_kernel.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int PC_WAVES = 8;
+// Block shape (measured at B = 8192, npts 10; -DSCVX_PC_WAVES / -DSCVX_PC_PROD rebuild the variants): 8 wavefronts with
+// the producer first is the best that fits — 2.96 ms; 7 / 6 / 5 wavefronts 3.29 / 3.60 / 4.28 ms (the time per substep of
+// a block does not depend on its width: each wavefront is latency-bound, so throughput goes with the number of consumer
+// wavefronts per CU); 10 or 12 wavefronts need <= 168 VGPRs, spill 260 registers and run 3-4x slower.
+#ifndef SCVX_PC_WAVES
+#define SCVX_PC_WAVES 8
+#endif
+#ifndef SCVX_PC_PROD
+#define SCVX_PC_PROD 0
+#endif
+constexpr int PC_WAVES = SCVX_PC_WAVES;
+constexpr int PC_PROD = SCVX_PC_PROD;
 constexpr int PC_GROUP = 4;              // stages published per barrier (one RK4 substep)
 // SG (stage-granular, the default): one barrier per RK stage and the producer one STAGE ahead (2-slot ring) instead of
 // one barrier per substep and the producer one substep ahead: the pipeline fills after one stage instead of four (at
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
     const double h = dt / (double)nsub;
     const double inv_n = 1.0 / (double)nsub;
 
-    if (wave == 0) {
+    if (wave == PC_PROD) {
         // ---------------- producer: lane = segment ----------------
         const bool live = lane < NS;
         long seg = seg_base + (live ? lane : 0);
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
     }
 
     // ---------------- consumers: lane = (segment, column) ----------------
-    const int cw = wave - 1;
+    const int cw = wave < PC_PROD ? wave : wave - 1;
     const int sl = lane / LPS;
     const int slot = lane - sl * LPS;
     const int col = AERO ? slot : exo_slot_to_col(slot);
