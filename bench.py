@@ -201,6 +201,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20261004)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traj-check", action="store_true", help="skip the B=1 full-solve parity figure (profiling runs)")
+    ap.add_argument("--no-k1-sweep", action="store_true", help="skip the K1-by-npts leg (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -328,7 +329,7 @@ def main():
             "solver_stats_last_step": {"ipm_iters_mean": float(np.mean(its)), "ipm_iters_max": int(np.max(its)),
                                        "status_optimal_frac": float(np.mean(st == 0)), "merit_max": float(np.max(merit))},
         }
-        if world == 1:
+        if world == 1 and not args.no_k1_sweep:
             line["roofline_k1_by_npts"] = k1_by_npts(cache, batch, torch, K, B, args.npts)
         if world == 1 and not args.no_traj_check:
             line["traj_linf_vs_oracle"] = traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts)

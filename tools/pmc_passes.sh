@@ -10,6 +10,6 @@ for G in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ
          "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" \
          "TCC_HIT_sum TCC_MISS_sum"; do
     NAME=$(echo $G | cut -d' ' -f1)
-    rocprofv3 --pmc $G --kernel-trace --output-format csv -d gpurun_out/${TAG}_${NAME} -- python3 bench.py --steps 1 --warmup 0 --batch $B --no-cpu-baseline --no-traj-check > gpurun_out/${TAG}_${NAME}.log 2>&1
+    rocprofv3 --pmc $G --kernel-trace --output-format csv -d gpurun_out/${TAG}_${NAME} -- python3 bench.py --steps 1 --warmup 0 --batch $B --no-cpu-baseline --no-traj-check --no-k1-sweep > gpurun_out/${TAG}_${NAME}.log 2>&1
     echo "pass $NAME done"
 done
