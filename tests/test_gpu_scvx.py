@@ -352,3 +352,54 @@ def test_flyable_problem_converges_and_freezes():
     before = b.trajectory_record().copy()
     st2, _, _ = b.solve_step()
     assert np.array_equal(b.trajectory_record(), before) and np.all(st2 == 0)
+
+
+def test_nonfinite_trajectory_is_reported_and_frozen_the_rest_continue():
+    """The reference throws when a solve is not optimal (rocketland.jl:273-276); a batch cannot: the offending trajectory
+    gets status SOLVER (3) / NONFINITE (4), keeps its iterate and drops out, every other trajectory advances exactly
+    as it does without the bad neighbour."""
+    from oracle import model
+    po = model.base_prob_scaled()
+    B = 5
+    ic = model.disperse_ics(po, B, 20261004)
+    c, good = _setup(B, ic)
+    st_g, nu_g, dj_g = good.solve_step()
+    xg, ug, sg = good.trajectory()
+    good.close()
+    c2, b = _setup(B, ic)
+    x, u, s = b.trajectory()
+    x[2, 7, 4] = np.nan                      # one poisoned node of trajectory 2
+    b.set_trajectory(x, u, s)
+    st, nu, dj = b.solve_step()
+    assert st[2] in (3, 4), st
+    keep = [0, 1, 3, 4]
+    assert np.array_equal(st[keep], st_g[keep])
+    x1, u1, s1 = b.trajectory()
+    assert np.abs(x1[keep] - xg[keep]).max() < 1e-9 and np.abs(u1[keep] - ug[keep]).max() < 1e-9
+    assert np.all(np.isfinite(x1[keep])) and np.all(np.isfinite(u1[keep]))
+    # frozen: a second step leaves it alone and still runs the others
+    st2, _, _ = b.solve_step()
+    assert st2[2] in (3, 4)
+    x2, _, _ = b.trajectory()
+    assert np.array_equal(np.isnan(x2[2]), np.isnan(x1[2]))
+    b.close(); c.close(); c2.close()
+
+
+def test_batch_api_argument_and_state_errors():
+    from successiveconvexification_amd import _lib, sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    c = IntegratorCache(sp.base_prob_scaled)
+    with pytest.raises(_lib.ScvxError):
+        ScvxBatch(c, 0)                      # B >= 1
+    b = ScvxBatch(c, 2)
+    with pytest.raises(_lib.ScvxError):
+        b.solve_step()                       # before scvx_batch_init
+    with pytest.raises(ValueError):
+        b.init(np.zeros((3, 6)))             # ic must be [B][6]
+    with pytest.raises(_lib.ScvxError):
+        ScvxBatch(c, 2, tol=-1.0)            # bad solver options
+    b.init(None)
+    st, nu, dj = b.solve_step()
+    assert st.shape == (2,) and np.all(st == 1)
+    b.close(); c.close()
