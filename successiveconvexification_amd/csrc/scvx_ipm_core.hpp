@@ -42,6 +42,10 @@
 #ifndef SCVX_STALL_ITERS
 #define SCVX_STALL_ITERS 2
 #endif
+// factor of Mehrotra's balancing shift of the starting point (0 disables)
+#ifndef SCVX_INIT_BALANCE
+#define SCVX_INIT_BALANCE 0.5
+#endif
 #ifndef SCVX_STREAM_U
 #define SCVX_STREAM_U 4   // elements in flight per lane in the streaming loops (Solver::stream)
 #endif
@@ -1578,6 +1582,21 @@ struct Solver {
         SCVX_DBG("init: |V|^2 %.12e s %.6e tnu %.6e ttr %.6e ts %.6e |y|^2 %.6e |S|^2 %.12e |Z|^2 %.6e\n", dot(V, V, L.nv), V[L.iS], V[L.iTNU], V[L.iTTR], V[L.iTS], dot(y, y, L.ny), dot(S, S, L.nc), dot(Z, Z, L.nc));
         shift_into_cone(S);
         shift_into_cone(Z);
+        if (SCVX_INIT_BALANCE > 0.0) {
+            // Mehrotra's second shift: S += (s'z / 2 e'z) e, Z += (s'z / 2 e's) e balances the complementarity products of
+            // the starting point (the dual least-squares solution carries the 1e4 virtual-control weight in a few entries).
+            // Measured at B = 8192: 20.9 -> 19.9 iterations per solve, same merit distribution of the returned iterates.
+            const double sz = dot(S, Z, L.nc);
+            double es = 0, ez = 0;
+            all_small([&](auto, int off, int) { es += S[off]; ez += Z[off]; }, true);
+            if (ex.lane() == 0) { es += S[L.o_nu] + S[L.o_tr]; ez += Z[L.o_nu] + Z[L.o_tr]; }
+            es = ex.sum(es); ez = ex.sum(ez);
+            const double dsh = SCVX_INIT_BALANCE * sz / ez, dzh = SCVX_INIT_BALANCE * sz / es;
+            ex.sync();
+            all_small([&](auto, int off, int) { S[off] += dsh; Z[off] += dzh; }, true);
+            if (ex.lane() == 0) { S[L.o_nu] += dsh; S[L.o_tr] += dsh; Z[L.o_nu] += dzh; Z[L.o_tr] += dzh; }
+            ex.sync();
+        }
         SCVX_DBG("shifted: |S|^2 %.12e |Z|^2 %.12e\n", dot(S, S, L.nc), dot(Z, Z, L.nc));
 
         double best_merit = INFINITY; int best_it = 0;
