@@ -1644,7 +1644,10 @@ struct Solver {
             { SCVX_TS(tN_); newton_solve(); SCVX_TE(tN_, 10); }   // predictor: affine right-hand side -lam o lam
             double alpha = dir_pass<true>();
             if (alpha > 1.0) alpha = 1.0;
-            const double sig = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
+            // centering parameter (1 - alpha_aff)^4: the usual cube needs as many iterations (19.9 vs 19.8 per solve at
+            // B = 8192) but leaves 5.7 % of the returned iterates above merit 1e-7, the fourth power 2.5 %
+            const double om = 1.0 - alpha;
+            const double sig = (om * om) * (om * om);
             SCVX_DBG("    aff alpha %.6e |dw|^2 %.6e ds %.6e dtnu %.6e dttr %.6e\n", alpha, dot(dw, dw, L.nv), dw[L.iS], dw[L.iTNU], dw[L.iTTR]);
             corr_rhs_pass(sig * mu);
             { SCVX_TS(tN_); newton_solve(); SCVX_TE(tN_, 10); }
