@@ -46,11 +46,15 @@
 #ifndef SCVX_INIT_BALANCE
 #define SCVX_INIT_BALANCE 0.5
 #endif
+// fraction of the distance to the cone boundary taken by the combined step
+#ifndef SCVX_STEP_FRAC
+#define SCVX_STEP_FRAC 0.98
+#endif
 #ifndef SCVX_STREAM_U
 #define SCVX_STREAM_U 4   // elements in flight per lane in the streaming loops (Solver::stream)
 #endif
 #ifndef SCVX_REFINE_FROM
-#define SCVX_REFINE_FROM 1e-4
+#define SCVX_REFINE_FROM 1e-5
 #endif
 #if defined(__HIPCC__)
 #define SCVX_UNROLL _Pragma("unroll")
@@ -1651,7 +1655,7 @@ struct Solver {
             SCVX_DBG("    aff alpha %.6e |dw|^2 %.6e ds %.6e dtnu %.6e dttr %.6e\n", alpha, dot(dw, dw, L.nv), dw[L.iS], dw[L.iTNU], dw[L.iTTR]);
             corr_rhs_pass(sig * mu);
             { SCVX_TS(tN_); newton_solve(); SCVX_TE(tN_, 10); }
-            alpha = 0.99 * dir_pass<false>();
+            alpha = SCVX_STEP_FRAC * dir_pass<false>();
             if (alpha > 1.0) alpha = 1.0;
             SCVX_DBG("    cmb alpha %.6e |dw|^2 %.6e\n", alpha, dot(dw, dw, L.nv));
             if (!(alpha == alpha)) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 3; break; }
