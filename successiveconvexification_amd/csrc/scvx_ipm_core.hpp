@@ -932,18 +932,32 @@ struct Solver {
         SCVX_T1(23);
     }
 
-    // ---- Hb^-1 on a local vector (dx, du, nu); in may alias out ----
+    // ---- Hb^-1 on a local vector (dx, du, nu); g and out must not alias ----
+    // One lane per output ROW: row j of the compact node inverse has at most three entries (hxi_apply's formulas), so
+    // every lane loads three coefficients and three inputs that sit next to those of its neighbours.  (One lane per
+    // node, as build_kkt assembles the blocks, reads 51 elements at a stride of 25 doubles: no two lanes share a line.)
     SCVX_HD_NI void Hb_inv(cgptr g, gptr out) {
         SCVX_T0();
         const int K = L.K;
-        for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
-            double xin[14], yo[14];
-            for (int j = 0; j < 14; j++) xin[j] = g[14 * k + j];
-            hxi_apply(hx + (size_t)k * HX_SZ, xin, yo);
-            for (int j = 0; j < 14; j++) out[14 * k + j] = yo[j];
-            cgptr h = hu + 9 * k;
-            const double u0 = g[L.nx + 3 * k], u1 = g[L.nx + 3 * k + 1], u2 = g[L.nx + 3 * k + 2];
-            for (int c = 0; c < 3; c++) out[L.nx + 3 * k + c] = h[3 * c] * u0 + h[3 * c + 1] * u1 + h[3 * c + 2] * u2;
+        const cgptr hx_ = hx; const cgptr hu_ = hu;
+        stream(0, L.nx,
+               [&](int t) {
+                   const int k = t / 14, j = t - 14 * k;
+                   // first coefficient / first input / number of terms of row j
+                   const int hb = j == 0 ? HX_M : j < 4 ? HX_R + 3 * (j - 1) : j < 7 ? HX_V : j < 9 ? HX_Q
+                                  : j < 11 ? HX_Q34 + 2 * (j - 9) : HX_W + 3 * (j - 11);
+                   const int gb = j == 0 ? 0 : j < 4 ? 1 : j < 9 ? j : j < 11 ? 9 : 11;
+                   const int n = (j == 0 || (j >= 4 && j < 9)) ? 1 : (j == 9 || j == 10) ? 2 : 3;
+                   cgptr h = hx_ + (size_t)k * HX_SZ + hb; cgptr x = g + 14 * k + gb;
+                   const int i1 = n > 1 ? 1 : 0, i2 = n > 2 ? 2 : 0;
+                   return D6{h[0], n > 1 ? h[i1] : 0.0, n > 2 ? h[i2] : 0.0, x[0], x[i1], x[i2]};
+               },
+               [&](int t, const D6& w) { out[t] = w.a * w.d + w.b * w.e + w.c * w.f; });
+        {
+            cgptr gu = g + L.nx; gptr ou = out + L.nx;
+            stream(0, L.nu_,
+                   [&](int t) { const int k = t / 3; cgptr h = hu_ + 3 * t; cgptr x = gu + 3 * k; return D6{h[0], h[1], h[2], x[0], x[1], x[2]}; },
+                   [&](int t, const D6& w) { ou[t] = w.a * w.d + w.b * w.e + w.c * w.f; });
         }
         {
             cgptr gn = g + L.nx + L.nu_; gptr on = out + L.nx + L.nu_;
