@@ -24,6 +24,6 @@ for path in sys.argv[1:]:
     m = np.concatenate(merit_all)
     x, u, sg = b.trajectory()
     print(path, "traj-it/s %.0f" % (B * STEPS / t), "ipm its/step", np.round(its_all, 2), "optimal", min(ok),
-          "merit max %.2e p99.9 %.2e p99 %.2e mean %.2e  frac>1e-7 %.4f" % (m.max(), np.quantile(m, 0.999), np.quantile(m, 0.99), m.mean(), (m > 1e-7).mean()),
+          "merit max %.2e p99.9 %.2e p99 %.2e mean %.2e  frac>1e-7 %.4f  clean(<1e-8) %.3f" % (m.max(), np.quantile(m, 0.999), np.quantile(m, 0.99), m.mean(), (m > 1e-7).mean(), (m < 1e-8).mean()),
           "cksum x %.12e" % np.abs(x).sum(), flush=True)
     b.close(); c.close()
