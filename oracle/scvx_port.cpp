@@ -71,11 +71,9 @@ struct HostEx {
         }
         return ok;
     }
-    void chain3(int K, const double* z0, const double* z1, const double* z2, const double* N, double* o0, double* o1,
-                double* o2, bool reverse) {
-        chain(K, z0, N, o0, reverse);
-        chain(K, z1, N, o1, reverse);
-        chain(K, z2, N, o2, reverse);
+    template <int NR>
+    void chain_n(int K, const double* const (&z)[NR], const double* N, double* const (&o)[NR], bool reverse) {
+        for (int q = 0; q < NR; q++) chain(K, z[q], N, o[q], reverse);
     }
     // out_k = z_k + N_k out_{k-1} (forward) or out_k = z_k + N_{k+1}' out_{k+1} (reverse); 14-vectors; N_k is the negated
     // coupling tile stored transposed (element (i, j) at 14 j + i), as Solver::build_kkt writes it

@@ -165,7 +165,7 @@ struct WaveEx {
     // (A[row][16 + g] = z_g[row], B[16 + g][n] = delta(g, n)), issued ahead of the dependent four.  Operands for step
     // s + R are requested while step s runs (R x 10 VGPRs in flight).
     template <int NR>
-    __device__ __forceinline__ void chain_mfma(int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
+    __device__ __forceinline__ void chain_n(int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
                                                bool reverse) {
         static_assert(NR >= 1 && NR <= 4, "right-hand sides ride in k-slots 16..19");
         constexpr int R = 8;
@@ -239,13 +239,7 @@ struct WaveEx {
     __device__ __forceinline__ void chain(int K, ipm::cgptr z, ipm::cgptr N, ipm::gptr out, bool reverse) {
         const ipm::cgptr zs[1] = {z};
         const ipm::gptr os[1] = {out};
-        chain_mfma<1>(K, zs, N, os, reverse);
-    }
-    __device__ __forceinline__ void chain3(int K, ipm::cgptr z0, ipm::cgptr z1, ipm::cgptr z2, ipm::cgptr N, ipm::gptr o0,
-                                           ipm::gptr o1, ipm::gptr o2, bool reverse) {
-        const ipm::cgptr zs[3] = {z0, z1, z2};
-        const ipm::gptr os[3] = {o0, o1, o2};
-        chain_mfma<3>(K, zs, N, os, reverse);
+        chain_n<1>(K, zs, N, os, reverse);
     }
 };
 
@@ -300,9 +294,9 @@ struct BlockEx {
     __device__ __forceinline__ void chain(int K, ipm::cgptr z, ipm::cgptr N, ipm::gptr out, bool reverse) {
         if (first()) w0.chain(K, z, N, out, reverse);
     }
-    __device__ __forceinline__ void chain3(int K, ipm::cgptr z0, ipm::cgptr z1, ipm::cgptr z2, ipm::cgptr N, ipm::gptr o0,
-                                           ipm::gptr o1, ipm::gptr o2, bool reverse) {
-        if (first()) w0.chain3(K, z0, z1, z2, N, o0, o1, o2, reverse);
+    template <int NR>
+    __device__ __forceinline__ void chain_n(int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR], bool reverse) {
+        if (first()) w0.template chain_n<NR>(K, z, N, o, reverse);
     }
 };
 

@@ -123,7 +123,7 @@ struct Layout {
         size_t n = 0;
         n += (size_t)ny;                 // dk
         n += (size_t)nv * 8;             // V, rx, gx, dw, r1, cw, Vbest, tmpv
-        n += (size_t)ny * 7;             // y, ry, dy, r2, cy, tmpy, tmpy2
+        n += (size_t)ny * 10;            // y, ry, dy, r2, cy, tmpy, tmpy2, rp, tq0, tq1
         n += (size_t)nc * 8;             // S, Z, lam, Wv, Wibz, tmpc, Wirz, sd
         n += (size_t)ncones;             // Wbeta
         n += (size_t)(K + 1) * 25 + (size_t)(K + 1) * 9;  // hx, hu
@@ -261,7 +261,7 @@ struct Solver {
     double rk;
     // workspace
     gptr dk, V, rx, gx, dw, r1, cw, Vbest, tmpv;
-    gptr y, ry, dy, r2, cy, tmpy, tmpy2;
+    gptr y, ry, dy, r2, cy, tmpy, tmpy2, rp, tq0, tq1;
     gptr S, Z, lam, Wv, Wibz, tmpc, Wirz, sd;
     gptr Wbeta;
     gptr hx, hu;
@@ -283,7 +283,7 @@ struct Solver {
         dk = w; w += ny;
         V = w; w += nv; rx = w; w += nv; gx = w; w += nv; dw = w; w += nv; r1 = w; w += nv; cw = w; w += nv;
         Vbest = w; w += nv; tmpv = w; w += nv;
-        y = w; w += ny; ry = w; w += ny; dy = w; w += ny; r2 = w; w += ny; cy = w; w += ny; tmpy = w; w += ny; tmpy2 = w; w += ny;
+        y = w; w += ny; ry = w; w += ny; dy = w; w += ny; r2 = w; w += ny; cy = w; w += ny; tmpy = w; w += ny; tmpy2 = w; w += ny; rp = w; w += ny; tq0 = w; w += ny; tq1 = w; w += ny;
         S = w; w += nc; Z = w; w += nc; lam = w; w += nc; Wv = w; w += nc;
         Wibz = w; w += nc; tmpc = w; w += nc; Wirz = w; w += nc; sd = w; w += nc;
         Wbeta = w; w += L.ncones;
@@ -1021,71 +1021,108 @@ struct Solver {
         SCVX_T1(0);
     }
 
-    // Three right-hand sides through the block-tridiagonal solve with ONE pass over Linv / Nf per sweep.
-    // r*, x*: [K][14]; scratch t0,t1,t2: [K][14]; nothing may alias.
-    SCVX_HD_NI void S_solve3(cgptr r0, cgptr r1, cgptr r2_, gptr x0, gptr x1, gptr x2,
-                             gptr t0, gptr t1, gptr t2) {
+    // N right-hand sides (N <= 4) through the block-tridiagonal solve with ONE pass over Linv / Nf per sweep.
+    // r, x, t: N arrays of [K][14] each (t: scratch); nothing may alias.
+    template <int N>
+    SCVX_HD_NI void S_solveN(const cgptr (&r)[N], const gptr (&x)[N], const gptr (&t)[N]) {
         const int K = L.K;
         const cgptr Linv = this->Linv;
         const cgptr Nf = this->Nf;
-        for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
-            const int k = t / 14, i = t - 14 * k;
+        for (int e = ex.lane(); e < 14 * K; e += ex.nlanes()) {
+            const int k = e / 14, i = e - 14 * k;
             cgptr Li = Linv + (size_t)k * LINV_SZ + linv_row(i);
-            double a0 = 0, a1 = 0, a2 = 0;
+            double a[N];
+            for (int q = 0; q < N; q++) a[q] = 0;
             SCVX_UNROLL
-            for (int j = 0; j < 14; j++) { const double l = j <= i ? Li[j <= i ? j : i] : 0.0; a0 += l * r0[14 * k + j]; a1 += l * r1[14 * k + j]; a2 += l * r2_[14 * k + j]; }
-            t0[t] = a0; t1[t] = a1; t2[t] = a2;
+            for (int j = 0; j < 14; j++) {
+                const double l = j <= i ? Li[j <= i ? j : i] : 0.0;
+                for (int q = 0; q < N; q++) a[q] += l * r[q][14 * k + j];
+            }
+            for (int q = 0; q < N; q++) t[q][e] = a[q];
         }
         ex.sync();
-        ex.chain3(K, t0, t1, t2, Nf, x0, x1, x2, false);
+        {
+            cgptr tz[N];
+            for (int q = 0; q < N; q++) tz[q] = t[q];
+            ex.template chain_n<N>(K, tz, Nf, x, false);
+        }
         ex.sync();
-        ex.chain3(K, x0, x1, x2, Nf, t0, t1, t2, true);
+        {
+            cgptr xz[N];
+            for (int q = 0; q < N; q++) xz[q] = x[q];
+            ex.template chain_n<N>(K, xz, Nf, t, true);
+        }
         ex.sync();
-        for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
-            const int k = t / 14, i = t - 14 * k;
+        for (int e = ex.lane(); e < 14 * K; e += ex.nlanes()) {
+            const int k = e / 14, i = e - 14 * k;
             cgptr Lk = Linv + (size_t)k * LINV_SZ;
-            double a0 = 0, a1 = 0, a2 = 0;
+            double a[N];
+            for (int q = 0; q < N; q++) a[q] = 0;
             SCVX_UNROLL
-            for (int j = 0; j < 14; j++) { const double l = j >= i ? Lk[linv_row(j) + (j >= i ? i : j)] : 0.0; a0 += l * t0[14 * k + j]; a1 += l * t1[14 * k + j]; a2 += l * t2[14 * k + j]; }
-            x0[t] = a0; x1[t] = a1; x2[t] = a2;
+            for (int j = 0; j < 14; j++) {
+                const double l = j >= i ? Lk[linv_row(j) + (j >= i ? i : j)] : 0.0;
+                for (int q = 0; q < N; q++) a[q] += l * t[q][14 * k + j];
+            }
+            for (int q = 0; q < N; q++) x[q][e] = a[q];
         }
         ex.sync();
     }
-    // g_r = E_loc' y_r on (dx, du) for three vectors with one pass over D; the nu block of E_loc' y is y itself
-    SCVX_HD_NI void Et_apply3(cgptr y0, cgptr y1, cgptr y2, gptr g0, gptr g1, gptr g2) {
+    // g_q = E_loc' y_q on (dx, du) for N vectors with one pass over D / At; the nu block of E_loc' y is y itself
+    template <int N>
+    SCVX_HD_NI void Et_applyN(const cgptr (&y)[N], const gptr (&g)[N]) {
         const int K = L.K;
         const cgptr D = this->D;
         const cgptr At = this->At;
         for (int t = ex.lane(); t < L.nx; t += ex.nlanes()) {
             const int k = t / 14, j = t - 14 * k;
-            double a0 = 0, a1 = 0, a2 = 0;
+            double a[N];
+            for (int q = 0; q < N; q++) a[q] = 0;
             if (k < K) {
                 cgptr col = At + (size_t)k * 196 + j;
                 SCVX_UNROLL
-                for (int i = 0; i < 14; i++) { const double c = col[14 * i]; a0 += c * y0[14 * k + i]; a1 += c * y1[14 * k + i]; a2 += c * y2[14 * k + i]; }
+                for (int i = 0; i < 14; i++) { const double c = col[14 * i]; for (int q = 0; q < N; q++) a[q] += c * y[q][14 * k + i]; }
             }
-            if (k > 0) { a0 -= y0[14 * (k - 1) + j]; a1 -= y1[14 * (k - 1) + j]; a2 -= y2[14 * (k - 1) + j]; }
-            g0[t] = a0; g1[t] = a1; g2[t] = a2;
+            if (k > 0) for (int q = 0; q < N; q++) a[q] -= y[q][14 * (k - 1) + j];
+            for (int q = 0; q < N; q++) g[q][t] = a[q];
         }
         for (int t = ex.lane(); t < L.nu_; t += ex.nlanes()) {
             const int k = t / 3, c = t - 3 * k;
-            double a0 = 0, a1 = 0, a2 = 0;
+            double a[N];
+            for (int q = 0; q < N; q++) a[q] = 0;
             if (k < K) {
                 cgptr col = D + (size_t)k * 294 + 14 * (14 + c);
                 SCVX_UNROLL
-                for (int i = 0; i < 14; i++) { const double cc = col[i]; a0 += cc * y0[14 * k + i]; a1 += cc * y1[14 * k + i]; a2 += cc * y2[14 * k + i]; }
+                for (int i = 0; i < 14; i++) { const double cc = col[i]; for (int q = 0; q < N; q++) a[q] += cc * y[q][14 * k + i]; }
             }
             if (k > 0) {
                 cgptr col = D + (size_t)(k - 1) * 294 + 14 * (17 + c);
                 SCVX_UNROLL
-                for (int i = 0; i < 14; i++) { const double cc = col[i]; a0 += cc * y0[14 * (k - 1) + i]; a1 += cc * y1[14 * (k - 1) + i]; a2 += cc * y2[14 * (k - 1) + i]; }
+                for (int i = 0; i < 14; i++) { const double cc = col[i]; for (int q = 0; q < N; q++) a[q] += cc * y[q][14 * (k - 1) + i]; }
             }
-            g0[L.nx + t] = a0; g1[L.nx + t] = a1; g2[L.nx + t] = a2;
+            for (int q = 0; q < N; q++) g[q][L.nx + t] = a[q];
         }
         ex.sync();
     }
+    // out0 = E v0, out1 = E v1 + add1 (both without the s column) with one pass over D
+    SCVX_HD_NI void E_apply2(cgptr v0, cgptr v1, gptr out0, gptr out1, cgptr add1) {
+        SCVX_T0();
+        const int K = L.K;
+        for (int r = ex.lane(); r < 14 * K; r += ex.nlanes()) {
+            const int k = r / 14, i = r - 14 * k;
+            cgptr Dk = D + (size_t)k * 294 + i;
+            const double ad = add1[r];
+            double a = 0, b = 0;
+            for (int j = 0; j < 14; j++) { const double d = Dk[14 * j]; a += d * v0[14 * k + j]; b += d * v1[14 * k + j]; }
+            for (int j = 0; j < 6; j++) { const double d = Dk[14 * (14 + j)]; a += d * v0[L.nx + 3 * k + j]; b += d * v1[L.nx + 3 * k + j]; }
+            a += v0[L.nx + L.nu_ + r] - v0[14 * (k + 1) + i];
+            b += v1[L.nx + L.nu_ + r] - v1[14 * (k + 1) + i];
+            out0[r] = a;
+            out1[r] = b + ad;
+        }
+        ex.sync();
+        SCVX_T1(1);
+    }
 
-    // [Hb E'; E 0][dl; dyv] = [gl; ryv]   (gl: local part of a var vector; outputs may not alias inputs)
     // The equality right-hand side is rsign * ryv (ryv may be null).
     SCVX_HD_NI void band_solve(cgptr gl, cgptr ryv, double rsign, gptr dl, gptr dyv) {
         Hb_inv(gl, tmpl);
@@ -1096,7 +1133,10 @@ struct Solver {
     }
 
     // ---- factorisation for the current scaling (Wv, Wbeta) ----
-    SCVX_HD_NI bool build_kkt() {
+    // with_pred: gx holds the (masked) predictor right-hand side and ry the equality residual; their banded solution
+    // [Hb E'; E 0][dw; dy] = [gx; -ry] is produced alongside the three border systems (dw, dy), so the predictor's
+    // solve adds no pass of its own over the factor and over D.
+    SCVX_HD_NI bool build_kkt(bool with_pred = false) {
         const int K = L.K;
         // big-cone scalars
         {
@@ -1333,25 +1373,46 @@ struct Solver {
         //   s  : g = 0,            r = -Sg   ->  S y = +Sg
         //   tr : g = (Ptr, 0, 0),  r = 0     ->  S y = E_loc Hb^-1 g
         //   nu : g = (0, 0, Pnu),  r = 0     ->  S y = hnui Pnu          (E_loc is the identity on the nu block)
+        // and, with_pred, a fourth one on the same sweeps:  g = gx, r = -ry  (the predictor's banded solve)
         {
             const int nxu = L.nx + L.nu_;
-            gptr g_tr = gx;     // nloc: Ptr on (dx,du), 0 on nu
+            const gptr g_tr = r1;     // nloc: Ptr on (dx,du), 0 on nu   (r1: refinement scratch, idle here)
             {
                 cgptr wt = Wv + L.o_tr + 1;
                 stream<8>(0, L.nloc, [&](int i) { return i < nxu ? wt[i] : 0.0; }, [&](int i, double v) { g_tr[i] = v; });
             }
             ex.sync();
             Hb_inv(g_tr, tmpl);
-            E_apply(tmpl, tmpy2, false);                       // r_tr
+            if (with_pred) {
+                Hb_inv(gx, cw);
+                E_apply2(tmpl, cw, tmpy2, rp, ry);                 // r_tr, r_pred = E Hb^-1 gx + ry
+            } else {
+                E_apply(tmpl, tmpy2, false);                       // r_tr
+            }
             {
                 gptr ty = tmpy; gptr r2_ = r2; cgptr wn = Wv + L.o_nu + 1;
                 stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D2{D_[(size_t)k * 294 + 14 * 20 + i], wn[r]}; },
                        [&](int r, const D2& v) { ty[r] = v.a; r2_[r] = hnui_ * v.b; });   // r_s = +Sg, r_nu
             }
             ex.sync();
-            S_solve3(tmpy, tmpy2, r2, ys, ytr, ynu, tchain, cy, dy);
-            Et_apply3(ys, ytr, ynu, tmpl, tmpl2, tmpv);
-            // l = Hb^-1 (g - E' y): assemble the three right-hand sides in place, then invert
+            if (with_pred) {
+                const cgptr rr[4] = {tmpy, tmpy2, r2, rp};
+                const gptr xx[4] = {ys, ytr, ynu, dy};
+                const gptr tt4[4] = {tchain, cy, tq0, tq1};
+                S_solveN<4>(rr, xx, tt4);
+                const cgptr yy[4] = {ys, ytr, ynu, dy};
+                const gptr gg[4] = {tmpl, tmpl2, tmpv, cw};
+                Et_applyN<4>(yy, gg);
+            } else {
+                const cgptr rr[3] = {tmpy, tmpy2, r2};
+                const gptr xx[3] = {ys, ytr, ynu};
+                const gptr tt3[3] = {tchain, cy, tq0};
+                S_solveN<3>(rr, xx, tt3);
+                const cgptr yy[3] = {ys, ytr, ynu};
+                const gptr gg[3] = {tmpl, tmpl2, tmpv};
+                Et_applyN<3>(yy, gg);
+            }
+            // l = Hb^-1 (g - E' y): assemble the right-hand sides in place, then invert
             {
                 gptr t0 = tmpl; gptr t1 = tmpl2; gptr t2 = tmpv;
                 cgptr y0 = ys; cgptr y1 = ytr; cgptr y2 = ynu; cgptr wn = Wv + L.o_nu + 1;
@@ -1361,11 +1422,17 @@ struct Solver {
                                      g_tr[i], isnu ? wn[i - nxu] : 0.0};
                        },
                        [&](int i, const D5& v) { t0[i] = -v.a; t1[i] = v.d - v.b; t2[i] = v.e - v.c; });
+                if (with_pred) {
+                    gptr t3 = cw; cgptr y3 = dy; cgptr g3 = gx;
+                    stream(0, L.nloc, [&](int i) { return D2{i >= nxu ? y3[i - nxu] : t3[i], g3[i]}; },
+                           [&](int i, const D2& v) { t3[i] = v.b - v.a; });
+                }
             }
             ex.sync();
             Hb_inv(tmpl, ls);
             Hb_inv(tmpl2, ltr);
             Hb_inv(tmpv, lnu);
+            if (with_pred) Hb_inv(cw, dw);
         }
         // border coefficients
         {
@@ -1386,8 +1453,9 @@ struct Solver {
     }
 
     // full reduced KKT: [H E'; E 0][dwv; dyv] = [g; ryv]  (g var-shaped incl. 4 globals)
-    SCVX_HD_NI void kkt_solve(cgptr g, cgptr ryv, gptr dwv, gptr dyv, double rsign = 1.0) {
-        band_solve(g, ryv, rsign, dwv, dyv);
+    // have_band: (dwv, dyv) already hold the banded solution for (g, rsign ryv) (build_kkt(with_pred))
+    SCVX_HD_NI void kkt_solve(cgptr g, cgptr ryv, gptr dwv, gptr dyv, double rsign = 1.0, bool have_band = false) {
+        if (!have_band) band_solve(g, ryv, rsign, dwv, dyv);
         double a = 0;
         {
             const cgptr D_ = D;
@@ -1452,10 +1520,13 @@ struct Solver {
     }
 
     // Newton step for the cone right-hand side held in tmpc = W^-1 Wibz (scale_pass / corr_rhs_pass): results in dw, dy
-    SCVX_HD_NI void newton_solve() {
-        cone_map_t(tmpc, gx, rx);      // gx = -rx - J' W^-1 Wibz
-        mask_fixed(gx);
-        kkt_solve(gx, ry, dw, dy, -1.0);   // equality right-hand side -ry
+    // pred: gx and the banded part of the solve were prepared before / inside build_kkt(true)
+    SCVX_HD_NI void newton_solve(bool pred) {
+        if (!pred) {
+            cone_map_t(tmpc, gx, rx);      // gx = -rx - J' W^-1 Wibz
+            mask_fixed(gx);
+        }
+        kkt_solve(gx, ry, dw, dy, -1.0, pred);   // equality right-hand side -ry
 #if defined(SCVX_IPM_DEBUG) && !defined(__HIPCC__)
         {
             H_apply(dw, r1);
@@ -1657,9 +1728,11 @@ struct Solver {
             if (pres < C.tol && dres < C.tol && relgap < C.tol) { res.status = 0; break; }
             if (it - best_it >= SCVX_STALL_ITERS && best_merit < 1e-5) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
             if (it == C.max_iter) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 1; break; }
-            if (!build_kkt()) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
+            cone_map_t(tmpc, gx, rx);      // predictor right-hand side gx = -rx - J' W^-1 (lam - W^-1 rz), solved with the border
+            mask_fixed(gx);
+            if (!build_kkt(true)) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
             const double mu = gap / degree;
-            { SCVX_TS(tN_); newton_solve(); SCVX_TE(tN_, 10); }   // predictor: affine right-hand side -lam o lam
+            { SCVX_TS(tN_); newton_solve(true); SCVX_TE(tN_, 10); }   // predictor: affine right-hand side -lam o lam
             double alpha = dir_pass<true>();
             if (alpha > 1.0) alpha = 1.0;
             // centering parameter (1 - alpha_aff)^4: the usual cube needs as many iterations (19.9 vs 19.8 per solve at
@@ -1668,7 +1741,7 @@ struct Solver {
             const double sig = (om * om) * (om * om);
             SCVX_DBG("    aff alpha %.6e |dw|^2 %.6e ds %.6e dtnu %.6e dttr %.6e\n", alpha, dot(dw, dw, L.nv), dw[L.iS], dw[L.iTNU], dw[L.iTTR]);
             corr_rhs_pass(sig * mu);
-            { SCVX_TS(tN_); newton_solve(); SCVX_TE(tN_, 10); }
+            { SCVX_TS(tN_); newton_solve(false); SCVX_TE(tN_, 10); }
             alpha = SCVX_STEP_FRAC * dir_pass<false>();
             if (alpha > 1.0) alpha = 1.0;
             SCVX_DBG("    cmb alpha %.6e |dw|^2 %.6e\n", alpha, dot(dw, dw, L.nv));
