@@ -25,6 +25,10 @@
 
 using scvx::fail;
 
+#ifndef SCVX_CHAIN_R
+#define SCVX_CHAIN_R 8   // steps of the block recurrence whose operands are in flight (10 VGPRs each)
+#endif
+
 namespace scvx {
 
 // The tile scratch of socp_kernel (one wavefront per block).  File scope on purpose: every routine of the solver
@@ -130,7 +134,7 @@ struct WaveEx {
 #pragma unroll
             for (int c = j + 1; c < 14; c++) {
                 const double lcj = bcast(m[j], c);
-                if (i >= c) m[c] = fma(-m[j], lcj, m[c]);
+                m[c] = fma(-m[j], lcj, m[c]);   // rows i < c update junk (their upper triangle is never read): no select
             }
         }
         // inverse: lane c owns column c of L^-1: x[i] = (delta_ic - sum_{t=c}^{i-1} L[i][t] x[t]) / L[i][i]
@@ -141,7 +145,7 @@ struct WaveEx {
 #pragma unroll
             for (int t = 0; t < a; t++) {
                 const double lat = bcast(m[t], a);  // L[a][t]
-                if (t >= i) acc = fma(-lat, x[t], acc);
+                acc = fma(-lat, x[t], acc);         // x[t] = 0 for t < i: no select
             }
             x[a] = (a >= i) ? acc * ipv[a] : 0.0;
         }
@@ -168,7 +172,7 @@ struct WaveEx {
     __device__ __forceinline__ void chain_n(int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
                                                bool reverse) {
         static_assert(NR >= 1 && NR <= 4, "right-hand sides ride in k-slots 16..19");
-        constexpr int R = 8;
+        constexpr int R = SCVX_CHAIN_R;
         const int l = lane(), n = l & 15, g = l >> 4;
         const bool rin = n < 14;   // for the A operands n is the tile row
         // every lane loads from a valid (clamped) address and masks the value afterwards: a predicated load would
