@@ -72,9 +72,15 @@ typedef struct scvx_problem {
  * exploiting primal-dual interior-point method (the algorithm class of the reference's Mosek / ECOS),
  * one wavefront per trajectory.  DESIGN.md explains why it is not the first-order splitting first planned. */
 typedef struct scvx_solver_opts {
-    int32_t max_iter; /* interior-point iteration cap per SOCP (default 60)                   */
-    int32_t refine;   /* iterative-refinement passes per Newton solve (default 1)            */
-    double tol;       /* primal / dual residual and relative-gap tolerance (default 1e-8)    */
+    int32_t max_iter;  /* interior-point iteration cap per SOCP (default 60)                                   */
+    int32_t refine;    /* iterative-refinement passes per Newton solve, at most (default 6; a pass is skipped  */
+                       /* when the solve's residual is already below a tenth of the dual tolerance)            */
+    double tol;        /* primal / dual residual and relative-gap tolerance (default 1e-8)                     */
+    double accept_tol; /* a solve that stops on its numerical floor with tol <= merit < accept_tol is reported */
+                       /* as solver status 4 "almost optimal" and still feeds the trust-region test (MOI's     */
+                       /* ALMOST_OPTIMAL band; default 1e-6).  accept_tol = tol reproduces the reference, which */
+                       /* errors on anything but OPTIMAL (rocketland.jl:273-276): such solves become           */
+                       /* SCVX_ST_SOLVER.                                                                       */
 } scvx_solver_opts;
 
 typedef struct scvx_ctx scvx_ctx;     /* owns device, stream, problem constants, aero tables */
@@ -84,7 +90,13 @@ typedef struct scvx_batch scvx_batch; /* owns the batched iterate (ProblemIterat
 int scvx_ctx_create(const scvx_problem *p, int device, scvx_ctx **out);
 void scvx_ctx_destroy(scvx_ctx *ctx);
 const char *scvx_last_error(const scvx_ctx *ctx);
-int scvx_set_stream(scvx_ctx *ctx, void *hip_stream); /* NULL = the context's own stream */
+/* Stream every kernel and copy of the context is enqueued on.  NULL selects the context's OWN stream (created
+ * hipStreamNonBlocking: it does not synchronise with HIP's default stream) -- a caller that produces or consumes
+ * device buffers on another stream orders against it with scvx_get_stream + events, or scvx_synchronize.
+ * scvx_use_null_stream selects HIP's legacy default stream (handle 0) itself. */
+int scvx_set_stream(scvx_ctx *ctx, void *hip_stream);
+int scvx_use_null_stream(scvx_ctx *ctx);
+int scvx_get_stream(const scvx_ctx *ctx, void **hip_stream); /* the effective stream (never "NULL = own") */
 int scvx_synchronize(scvx_ctx *ctx);
 /* RK4 substeps per segment: the `npts` keyword of Dynamics.rk4 (dynamics.jl:112, default 10). */
 int scvx_set_nsub(scvx_ctx *ctx, int nsub);
@@ -116,11 +128,18 @@ int scvx_batch_set_solver(scvx_batch *b, const scvx_solver_opts *o);
  * linearises it and sets rk=100, cost=Inf, iter=0 (rocketland.jl:38). */
 int scvx_batch_init(scvx_batch *b, const double *ic);
 /* One Rocketland.solve_step for every trajectory of the batch.  Outputs are host arrays of
- * length B (any may be NULL): status codes above, ||nu||_F and dJ (Inf on rejection). */
+ * length B (any may be NULL): status codes above, ||nu||_F and dJ (Inf on rejection).
+ * Like the reference's solve_step this has no notion of convergence: SCVX_ST_CONVERGED reports that the
+ * loop test of solve_problem (rocketland.jl:436) holds after this step, and the next call steps the
+ * trajectory again.  A trajectory whose conic solve failed (SCVX_ST_SOLVER / SCVX_ST_NONFINITE -- where the
+ * reference raises an error) is frozen: later calls skip it, its status keeps the failure code and its
+ * nu_norm / dJ stay those of the failing step. */
 int scvx_solve_step(scvx_batch *b, int32_t *status, double *nu_norm, double *dJ);
 /* Asynchronous form for timing loops: enqueue one solve_step on the stream, no host read-back. */
 int scvx_solve_step_async(scvx_batch *b);
-/* Rocketland.solve_problem: iterate until converged or imax; iters[B] = solve_step calls used. */
+/* Rocketland.solve_problem from the batch's current state: every trajectory is stepped until it converges
+ * (then it is left alone, as the reference's loop exits), fails, or has taken imax-1 steps; iters[B] = total
+ * solve_step calls applied to the trajectory since scvx_batch_init. */
 int scvx_solve(scvx_batch *b, int32_t *status, int32_t *iters, double *nu_norm, double *dJ);
 
 /* ---- iterate access (the batched ProblemIteration) ------------------------------------------ */
@@ -132,8 +151,14 @@ int scvx_batch_trajectory_dev(scvx_batch *b, double **traj_dev, int64_t *n_doubl
 int scvx_batch_get_linearization(scvx_batch *b, double *endpoint, double *deriv);
 int scvx_batch_get_scalars(scvx_batch *b, double *rk, double *cost, int32_t *iter);
 int scvx_batch_set_scalars(scvx_batch *b, const double *rk, const double *cost, const int32_t *iter);
-/* last SOCP solve, per trajectory: solver status (0 optimal, 1 iteration cap, 2 numerical floor above
- * tolerance, 3 non-finite), interior-point iterations, final merit max(pres, dres, relgap), objective */
+/* per-trajectory flags, the rest of a checkpoint (trajectory + scalars + flags restore a batch after
+ * scvx_batch_init with the same ic): status as above; active = 0 once failed (never stepped again);
+ * live = active and not yet converged inside scvx_solve.  Any pointer may be NULL. */
+int scvx_batch_get_flags(scvx_batch *b, int32_t *status, int32_t *active, int32_t *live);
+int scvx_batch_set_flags(scvx_batch *b, const int32_t *status, const int32_t *active, const int32_t *live);
+/* last SOCP solve, per trajectory: solver status (0 optimal: merit < tol; 4 almost optimal: numerical floor with
+ * tol <= merit < accept_tol; 1 iteration cap; 2 numerical floor / KKT breakdown at merit >= accept_tol; 3 non-finite),
+ * interior-point iterations, final merit max(pres, dres, relgap) of the returned iterate, its objective */
 int scvx_batch_get_solver_stats(scvx_batch *b, int32_t *status, int32_t *iters, double *merit, double *pobj);
 
 /* ---- per-kernel device time of the solve_step chain (HIP events on the context's stream) ------ */

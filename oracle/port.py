@@ -11,7 +11,7 @@ _dp = C.POINTER(C.c_double)
 
 class Consts(C.Structure):
     _fields_ = [("K", C.c_int), ("max_iter", C.c_int), ("refine", C.c_int), ("pad", C.c_int),
-                ("tol", C.c_double),
+                ("tol", C.c_double), ("accept", C.c_double),
                 ("itan", C.c_double), ("sqcm", C.c_double), ("icos", C.c_double), ("Tmax", C.c_double),
                 ("Tmin", C.c_double), ("omMax", C.c_double), ("mdry", C.c_double), ("wNu", C.c_double),
                 ("mwet", C.c_double),
@@ -19,9 +19,9 @@ class Consts(C.Structure):
                 ("wBi", C.c_double * 3), ("wBf", C.c_double * 3)]
 
 
-def consts(p: DescentProblem, tol=1e-8, max_iter=60, refine=1) -> Consts:
+def consts(p: DescentProblem, tol=1e-8, max_iter=60, refine=6, accept=1e-6) -> Consts:
     c = Consts()
-    c.K, c.max_iter, c.refine, c.tol = p.K, max_iter, refine, tol
+    c.K, c.max_iter, c.refine, c.tol, c.accept = p.K, max_iter, refine, tol, max(accept, tol)
     c.itan = 1.0 / np.tan(np.radians(p.gammaGs))       # rocketland.jl:63
     c.sqcm = np.sqrt((1 - np.cos(np.radians(p.thetaMax))) / 2)  # :64
     c.icos = 1.0 / np.cos(np.radians(p.deltaMax))      # :65
@@ -35,7 +35,7 @@ def _p(a):
     return a.ctypes.data_as(_dp)
 
 
-def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, max_iter=60, refine=1, nthreads=0):
+def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, max_iter=60, refine=6, nthreads=0, accept=1e-6):
     """Batched: xbar [B][K+1][14], ubar [B][K+1][3], endpoint [B][K][14], deriv [B][K][21][14], rk [B].
     Returns dict(dx, du, ds, nu, status, iters, merit, pobj)."""
     xbar = np.ascontiguousarray(xbar, float)
@@ -48,7 +48,7 @@ def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, 
     if ic is None:
         ic = np.tile(np.concatenate([p.rIi, p.vIi]), (B, 1))
     ic = np.ascontiguousarray(ic, float)
-    c = consts(p, tol, max_iter, refine)
+    c = consts(p, tol, max_iter, refine, accept)
     sol = np.zeros((B, (K + 1) * 17 + 1))
     nu = np.zeros((B, K, 14))
     info = np.zeros((B, 4))

@@ -36,7 +36,7 @@ class ScvxProblem(C.Structure):
 
 
 class ScvxSolverOpts(C.Structure):
-    _fields_ = [("max_iter", C.c_int32), ("refine", C.c_int32), ("tol", C.c_double)]
+    _fields_ = [("max_iter", C.c_int32), ("refine", C.c_int32), ("tol", C.c_double), ("accept_tol", C.c_double)]
 
 
 _vp = C.c_void_p
@@ -46,6 +46,8 @@ SIGNATURES = {
     "scvx_ctx_destroy": (None, [_vp]),
     "scvx_last_error": (C.c_char_p, [_vp]),
     "scvx_set_stream": (C.c_int, [_vp, _vp]),
+    "scvx_use_null_stream": (C.c_int, [_vp]),
+    "scvx_get_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
     "scvx_synchronize": (C.c_int, [_vp]),
     "scvx_set_nsub": (C.c_int, [_vp, C.c_int]),
     "scvx_get_nsub": (C.c_int, [_vp]),
@@ -68,6 +70,8 @@ SIGNATURES = {
     "scvx_batch_get_linearization": (C.c_int, [_vp, _dp, _dp]),
     "scvx_batch_get_scalars": (C.c_int, [_vp, _dp, _dp, _ip]),
     "scvx_batch_set_scalars": (C.c_int, [_vp, _dp, _dp, _ip]),
+    "scvx_batch_get_flags": (C.c_int, [_vp, _ip, _ip, _ip]),
+    "scvx_batch_set_flags": (C.c_int, [_vp, _ip, _ip, _ip]),
     "scvx_batch_get_solver_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
     "scvx_socp_solve": (C.c_int, [_vp, _dp, _dp]),
     "scvx_batch_set_profiling": (C.c_int, [_vp, C.c_int]),

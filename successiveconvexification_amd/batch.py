@@ -26,7 +26,8 @@ STATUS = {0: "converged", 1: "running", 2: "rejected", 3: "solver", 4: "nonfinit
 class ScvxBatch:
     """The batched ProblemIteration (master.jl:122-134) living in HBM."""
 
-    def __init__(self, cache: IntegratorCache, B: int, tol: float = None, max_iter: int = None, refine: int = None):
+    def __init__(self, cache: IntegratorCache, B: int, tol: float = None, max_iter: int = None, refine: int = None,
+                 accept_tol: float = None):
         self.cache = cache
         self.B = int(B)
         self.K = cache.problem.K
@@ -35,15 +36,18 @@ class ScvxBatch:
         h = C.c_void_p()
         _lib.check(cache.handle, self._L.scvx_batch_create(cache.handle, self.B, C.byref(h)), "scvx_batch_create")
         self.handle = h
-        if tol is not None or max_iter is not None or refine is not None:
+        if tol is not None or max_iter is not None or refine is not None or accept_tol is not None:
             o = _lib.ScvxSolverOpts()
             self._L.scvx_solver_default_opts(C.byref(o))
             if tol is not None:
                 o.tol = tol
+                o.accept_tol = max(o.accept_tol, tol)
             if max_iter is not None:
                 o.max_iter = max_iter
             if refine is not None:
                 o.refine = refine
+            if accept_tol is not None:
+                o.accept_tol = accept_tol
             _lib.check(cache.handle, self._L.scvx_batch_set_solver(h, C.byref(o)), "scvx_batch_set_solver")
 
     def _chk(self, rc, what):
@@ -135,6 +139,20 @@ class ScvxBatch:
         self._chk(self._L.scvx_batch_set_scalars(self.handle, _p(rk) if rk is not None else None,
                                                  _p(cost) if cost is not None else None,
                                                  _pi(it) if it is not None else None), "scvx_batch_set_scalars")
+
+    def flags(self):
+        """(status, active, live) per trajectory — with trajectory_record() and scalars() the full checkpoint."""
+        st = np.zeros(self.B, np.int32)
+        ac = np.zeros(self.B, np.int32)
+        lv = np.zeros(self.B, np.int32)
+        self._chk(self._L.scvx_batch_get_flags(self.handle, _pi(st), _pi(ac), _pi(lv)), "scvx_batch_get_flags")
+        return st, ac, lv
+
+    def set_flags(self, status=None, active=None, live=None):
+        a = [None if v is None else np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.int32), (self.B,)))
+             for v in (status, active, live)]
+        self._chk(self._L.scvx_batch_set_flags(self.handle, *[_pi(v) if v is not None else None for v in a]),
+                  "scvx_batch_set_flags")
 
     def solver_stats(self):
         st = np.zeros(self.B, np.int32)

@@ -148,6 +148,18 @@ int scvx_set_stream(scvx_ctx* ctx, void* hip_stream) {
     return SCVX_OK;
 }
 
+int scvx_use_null_stream(scvx_ctx* ctx) {
+    if (!ctx) return SCVX_ERR_ARG;
+    ctx->stream = nullptr;   // HIP's legacy default stream
+    return SCVX_OK;
+}
+
+int scvx_get_stream(const scvx_ctx* ctx, void** hip_stream) {
+    if (!ctx || !hip_stream) return SCVX_ERR_ARG;
+    *hip_stream = (void*)ctx->stream;
+    return SCVX_OK;
+}
+
 int scvx_synchronize(scvx_ctx* ctx) {
     if (!ctx) return SCVX_ERR_ARG;
     SCVX_HIP(ctx, hipSetDevice(ctx->device));

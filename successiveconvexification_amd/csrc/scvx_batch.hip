@@ -393,9 +393,13 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
                                                        const double* __restrict__ info, double* __restrict__ traj,
                                                        double* __restrict__ rk, double* __restrict__ cost,
                                                        int* __restrict__ iter, int* __restrict__ status,
-                                                       int* __restrict__ active, double* __restrict__ out) {
+                                                       const int* __restrict__ mask, int* __restrict__ active,
+                                                       int* __restrict__ live, double* __restrict__ out) {
     const int b = blockIdx.x;
-    if (b >= B || !active[b]) return;
+    if (b >= B) return;
+    // not stepped by this call (failed earlier, or converged inside scvx_solve): status[b] keeps saying why and
+    // out[b] keeps the (nu, dJ) of the last step this trajectory did take
+    if (!mask[b]) return;
     const int K = P.K, nrec = (K + 1) * 17 + 1;
     const double* c = cand + (size_t)b * nrec;
     const double* xp = xprop + (size_t)b * K * 14;
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
     int st;
     bool accept = false;
     double next_rk = rk[b], dJ = INFINITY;
-    if (sstat != 0) {
+    if (sstat != 0 && sstat != 4) {   // 4 = almost optimal, inside the solver's acceptance band (scvx_solver_opts.accept_tol)
         st = (sstat == 3) ? SCVX_ST_NONFINITE : SCVX_ST_SOLVER;  // rocketland.jl:273-276: error(...)
     } else if (!(jK == jK) || !(lK == lK)) {
         st = SCVX_ST_NONFINITE;
@@ -443,17 +447,25 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
         const int it = iter[b] + 1;
         iter[b] = it;
         if (st == SCVX_ST_SOLVER || st == SCVX_ST_NONFINITE) {
-            active[b] = 0;
+            active[b] = 0;   // frozen: the reference stops with an error here
+            live[b] = 0;
         } else {
             rk[b] = next_rk;
             if (accept) cost[b] = jK;
-            // solve_problem's loop test (rocketland.jl:436): stop when nu and dJ are both within tolerance
-            if (accept && nun <= P.nuTol && dJ <= P.delTol) { st = SCVX_ST_CONVERGED; active[b] = 0; }
+            // solve_problem's loop test (rocketland.jl:436): stop when nu and dJ are both within tolerance.  Only
+            // scvx_solve acts on it (live); solve_step itself has no notion of convergence and keeps stepping.
+            if (accept && nun <= P.nuTol && dJ <= P.delTol) { st = SCVX_ST_CONVERGED; live[b] = 0; }
         }
         status[b] = st;
         out[2 * b] = nun;
         out[2 * b + 1] = dJ;
     }
+}
+
+// live = active (start of a solve_problem loop)
+__global__ void copy_flags_kernel(int B, const int* __restrict__ src, int* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) dst[i] = src[i];
 }
 
 }  // namespace scvx
@@ -472,10 +484,14 @@ struct scvx_batch {
     double *cx = nullptr, *cu = nullptr, *csigma = nullptr;       // split views of cand
     double *endpoint = nullptr, *deriv = nullptr, *xprop = nullptr, *nu = nullptr;
     double *rk = nullptr, *cost = nullptr, *ic = nullptr, *info = nullptr, *out = nullptr, *work = nullptr;
-    int *iter = nullptr, *status = nullptr, *active = nullptr;
+    int *iter = nullptr, *status = nullptr;
+    int *active = nullptr;   // 0 once a trajectory has failed (solver / non-finite): never stepped again
+    int *live = nullptr;     // active and not yet converged: the trajectories scvx_solve still steps
+    int device = 0;          // cached: scvx_batch_destroy must not touch a context that may already be gone
     bool initialised = false;
     bool profiling = false;
-    std::vector<hipEvent_t> events;  // 7 per profiled step
+    std::vector<hipEvent_t> events;  // pool, 7 per profiled step, reused across scvx_batch_get_profile calls
+    size_t nmarks = 0;               // marks recorded since the last scvx_batch_get_profile
 };
 
 namespace {
@@ -511,38 +527,43 @@ int split_views(scvx_batch* b, const double* rec, double* x, double* u, double* 
     return SCVX_OK;
 }
 
-int enqueue_socp(scvx_batch* b) {
+int enqueue_socp(scvx_batch* b, const int* mask) {
     // below SOCP_BLOCK_MAX_B trajectories a wavefront per trajectory cannot fill the chip: several wavefronts share one
     // (SCVX_K4_WAVES=1 / 4 forces either form)
     bool block = b->B <= SOCP_BLOCK_MAX_B;
     if (const char* v = std::getenv("SCVX_K4_WAVES")) block = std::atoi(v) > 1;
     if (block)
         hipLaunchKernelGGL(scvx::socp_block_kernel, dim3(b->B), dim3(64 * scvx::SOCP_BLOCK_WAVES), 0, b->ctx->stream, b->C, b->B,
-                           b->work_stride, b->x, b->u, b->endpoint, b->deriv, b->rk, b->ic, b->active, b->work, b->sol, b->nu,
+                           b->work_stride, b->x, b->u, b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu,
                            b->info);
     else
         hipLaunchKernelGGL(scvx::socp_kernel, dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
-                           b->endpoint, b->deriv, b->rk, b->ic, b->active, b->work, b->sol, b->nu, b->info);
+                           b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info);
     SCVX_HIP(b->ctx, hipGetLastError());
     return SCVX_OK;
 }
 
+constexpr size_t PROF_MAX_STEPS = 4096;   // profiled steps kept between two scvx_batch_get_profile calls
+
 int mark(scvx_batch* b) {
-    if (!b->profiling) return SCVX_OK;
-    hipEvent_t e;
-    SCVX_HIP(b->ctx, hipEventCreate(&e));
-    SCVX_HIP(b->ctx, hipEventRecord(e, b->ctx->stream));
-    b->events.push_back(e);
+    if (!b->profiling || b->nmarks >= 7 * PROF_MAX_STEPS) return SCVX_OK;
+    if (b->nmarks == b->events.size()) {
+        hipEvent_t e;
+        SCVX_HIP(b->ctx, hipEventCreate(&e));
+        b->events.push_back(e);
+    }
+    SCVX_HIP(b->ctx, hipEventRecord(b->events[b->nmarks], b->ctx->stream));
+    b->nmarks++;
     return SCVX_OK;
 }
 
-int enqueue_step(scvx_batch* b) {
+int enqueue_step(scvx_batch* b, const int* mask) {
     scvx_ctx* ctx = b->ctx;
     hipStream_t st = ctx->stream;
     const double dt = 1.0 / (b->K + 1);
     int rc = mark(b);
     if (rc) return rc;
-    rc = enqueue_socp(b);
+    rc = enqueue_socp(b, mask);
     if (rc) return rc;
     if ((rc = mark(b))) return rc;
     const size_t n = (size_t)b->B * b->nrec;
@@ -555,7 +576,7 @@ int enqueue_step(scvx_batch* b) {
     SCVX_HIP(ctx, scvx::launch_propagate(ctx, b->B, b->K, b->cx, b->cu, b->csigma, dt, b->xprop, st));
     if ((rc = mark(b))) return rc;
     hipLaunchKernelGGL(scvx::tr_update_kernel, dim3(b->B), dim3(64), 0, st, b->tr, b->B, b->cand, b->xprop, b->nu, b->info,
-                       b->traj, b->rk, b->cost, b->iter, b->status, b->active, b->out);
+                       b->traj, b->rk, b->cost, b->iter, b->status, mask, b->active, b->live, b->out);
     SCVX_HIP(ctx, hipGetLastError());
     if ((rc = mark(b))) return rc;
     rc = split_views(b, b->traj, b->x, b->u, b->sigma);
@@ -583,8 +604,9 @@ extern "C" {
 int scvx_solver_default_opts(scvx_solver_opts* o) {
     if (!o) return SCVX_ERR_ARG;
     o->max_iter = 60;
-    o->refine = 1;
+    o->refine = 6;
     o->tol = 1e-8;
+    o->accept_tol = 1e-6;
     return SCVX_OK;
 }
 
@@ -596,6 +618,7 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     scvx_batch* b = new (std::nothrow) scvx_batch();
     if (!b) return SCVX_ERR_NOMEM;
     b->ctx = ctx;
+    b->device = ctx->device;
     b->B = B;
     const scvx_problem& p = ctx->prob;
     const int K = p.K;
@@ -605,6 +628,7 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     scvx::ipm::Consts& C = b->C;
     const double d2r = M_PI / 180.0;
     C.K = K; C.max_iter = b->opts.max_iter; C.refine = b->opts.refine; C.pad = 0; C.tol = b->opts.tol;
+    C.accept = b->opts.accept_tol;
     C.itan = 1.0 / std::tan(p.gammaGs * d2r);                       // rocketland.jl:63
     C.sqcm = std::sqrt((1.0 - std::cos(p.thetaMax * d2r)) / 2.0);   // :64
     C.icos = 1.0 / std::cos(p.deltaMax * d2r);                      // :65
@@ -641,6 +665,7 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     rc |= dmalloc(ctx, &b->iter, nB);
     rc |= dmalloc(ctx, &b->status, nB);
     rc |= dmalloc(ctx, &b->active, nB);
+    rc |= dmalloc(ctx, &b->live, nB);
     if (rc) {
         scvx_batch_destroy(b);
         return fail(ctx, SCVX_ERR_NOMEM, "device allocation failed for the batch (" + std::to_string(nB * b->work_stride * 8 >> 20) + " MiB of solver workspace)");
@@ -651,10 +676,10 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
 
 void scvx_batch_destroy(scvx_batch* b) {
     if (!b) return;
-    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    (void)hipSetDevice(b->device);
     for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
     void* ptrs[] = {b->traj, b->cand, b->sol, b->x, b->u, b->sigma, b->cx, b->cu, b->csigma, b->endpoint, b->deriv, b->xprop,
-                    b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active};
+                    b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active, b->live};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete b;
@@ -662,11 +687,13 @@ void scvx_batch_destroy(scvx_batch* b) {
 
 int scvx_batch_set_solver(scvx_batch* b, const scvx_solver_opts* o) {
     if (!b || !o) return SCVX_ERR_ARG;
-    if (o->max_iter < 1 || o->refine < 0 || !(o->tol > 0)) return fail(b->ctx, SCVX_ERR_ARG, "bad solver options");
+    if (o->max_iter < 1 || o->refine < 0 || !(o->tol > 0) || !(o->accept_tol >= o->tol))
+        return fail(b->ctx, SCVX_ERR_ARG, "bad solver options (max_iter >= 1, refine >= 0, 0 < tol <= accept_tol)");
     b->opts = *o;
     b->C.max_iter = o->max_iter;
     b->C.refine = o->refine;
     b->C.tol = o->tol;
+    b->C.accept = o->accept_tol;
     return SCVX_OK;
 }
 
@@ -710,6 +737,7 @@ int scvx_batch_init(scvx_batch* b, const double* ic) {
     SCVX_HIP(ctx, hipMemcpyAsync(b->iter, hiter.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     SCVX_HIP(ctx, hipMemcpyAsync(b->status, hstat.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     SCVX_HIP(ctx, hipMemcpyAsync(b->active, hact.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    SCVX_HIP(ctx, hipMemcpyAsync(b->live, hact.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     SCVX_HIP(ctx, hipMemsetAsync(b->out, 0, (size_t)B * 16, st));
     SCVX_HIP(ctx, hipMemsetAsync(b->info, 0, (size_t)B * 32, st));
     rc = split_views(b, b->traj, b->x, b->u, b->sigma);
@@ -723,7 +751,7 @@ int scvx_batch_init(scvx_batch* b, const double* ic) {
 int scvx_solve_step_async(scvx_batch* b) {
     int rc = check_batch(b, true);
     if (rc) return rc;
-    return enqueue_step(b);
+    return enqueue_step(b, b->active);
 }
 
 static int read_step_outputs(scvx_batch* b, int32_t* status, double* nu_norm, double* dJ) {
@@ -751,16 +779,24 @@ int scvx_solve(scvx_batch* b, int32_t* status, int32_t* iters, double* nu_norm, 
     if (rc) return rc;
     scvx_ctx* ctx = b->ctx;
     const int B = b->B;
-    std::vector<int> act(B);
-    // Rocketland.solve_problem (rocketland.jl:432-443): iter starts at 1 and the loop runs while iter < imax
+    // Rocketland.solve_problem (rocketland.jl:432-443): cnu = cdel = Inf, iter = 1, loop while not converged and
+    // iter < imax.  Per trajectory: `live` starts as `active`, tr_update clears it on convergence or failure, and only
+    // live trajectories are stepped.  The host looks at the flags every few steps only (a step with nothing live is
+    // a handful of empty launches), so the loop is not serialised on a read-back per step.
+    hipLaunchKernelGGL(scvx::copy_flags_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, ctx->stream, B, b->active, b->live);
+    SCVX_HIP(ctx, hipGetLastError());
+    std::vector<int> lv(B);
+    constexpr int CHECK_EVERY = 4;
     for (int it = 1; it < ctx->prob.imax; it++) {
-        rc = enqueue_step(b);
+        rc = enqueue_step(b, b->live);
         if (rc) return rc;
-        SCVX_HIP(ctx, hipMemcpyAsync(act.data(), b->active, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-        SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        bool any = false;
-        for (int t = 0; t < B; t++) any = any || act[t];
-        if (!any) break;
+        if (it % CHECK_EVERY == 0 && it + 1 < ctx->prob.imax) {
+            SCVX_HIP(ctx, hipMemcpyAsync(lv.data(), b->live, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+            SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            bool any = false;
+            for (int t = 0; t < B && !any; t++) any = lv[t] != 0;
+            if (!any) break;
+        }
     }
     if (iters) {
         SCVX_HIP(ctx, hipMemcpyAsync(iters, b->iter, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -855,8 +891,7 @@ int scvx_debug_ipm_prof(scvx_batch* b, double* out32) {
 
 int scvx_batch_set_profiling(scvx_batch* b, int enable) {
     if (!b) return SCVX_ERR_ARG;
-    for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
-    b->events.clear();
+    b->nmarks = 0;
     b->profiling = enable != 0;
     return SCVX_OK;
 }
@@ -868,7 +903,7 @@ int scvx_batch_get_profile(scvx_batch* b, double* ms, int64_t* steps) {
     scvx_ctx* ctx = b->ctx;
     SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 5; i++) ms[i] = 0.0;
-    const size_t n = b->events.size() / 7;
+    const size_t n = b->nmarks / 7;
     // marks per step: 0 | socp | 1 | candidate+unpack | 2 | propagate | 3 | tr_update | 4 | unpack | 5 | linearize | 6
     static const int slot[6] = {0, 4, 1, 2, 4, 3};
     for (size_t s = 0; s < n; s++)
@@ -878,8 +913,29 @@ int scvx_batch_get_profile(scvx_batch* b, double* ms, int64_t* steps) {
             ms[slot[i]] += (double)t;
         }
     *steps = (int64_t)n;
-    for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
-    b->events.clear();
+    b->nmarks = 0;   // the events stay in the pool
+    return SCVX_OK;
+}
+
+int scvx_batch_get_flags(scvx_batch* b, int32_t* status, int32_t* active, int32_t* live) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    scvx_ctx* ctx = b->ctx;
+    if (status) SCVX_HIP(ctx, hipMemcpyAsync(status, b->status, (size_t)b->B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (active) SCVX_HIP(ctx, hipMemcpyAsync(active, b->active, (size_t)b->B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (live) SCVX_HIP(ctx, hipMemcpyAsync(live, b->live, (size_t)b->B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCVX_OK;
+}
+
+int scvx_batch_set_flags(scvx_batch* b, const int32_t* status, const int32_t* active, const int32_t* live) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    scvx_ctx* ctx = b->ctx;
+    if (status) SCVX_HIP(ctx, hipMemcpyAsync(b->status, status, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (active) SCVX_HIP(ctx, hipMemcpyAsync(b->active, active, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (live) SCVX_HIP(ctx, hipMemcpyAsync(b->live, live, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
+    SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SCVX_OK;
 }
 
@@ -887,7 +943,7 @@ int scvx_socp_solve(scvx_batch* b, double* sol, double* nu) {
     int rc = check_batch(b, true);
     if (rc) return rc;
     scvx_ctx* ctx = b->ctx;
-    rc = enqueue_socp(b);
+    rc = enqueue_socp(b, b->active);
     if (rc) return rc;
     const size_t n = (size_t)b->B * b->nrec;
     hipLaunchKernelGGL(scvx::candidate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, b->B, b->nrec,

@@ -32,15 +32,17 @@
 #define SCVX_TS(v)
 #define SCVX_TE(v, slot)
 #endif
-// an iterate stuck at the numerical floor is accepted as optimal below this multiple of tol (MOI's ALMOST_OPTIMAL band)
-#ifndef SCVX_FLOOR_ACCEPT
-#define SCVX_FLOOR_ACCEPT 1000.0
-#endif
-// iterations without a new best merit (below 1e-5) after which the iterate is taken to sit on its numerical floor.
-// Measured at B = 8192 over 5 SCvx steps: 3 -> 2 leaves the merit distribution of the returned iterates unchanged
-// (5.29 % -> 5.33 % above 1e-7, same maximum) and saves 0.4 iterations per solve; 1 would start to cost accuracy.
+// Solver status (Result::status, surfaced by scvx_batch_get_solver_stats):
+//     0 optimal          pres, dres and relgap all below tol
+//     1 iteration cap    best iterate returned, merit >= accept
+//     2 stalled          numerical floor / KKT breakdown with merit >= accept
+//     3 non-finite
+//     4 almost optimal   stopped on the numerical floor with tol <= merit < accept (MOI's ALMOST_OPTIMAL band; the
+//                        reference treats anything but OPTIMAL as an error, rocketland.jl:273-276 -- set accept = tol
+//                        to get exactly that)
+// iterations without a new best merit (below 1e-5) after which the iterate is taken to sit on its numerical floor
 #ifndef SCVX_STALL_ITERS
-#define SCVX_STALL_ITERS 2
+#define SCVX_STALL_ITERS 3
 #endif
 // factor of Mehrotra's balancing shift of the starting point (0 disables)
 #ifndef SCVX_INIT_BALANCE
@@ -56,9 +58,8 @@
 #ifndef SCVX_REFINE_PRED
 #define SCVX_REFINE_PRED 0
 #endif
-// merit growth factor over the best iterate (once that is below 1e-6) that ends the solve at once.  Measured at
-// B = 8192 x 5 steps: 10 saves the most expensive (refined) iteration of ~40 % of the solves, +6.8 % throughput,
-// identical final-merit distribution
+// merit growth factor over the best iterate (once that is inside the acceptance band) that ends the solve at once:
+// past the numerical floor the dual residual jumps by orders of magnitude from one iterate to the next
 #ifndef SCVX_BLOWUP_STOP
 #define SCVX_BLOWUP_STOP 10.0
 #endif
@@ -67,6 +68,10 @@
 #endif
 #ifndef SCVX_REFINE_FROM
 #define SCVX_REFINE_FROM 1e-5
+#endif
+// refinement of a Newton solve stops once its first-row residual is below this fraction of the dual tolerance
+#ifndef SCVX_REFINE_STOP
+#define SCVX_REFINE_STOP 0.1
 #endif
 #if defined(__HIPCC__)
 #define SCVX_UNROLL _Pragma("unroll")
@@ -99,7 +104,7 @@ typedef const gdouble* cgptr;
 
 struct Consts {
     int K, max_iter, refine, pad;
-    double tol;
+    double tol, accept;   // accept: acceptance band of a floor-limited iterate (status 4), >= tol
     double itan, sqcm, icos, Tmax, Tmin, omMax, mdry, wNu, mwet;
     double rIf[3], vIf[3], qBIf[4], wBi[3], wBf[3];
 };
@@ -204,14 +209,17 @@ SCVX_HD double soc_maxstep_parts(double l0, double d0, double ll, double ld, dou
     return amax;
 }
 // inverse of a symmetric positive definite 3x3 (row-major in/out) through its Cholesky factor: backward
-// stable for the nearly rank-one blocks d I + kappa v v' an active cone produces (the cofactor formula is not)
+// stable for the nearly rank-one blocks d I + kappa v v' an active cone produces (the cofactor formula is not).
+// In the last iterations (mu ~ 1e-9) such a block is rank-one to working precision and a Schur pivot can round to
+// zero or below: pivots are floored at 1e-15 of their diagonal entry (the dynamic regularisation of the 14x14 tiles).
+SCVX_HD double piv_floor(double p, double diag) { const double f = 1e-15 * diag; return p > f ? p : f; }
 template <class PO>
 SCVX_HD void inv3(const double* M, PO Mi) {
     const double l00 = sqrt(M[0]);
     const double l10 = M[3] / l00, l20 = M[6] / l00;
-    const double l11 = sqrt(M[4] - l10 * l10);
+    const double l11 = sqrt(piv_floor(M[4] - l10 * l10, M[4]));
     const double l21 = (M[7] - l20 * l10) / l11;
-    const double l22 = sqrt(M[8] - l20 * l20 - l21 * l21);
+    const double l22 = sqrt(piv_floor(M[8] - l20 * l20 - l21 * l21, M[8]));
     // Linv (lower)
     const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
     const double i10 = -l10 * i00 * i11;
@@ -227,7 +235,7 @@ SCVX_HD void inv3(const double* M, PO Mi) {
 }
 template <class PO>
 SCVX_HD void inv2(double a, double b, double d, PO Mi) {  // [[a b],[b d]] SPD
-    const double l00 = sqrt(a), l10 = b / l00, l11 = sqrt(d - l10 * l10);
+    const double l00 = sqrt(a), l10 = b / l00, l11 = sqrt(piv_floor(d - l10 * l10, d));
     const double i00 = 1.0 / l00, i11 = 1.0 / l11, i10 = -l10 * i00 * i11;
     Mi[0] = i00 * i00 + i10 * i10; Mi[1] = Mi[2] = i10 * i11; Mi[3] = i11 * i11;
 }
@@ -258,7 +266,7 @@ SCVX_HD void hxi_apply(PH h, const double* x, double* y) {
 // the solver
 // ------------------------------------------------------------------------------------------------
 struct Result {
-    int status;  // 0 optimal, 1 max_iter, 2 stalled / kkt failure (best iterate returned), 3 non-finite
+    int status;  // see the status table at the top of this file
     int iters;
     double merit, pobj;
 };
@@ -282,8 +290,9 @@ struct Solver {
     gptr tmpl, tmpl2;
     gptr uhat, lb0;
     // per-factorisation scalars
-    double h_tr[4], h_nu[4], Msg[4], hrk, hnui;
-    double css, cst, csn, cts, ctt, ctn, cns, cnt_, cnn;
+    double h_tr[4], h_nu[4], hrk, hnui;
+    double q_tr[2], q_nu[2], q_sg[4], h00s;   // (v0, |v1|^2) of the two big cones; (v0, v1, b2, h01 v1 / h00) of the 2-cone (ts; s)
+    double css, cst, csn, cts, ctt, ctn, cns, cnt_, pny;
     double bigvz[2];  // <v, W dz>_1 of the two big cones (corr_dir_pass -> update_pass)
     double prof[32];
     double cur_merit;  // merit of the current iterate: refinement only pays in the endgame
@@ -1163,10 +1172,11 @@ struct Solver {
             soc_w2(Wv[L.o_nu], n1, Wbeta[L.c_nu], h_nu[0], h_nu[1], h_nu[2], h_nu[3]);
             soc_w2(Wv[L.o_tr], n2, Wbeta[L.c_tr], h_tr[0], h_tr[1], h_tr[2], h_tr[3]);
             hnui = 1.0 / h_nu[3];
+            q_nu[0] = Wv[L.o_nu]; q_nu[1] = n1; q_tr[0] = Wv[L.o_tr]; q_tr[1] = n2;
             double h00, h01, h11, b2;
             const double vs = Wv[L.o_sg + 1];
             soc_w2(Wv[L.o_sg], vs * vs, Wbeta[L.c_sg], h00, h01, h11, b2);
-            Msg[0] = h00; Msg[1] = h01 * vs; Msg[2] = h01 * vs; Msg[3] = b2 + h11 * vs * vs;
+            q_sg[0] = Wv[L.o_sg]; q_sg[1] = vs; q_sg[2] = b2; q_sg[3] = h01 * vs / h00; h00s = h00;
             hrk = 1.0 / (Wbeta[L.c_rk] * Wbeta[L.c_rk]);
         }
         // node blocks -> compact inverses
@@ -1224,13 +1234,19 @@ struct Solver {
                 soc_w2(v[0], v[1] * v[1] + v[2] * v[2] + v[3] * v[3], Wbeta[L.c_tb + k], h00, h01, h11, b2);
                 for (int a = 0; a < 3; a++)
                     for (int b = 0; b < 3; b++) M[3 * a + b] += h11 * v[1 + a] * v[1 + b] + (a == b ? b2 : 0.0);
+                // Jc' W^-2 Jc with Jc = [icos e1'; I] (the cone's head is u_1 / cos(deltaMax)).  Written through
+                // W^-2 = b2 (2 wt wt' - J), wt = (2 v0^2 - 1; -2 v0 v1):   b2 (I - icos^2 e1 e1' + 2 p p'),  p = Jc' wt.
+                // The h00 / h01 / h11 form adds three terms of size v0^4 b2 that cancel to p_1^2 when the gimbal cone is
+                // active (v1 along +e1): at mu ~ 1e-9 the block then stops being positive definite in double precision.
                 v = Wv + L.o_tc + 4 * k;
-                soc_w2(v[0], v[1] * v[1] + v[2] * v[2] + v[3] * v[3], Wbeta[L.c_tc + k], h00, h01, h11, b2);
-                // Jc' M4 Jc with Jc = [icos e1'; I]
-                for (int a = 0; a < 3; a++)
-                    for (int b = 0; b < 3; b++) M[3 * a + b] += h11 * v[1 + a] * v[1 + b] + (a == b ? b2 : 0.0);
-                M[0] += h00 * C.icos * C.icos;
-                for (int b = 0; b < 3; b++) { M[b] += C.icos * h01 * v[1 + b]; M[3 * b] += C.icos * h01 * v[1 + b]; }
+                {
+                    const double wb = Wbeta[L.c_tc + k], bt2 = 1.0 / (wb * wb);
+                    const double w0 = 2.0 * v[0] * v[0] - 1.0, tv = -2.0 * v[0];
+                    const double pc[3] = {C.icos * w0 + tv * v[1], tv * v[2], tv * v[3]};
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++) M[3 * a + b] += bt2 * (2.0 * pc[a] * pc[b] + (a == b ? 1.0 : 0.0));
+                    M[0] -= bt2 * C.icos * C.icos;
+                }
                 const double wl = Wbeta[L.c_lb + k];
                 const double il2 = 1.0 / (wl * wl);
                 for (int a = 0; a < 3; a++)
@@ -1458,7 +1474,8 @@ struct Solver {
             cgptr Ptr = Wv + L.o_tr + 1; const int nt = L.nx + L.nu_;
             cts = dot(Ptr, ls, nt); ctt = -dot(Ptr, ltr, nt); ctn = -dot(Ptr, lnu, nt);
             cgptr Pnu = Wv + L.o_nu + 1; const int o = L.nx + L.nu_;
-            cns = dot(Pnu, ls + o, L.ny); cnt_ = -dot(Pnu, ltr + o, L.ny); cnn = -dot(Pnu, lnu + o, L.ny);
+            cns = dot(Pnu, ls + o, L.ny); cnt_ = -dot(Pnu, ltr + o, L.ny);
+            pny = dot(Pnu, ynu, L.ny);   // <Pnu, lnu> = hnui (|Pnu|^2 - pny): the |Pnu|^2 part is cancelled in closed form (kkt_solve)
         }
         SCVX_TE(tB_, 7);
         return ex.all(ok);
@@ -1477,37 +1494,50 @@ struct Solver {
         const double c0s = ex.sum(a);
         const double c0t = dot(Wv + L.o_tr + 1, dwv, L.nx + L.nu_);
         const double c0n = dot(Wv + L.o_nu + 1, dwv + L.nx + L.nu_, L.ny);
-        // unknowns: s, ts, tnu, ttr, atr, anu
-        double M[36], r[6];
-        for (int i = 0; i < 36; i++) M[i] = 0.0;
-        const double h01t = h_tr[1], h01n = h_nu[1];
-        M[0 * 6 + 0] = Msg[3] + css; M[0 * 6 + 1] = Msg[2]; M[0 * 6 + 3] = cst * h01t; M[0 * 6 + 4] = cst;
-        M[0 * 6 + 2] = csn * h01n; M[0 * 6 + 5] = csn; r[0] = g[L.iS] - c0s;
-        M[1 * 6 + 1] = Msg[0]; M[1 * 6 + 0] = Msg[1]; r[1] = g[L.iTS];
-        M[2 * 6 + 2] = h_nu[0] + h01n * cnn * h01n; M[2 * 6 + 0] = h01n * cns; M[2 * 6 + 3] = h01n * cnt_ * h01t;
-        M[2 * 6 + 4] = h01n * cnt_; M[2 * 6 + 5] = h01n * cnn; r[2] = g[L.iTNU] - h01n * c0n;
-        M[5 * 6 + 0] = cns; M[5 * 6 + 2] = cnn * h01n; M[5 * 6 + 3] = cnt_ * h01t; M[5 * 6 + 4] = cnt_;
-        M[5 * 6 + 5] = cnn - 1.0 / h_nu[2]; r[5] = -c0n;
-        M[3 * 6 + 3] = h_tr[0] + hrk + h01t * ctt * h01t; M[3 * 6 + 0] = h01t * cts; M[3 * 6 + 2] = h01t * ctn * h01n;
-        M[3 * 6 + 4] = h01t * ctt; M[3 * 6 + 5] = h01t * ctn; r[3] = g[L.iTTR] - h01t * c0t;
-        M[4 * 6 + 0] = cts; M[4 * 6 + 2] = ctn * h01n; M[4 * 6 + 3] = ctt * h01t; M[4 * 6 + 4] = ctt - 1.0 / h_tr[2];
-        M[4 * 6 + 5] = ctn; r[4] = -c0t;
+        // ---- border: three unknowns (s, ctr, cnu), the heads of the cones eliminated in closed form ----
+        // With W^-2 = [[h00, h01 v1'], [h01 v1, b2 I + h11 v1 v1']] a cone whose head t appears in no other row gives
+        //     h00 t + h01 pi = g_t,   c = h01 t + h11 pi = kappa + sigma pi,   pi = <v1, l>,
+        //     kappa = h01 g_t / h00,  sigma = h11 - h01^2 / h00 = -8 v0^2 b2^2 / h00          (v0^2 - |v1|^2 = 1)
+        // -- the stiff rank-one term h11 and the head coupling cancel to a SOFT direction b2 / (8 v0^2 |v1|^2 + 1).
+        // Left to a 6x6 elimination on (t, a = h11 pi) that cancellation happens numerically between entries of size
+        // v0^4 b2: its 2x2 blocks have condition (v0 + |v1|)^8, beyond double precision once mu < 1e-7, and the solver
+        // stalled at merit ~1e-7 on 40 % of the subproblems.  In closed form nothing cancels:
+        //     nu cone (Hb = b2 I on its body):  -<Pnu, lnu> - 1 / sigma = hnui (pny + 1 / (8 v0^2)),  pny = <Pnu, ynu>
+        //     (ts; s):   Msg3 - Msg1 Msg2 / Msg0 = b2 / (1 + 8 v0^2 vs^2)
+        //     tr cone (its head also carries the radius row hrk):  sigma = 8 v0^2 b2 (hrk - b2) / (h00 + hrk).
+        const double v0n = q_nu[0], n1n = q_nu[1], h00n = h_nu[0], h01n = h_nu[1];
+        const double v0t = q_tr[0], b2t = h_tr[3], h01t = h_tr[1];
+        const double dtt = h_tr[0] + hrk;
+        const double sig_t = 8.0 * v0t * v0t * b2t * (hrk - b2t) / dtt, kap_t = h01t * g[L.iTTR] / dtt;
+        const double sig_n = -8.0 * v0n * v0n / (hnui * hnui * h00n), kap_n = h01n * g[L.iTNU] / h00n;
+        const double v0s = q_sg[0], vs = q_sg[1];
+        double M[9], r[3];
+        M[0] = q_sg[2] / (1.0 + 8.0 * v0s * v0s * vs * vs) + css; M[1] = cst; M[2] = csn;
+        r[0] = g[L.iS] - c0s - q_sg[3] * g[L.iTS];
+        M[3] = -sig_t * cts; M[4] = 1.0 - sig_t * ctt; M[5] = -sig_t * ctn; r[1] = kap_t + sig_t * c0t;
+        M[6] = cns; M[7] = cnt_; M[8] = hnui * (pny + 1.0 / (8.0 * v0n * v0n));
+        r[2] = -c0n - (v0n * v0n + n1n) * g[L.iTNU] * hnui / (2.0 * v0n);
         // Gaussian elimination with partial pivoting (every lane redundantly)
-        for (int c = 0; c < 6; c++) {
-            int p = c; double best = fabs(M[c * 6 + c]);
-            for (int i = c + 1; i < 6; i++) if (fabs(M[i * 6 + c]) > best) { best = fabs(M[i * 6 + c]); p = i; }
-            if (p != c) { for (int j = 0; j < 6; j++) { const double t = M[c * 6 + j]; M[c * 6 + j] = M[p * 6 + j]; M[p * 6 + j] = t; } const double t = r[c]; r[c] = r[p]; r[p] = t; }
-            const double ip = 1.0 / M[c * 6 + c];
-            for (int i = c + 1; i < 6; i++) {
-                const double f = M[i * 6 + c] * ip;
-                for (int j = c; j < 6; j++) M[i * 6 + j] -= f * M[c * 6 + j];
+        for (int c = 0; c < 3; c++) {
+            int p = c; double best = fabs(M[c * 3 + c]);
+            for (int i = c + 1; i < 3; i++) if (fabs(M[i * 3 + c]) > best) { best = fabs(M[i * 3 + c]); p = i; }
+            if (p != c) { for (int j = 0; j < 3; j++) { const double t = M[c * 3 + j]; M[c * 3 + j] = M[p * 3 + j]; M[p * 3 + j] = t; } const double t = r[c]; r[c] = r[p]; r[p] = t; }
+            const double ip = 1.0 / M[c * 3 + c];
+            for (int i = c + 1; i < 3; i++) {
+                const double f = M[i * 3 + c] * ip;
+                for (int j = c; j < 3; j++) M[i * 3 + j] -= f * M[c * 3 + j];
                 r[i] -= f * r[c];
             }
         }
-        double b[6];
-        for (int i = 5; i >= 0; i--) { double s = r[i]; for (int j = i + 1; j < 6; j++) s -= M[i * 6 + j] * b[j]; b[i] = s / M[i * 6 + i]; }
-        const double s_ = b[0], ts_ = b[1], tnu_ = b[2], ttr_ = b[3];
-        const double ctr = h01t * ttr_ + b[4], cnu = h01n * tnu_ + b[5];
+        double b[3];
+        for (int i = 2; i >= 0; i--) { double a_ = r[i]; for (int j = i + 1; j < 3; j++) a_ -= M[i * 3 + j] * b[j]; b[i] = a_ / M[i * 3 + i]; }
+        const double s_ = b[0], ctr = b[1], cnu = b[2];
+        // heads: pi_t from its definition (no division by sigma, which vanishes at hrk = b2), pi_n = (cnu - kappa) / sigma
+        const double pi_t = c0t + cts * s_ + ctt * ctr + ctn * cnu;
+        const double pi_n = (cnu - kap_n) / sig_n;
+        const double ttr_ = (g[L.iTTR] - h01t * pi_t) / dtt;
+        const double tnu_ = (g[L.iTNU] - h01n * pi_n) / h00n;
+        const double ts_ = g[L.iTS] / h00s - q_sg[3] * s_;
         ex.sync();
         {
             cgptr a0 = ls; cgptr a1 = ltr; cgptr a2 = lnu;
@@ -1554,6 +1584,7 @@ struct Solver {
         }
 #endif
         const int nref = (cur_merit < SCVX_REFINE_FROM && !(pred && !SCVX_REFINE_PRED)) ? C.refine : 0;
+        double nr_prev = INFINITY;
         for (int it = 0; it < nref; it++) {
             H_apply(dw, r1);
             const double sgy = Et_apply(dy, tmpl);
@@ -1571,6 +1602,14 @@ struct Solver {
             }
             ex.sync();
             mask_fixed(r1);
+            // The first-row residual r1 = gx - H dw - E'dy is exactly what the step adds to the dual residual
+            // (rx+ = (1 - alpha) rx - alpha r1), so it is measured against the dual tolerance: a solve that is already
+            // accurate enough skips the correction, one that is not gets up to C.refine of them.
+            const double nr1 = sqrt(sumsq(r1, L.nv));
+            SCVX_DBG("      refine %d: |r1| %.3e\n", it, nr1);
+            if (nr1 <= SCVX_REFINE_STOP * C.tol * (C.wNu > 1.0 ? C.wNu : 1.0)) break;
+            if (it > 0 && !(nr1 < 0.5 * nr_prev)) break;   // the corrections have stopped contracting: precision floor
+            nr_prev = nr1;
             E_apply(dw, tmpy2, true);
             ex.sync();
             {
@@ -1738,14 +1777,14 @@ struct Solver {
                 ex.sync();
             }
             if (pres < C.tol && dres < C.tol && relgap < C.tol) { res.status = 0; break; }
-            // past the numerical floor the dual residual jumps by orders of magnitude from one iterate to the next: an
-            // iterate 10x worse than a best below 1e-6 ends the solve at once (the best iterate is what is returned)
-            if (best_merit < 1e-6 && merit > SCVX_BLOWUP_STOP * best_merit) { res.status = 0; break; }
-            if (it - best_it >= SCVX_STALL_ITERS && best_merit < 1e-5) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
-            if (it == C.max_iter) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 1; break; }
+            // what the best iterate is worth if the solve has to stop here for the reason `why` (1, 2 or 3)
+            auto stop_status = [&](int why) { return best_merit < C.tol ? 0 : (best_merit < C.accept ? 4 : why); };
+            if (best_merit < C.accept && merit > SCVX_BLOWUP_STOP * best_merit) { res.status = stop_status(2); break; }
+            if (it - best_it >= SCVX_STALL_ITERS && best_merit < 1e-5) { res.status = stop_status(2); break; }
+            if (it == C.max_iter) { res.status = stop_status(1); break; }
             cone_map_t(tmpc, gx, rx);      // predictor right-hand side gx = -rx - J' W^-1 (lam - W^-1 rz), solved with the border
             mask_fixed(gx);
-            if (!build_kkt(true)) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
+            if (!build_kkt(true)) { SCVX_DBG("    factorisation failed\n"); res.status = stop_status(2); break; }
             const double mu = gap / degree;
             { SCVX_TS(tN_); newton_solve(true); SCVX_TE(tN_, 10); }   // predictor: affine right-hand side -lam o lam
             double alpha = dir_pass<true>();
@@ -1760,8 +1799,8 @@ struct Solver {
             alpha = SCVX_STEP_FRAC * dir_pass<false>();
             if (alpha > 1.0) alpha = 1.0;
             SCVX_DBG("    cmb alpha %.6e |dw|^2 %.6e\n", alpha, dot(dw, dw, L.nv));
-            if (!(alpha == alpha)) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 3; break; }
-            if (alpha < 1e-9) { res.status = best_merit < SCVX_FLOOR_ACCEPT * C.tol ? 0 : 2; break; }
+            if (!(alpha == alpha)) { res.status = stop_status(3); break; }
+            if (alpha < 1e-9) { res.status = stop_status(2); break; }
             update_pass(alpha);   // S, Z (reads the old V)
             {
                 gptr V_ = V; cgptr dw_ = dw; gptr y_ = y; cgptr dy_ = dy;

@@ -1,12 +1,12 @@
 """The conic subproblem and the SCvx step on the MI355X vs the oracles.
 
 Three references, from tightest to loosest:
-  * the CPU twin of the same algorithm (oracle/scvx_port.cpp): objectives to 1e-7 relative; minimisers to
-    1e-4 (they follow the same iteration path to 1e-11 unless one side hits the numerical floor an iteration
-    earlier, and the optimum is flat at the 1e-5..1e-4 level in u),
-  * the independent interior-point oracle on the full Rocketland.build_model form (oracle/ipm.py):
-    agreement to the flatness of the optimum, 2e-4 (see DESIGN.md "parity tolerance"),
-  * size-independent properties at the full batch (feasibility of what the solver returns).
+  * the CPU twin of the same algorithm (oracle/scvx_port.cpp): same iteration path, 1e-6 on the minimiser,
+  * the INDEPENDENT interior-point oracle on the full Rocketland.build_model form (oracle/ipm.py + oracle/socp.py):
+    2e-5 on the minimiser at the default tolerance 1e-8, 5e-6 with both solvers at 1e-10, objective 1e-8 relative
+    (SURVEY.md 8c asked for <= 1e-5 on trajectories; DESIGN.md "parity tolerance"),
+  * size-independent properties at the full batch (feasibility of what the solver returns, the linearised dynamics
+    rows, the solver reaching its tolerance on every trajectory).
 """
 import numpy as np
 import pytest
@@ -59,23 +59,24 @@ def test_socp_matches_cpu_twin_and_oracle_ipm():
     def obj(dx, du, ds, nv):
         return (-dx[:, K, 0] + po.wNu * np.sqrt((nv**2).sum((1, 2))) + 0.5 * np.sqrt((dx**2).sum((1, 2)) + (du**2).sum((1, 2))) + np.abs(ds))
     og, ot = obj(x - xb, u - ub, snew - sg, nu), obj(tw["dx"], tw["du"], tw["ds"], tw["nu"])
-    assert np.abs(og - ot).max() < 1e-7 * np.abs(ot).max()
-    assert np.abs(x - (xb + tw["dx"])).max() < 1e-4
-    assert np.abs(u - (ub + tw["du"])).max() < 1e-4
-    assert np.abs(snew - (sg + tw["ds"])).max() < 1e-4
-    assert np.abs(nu - tw["nu"]).max() < 1e-4
+    assert np.abs(og - ot).max() < 1e-9 * np.abs(ot).max()
+    assert np.abs(x - (xb + tw["dx"])).max() < 1e-6
+    assert np.abs(u - (ub + tw["du"])).max() < 1e-6
+    assert np.abs(snew - (sg + tw["ds"])).max() < 1e-6
+    assert np.abs(nu - tw["nu"]).max() < 1e-6
+    assert merit.max() < 1e-8 and tw["merit"].max() < 1e-8
     # independent oracle: the full build_model form solved by oracle.ipm (first trajectory only: seconds)
     it0 = oscvx.create_initial(po, 10, ic[0, :3], ic[0, 3:])
     sol, ix = oscvx.solve_socp(it0)
     assert sol.status == "optimal"
     z = sol.x
-    assert np.abs(x[0] - z[ix.xv].T).max() < 2e-4
-    assert np.abs(u[0] - z[ix.uv].T).max() < 2e-4
-    assert abs(snew[0] - sg[0] - z[ix.dsig]) < 2e-4
-    assert np.abs(nu[0] - z[ix.nuv].T[1:]).max() < 2e-4
+    assert np.abs(x[0] - z[ix.xv].T).max() < 2e-5
+    assert np.abs(u[0] - z[ix.uv].T).max() < 2e-5
+    assert abs(snew[0] - sg[0] - z[ix.dsig]) < 2e-5
+    assert np.abs(nu[0] - z[ix.nuv].T[1:]).max() < 2e-5
     # objective parity is much tighter than solution parity (the optimum is flat)
     obj = -x[0, -1, 0] + po.wNu * np.linalg.norm(nu[0]) + 0.5 * np.linalg.norm(np.concatenate([(x - xb)[0].ravel(), (u - ub)[0].ravel()])) + abs(snew[0] - sg[0])
-    assert abs(obj - sol.pobj) < 1e-5 * abs(sol.pobj)
+    assert abs(obj - sol.pobj) < 1e-8 * abs(sol.pobj)
 
 
 def test_both_socp_executors_agree(monkeypatch):
@@ -97,10 +98,10 @@ def test_both_socp_executors_agree(monkeypatch):
         res[waves] = (x, u, snew, nu, its, pobj)
         b.close(); c.close()
     a, bq = res["1"], res["4"]
-    assert np.abs(a[4] - bq[4]).max() <= 3          # iteration counts: the floor-acceptance rule looks 3 iterations back
-    assert np.abs(a[5] - bq[5]).max() < 1e-7 * np.abs(a[5]).max()
+    assert np.abs(a[4] - bq[4]).max() <= 1          # iteration counts
+    assert np.abs(a[5] - bq[5]).max() < 1e-8 * np.abs(a[5]).max()
     for i in range(4):
-        assert np.abs(a[i] - bq[i]).max() < 1e-4
+        assert np.abs(a[i] - bq[i]).max() < 2e-6
 
 
 def test_solve_step_matches_oracle_scvx_two_iterations():
@@ -116,33 +117,30 @@ def test_solve_step_matches_oracle_scvx_two_iterations():
         rk, cost, iters = b.scalars()
         assert iters[0] == it.iter
         assert rk[0] == it.rk
-        assert abs(s[0] - it.sigma) < 5e-4
-        assert np.abs(x[0] - it.x).max() < 5e-4
-        assert np.abs(u[0] - it.u).max() < 5e-4
-        assert abs(nun[0] - cnu) < 1e-5
-        assert abs(cost[0] - it.cost) < 1e-3 * abs(it.cost)
+        assert abs(s[0] - it.sigma) < 5e-5
+        assert np.abs(x[0] - it.x).max() < 5e-5
+        assert np.abs(u[0] - it.u).max() < 5e-5
+        assert abs(nun[0] - cnu) < 1e-6
+        assert abs(cost[0] - it.cost) < 1e-4 * abs(it.cost)
         if np.isinf(cdel):
             assert np.isinf(dj[0])
         else:
-            assert abs(dj[0] - cdel) < 1e-3 * abs(cdel)
+            assert abs(dj[0] - cdel) < 1e-4 * abs(cdel)
 
 
-def test_returned_iterate_is_feasible_full_batch():
-    """Size-independent properties at the full batch B = 8192: what the solver returns satisfies every constraint of
-    Rocketland.build_model to the solver tolerance, and the linearised dynamics hold exactly with nu."""
-    from oracle import model
-    po = model.base_prob_scaled()
-    B = 8192
-    import bench
-    ic = bench.disperse_ics(po, 0, B, 20261004)
-    c, b = _setup(B, ic, npts=4)
+def _check_socp_properties(po, ic, b, rk, tol=1e-6, rows=True):
+    """Size-independent properties of one conic solve at the batch's current iterate: the solver reaches its
+    tolerance on every trajectory, and what it returns satisfies every row of Rocketland.build_model
+    (rocketland.jl:109-216): boundary rows exactly, the linearised dynamics with nu to 1e-9, every cone to `tol`."""
     xb, ub, sg = b.trajectory()
-    e, d = b.linearization()
     x, u, snew, nu = b.socp_solve()
     st, its, merit, pobj = b.solver_stats()
-    assert np.all(st == 0), np.unique(st, return_counts=True)
-    K = po.K
-    tol = 1e-6
+    B, K = x.shape[0], po.K
+    # solver status 0 = merit < tol (1e-8); 4 = stopped on the numerical floor inside the acceptance band.  At least
+    # 99.5 % of the batch must be strictly optimal and nothing may be worse than 1e-7 (VERDICT r1 "done when")
+    assert np.all((st == 0) | (st == 4)), np.unique(st, return_counts=True)
+    assert (st == 0).mean() >= 0.995, np.unique(st, return_counts=True)
+    assert merit.max() < 1e-7, merit.max()
     # boundary rows (rocketland.jl:109-115)
     assert np.abs(x[:, 0, 0] - po.mwet).max() < 1e-12
     assert np.abs(x[:, 0, 1:4] - ic[:, :3]).max() < 1e-12 and np.abs(x[:, 0, 4:7] - ic[:, 3:]).max() < 1e-12
@@ -150,9 +148,11 @@ def test_returned_iterate_is_feasible_full_batch():
     assert np.abs(u[:, K, 1:]).max() < 1e-12
     # dynamics rows (:117-133)
     dx, du = x - xb, u - ub
-    delta = np.concatenate([dx[:, :-1], du[:, :-1], du[:, 1:], np.broadcast_to((snew - sg)[:, None, None], (B, K, 1))], axis=-1)
-    lhs = np.einsum("bkji,bkj->bki", d, delta) + nu - dx[:, 1:] + (e - xb[:, 1:])
-    assert np.abs(lhs).max() < 1e-9
+    if rows:   # needs the whole linearisation on the host: 118 KB per trajectory at K = 50
+        e, d = b.linearization()
+        delta = np.concatenate([dx[:, :-1], du[:, :-1], du[:, 1:], np.broadcast_to((snew - sg)[:, None, None], (B, K, 1))], axis=-1)
+        lhs = np.einsum("bkji,bkj->bki", d, delta) + nu - dx[:, 1:] + (e - xb[:, 1:])
+        assert np.abs(lhs).max() < 1e-9
     # cones (:137-201)
     assert (x[:, 1:, 0] - po.mdry).min() > -tol
     assert (x[:, :K, 1] / np.tan(np.radians(po.gammaGs)) - np.linalg.norm(x[:, :K, 2:4], axis=-1)).min() > -tol
@@ -162,7 +162,105 @@ def test_returned_iterate_is_feasible_full_batch():
     assert (po.Tmax - un).min() > -tol and (u[..., 0] / np.cos(np.radians(po.deltaMax)) - un).min() > -tol
     ubn = np.linalg.norm(ub, axis=-1)
     assert (np.sum(ub / ubn[..., None] * du, axis=-1) - (po.Tmin - ubn)).min() > -tol
-    assert (np.sqrt(np.sum(dx**2, axis=(1, 2)) + np.sum(du**2, axis=(1, 2))) - 100.0).max() < tol
+    assert (np.sqrt(np.sum(dx**2, axis=(1, 2)) + np.sum(du**2, axis=(1, 2))) - rk).max() < tol
+    return x, u, snew, nu, its, merit
+
+
+def test_returned_iterate_is_feasible_full_batch():
+    """BASELINE configs[3] shape at the benchmarked settings (B = 8192, K = 50, rk4 npts = 10)."""
+    from oracle import model
+    po = model.base_prob_scaled()
+    B = 8192
+    import bench
+    ic = bench.disperse_ics(po, 0, B, 20261004)
+    c, b = _setup(B, ic, npts=10)
+    _check_socp_properties(po, ic, b, 100.0)
+    # and after two accepted steps (the radius has grown to 100 * 3.2^2, the iterate is no longer the straight line)
+    b.solve_step(); b.solve_step()
+    rk, _, _ = b.scalars()
+    _check_socp_properties(po, ic, b, rk)
+    b.close(); c.close()
+
+
+def test_config5_shape_K100_B32768_properties():
+    """BASELINE configs[4] shape: K = 100, B = 32768 (one GPU holds it: 1.2 MB of solver state per trajectory).  The fin
+    model of that config is a stub in the reference: this runs control_dim = 3, as SURVEY 8d prescribes when
+    the fin model is not built."""
+    from dataclasses import replace
+    from oracle import model
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    import bench
+    K, B = 100, 32768
+    po = replace(model.base_prob_scaled(), K=K)
+    pp = replace(sp.base_prob_scaled, K=K)
+    ic = bench.disperse_ics(po, 0, B, 20261005)
+    c = IntegratorCache(pp, npts=10)
+    # dynamics rows on a 1,024-trajectory batch (the host copy of the linearisation is 235 KB per trajectory here) ...
+    bs = ScvxBatch(c, 1024).init(ic[:1024])
+    _check_socp_properties(po, ic[:1024], bs, 100.0)
+    bs.close()
+    # ... everything else at the full size
+    b = ScvxBatch(c, B).init(ic)
+    x, u, snew, nu, its, merit = _check_socp_properties(po, ic, b, 100.0, rows=False)
+    st, nun, dj = b.solve_step()
+    assert np.all(st == 1) and np.isfinite(nun).all()
+    b.close(); c.close()
+
+
+def test_aero_B256_dispersed_matches_oracle_on_a_sample(aero_tables):
+    """BASELINE configs[2] as written: 6-DoF + aero tables, K = 50, B = 256 dispersed (SURVEY 8d law, seed 20261003).
+    Four trajectories are checked against the INDEPENDENT oracle (oracle/scvx.py: IPM on the exact build_model rows +
+    RK4 variational equations with the spline tables), all 256 through the size-independent properties."""
+    from oracle import model, scvx as oscvx
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.defns import AtmosphericData
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    d, l, t = aero_tables
+    pp = sp.base_prob_aero_scaled(AtmosphericData(d, l, t))
+    po = model.base_prob_scaled(model.AeroData(d, l, t))
+    B = 256
+    ic = model.disperse_ics(po, B, 20261003)
+    c = IntegratorCache(pp, npts=10)
+    b = ScvxBatch(c, B).init(ic)
+    x, u, snew, nu, its, merit = _check_socp_properties(po, ic, b, 100.0)
+    st, nun, dj = b.solve_step()
+    assert np.all(st == 1)
+    xs, us, ss = b.trajectory()
+    for tr in (0, 85, 170, 255):
+        it0 = oscvx.create_initial(po, 10, ic[tr, :3], ic[tr, 3:])
+        it1, cnu, cdel = oscvx.solve_step(it0)
+        assert np.abs(xs[tr] - it1.x).max() < 2e-5 and np.abs(us[tr] - it1.u).max() < 2e-5, tr
+        assert abs(ss[tr] - it1.sigma) < 2e-5 and abs(nun[tr] - cnu) < 1e-6
+    # second step on the whole batch: still optimal everywhere
+    st, nun, dj = b.solve_step()
+    sst, its, merit, _ = b.solver_stats()
+    assert np.all((sst == 0) | (sst == 4)) and (sst == 0).mean() >= 0.99 and merit.max() < 1e-7
+    b.close(); c.close()
+
+
+def test_tight_tolerance_agrees_with_independent_oracle_to_5e6():
+    """Both solvers at 1e-10: the device minimiser and the independent oracle's agree to 5e-6 (the flatness of the
+    optimum limits the default-tolerance comparison to 2e-5, not the solver)."""
+    from oracle import model, scvx as oscvx
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    po = model.base_prob_scaled()
+    c = IntegratorCache(sp.base_prob_scaled, npts=10)
+    b = ScvxBatch(c, 1, tol=1e-10).init(None)
+    xb, ub, sg = b.trajectory()
+    x, u, snew, nu = b.socp_solve()
+    st, its, merit, pobj = b.solver_stats()
+    assert st[0] in (0, 4) and merit[0] < 1e-9, (st, merit)
+    it0 = oscvx.create_initial(po, 10)
+    sol, ix = oscvx.solve_socp(it0, tol=1e-10)
+    z = sol.x
+    assert np.abs(x[0] - z[ix.xv].T).max() < 5e-6 and np.abs(u[0] - z[ix.uv].T).max() < 5e-6
+    assert abs(snew[0] - sg[0] - z[ix.dsig]) < 5e-6 and np.abs(nu[0] - z[ix.nuv].T[1:]).max() < 5e-6
+    b.close(); c.close()
 
 
 def test_solve_runs_to_imax_and_reports_status():
@@ -194,8 +292,8 @@ def test_rocketland_mirror_single_trajectory():
     pi1, cnu, cdel = Rocketland.solve_step(pi, cache)
     it = oscvx.create_initial(model.base_prob_scaled(), 10)
     it1, onu, odel = oscvx.solve_step(it)
-    assert pi1.iter == 1 and pi1.rk == it1.rk and abs(pi1.sigma - it1.sigma) < 5e-4 and abs(cnu - onu) < 1e-5 and np.isinf(cdel)
-    assert np.abs(np.stack([p.state for p in pi1.about]) - it1.x).max() < 5e-4
+    assert pi1.iter == 1 and pi1.rk == it1.rk and abs(pi1.sigma - it1.sigma) < 2e-5 and abs(cnu - onu) < 1e-6 and np.isinf(cdel)
+    assert np.abs(np.stack([p.state for p in pi1.about]) - it1.x).max() < 2e-5
     # Dynamics entry points with the reference's signatures
     lr = linearize_dynamics(pi1.about, pi1.sigma, 1 / (prob.K + 1), cache)
     assert np.abs(lr[3].derivative - pi1.dynam[3].derivative).max() < 1e-13
@@ -209,7 +307,7 @@ def test_rocketland_mirror_single_trajectory():
     true = predict_state(a.state + pert, a.control, an.control, pi1.sigma, 1 / (prob.K + 1), None, cache)
     assert np.abs(pred - true).max() < 1e-7
     trjs, tfs = Rocketland.run_iters(prob, 2, cache)
-    assert len(trjs) == 2 and trjs[0].shape == (3, prob.K + 1) and abs(tfs[0] - it1.sigma) < 5e-4
+    assert len(trjs) == 2 and trjs[0].shape == (3, prob.K + 1) and abs(tfs[0] - it1.sigma) < 2e-5
 
 
 def test_checkpoint_restore_roundtrip():
@@ -224,6 +322,7 @@ def test_checkpoint_restore_roundtrip():
     c2, b2 = _setup(3, ic, npts=4)
     b2.set_trajectory(x, u, s)
     b2.set_scalars(rk, cost, it)
+    b2.set_flags(*b.flags())
     st1, nu1, dj1 = b.solve_step()
     st2, nu2, dj2 = b2.solve_step()
     assert np.array_equal(st1, st2) and np.array_equal(nu1, nu2) and np.array_equal(dj1, dj2)  # bitwise: same kernels, same data
@@ -256,10 +355,10 @@ def test_solve_step_with_aero_tables_matches_oracle(aero_tables):
     st, nun, dj = b.solve_step()
     it1, cnu, cdel = oscvx.solve_step(it)
     x, u, s = b.trajectory()
-    assert st[0] == 1 and abs(nun[0] - cnu) < 1e-5 and abs(s[0] - it1.sigma) < 5e-4
-    assert np.abs(x[0] - it1.x).max() < 5e-4 and np.abs(u[0] - it1.u).max() < 5e-4
+    assert st[0] == 1 and abs(nun[0] - cnu) < 1e-6 and abs(s[0] - it1.sigma) < 2e-5
+    assert np.abs(x[0] - it1.x).max() < 2e-5 and np.abs(u[0] - it1.u).max() < 2e-5
     e1, d1 = b.linearization()
-    assert np.abs(d1[0] - it1.deriv).max() < 5e-3  # linearisation about a point that itself agrees to 5e-4
+    assert np.abs(d1[0] - it1.deriv).max() < 5e-4  # linearisation about a point that itself agrees to 2e-5
 
 
 def test_rejection_path_and_radius_schedule_match_oracle():
@@ -282,13 +381,13 @@ def test_rejection_path_and_radius_schedule_match_oracle():
             seen_reject = True
             assert np.array_equal(b.trajectory()[0], xprev) and np.isinf(dj[0])  # about/dynam kept (rocketland.jl:301)
         else:
-            assert np.abs(b.trajectory()[0][0] - it.x).max() < 2e-3
-            assert abs(cost[0] - it.cost) < 2e-3 * abs(it.cost)
+            assert np.abs(b.trajectory()[0][0] - it.x).max() < 1e-4
+            assert abs(cost[0] - it.cost) < 1e-4 * abs(it.cost)
     assert seen_reject
 
 
 @pytest.mark.parametrize("K", [30, 100])
-def test_other_horizons_match_cpu_twin(K):
+def test_other_horizons_match_twin_and_independent_oracle(K):
     """BASELINE configs[0] uses K=30, configs[4] K=100: same kernels, sizes from K at run time."""
     from dataclasses import replace
     from oracle import dynamics as od, model, port
@@ -310,22 +409,27 @@ def test_other_horizons_match_cpu_twin(K):
     assert np.all(st == 0)
     tw = port.socp(po, xb, ub, e, d, 100.0, ic)
     assert np.all(tw["status"] == 0)
-    # Twin and device follow the same iteration path (1e-11 apart) unless one reaches the numerical floor an
-    # iteration earlier; then objectives still agree to ~1e-8 while the minimiser moves by ~1e-4 in u: the optimum
-    # is that flat (tools/diag_twin.py).  Tight on the objective, flatness-level on the minimiser.
     def obj(dx, du, ds, nv):
         return (-dx[:, K, 0] + po.wNu * np.sqrt((nv**2).sum((1, 2))) + 0.5 * np.sqrt((dx**2).sum((1, 2)) + (du**2).sum((1, 2))) + np.abs(ds))
     og, ot = obj(x - xb, u - ub, s - sg, nu), obj(tw["dx"], tw["du"], tw["ds"], tw["nu"])
-    assert np.abs(og - ot).max() < 1e-6 * np.abs(ot).max()
-    assert np.abs(x - (xb + tw["dx"])).max() < 5e-4 and np.abs(u - (ub + tw["du"])).max() < 5e-4
+    assert np.abs(og - ot).max() < 1e-9 * np.abs(ot).max()
+    assert np.abs(x - (xb + tw["dx"])).max() < 1e-6 and np.abs(u - (ub + tw["du"])).max() < 1e-6
+    # the INDEPENDENT oracle (full build_model form, oracle/ipm.py) on the first trajectory at this horizon
+    from oracle import scvx as oscvx
+    it0 = oscvx.create_initial(po, 4, ic[0, :3], ic[0, 3:])
+    sol, ix = oscvx.solve_socp(it0)
+    assert sol.status == "optimal"
+    z = sol.x
+    assert np.abs(x[0] - z[ix.xv].T).max() < 2e-5 and np.abs(u[0] - z[ix.uv].T).max() < 2e-5
+    assert abs(s[0] - sg[0] - z[ix.dsig]) < 2e-5 and np.abs(nu[0] - z[ix.nuv].T[1:]).max() < 2e-5
     st2, nun, dj = b.solve_step()
     assert np.all(st2 == 1)
 
 
-def test_flyable_problem_converges_and_freezes():
+def test_flyable_problem_converges():
     """A variant of the sample problem with enough propellant (the reference's own sample never converges: 71 kg):
     every trajectory reaches SCVX_ST_CONVERGED (||nu|| <= nuTol and dJ <= delTol, rocketland.jl:436) with nu driven to
-    zero, converged trajectories are frozen, and the conic solver never fails in the harder endgame where the nu-cone
+    zero, scvx_solve leaves converged trajectories alone, and the conic solver never fails in the harder endgame where the nu-cone
     collapses to its vertex (dynamic pivot regularisation)."""
     from dataclasses import replace
     import bench
@@ -348,10 +452,14 @@ def test_flyable_problem_converges_and_freezes():
     assert (x[:, -1, 0] > p.mdry).all() and (s > 5).all()
     un = np.linalg.norm(u, axis=-1)
     assert (un <= p.Tmax + 1e-6).all() and (un >= p.Tmin - 1e-4).all()
-    # frozen: another solve_step changes nothing for converged trajectories
-    before = b.trajectory_record().copy()
-    st2, _, _ = b.solve_step()
-    assert np.array_equal(b.trajectory_record(), before) and np.all(st2 == 0)
+    # inside scvx_solve a converged trajectory is left alone (the reference's loop exits): live = 0, still active
+    stf, act, live = b.flags()
+    assert np.all(stf == 0) and np.all(act == 1) and np.all(live == 0)
+    # solve_step itself has no notion of convergence (rocketland.jl:226-321): it steps them again
+    _, _, it_before = b.scalars()
+    st2, nu2, _ = b.solve_step()
+    _, _, it_after = b.scalars()
+    assert np.all(it_after == it_before + 1) and np.all((st2 == 0) | (st2 == 1) | (st2 == 2)) and nu2.max() < 1e-5
 
 
 def test_nonfinite_trajectory_is_reported_and_frozen_the_rest_continue():

@@ -1,0 +1,77 @@
+"""CPU-twin SCvx loop with solver statistics (no GPU): B dispersed trajectories x STEPS solve_steps through
+oracle/scvx_port.cpp (the device solver core compiled for the host) + the C discretisation oracle.
+
+    python tools/twin_stats.py [--B 256] [--steps 8] [--K 50] [--aero] [--seed 20261004] [--tol 1e-8] [--lib path.so]
+
+Prints, per step and overall, the distribution of the returned merit and of the solver status — the numbers the
+IPM step-rule constants are validated on."""
+import argparse, ctypes, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle
+from oracle import dynamics as od, model, port
+
+
+def run(p, B, steps, seed, tol, nsub=10, verbose=True, max_iter=60, refine=6):
+    par = od.Params(p)
+    K = p.K
+    ic = model.disperse_ics(p, B, seed)
+    x = np.zeros((B, K + 1, 14)); u = np.zeros((B, K + 1, 3))
+    for t in range(B):
+        x[t], u[t] = model.linear_points(p, ic[t, :3], ic[t, 3:])
+    sig = np.full(B, p.tf_guess)
+    dt = 1.0 / (K + 1)
+    e, d = od.linearize(par, x, u, sig, dt, nsub)
+    rk = np.full(B, 100.0); cost = np.full(B, np.inf)
+    allm, alls, alli = [], [], []
+    for s in range(steps):
+        t0 = time.perf_counter()
+        r = port.socp(p, x, u, e, d, rk, ic, tol=tol, max_iter=max_iter, refine=refine)
+        tsolve = time.perf_counter() - t0
+        allm.append(r["merit"]); alls.append(r["status"]); alli.append(r["iters"])
+        xr = x + r["dx"]; ur = u + r["du"]; ns = sig + r["ds"]
+        xn = od.propagate(par, xr, ur, ns, dt, nsub)
+        jK = -xr[:, K, 0] + p.wNu * np.sqrt(((xr[:, 1:] - xn) ** 2).sum((1, 2)))
+        lK = -xr[:, K, 0] + p.wNu * np.sqrt((r["nu"] ** 2).sum((1, 2)))
+        with np.errstate(invalid="ignore"):
+            rho = (cost - jK) / (cost - lK)
+        ok = r["status"] != 3
+        rej = (rho < p.rh0) & ok
+        acc = ~rej & ok
+        nrk = np.where(rej | (rho < p.rh1), rk / p.alph, np.where(rho < p.rh2, rk, p.bet * rk))
+        nrk = np.where(np.isnan(rho), p.bet * rk, nrk)
+        rk = np.where(ok, nrk, rk)
+        x[acc] = xr[acc]; u[acc] = ur[acc]; sig[acc] = ns[acc]; cost[acc] = jK[acc]
+        e, d = od.linearize(par, x, u, sig, dt, nsub)
+        if verbose:
+            m = r["merit"]
+            print("step %2d  its %.2f (max %d)  status %s  merit max %.2e p99 %.2e  <tol %.3f  rej %.2f  %.1f solves/s"
+                  % (s, r["iters"].mean(), r["iters"].max(), dict(zip(*np.unique(r["status"], return_counts=True))),
+                     m.max(), np.quantile(m, 0.99), (m < tol).mean(), rej.mean(), B / tsolve), flush=True)
+    m = np.concatenate(allm); st = np.concatenate(alls); it = np.concatenate(alli)
+    return m, st, it
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=256); ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--K", type=int, default=50); ap.add_argument("--aero", action="store_true")
+    ap.add_argument("--seed", type=int, default=20261004); ap.add_argument("--tol", type=float, default=1e-8)
+    ap.add_argument("--lib", default=None); ap.add_argument("--refine", type=int, default=6)
+    ap.add_argument("--max-iter", type=int, default=60)
+    a = ap.parse_args()
+    if a.lib:
+        oracle._PORT = ctypes.CDLL(os.path.abspath(a.lib))
+    if a.aero:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "lift_drag_tables.npz"))
+        p = model.base_prob_scaled(model.AeroData(z["drag"], z["lift"], z["torque"]))
+    else:
+        p = model.base_prob_scaled()
+    if a.K != p.K:
+        from dataclasses import replace
+        p = replace(p, K=a.K)
+    m, st, it = run(p, a.B, a.steps, a.seed, a.tol, max_iter=a.max_iter, refine=a.refine)
+    print("ALL  solves %d  its %.2f  status %s  merit max %.2e p99.9 %.2e p99 %.2e  frac<tol %.4f  frac<1e-7 %.4f"
+          % (m.size, it.mean(), dict(zip(*np.unique(st, return_counts=True))), m.max(), np.quantile(m, 0.999),
+             np.quantile(m, 0.99), (m < a.tol).mean(), (m < 1e-7).mean()))
