@@ -71,29 +71,34 @@ struct HostEx {
         }
         return ok;
     }
-    template <int NR>
-    void chain_n(int K, const double* const (&z)[NR], const double* N, double* const (&o)[NR], bool reverse) {
+    template <int NR, class CP, class GP>
+    void chain_n(int K, CP const (&z)[NR], CP N, GP const (&o)[NR], bool reverse) {
         for (int q = 0; q < NR; q++) chain(K, z[q], N, o[q], reverse);
     }
     // out_k = z_k + N_k out_{k-1} (forward) or out_k = z_k + N_{k+1}' out_{k+1} (reverse); 14-vectors; N_k is the negated
-    // coupling tile stored transposed (element (i, j) at 14 j + i), as Solver::build_kkt writes it
-    void chain(int K, const double* z, const double* N, double* out, bool reverse) {
+    // coupling tile stored transposed (element (i, j) at 14 j + i), as Solver::build_kkt writes it.  T = storage type
+    // (double, or float for the f32-storage twin): the running vector is carried in double, as in the device's MFMA
+    // accumulators, and rounded once when it is stored.
+    template <class T>
+    void chain(int K, const T* z, const T* N, T* out, bool reverse) {
+        double run[14] = {0};
         for (int step = 0; step < K; step++) {
             const int k = reverse ? K - 1 - step : step;
-            const int prev = reverse ? k + 1 : k - 1;
+            double nxt[14];
             for (int i = 0; i < 14; i++) {
                 double a = z[14 * k + i];
                 if (step > 0) {
                     if (!reverse) {
-                        const double* col = N + (size_t)k * 196 + i;
-                        for (int j = 0; j < 14; j++) a += col[14 * j] * out[14 * prev + j];
+                        const T* col = N + (size_t)k * 196 + i;
+                        for (int j = 0; j < 14; j++) a += (double)col[14 * j] * run[j];
                     } else {
-                        const double* row = N + (size_t)(k + 1) * 196 + 14 * i;
-                        for (int j = 0; j < 14; j++) a += row[j] * out[14 * prev + j];
+                        const T* row = N + (size_t)(k + 1) * 196 + 14 * i;
+                        for (int j = 0; j < 14; j++) a += (double)row[j] * run[j];
                     }
                 }
-                out[14 * k + i] = a;
+                nxt[i] = a;
             }
+            for (int i = 0; i < 14; i++) { run[i] = nxt[i]; out[14 * k + i] = (T)nxt[i]; }
         }
     }
 };
@@ -107,12 +112,15 @@ size_t scvx_port_work_doubles(int K) {
     return L.work_doubles();
 }
 
+}  // extern "C"
+
 // Solve B subproblems.  Layouts as include/scvx.h: xbar [B][K+1][14], ubar [B][K+1][3], endpoint [B][K][14],
 // deriv [B][K][21][14], rk [B], ic [B][6].  Outputs: sol [B][(K+1)*17+1] = dx, du, dsigma ; nu [B][K][14];
-// info [B][4] = status, iters, merit, pobj.
-int scvx_port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
-                   const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
-                   int nthreads) {
+// info [B][4] = status, iters, merit, pobj.  Stor = storage type of the linearisation and of the solver workspace.
+template <class Stor>
+static int port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
+                     const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
+                     int nthreads) {
     const int K = C->K;
     scvx::ipm::Layout L;
     L.init(K);
@@ -120,21 +128,35 @@ int scvx_port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, const 
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel
     {
-        std::vector<double> work(nw);
+        std::vector<Stor> work(nw), D((size_t)K * 294);
         HostEx ex;
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < B; b++) {
-            scvx::ipm::Solver<HostEx> S(ex, *C);
+            for (size_t i = 0; i < D.size(); i++) D[i] = (Stor)deriv[(size_t)b * K * 294 + i];
+            scvx::ipm::Solver<HostEx, Stor> S(ex, *C);
             scvx::ipm::Result r = S.solve(xbar + (size_t)b * (K + 1) * 14, ubar + (size_t)b * (K + 1) * 3,
-                                          endpoint + (size_t)b * K * 14, deriv + (size_t)b * K * 294, rk[b],
-                                          ic + (size_t)b * 6, work.data());
+                                          endpoint + (size_t)b * K * 14, D.data(), rk[b], ic + (size_t)b * 6, work.data());
             double* so = sol + (size_t)b * ((K + 1) * 17 + 1);
-            std::memcpy(so, S.V, sizeof(double) * (size_t)(L.nx + L.nu_));
+            for (int i = 0; i < L.nx + L.nu_; i++) so[i] = S.V[i];
             so[L.nx + L.nu_] = S.V[L.iS];
-            std::memcpy(nu + (size_t)b * K * 14, S.V + L.nx + L.nu_, sizeof(double) * (size_t)L.ny);
+            for (int i = 0; i < L.ny; i++) nu[(size_t)b * K * 14 + i] = S.V[L.nx + L.nu_ + i];
             info[4 * b + 0] = r.status; info[4 * b + 1] = r.iters; info[4 * b + 2] = r.merit; info[4 * b + 3] = r.pobj;
         }
     }
     return 0;
+}
+
+extern "C" {
+
+int scvx_port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
+                   const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
+                   int nthreads) {
+    return port_socp<double>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads);
+}
+// f32 storage: the linearisation and the whole solver workspace are float, arithmetic stays double
+int scvx_port_socp_f32(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
+                       const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
+                       int nthreads) {
+    return port_socp<float>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads);
 }
 }

@@ -67,7 +67,7 @@
 #define SCVX_STREAM_U 4   // elements in flight per lane in the streaming loops (Solver::stream)
 #endif
 #ifndef SCVX_REFINE_FROM
-#define SCVX_REFINE_FROM 1e-5
+#define SCVX_REFINE_FROM 1e-4
 #endif
 // refinement of a Newton solve stops once its first-row residual is below this fraction of the dual tolerance
 #ifndef SCVX_REFINE_STOP
@@ -94,13 +94,25 @@ namespace ipm {
 // access compiles to global_load/global_store (vmcnt only).  A plain `double*` kept in the solver object is
 // reloaded from memory in each non-inlined routine, loses its address space and becomes a flat access, which counts
 // against lgkmcnt as well -- and every wait for an LDS tile then also waits for the HBM traffic in flight.
+//
+// STORAGE TYPE.  The solver is a template on the element type T of what it keeps in HBM: the linearisation D it reads
+// and its whole workspace.  T = double is the reference precision; T = float ("f32 storage", BASELINE configs[3-4])
+// halves the bytes of a kernel that is bound by them.  All arithmetic is double either way: every load widens, every
+// store rounds, and norms / dot products / the Schur pivots accumulate in double registers and LDS.  The
+// SCvx iterate itself (xbar, ubar, endpoint: 1,600 values per trajectory) stays double in both modes.
 #if defined(__HIP_DEVICE_COMPILE__)
-typedef __attribute__((address_space(1))) double gdouble;
+#define SCVX_GLOBAL __attribute__((address_space(1)))
 #else
-typedef double gdouble;
+#define SCVX_GLOBAL
 #endif
-typedef gdouble* gptr;
-typedef const gdouble* cgptr;
+template <class T> struct gp {
+    typedef SCVX_GLOBAL T elem;
+    typedef elem* ptr;
+    typedef const elem* cptr;
+};
+typedef gp<double>::elem gdouble;
+typedef gp<double>::ptr gptr;    // double storage: what the device executors are written against
+typedef gp<double>::cptr cgptr;
 
 struct Consts {
     int K, max_iter, refine, pad;
@@ -271,13 +283,17 @@ struct Result {
     double merit, pobj;
 };
 
-template <class Ex>
+template <class Ex, class Stor = double>
 struct Solver {
+    typedef typename gp<Stor>::ptr gptr;     // workspace and linearisation (storage type)
+    typedef typename gp<Stor>::cptr cgptr;
+    typedef typename gp<double>::cptr cdptr;  // the SCvx iterate: always double
     Ex& ex;
     const Consts& C;
     Layout L;
     // inputs
-    cgptr xbar, ubar, D, endpoint;
+    cdptr xbar, ubar, endpoint;
+    cgptr D;
     double rk;
     // workspace
     gptr dk, V, rx, gx, dw, r1, cw, Vbest, tmpv;
@@ -295,7 +311,8 @@ struct Solver {
     double css, cst, csn, cts, ctt, ctn, cns, cnt_, pny;
     double bigvz[2];  // <v, W dz>_1 of the two big cones (corr_dir_pass -> update_pass)
     double prof[32];
-    double cur_merit;  // merit of the current iterate: refinement only pays in the endgame
+    double cur_gate;   // max(pres, relgap) of the current iterate: refinement only pays in the endgame (dres is left out:
+                       // an inaccurate solve RAISES it, and must not switch the refinement off)
 
     SCVX_HD Solver(Ex& e, const Consts& c) : ex(e), C(c) { L.init(c.K); for (int i = 0; i < 32; i++) prof[i] = 0.0; }
 
@@ -645,14 +662,14 @@ struct Solver {
         if constexpr (GRP == G_GS3) {
             const bool gs = q < K;
             const int k = gs ? q : q - K;
-            cgptr dx = v + 14 * k; cgptr xb = xbar + 14 * k;
+            cgptr dx = v + 14 * k; cdptr xb = xbar + 14 * k;
             const int i1 = gs ? 2 : 9, i2 = gs ? 3 : 10;
             const double x1 = af * xb[1] + dx[1];
             o[0] = gs ? x1 * C.itan : af * C.sqcm;
             o[1] = af * xb[i1] + dx[i1];
             o[2] = af * xb[i2] + dx[i2];
         } else if constexpr (GRP == G_RATE) {
-            cgptr dx = v + 14 * q; cgptr xb = xbar + 14 * q;
+            cgptr dx = v + 14 * q; cdptr xb = xbar + 14 * q;
             o[0] = af * C.omMax;
             for (int j = 0; j < 3; j++) o[1 + j] = af * xb[11 + j] + dx[11 + j];
         } else if constexpr (GRP == G_MASS) {
@@ -661,7 +678,7 @@ struct Solver {
         } else if constexpr (GRP == G_T4) {
             const bool tb = q <= K;
             const int k = tb ? q : q - (K + 1);
-            cgptr du = v + L.nx + 3 * k; cgptr ub = ubar + 3 * k;
+            cgptr du = v + L.nx + 3 * k; cdptr ub = ubar + 3 * k;
             double u[3];
             for (int c = 0; c < 3; c++) u[c] = af * ub[c] + du[c];
             o[0] = tb ? af * C.Tmax : u[0] * C.icos;
@@ -1583,7 +1600,7 @@ struct Solver {
                      gx[L.iTNU] - r1[L.iTNU], gx[L.iTTR] - r1[L.iTTR], gx[L.iTS] - r1[L.iTS], sqrt(e3));
         }
 #endif
-        const int nref = (cur_merit < SCVX_REFINE_FROM && !(pred && !SCVX_REFINE_PRED)) ? C.refine : 0;
+        const int nref = (cur_gate < SCVX_REFINE_FROM && !(pred && !SCVX_REFINE_PRED)) ? C.refine : 0;
         double nr_prev = INFINITY;
         for (int it = 0; it < nref; it++) {
             H_apply(dw, r1);
@@ -1656,8 +1673,8 @@ struct Solver {
     }
 
     // ---- the solve.  ic: (rIi, vIi) of this trajectory.  Outputs in V (dx, du, nu, s, ...). ----
-    SCVX_HD Result solve(cgptr xbar_, cgptr ubar_, cgptr endpoint_, cgptr D_,
-                         double rk_, cgptr ic, gptr work) {
+    SCVX_HD Result solve(cdptr xbar_, cdptr ubar_, cdptr endpoint_, cgptr D_,
+                         double rk_, cdptr ic, gptr work) {
         xbar = xbar_; ubar = ubar_; endpoint = endpoint_; D = D_; rk = rk_;
         SCVX_TS(tTot_);
         carve(work);
@@ -1670,7 +1687,7 @@ struct Solver {
                    [&](int e, double v) { At_[e] = v; });
         }
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
-            cgptr u = ubar + 3 * k;
+            cdptr u = ubar + 3 * k;
             const double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
             for (int c = 0; c < 3; c++) uhat[3 * k + c] = u[c] / un;  // rocketland.jl:199 (un = 0 -> NaN, as in the reference)
             lb0[k] = C.Tmin - un;
@@ -1681,7 +1698,7 @@ struct Solver {
             // fixed components: w = bc - xbar (rocketland.jl:109-115)
             V[0] = C.mwet - xbar[0];
             for (int i = 0; i < 3; i++) { V[1 + i] = ic[i] - xbar[1 + i]; V[4 + i] = ic[3 + i] - xbar[4 + i]; V[11 + i] = C.wBi[i] - xbar[11 + i]; }
-            cgptr xK = xbar + 14 * K;
+            cdptr xK = xbar + 14 * K;
             gptr vK = V + 14 * K;
             for (int i = 0; i < 3; i++) { vK[1 + i] = C.rIf[i] - xK[1 + i]; vK[4 + i] = C.vIf[i] - xK[4 + i]; vK[11 + i] = C.wBf[i] - xK[11 + i]; }
             for (int i = 0; i < 4; i++) vK[7 + i] = C.qBIf[i] - xK[7 + i];
@@ -1690,7 +1707,7 @@ struct Solver {
         }
         ex.sync();
         Result res; res.status = 1; res.iters = 0; res.merit = INFINITY; res.pobj = 0;
-        cur_merit = INFINITY;
+        cur_gate = INFINITY;
         // ---- initial point (CVXOPT conelp style, W = I): two least-squares problems on one factorisation ----
         //   primal:  min ||s||  s.t. E w = e, s = a(w)        -> w, s     (the cost does not enter)
         //   dual:    min ||z||  s.t. -J'z + E'y + c = 0       -> y, z = -J w'
@@ -1770,7 +1787,7 @@ struct Solver {
             if (relgap > merit) merit = relgap;
             SCVX_DBG("%3d pobj %+.8e gap %.2e pres %.2e (ry %.2e rz %.2e) dres %.2e\n", it, pobj, gap, pres, nry, nrz, dres);
             if (!(merit == merit) || !(gap == gap)) { res.status = 3; break; }
-            cur_merit = merit;
+            cur_gate = pres > relgap ? pres : relgap;
             if (merit < best_merit) {
                 best_merit = merit; best_it = it; res.pobj = pobj;
                 copy(Vbest, V, L.nv);

@@ -13,7 +13,7 @@ import oracle
 from oracle import dynamics as od, model, port
 
 
-def run(p, B, steps, seed, tol, nsub=10, verbose=True, max_iter=60, refine=6):
+def run(p, B, steps, seed, tol, nsub=10, verbose=True, max_iter=60, refine=6, f32=False, accept=1e-6, ret_traj=False):
     par = od.Params(p)
     K = p.K
     ic = model.disperse_ics(p, B, seed)
@@ -27,7 +27,7 @@ def run(p, B, steps, seed, tol, nsub=10, verbose=True, max_iter=60, refine=6):
     allm, alls, alli = [], [], []
     for s in range(steps):
         t0 = time.perf_counter()
-        r = port.socp(p, x, u, e, d, rk, ic, tol=tol, max_iter=max_iter, refine=refine)
+        r = port.socp(p, x, u, e, d.astype(np.float32).astype(np.float64) if f32 else d, rk, ic, tol=tol, max_iter=max_iter, refine=refine, f32=f32, accept=max(accept, tol))
         tsolve = time.perf_counter() - t0
         allm.append(r["merit"]); alls.append(r["status"]); alli.append(r["iters"])
         xr = x + r["dx"]; ur = u + r["du"]; ns = sig + r["ds"]
@@ -50,6 +50,8 @@ def run(p, B, steps, seed, tol, nsub=10, verbose=True, max_iter=60, refine=6):
                   % (s, r["iters"].mean(), r["iters"].max(), dict(zip(*np.unique(r["status"], return_counts=True))),
                      m.max(), np.quantile(m, 0.99), (m < tol).mean(), rej.mean(), B / tsolve), flush=True)
     m = np.concatenate(allm); st = np.concatenate(alls); it = np.concatenate(alli)
+    if ret_traj:
+        return m, st, it, (x, u, sig, rk)
     return m, st, it
 
 
@@ -59,7 +61,8 @@ if __name__ == "__main__":
     ap.add_argument("--K", type=int, default=50); ap.add_argument("--aero", action="store_true")
     ap.add_argument("--seed", type=int, default=20261004); ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--lib", default=None); ap.add_argument("--refine", type=int, default=6)
-    ap.add_argument("--max-iter", type=int, default=60)
+    ap.add_argument("--max-iter", type=int, default=60); ap.add_argument("--f32", action="store_true")
+    ap.add_argument("--accept", type=float, default=1e-6)
     a = ap.parse_args()
     if a.lib:
         oracle._PORT = ctypes.CDLL(os.path.abspath(a.lib))
@@ -71,7 +74,7 @@ if __name__ == "__main__":
     if a.K != p.K:
         from dataclasses import replace
         p = replace(p, K=a.K)
-    m, st, it = run(p, a.B, a.steps, a.seed, a.tol, max_iter=a.max_iter, refine=a.refine)
+    m, st, it = run(p, a.B, a.steps, a.seed, a.tol, max_iter=a.max_iter, refine=a.refine, f32=a.f32, accept=a.accept)
     print("ALL  solves %d  its %.2f  status %s  merit max %.2e p99.9 %.2e p99 %.2e  frac<tol %.4f  frac<1e-7 %.4f"
           % (m.size, it.mean(), dict(zip(*np.unique(st, return_counts=True))), m.max(), np.quantile(m, 0.999),
              np.quantile(m, 0.99), (m < a.tol).mean(), (m < 1e-7).mean()))
