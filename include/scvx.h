@@ -41,6 +41,7 @@ extern "C" {
 #define SCVX_ERR_HIP -2
 #define SCVX_ERR_STATE -3
 #define SCVX_ERR_NOMEM -4
+#define SCVX_ERR_COMM -5 /* RCCL missing or a collective failed */
 
 /* per-trajectory status codes written by scvx_solve_step / scvx_solve */
 #define SCVX_ST_CONVERGED 0   /* ||nu|| <= nuTol and dJ <= delTol             (rocketland.jl:436) */
@@ -127,6 +128,10 @@ int scvx_batch_set_solver(scvx_batch *b, const scvx_solver_opts *o);
  * every trajectory uses the problem's own.  Builds the straight-line guess (initial_solve.jl:113-129),
  * linearises it and sets rk=100, cost=Inf, iter=0 (rocketland.jl:38). */
 int scvx_batch_init(scvx_batch *b, const double *ic);
+/* create_initial again for the same initial conditions, entirely on the device and asynchronous on the stream: the
+ * straight-line guess kept from scvx_batch_init is restored, rk=100, cost=Inf, iter=0, flags cleared, and the guess is
+ * re-linearised.  (A Monte-Carlo driver that re-runs solve_problem, or a benchmark loop, needs no host round trip.) */
+int scvx_batch_reset(scvx_batch *b);
 /* One Rocketland.solve_step for every trajectory of the batch.  Outputs are host arrays of
  * length B (any may be NULL): status codes above, ||nu||_F and dJ (Inf on rejection).
  * Like the reference's solve_step this has no notion of convergence: SCVX_ST_CONVERGED reports that the
@@ -146,7 +151,7 @@ int scvx_solve(scvx_batch *b, int32_t *status, int32_t *iters, double *nu_norm, 
 /* traj [B][(K+1)*17 + 1]: per trajectory x[K+1][14], u[K+1][3], sigma.  */
 int scvx_batch_get_trajectory(scvx_batch *b, double *traj);
 int scvx_batch_set_trajectory(scvx_batch *b, const double *traj);
-/* device pointer to the same layout (for RCCL all-gather by the caller); valid until destroy */
+/* device pointer to the same layout (zero-copy views; scvx_allgather_trajectories gathers it); valid until destroy */
 int scvx_batch_trajectory_dev(scvx_batch *b, double **traj_dev, int64_t *n_doubles);
 int scvx_batch_get_linearization(scvx_batch *b, double *endpoint, double *deriv);
 int scvx_batch_get_scalars(scvx_batch *b, double *rk, double *cost, int32_t *iter);
@@ -166,6 +171,24 @@ int scvx_batch_set_profiling(scvx_batch *b, int enable);
 /* ms[5] = {socp (K4), propagate (K2), tr_update (K5), linearize (K1), glue (K3: candidate/unpack)}
  * summed over the `steps` solve_steps enqueued since the last call; synchronises and resets. */
 int scvx_batch_get_profile(scvx_batch *b, double *ms, int64_t *steps);
+
+/* ---- multi-GPU: the single exchange step of the path (no counterpart in the reference) ---- */
+/* One process per GPU, one context per process, contiguous shards of the Monte-Carlo batch; nothing inside the
+ * SCvx iteration communicates.  The final records are all-gathered over RCCL (xGMI inside a node) on the
+ * context's stream.  Bootstrap as with NCCL: rank 0 calls scvx_comm_unique_id, the host language ships the
+ * SCVX_COMM_ID_BYTES to every rank by whatever channel it has, every rank calls scvx_comm_create. */
+#define SCVX_COMM_ID_BYTES 128
+int scvx_comm_unique_id(void *id_out /* SCVX_COMM_ID_BYTES */);
+int scvx_comm_create(scvx_ctx *ctx, const void *unique_id, int rank, int world);
+int scvx_comm_destroy(scvx_ctx *ctx);
+int scvx_comm_info(const scvx_ctx *ctx, int *rank, int *world); /* world = 0: no communicator */
+/* out_dev [world][B][(K+1)*17+1]: every rank's trajectory records (all ranks hold the same B), asynchronous on the
+ * context's stream; status_out_dev / iters_out_dev [world][B] (either may be NULL). */
+int scvx_allgather_trajectories(scvx_batch *b, double *out_dev);
+int scvx_allgather_status(scvx_batch *b, int32_t *status_out_dev, int32_t *iters_out_dev);
+/* raw collectives on the context's communicator and stream (count elements per rank) */
+int scvx_allgather_f64(scvx_ctx *ctx, const double *send_dev, double *recv_dev, int64_t count);
+int scvx_allgather_i32(scvx_ctx *ctx, const int32_t *send_dev, int32_t *recv_dev, int64_t count);
 
 /* ---- the conic subproblem alone (replaces MOI.optimize!, rocketland.jl:271) ------------------ */
 /* Solves the trust-region SOCP at the batch's current (about, dynam, rk).  sol [B][(K+1)*17+1] as

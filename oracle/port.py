@@ -59,3 +59,50 @@ def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, 
     return dict(dx=sol[:, :nx].reshape(B, K + 1, 14), du=sol[:, nx:nx + 3 * (K + 1)].reshape(B, K + 1, 3),
                 ds=sol[:, -1], nu=nu, status=info[:, 0].astype(int), iters=info[:, 1].astype(int),
                 merit=info[:, 2], pobj=info[:, 3])
+
+
+def scvx_steps(p: DescentProblem, ic, steps, nsub=10, nthreads=0, tol=1e-8, accept=1e-6, max_iter=60, refine=6, f32=False,
+               on_step=None):
+    """`steps` Rocketland.solve_step calls (rocketland.jl:226-321) on B dispersed trajectories, all on the host: the conic
+    solve by the CPU twin of the device solver (scvx_port.cpp), discretisation and propagation by the C oracle
+    (scvx_oracle.c), accept / reject and radius update in numpy.  Starts from create_initial (straight-line guess).
+    Returns dict(x, u, sigma, rk, cost, merit [steps][B], status, iters, rejected)."""
+    from . import dynamics as od
+    from .model import linear_points
+    par = od.Params(p)
+    K = p.K
+    ic = np.ascontiguousarray(ic, float)
+    B = ic.shape[0]
+    x = np.zeros((B, K + 1, 14)); u = np.zeros((B, K + 1, 3))
+    for t in range(B):
+        x[t], u[t] = linear_points(p, ic[t, :3], ic[t, 3:])
+    sig = np.full(B, p.tf_guess)
+    dt = 1.0 / (K + 1)
+    if nthreads > 0:   # the OpenMP runtime is shared by both oracle libraries: this also pins the discretisation
+        port_lib().scvx_port_set_threads(C.c_int(nthreads))
+    e, d = od.linearize(par, x, u, sig, dt, nsub)
+    rk = np.full(B, 100.0); cost = np.full(B, np.inf)
+    out = dict(merit=[], status=[], iters=[], rejected=[])
+    for s in range(steps):
+        r = socp(p, x, u, e, d.astype(np.float32).astype(np.float64) if f32 else d, rk, ic, tol=tol, max_iter=max_iter,
+                 refine=refine, nthreads=nthreads, accept=accept, f32=f32)
+        xr = x + r["dx"]; ur = u + r["du"]; ns = sig + r["ds"]
+        xn = od.propagate(par, xr, ur, ns, dt, nsub)
+        jK = -xr[:, K, 0] + p.wNu * np.sqrt(((xr[:, 1:] - xn) ** 2).sum((1, 2)))      # rocketland.jl:289
+        lK = -xr[:, K, 0] + p.wNu * np.sqrt((r["nu"] ** 2).sum((1, 2)))                 # :290
+        with np.errstate(invalid="ignore"):
+            rho = (cost - jK) / (cost - lK)
+        ok = (r["status"] == 0) | (r["status"] == 4)
+        rej = (rho < p.rh0) & ok                                                        # :299-301
+        acc = ~rej & ok
+        nrk = np.where(rej | (rho < p.rh1), rk / p.alph, np.where(rho < p.rh2, rk, p.bet * rk))
+        nrk = np.where(np.isnan(rho), p.bet * rk, nrk)                                  # first call: rho = NaN -> grow
+        rk = np.where(ok, nrk, rk)
+        x[acc] = xr[acc]; u[acc] = ur[acc]; sig[acc] = ns[acc]; cost[acc] = jK[acc]
+        e, d = od.linearize(par, x, u, sig, dt, nsub)                                   # :318
+        out["merit"].append(r["merit"]); out["status"].append(r["status"]); out["iters"].append(r["iters"])
+        out["rejected"].append(rej)
+        if on_step is not None:
+            on_step(s, r, rej)
+    out.update(x=x, u=u, sigma=sig, rk=rk, cost=cost)
+    return out

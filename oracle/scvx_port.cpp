@@ -106,6 +106,8 @@ struct HostEx {
 
 extern "C" {
 
+void scvx_port_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+
 size_t scvx_port_work_doubles(int K) {
     scvx::ipm::Layout L;
     L.init(K);

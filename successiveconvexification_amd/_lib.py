@@ -61,6 +61,7 @@ SIGNATURES = {
     "scvx_batch_destroy": (None, [_vp]),
     "scvx_batch_set_solver": (C.c_int, [_vp, C.POINTER(ScvxSolverOpts)]),
     "scvx_batch_init": (C.c_int, [_vp, _dp]),
+    "scvx_batch_reset": (C.c_int, [_vp]),
     "scvx_solve_step": (C.c_int, [_vp, _ip, _dp, _dp]),
     "scvx_solve_step_async": (C.c_int, [_vp]),
     "scvx_solve": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
@@ -73,6 +74,14 @@ SIGNATURES = {
     "scvx_batch_get_flags": (C.c_int, [_vp, _ip, _ip, _ip]),
     "scvx_batch_set_flags": (C.c_int, [_vp, _ip, _ip, _ip]),
     "scvx_batch_get_solver_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
+    "scvx_comm_unique_id": (C.c_int, [_vp]),
+    "scvx_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "scvx_comm_destroy": (C.c_int, [_vp]),
+    "scvx_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "scvx_allgather_trajectories": (C.c_int, [_vp, _vp]),
+    "scvx_allgather_status": (C.c_int, [_vp, _vp, _vp]),
+    "scvx_allgather_f64": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
+    "scvx_allgather_i32": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "scvx_socp_solve": (C.c_int, [_vp, _dp, _dp]),
     "scvx_batch_set_profiling": (C.c_int, [_vp, C.c_int]),
     "scvx_batch_get_profile": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64)]),

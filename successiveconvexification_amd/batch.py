@@ -62,6 +62,11 @@ class ScvxBatch:
         self._chk(self._L.scvx_batch_init(self.handle, _p(ic) if ic is not None else None), "scvx_batch_init")
         return self
 
+    def reset(self):
+        """create_initial again on the device for the same initial conditions (asynchronous)."""
+        self._chk(self._L.scvx_batch_reset(self.handle), "scvx_batch_reset")
+        return self
+
     # solve_step (rocketland.jl:226-321)
     def solve_step(self):
         st = np.zeros(self.B, np.int32)
@@ -185,25 +190,5 @@ class ScvxBatch:
             pass
 
 
-# ---- multi-GPU: independent trajectories shard with no data-path collective ----------
-def shard_range(total: int, rank: int, world: int):
-    """Contiguous shard [lo, hi) of `total` trajectories for `rank`; sizes differ by at most one."""
-    base, rem = divmod(int(total), int(world))
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
-
-
-def gather_trajectories(rec, group=None):
-    """All-gather the per-rank trajectory records ([B_r][(K+1)*17+1] torch tensors, equal B_r) into
-    [world][B_r][...] — the single exchange step of the path (RCCL on GPUs, gloo in the CPU tests)."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
-    if rec.is_cuda:
-        dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
-    else:
-        parts = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(parts, rec.contiguous(), group=group)
-        out = torch.stack(parts)
-    return out
+# ---- multi-GPU: see montecarlo.py (kept importable from here) -------------------------------------------
+from .montecarlo import gather_records as gather_trajectories, shard_range  # noqa: E402,F401

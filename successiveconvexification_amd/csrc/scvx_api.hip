@@ -134,6 +134,7 @@ int scvx_ctx_create(const scvx_problem* p, int device, scvx_ctx** out) {
 void scvx_ctx_destroy(scvx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)scvx_comm_destroy(ctx);
     if (ctx->d_cdrag) (void)hipFree(ctx->d_cdrag);
     if (ctx->d_clift) (void)hipFree(ctx->d_clift);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -348,16 +348,16 @@ __global__ __launch_bounds__(64, 3) void socp_kernel(ipm::Consts C, int B, size_
     socp_body<WaveEx>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info);
 }
 
-// SOCP_BLOCK_WAVES wavefronts per trajectory (small batches)
-constexpr int SOCP_BLOCK_WAVES = 4;
-__global__ __launch_bounds__(64 * SOCP_BLOCK_WAVES) void socp_block_kernel(ipm::Consts C, int B, size_t work_stride,
+// NW wavefronts per trajectory (batches that cannot fill the chip with one wavefront each)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void socp_block_kernel(ipm::Consts C, int B, size_t work_stride,
                                                   const double* __restrict__ x, const double* __restrict__ u,
                                                   const double* __restrict__ endpoint, const double* __restrict__ deriv,
                                                   const double* __restrict__ rk, const double* __restrict__ ic,
                                                   const int* __restrict__ active, double* __restrict__ work,
                                                   double* __restrict__ sol, double* __restrict__ nu,
                                                   double* __restrict__ info) {
-    socp_body<BlockEx<SOCP_BLOCK_WAVES>>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info);
+    socp_body<BlockEx<NW>>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info);
 }
 
 // cand = about + step (x, u in one contiguous [B][(K+1)*17+1] trajectory record, sigma last)
@@ -462,6 +462,17 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
     }
 }
 
+// scvx_batch_reset: the scalars of create_initial (rocketland.jl:38) for every trajectory
+__global__ void reset_scalars_kernel(int B, double* __restrict__ rk, double* __restrict__ cost, int* __restrict__ iter,
+                                     int* __restrict__ status, int* __restrict__ active, int* __restrict__ live,
+                                     double* __restrict__ out, double* __restrict__ info) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    rk[i] = 100.0; cost[i] = INFINITY; iter[i] = 0; status[i] = SCVX_ST_RUNNING; active[i] = 1; live[i] = 1;
+    out[2 * i] = 0.0; out[2 * i + 1] = 0.0;
+    for (int q = 0; q < 4; q++) info[4 * i + q] = 0.0;
+}
+
 // live = active (start of a solve_problem loop)
 __global__ void copy_flags_kernel(int B, const int* __restrict__ src, int* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -480,6 +491,7 @@ struct scvx_batch {
     size_t work_stride = 0;
     // device state
     double *traj = nullptr, *cand = nullptr, *sol = nullptr;      // [B][nrec]
+    double *traj0 = nullptr;                                      // the straight-line guess of scvx_batch_init (scvx_batch_reset)
     double *x = nullptr, *u = nullptr, *sigma = nullptr;          // split views of traj (kernels' input layout)
     double *cx = nullptr, *cu = nullptr, *csigma = nullptr;       // split views of cand
     double *endpoint = nullptr, *deriv = nullptr, *xprop = nullptr, *nu = nullptr;
@@ -496,7 +508,8 @@ struct scvx_batch {
 
 namespace {
 
-constexpr int SOCP_BLOCK_MAX_B = 512;
+constexpr int SOCP_WAVES4_MAX_B = 512;    // 4 wavefronts per trajectory up to here
+constexpr int SOCP_WAVES2_MAX_B = 1536;   // 2 up to here, then one
 
 void rotation_between_e1(const double* b, double* q) {
     // Rotations.rotation_between([1,0,0], b) as [w,x,y,z] (initial_solve.jl:121-122)
@@ -527,15 +540,28 @@ int split_views(scvx_batch* b, const double* rec, double* x, double* u, double* 
     return SCVX_OK;
 }
 
+// Wavefronts per trajectory of the conic solve.  One wavefront per trajectory is the throughput form (3 per SIMD,
+// 3,072 in flight): below that many trajectories the chip is not full and a solve is latency-bound, so several
+// wavefronts share one trajectory (the sweeps and E / E' products spread over their lanes; the 14x14 tile arithmetic
+// stays on the first).  Thresholds from the measured B-sweep (profiles/r02_bsweep.md); SCVX_K4_WAVES = 1 / 2 / 4 forces.
+int socp_waves(int B) {
+    if (const char* v = std::getenv("SCVX_K4_WAVES")) {
+        const int w = std::atoi(v);
+        return w >= 4 ? 4 : (w >= 2 ? 2 : 1);
+    }
+    return B <= SOCP_WAVES4_MAX_B ? 4 : (B <= SOCP_WAVES2_MAX_B ? 2 : 1);
+}
+
+template <int NW>
+void launch_socp_block(scvx_batch* b, const int* mask) {
+    hipLaunchKernelGGL(scvx::socp_block_kernel<NW>, dim3(b->B), dim3(64 * NW), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x,
+                       b->u, b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info);
+}
+
 int enqueue_socp(scvx_batch* b, const int* mask) {
-    // below SOCP_BLOCK_MAX_B trajectories a wavefront per trajectory cannot fill the chip: several wavefronts share one
-    // (SCVX_K4_WAVES=1 / 4 forces either form)
-    bool block = b->B <= SOCP_BLOCK_MAX_B;
-    if (const char* v = std::getenv("SCVX_K4_WAVES")) block = std::atoi(v) > 1;
-    if (block)
-        hipLaunchKernelGGL(scvx::socp_block_kernel, dim3(b->B), dim3(64 * scvx::SOCP_BLOCK_WAVES), 0, b->ctx->stream, b->C, b->B,
-                           b->work_stride, b->x, b->u, b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu,
-                           b->info);
+    const int w = socp_waves(b->B);
+    if (w == 4) launch_socp_block<4>(b, mask);
+    else if (w == 2) launch_socp_block<2>(b, mask);
     else
         hipLaunchKernelGGL(scvx::socp_kernel, dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
                            b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info);
@@ -645,6 +671,7 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     int rc = 0;
     rc |= dmalloc(ctx, &b->traj, nB * b->nrec);
     rc |= dmalloc(ctx, &b->cand, nB * b->nrec);
+    rc |= dmalloc(ctx, &b->traj0, nB * b->nrec);
     rc |= dmalloc(ctx, &b->sol, nB * b->nrec);
     rc |= dmalloc(ctx, &b->x, nB * (K + 1) * 14);
     rc |= dmalloc(ctx, &b->u, nB * (K + 1) * 3);
@@ -678,7 +705,7 @@ void scvx_batch_destroy(scvx_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
-    void* ptrs[] = {b->traj, b->cand, b->sol, b->x, b->u, b->sigma, b->cx, b->cu, b->csigma, b->endpoint, b->deriv, b->xprop,
+    void* ptrs[] = {b->traj0, b->traj, b->cand, b->sol, b->x, b->u, b->sigma, b->cx, b->cu, b->csigma, b->endpoint, b->deriv, b->xprop,
                     b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active, b->live};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -731,6 +758,7 @@ int scvx_batch_init(scvx_batch* b, const double* ic) {
     }
     hipStream_t st = ctx->stream;
     SCVX_HIP(ctx, hipMemcpyAsync(b->traj, rec.data(), rec.size() * 8, hipMemcpyHostToDevice, st));
+    SCVX_HIP(ctx, hipMemcpyAsync(b->traj0, b->traj, rec.size() * 8, hipMemcpyDeviceToDevice, st));
     SCVX_HIP(ctx, hipMemcpyAsync(b->ic, hic.data(), hic.size() * 8, hipMemcpyHostToDevice, st));
     SCVX_HIP(ctx, hipMemcpyAsync(b->rk, hrk.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
     SCVX_HIP(ctx, hipMemcpyAsync(b->cost, hcost.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
@@ -745,6 +773,21 @@ int scvx_batch_init(scvx_batch* b, const double* ic) {
     SCVX_HIP(ctx, scvx::launch_linearize(ctx, B, K, b->x, b->u, b->sigma, 1.0 / (K + 1), b->endpoint, b->deriv, st));
     SCVX_HIP(ctx, hipStreamSynchronize(st));  // host staging buffers go out of scope
     b->initialised = true;
+    return SCVX_OK;
+}
+
+int scvx_batch_reset(scvx_batch* b) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    scvx_ctx* ctx = b->ctx;
+    hipStream_t st = ctx->stream;
+    SCVX_HIP(ctx, hipMemcpyAsync(b->traj, b->traj0, (size_t)b->B * b->nrec * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(scvx::reset_scalars_kernel, dim3((unsigned)((b->B + 255) / 256)), dim3(256), 0, st, b->B, b->rk, b->cost,
+                       b->iter, b->status, b->active, b->live, b->out, b->info);
+    SCVX_HIP(ctx, hipGetLastError());
+    rc = split_views(b, b->traj, b->x, b->u, b->sigma);
+    if (rc) return rc;
+    SCVX_HIP(ctx, scvx::launch_linearize(ctx, b->B, b->K, b->x, b->u, b->sigma, 1.0 / (b->K + 1), b->endpoint, b->deriv, st));
     return SCVX_OK;
 }
 
@@ -936,6 +979,20 @@ int scvx_batch_set_flags(scvx_batch* b, const int32_t* status, const int32_t* ac
     if (active) SCVX_HIP(ctx, hipMemcpyAsync(b->active, active, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
     if (live) SCVX_HIP(ctx, hipMemcpyAsync(b->live, live, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
     SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCVX_OK;
+}
+
+int scvx_allgather_trajectories(scvx_batch* b, double* out_dev) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    return scvx_allgather_f64(b->ctx, b->traj, out_dev, (int64_t)b->B * b->nrec);
+}
+
+int scvx_allgather_status(scvx_batch* b, int32_t* status_out_dev, int32_t* iters_out_dev) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    if (status_out_dev && (rc = scvx_allgather_i32(b->ctx, b->status, status_out_dev, b->B))) return rc;
+    if (iters_out_dev && (rc = scvx_allgather_i32(b->ctx, b->iter, iters_out_dev, b->B))) return rc;
     return SCVX_OK;
 }
 

@@ -16,10 +16,14 @@ struct scvx_ctx {
     int k1_sg = 1;       // producer/consumer pipeline per RK stage (1, default) or per substep (0); SCVX_K1_SG overrides
     double* d_cdrag = nullptr;
     double* d_clift = nullptr;
+    void* comm = nullptr;   // ncclComm_t of scvx_comm_create (RCCL, bound at run time: csrc/scvx_comm.hip)
+    int comm_rank = 0, comm_world = 0;
     std::string err;
 };
 
 namespace scvx {
+
+struct NcclId { char internal[SCVX_COMM_ID_BYTES]; };   // layout of ncclUniqueId (rccl.h), passed by value to RCCL
 
 // K1: endpoint[B*K][14], deriv[B*K][21][14] from x[B][K+1][14], u[B][K+1][3], sigma[B].
 hipError_t launch_linearize(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,

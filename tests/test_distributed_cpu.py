@@ -1,4 +1,7 @@
-"""The N>1 path on CPU: two gloo ranks shard a Monte-Carlo batch and all-gather the trajectory records."""
+"""The N>1 path on CPU: two gloo ranks run the sharding code bench.py runs (successiveconvexification_amd.montecarlo:
+Shard, disperse_ics by global index, gather_records, reduce_clock) -- everything of the multi-GPU path except the
+device calls and the RCCL transport (the library's communicator needs GPUs; its bootstrap is exercised up to the point
+where rank 0 must draw a unique id)."""
 import os
 import socket
 
@@ -17,34 +20,58 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total, nrec, q):
+def _worker(rank, world, port, batch, scaling, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from successiveconvexification_amd.batch import gather_trajectories, shard_range
-    lo, hi = shard_range(total, rank, world)
-    # each rank's "solution" is a function of the GLOBAL trajectory index, as a real solve would be
-    rec = torch.tensor(np.arange(lo, hi)[:, None] * 1000.0 + np.arange(nrec)[None, :], dtype=torch.float64)
-    out = gather_trajectories(rec)
+    from successiveconvexification_amd import montecarlo as mc, sample_problems as sp
+    p = sp.base_prob_scaled
+    nrec = (p.K + 1) * 17 + 1
+    shard = mc.Shard(p, batch, 20261004, rank, world, scaling)
+    # each rank's "solution" is a function of its initial conditions (as a real solve is) and of the GLOBAL index
+    rec = np.zeros((shard.B, nrec))
+    rec[:, 0] = np.arange(shard.lo, shard.hi)
+    rec[:, 1:7] = shard.ic
+    out = mc.gather_records(torch.tensor(rec), dist)
+    t, n = mc.reduce_clock(1.0 + rank, shard.B * 3, dist)
+    # the native communicator cannot exist without a GPU: the bootstrap must say so on every rank, not hang
+    class _Cache:  # what bootstrap_comm needs of an IntegratorCache
+        handle = None
+    from successiveconvexification_amd import _lib
+    why = mc.bootstrap_comm(_Cache(), dist, rank, world, lib=_lib.lib())
     if rank == 0:
-        q.put(out.numpy())
+        q.put((out.numpy(), t, n, shard.global_batch, why))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_and_gather():
-    world, total, nrec = 2, 12, (50 + 1) * 17 + 1
+@pytest.mark.parametrize("scaling,batch", [("weak", 6), ("strong", 12)])
+def test_two_rank_shard_and_gather(scaling, batch):
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, nrec, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, batch, scaling, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get(timeout=120)
+    out, t, n, total, why = q.get(timeout=180)
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=180)
         assert p.exitcode == 0
-    assert out.shape == (world, total // world, nrec)
-    flat = out.reshape(total, nrec)
-    assert np.array_equal(flat[:, 0], np.arange(total) * 1000.0)  # global order restored, nothing lost or duplicated
-    assert np.array_equal(flat[5], 5000.0 + np.arange(nrec))
+    assert total == 12 and out.shape[:2] == (world, total // world)
+    flat = out.reshape(total, -1)
+    assert np.array_equal(flat[:, 0], np.arange(total))  # global order restored, nothing lost or duplicated
+    from successiveconvexification_amd import montecarlo as mc, sample_problems as sp
+    assert np.array_equal(flat[:, 1:7], mc.disperse_ics(sp.base_prob_scaled, 0, total, 20261004))  # same ICs as one big batch
+    assert t == 2.0 and n == total * 3           # max over ranks of the clock, sum of the work
+    assert why is not None and ("unique_id" in why or "scvx_comm_create" in why)  # no GPU here: the bootstrap reports it, on every rank
+
+
+def test_strong_scaling_needs_divisible_batch():
+    from successiveconvexification_amd import montecarlo as mc, sample_problems as sp
+    with pytest.raises(ValueError):
+        mc.Shard(sp.base_prob_scaled, 13, 1, 0, 2, "strong")
+    s = mc.Shard(sp.base_prob_scaled, 8192, 1, 3, 8, "strong")
+    assert (s.lo, s.hi, s.B, s.global_batch) == (3072, 4096, 1024, 8192)   # BASELINE configs[3]: 1024 per GPU at N = 8
+    w = mc.Shard(sp.base_prob_scaled, 16, 1, 3, 8, "weak")
+    assert (w.lo, w.hi, w.global_batch) == (48, 64, 128)

@@ -511,3 +511,65 @@ def test_batch_api_argument_and_state_errors():
     st, nu, dj = b.solve_step()
     assert st.shape == (2,) and np.all(st == 1)
     b.close(); c.close()
+
+
+def test_reset_restores_create_initial_on_device():
+    """scvx_batch_reset: the straight-line guess, its linearisation and the scalars of create_initial come back without a
+    host round trip, and the next solve_problem reproduces the first bit for bit."""
+    from oracle import model
+    po = model.base_prob_scaled()
+    B = 6
+    ic = model.disperse_ics(po, B, 20261004)
+    c, b = _setup(B, ic)
+    x0, u0, s0 = b.trajectory()
+    e0, d0 = b.linearization()
+    first = [b.solve_step() for _ in range(3)]
+    x3 = b.trajectory()[0].copy()
+    b.reset()
+    x, u, s = b.trajectory()
+    e, d = b.linearization()
+    rk, cost, it = b.scalars()
+    st, act, live = b.flags()
+    assert np.array_equal(x, x0) and np.array_equal(u, u0) and np.array_equal(s, s0)
+    assert np.array_equal(e, e0) and np.array_equal(d, d0)
+    assert np.all(rk == 100.0) and np.all(np.isinf(cost)) and np.all(it == 0) and np.all(act == 1) and np.all(live == 1)
+    again = [b.solve_step() for _ in range(3)]
+    for a, bb in zip(first, again):
+        assert all(np.array_equal(p, q, equal_nan=True) for p, q in zip(a, bb))
+    assert np.array_equal(b.trajectory()[0], x3)
+    b.close(); c.close()
+
+
+def test_native_rccl_allgather_world_of_one():
+    """The library's own communicator (scvx_comm_create / scvx_allgather_trajectories, RCCL bound at run time): a world
+    of one rank on this box's GPU -- the N > 1 bootstrap and ordering are covered by the CPU gloo test, the transport by
+    the driver's 8-GPU bench."""
+    import ctypes as C
+    import torch
+    from oracle import model
+    from successiveconvexification_amd import _lib
+    po = model.base_prob_scaled()
+    B = 4
+    ic = model.disperse_ics(po, B, 20261004)
+    c, b = _setup(B, ic)
+    L = _lib.lib()
+    ident = (C.c_char * 128)()
+    assert L.scvx_comm_unique_id(ident) == 0
+    out = torch.zeros((1, B, b.nrec), dtype=torch.float64, device="cuda")
+    # no communicator yet: a clean state error, not a crash
+    assert L.scvx_allgather_trajectories(b.handle, C.c_void_p(out.data_ptr())) == -3
+    _lib.check(c.handle, L.scvx_comm_create(c.handle, ident, 0, 1), "scvx_comm_create")
+    r, w = C.c_int(-1), C.c_int(-1)
+    L.scvx_comm_info(c.handle, C.byref(r), C.byref(w))
+    assert (r.value, w.value) == (0, 1)
+    b.solve_step()
+    _lib.check(c.handle, L.scvx_allgather_trajectories(b.handle, C.c_void_p(out.data_ptr())), "scvx_allgather_trajectories")
+    stat = torch.zeros((1, B), dtype=torch.int32, device="cuda")
+    iters = torch.zeros((1, B), dtype=torch.int32, device="cuda")
+    _lib.check(c.handle, L.scvx_allgather_status(b.handle, C.c_void_p(stat.data_ptr()), C.c_void_p(iters.data_ptr())), "scvx_allgather_status")
+    c.synchronize()
+    assert np.array_equal(out.cpu().numpy()[0], b.trajectory_record())
+    assert np.all(iters.cpu().numpy() == 1) and np.all(stat.cpu().numpy() == 1)
+    assert L.scvx_comm_create(c.handle, ident, 0, 1) == -3     # one communicator per context
+    assert L.scvx_comm_destroy(c.handle) == 0
+    b.close(); c.close()

@@ -14,44 +14,21 @@ from oracle import dynamics as od, model, port
 
 
 def run(p, B, steps, seed, tol, nsub=10, verbose=True, max_iter=60, refine=6, f32=False, accept=1e-6, ret_traj=False):
-    par = od.Params(p)
-    K = p.K
     ic = model.disperse_ics(p, B, seed)
-    x = np.zeros((B, K + 1, 14)); u = np.zeros((B, K + 1, 3))
-    for t in range(B):
-        x[t], u[t] = model.linear_points(p, ic[t, :3], ic[t, 3:])
-    sig = np.full(B, p.tf_guess)
-    dt = 1.0 / (K + 1)
-    e, d = od.linearize(par, x, u, sig, dt, nsub)
-    rk = np.full(B, 100.0); cost = np.full(B, np.inf)
-    allm, alls, alli = [], [], []
-    for s in range(steps):
-        t0 = time.perf_counter()
-        r = port.socp(p, x, u, e, d.astype(np.float32).astype(np.float64) if f32 else d, rk, ic, tol=tol, max_iter=max_iter, refine=refine, f32=f32, accept=max(accept, tol))
-        tsolve = time.perf_counter() - t0
-        allm.append(r["merit"]); alls.append(r["status"]); alli.append(r["iters"])
-        xr = x + r["dx"]; ur = u + r["du"]; ns = sig + r["ds"]
-        xn = od.propagate(par, xr, ur, ns, dt, nsub)
-        jK = -xr[:, K, 0] + p.wNu * np.sqrt(((xr[:, 1:] - xn) ** 2).sum((1, 2)))
-        lK = -xr[:, K, 0] + p.wNu * np.sqrt((r["nu"] ** 2).sum((1, 2)))
-        with np.errstate(invalid="ignore"):
-            rho = (cost - jK) / (cost - lK)
-        ok = r["status"] != 3
-        rej = (rho < p.rh0) & ok
-        acc = ~rej & ok
-        nrk = np.where(rej | (rho < p.rh1), rk / p.alph, np.where(rho < p.rh2, rk, p.bet * rk))
-        nrk = np.where(np.isnan(rho), p.bet * rk, nrk)
-        rk = np.where(ok, nrk, rk)
-        x[acc] = xr[acc]; u[acc] = ur[acc]; sig[acc] = ns[acc]; cost[acc] = jK[acc]
-        e, d = od.linearize(par, x, u, sig, dt, nsub)
+    t0 = [time.perf_counter()]
+
+    def on_step(s, r, rej):
         if verbose:
-            m = r["merit"]
-            print("step %2d  its %.2f (max %d)  status %s  merit max %.2e p99 %.2e  <tol %.3f  rej %.2f  %.1f solves/s"
+            m = r["merit"]; t1 = time.perf_counter()
+            print("step %2d  its %.2f (max %d)  status %s  merit max %.2e p99 %.2e  <tol %.3f  rej %.2f  %.1f traj-iter/s"
                   % (s, r["iters"].mean(), r["iters"].max(), dict(zip(*np.unique(r["status"], return_counts=True))),
-                     m.max(), np.quantile(m, 0.99), (m < tol).mean(), rej.mean(), B / tsolve), flush=True)
-    m = np.concatenate(allm); st = np.concatenate(alls); it = np.concatenate(alli)
+                     m.max(), np.quantile(m, 0.99), (m < tol).mean(), rej.mean(), B / (t1 - t0[0])), flush=True)
+            t0[0] = t1
+    o = port.scvx_steps(p, ic, steps, nsub=nsub, tol=tol, accept=max(accept, tol), max_iter=max_iter, refine=refine, f32=f32,
+                        on_step=on_step)
+    m = np.concatenate(o["merit"]); st = np.concatenate(o["status"]); it = np.concatenate(o["iters"])
     if ret_traj:
-        return m, st, it, (x, u, sig, rk)
+        return m, st, it, (o["x"], o["u"], o["sigma"], o["rk"])
     return m, st, it
 
 
