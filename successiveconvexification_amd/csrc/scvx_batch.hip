@@ -338,7 +338,10 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t wo
 }
 
 // one wavefront per trajectory (large batches: the chip is filled by trajectories)
-__global__ __launch_bounds__(64, 3) void socp_kernel(ipm::Consts C, int B, size_t work_stride,
+#ifndef SCVX_K4_OCC
+#define SCVX_K4_OCC 3   // wavefronts per SIMD the single-wavefront solver is compiled for
+#endif
+__global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_kernel(ipm::Consts C, int B, size_t work_stride,
                                                   const double* __restrict__ x, const double* __restrict__ u,
                                                   const double* __restrict__ endpoint, const double* __restrict__ deriv,
                                                   const double* __restrict__ rk, const double* __restrict__ ic,
@@ -508,8 +511,8 @@ struct scvx_batch {
 
 namespace {
 
-constexpr int SOCP_WAVES4_MAX_B = 512;    // 4 wavefronts per trajectory up to here
-constexpr int SOCP_WAVES2_MAX_B = 1536;   // 2 up to here, then one
+constexpr int SOCP_WAVES4_MAX_B = 256;    // 4 wavefronts per trajectory up to here
+constexpr int SOCP_WAVES2_MAX_B = 512;    // 2 up to here, then one
 
 void rotation_between_e1(const double* b, double* q) {
     // Rotations.rotation_between([1,0,0], b) as [w,x,y,z] (initial_solve.jl:121-122)

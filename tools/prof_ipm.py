@@ -1,7 +1,7 @@
 import ctypes as C, numpy as np, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from successiveconvexification_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "libscvx_hip_prof.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "variants", "libscvx_hip_prof.so")
 from successiveconvexification_amd import sample_problems as sp
 from successiveconvexification_amd.batch import ScvxBatch
 from successiveconvexification_amd.dynamics import IntegratorCache
