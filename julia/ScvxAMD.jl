@@ -1,18 +1,20 @@
 # ScvxAMD.jl — ccall binding of libscvx_hip.so behind the reference's own API.
 #
 # NOT EXECUTED IN THE BUILD CONTAINER (no Julia there, SURVEY.md F6): this is the binding a maintainer of
-# BenChung/SuccessiveConvexification adds next to master.jl.  It keeps RocketlandDefns' types and replaces
-#   Dynamics.linearize_dynamics (dynamics.jl:321), Dynamics.predict_state (:315),
+# BenChung/SuccessiveConvexification adds next to master.jl (`include("ScvxAMD.jl")` after master.jl:137-142).
+# It keeps RocketlandDefns' types and replaces
+#   Dynamics.IntegratorCache (dynamics.jl:258), Dynamics.linearize_dynamics (:321), Dynamics.predict_state (:315),
 #   Rocketland.create_initial (rocketland.jl:34), solve_step (:226), solve_problem (:432)
-# with calls through include/scvx.h.  Every symbol used below is exercised by the Python ctypes host layer
-# (successiveconvexification_amd/_lib.py), which binds the identical C signatures.
+# with calls through include/scvx.h.  The exact ccall sequence, argument types and array layouts used below for the
+# reference's recipe (rocketland.jl:26-32, the aero problem) are replayed from C by tests/abi_harness.c on the GPU
+# and compared bit for bit with the Python host layer, which binds the identical C signatures.
 module ScvxAMD
 using ..RocketlandDefns
 using LinearAlgebra
 
 const LIB = get(ENV, "SCVX_HIP_LIB", joinpath(@__DIR__, "..", "successiveconvexification_amd", "libscvx_hip.so"))
 
-# struct scvx_problem (include/scvx.h) — field order and types must match exactly
+# struct scvx_problem (include/scvx.h) — field order and types must match exactly (tests check sizeof/offsets with gcc)
 struct CProblem
     g::Cdouble; mdry::Cdouble; mwet::Cdouble; Tmin::Cdouble; Tmax::Cdouble
     deltaMax::Cdouble; thetaMax::Cdouble; gammaGs::Cdouble; omMax::Cdouble; dpMax::Cdouble
@@ -43,21 +45,42 @@ end
 
 check(ctx, rc, what) = rc == 0 || error("$what failed ($rc): " * unsafe_string(ccall((:scvx_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx)))
 
-# IntegratorCache (dynamics.jl:258) becomes the owner of the device context
+# ---- IntegratorCache (dynamics.jl:258): owner of the device context -------------------------------------------------
 mutable struct Cache
     ctx::Ptr{Cvoid}
     problem::DescentProblem
 end
-function Cache(prob::DescentProblem; device::Int=0, npts::Int=10)
+
+# The raw table values behind AtmosphericData's interpolation objects (aerodynamics.jl:17-21): the three 181 x 61 grids
+# `reshape(col, 181, 61)` of lift_drag.csv, cos(AoA) fastest.  Interpolations.jl keeps the prefiltered coefficients, so
+# the shim reads the CSV columns the same way load_aerodata does and applies rescale_aerodata's force scalar through
+# the problem struct (force_scalar / length_scalar), exactly as the reference's generated module does.
+function upload_aero!(c::Cache, drag::Matrix{Float64}, lift::Matrix{Float64}, trq::Matrix{Float64};
+                      aoa0=-1.0, daoa=1 / 90, mach0=0.0, dmach=0.025)
+    n_aoa, n_mach = size(drag)
+    check(c.ctx, ccall((:scvx_set_aero_table, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cdouble, Cdouble, Cdouble, Cdouble),
+        c.ctx, drag, lift, trq, n_aoa, n_mach, aoa0, daoa, mach0, dmach), "scvx_set_aero_table")
+    return c
+end
+
+# IntegratorCache(prob, info, lin_mod) of the recipe: `info` and the generated module are not needed (the RHS and its
+# Jacobians are compiled into the library); `tables` = (drag, lift, trq) raw grids for an AtmosphericData problem.
+function Cache(prob::DescentProblem, info=nothing, lin_mod=nothing; device::Int=0, npts::Int=10, tables=nothing)
     ref = Ref{Ptr{Cvoid}}(C_NULL)
     cp = Ref(CProblem(prob))
     rc = ccall((:scvx_ctx_create, LIB), Cint, (Ref{CProblem}, Cint, Ref{Ptr{Cvoid}}), cp, device, ref)
     rc == 0 || error("scvx_ctx_create failed ($rc)")
     c = Cache(ref[], prob)
     check(c.ctx, ccall((:scvx_set_nsub, LIB), Cint, (Ptr{Cvoid}, Cint), c.ctx, npts), "scvx_set_nsub")
-    finalizer(x -> ccall((:scvx_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.ctx), c)
-    return c
+    if prob.aero isa AtmosphericData
+        tables === nothing && error("AtmosphericData problem: pass tables=(drag, lift, trq), the 181x61 grids of lift_drag.csv")
+        upload_aero!(c, tables...)
+    end
+    return c     # release with close(cache) AFTER every Batch made from it (no finalizers: their order is arbitrary)
 end
+Base.close(c::Cache) = (c.ctx == C_NULL || ccall((:scvx_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.ctx); c.ctx = C_NULL; nothing)
+make_dynamics_module(info) = nothing   # dynamics.jl:141: code generation is replaced by the compiled kernels
 
 # Dynamics.linearize_dynamics(states, tf_guess, base_dt, cache) -> Array{LinRes,1}   (dynamics.jl:321-334)
 function linearize_dynamics(states::Array{LinPoint,1}, tf_guess::Float64, base_dt::Float64, cache::Cache)
@@ -81,46 +104,93 @@ function predict_state(initial_state, uk, up, sigma, dt, pinfo, cache::Cache)
     return out[:, 1]
 end
 
-# The batched ProblemIteration.  B = 1 reproduces the reference's single-trajectory API.
+# ---- the batched iterate --------------------------------------------------------------------------------------------
 mutable struct Batch
     h::Ptr{Cvoid}
     cache::Cache
     B::Int
 end
-function create_initial(problem::DescentProblem, cache::Cache; ics::Union{Nothing,Matrix{Float64}}=nothing)
-    B = ics === nothing ? 1 : size(ics, 2)       # ics: 6 x B = (rIi; vIi) per trajectory
-    ref = Ref{Ptr{Cvoid}}(C_NULL)
-    check(cache.ctx, ccall((:scvx_batch_create, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), cache.ctx, B, ref), "scvx_batch_create")
-    b = Batch(ref[], cache, B)
-    finalizer(x -> ccall((:scvx_batch_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), b)
-    check(cache.ctx, ccall((:scvx_batch_init, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), b.h, ics === nothing ? C_NULL : ics), "scvx_batch_init")
-    return b
+Base.close(b::Batch) = (b.h == C_NULL || ccall((:scvx_batch_destroy, LIB), Cvoid, (Ptr{Cvoid},), b.h); b.h = C_NULL; nothing)
+
+# ProblemIteration (master.jl:122-134) with the same field names; `model` holds the device batch instead of MOI handles.
+struct Iteration
+    problem::DescentProblem
+    cache::Cache
+    sigma::Float64
+    about::Array{LinPoint,1}
+    dynam::Array{LinRes,1}
+    model::Batch
+    iter::Int64
+    rk::Float64
+    cost::Float64
 end
 
-# solve_step(iteration, cache) -> (iteration, ||nu||, dJ)     (rocketland.jl:226-321)
-function solve_step(b::Batch, cache::Cache=b.cache)
-    st = Vector{Int32}(undef, b.B); nu = Vector{Float64}(undef, b.B); dj = Vector{Float64}(undef, b.B)
-    check(cache.ctx, ccall((:scvx_solve_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}), b.h, st, nu, dj), "scvx_solve_step")
-    any(st .== 3) && error("Non-optimal result exiting")            # rocketland.jl:273-276
-    return b.B == 1 ? (b, nu[1], dj[1]) : (b, nu, dj)
-end
-
-# solve_problem(iprob, cache) -> (iteration, cnu, cdel)        (rocketland.jl:432-443)
-function solve_problem(iprob::DescentProblem, cache::Cache; ics=nothing)
-    b = create_initial(iprob, cache; ics=ics)
-    st = Vector{Int32}(undef, b.B); it = Vector{Int32}(undef, b.B); nu = Vector{Float64}(undef, b.B); dj = Vector{Float64}(undef, b.B)
-    check(cache.ctx, ccall((:scvx_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}), b.h, st, it, nu, dj), "scvx_solve")
-    return b.B == 1 ? (b, nu[1], dj[1]) : (b, nu, dj)
-end
-
-# iterate access: about::Array{LinPoint,1}, sigma  (master.jl:122-134)
-function about(b::Batch)
+# snapshot of trajectory t (1-based) of a batch as the reference's ProblemIteration
+function iteration(b::Batch, t::Int=1)
     K = b.cache.problem.K; nrec = (K + 1) * 17 + 1
     rec = Matrix{Float64}(undef, nrec, b.B)
     check(b.cache.ctx, ccall((:scvx_batch_get_trajectory, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), b.h, rec), "scvx_batch_get_trajectory")
-    map(1:b.B) do t
-        x = reshape(rec[1:14(K+1), t], 14, K + 1); u = reshape(rec[14(K+1)+1:17(K+1), t], 3, K + 1)
-        ([LinPoint(x[:, k], u[:, k]) for k = 1:K+1], rec[end, t])
-    end
+    endpoint = Array{Float64,3}(undef, 14, K, b.B); deriv = Array{Float64,4}(undef, 14, 21, K, b.B)
+    check(b.cache.ctx, ccall((:scvx_batch_get_linearization, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), b.h, endpoint, deriv), "scvx_batch_get_linearization")
+    rk = Vector{Float64}(undef, b.B); cost = Vector{Float64}(undef, b.B); it = Vector{Int32}(undef, b.B)
+    check(b.cache.ctx, ccall((:scvx_batch_get_scalars, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}), b.h, rk, cost, it), "scvx_batch_get_scalars")
+    x = reshape(rec[1:14(K+1), t], 14, K + 1); u = reshape(rec[14(K+1)+1:17(K+1), t], 3, K + 1)
+    Iteration(b.cache.problem, b.cache, rec[end, t],
+              [LinPoint(x[:, k], u[:, k]) for k = 1:K+1], [LinRes(endpoint[:, k, t], deriv[:, :, k, t]) for k = 1:K],
+              b, it[t], rk[t], cost[t])
 end
+
+# create_initial(problem, cache) -> ProblemIteration            (rocketland.jl:34-39); ics: 6 x B = (rIi; vIi) per trajectory
+function create_batch(problem::DescentProblem, cache::Cache; ics::Union{Nothing,Matrix{Float64}}=nothing)
+    B = ics === nothing ? 1 : size(ics, 2)
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    check(cache.ctx, ccall((:scvx_batch_create, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), cache.ctx, B, ref), "scvx_batch_create")
+    b = Batch(ref[], cache, B)
+    check(cache.ctx, ccall((:scvx_batch_init, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), b.h, ics === nothing ? C_NULL : ics), "scvx_batch_init")
+    return b
+end
+create_initial(problem::DescentProblem, cache::Cache) = iteration(create_batch(problem, cache))
+
+const STATUS_NAME = Dict(3 => "SLOW_PROGRESS", 4 => "NUMERICAL_ERROR")
+
+# one solve_step of every trajectory of a batch: (status, ||nu||, dJ) vectors
+function step!(b::Batch)
+    st = Vector{Int32}(undef, b.B); nu = Vector{Float64}(undef, b.B); dj = Vector{Float64}(undef, b.B)
+    check(b.cache.ctx, ccall((:scvx_solve_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}), b.h, st, nu, dj), "scvx_solve_step")
+    return st, nu, dj
+end
+
+# solve_step(iteration, cache) -> (ProblemIteration, ||nu||, dJ)     (rocketland.jl:226-321)
+function solve_step(iter::Iteration, cache::Cache=iter.cache)
+    st, nu, dj = step!(iter.model)
+    st[1] in (3, 4) && error("Non-optimal result $(STATUS_NAME[st[1]]) exiting")   # rocketland.jl:273-276
+    return iteration(iter.model), nu[1], dj[1]
+end
+
+# solve_problem(iprob, cache) -> (ProblemIteration, cnu, cdel)        (rocketland.jl:432-443)
+function solve_problem(iprob::DescentProblem, cache::Cache)
+    prob = create_initial(iprob, cache)
+    cnu = Inf; cdel = Inf; iter = 1
+    while (iprob.nuTol < cnu || iprob.delTol < cdel) && iter < iprob.imax
+        prob, cnu, cdel = solve_step(prob, cache)
+        iter = iter + 1
+    end
+    return prob, cnu, cdel
+end
+
+# batched solve_problem (new): every trajectory until converged, failed or imax; returns (batch, status, iters, nu, dJ)
+function solve_batch(iprob::DescentProblem, cache::Cache, ics::Matrix{Float64})
+    b = create_batch(iprob, cache; ics=ics)
+    st = Vector{Int32}(undef, b.B); it = Vector{Int32}(undef, b.B); nu = Vector{Float64}(undef, b.B); dj = Vector{Float64}(undef, b.B)
+    check(cache.ctx, ccall((:scvx_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}), b.h, st, it, nu, dj), "scvx_solve")
+    return b, st, it, nu, dj
+end
+
+# multi-GPU (one Julia process per GPU): rank 0 draws the id, the host ships its 128 bytes (Distributed / MPI.jl / a file)
+unique_id() = (id = Vector{UInt8}(undef, 128); ccall((:scvx_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id) == 0 || error("RCCL unavailable"); id)
+comm_create!(c::Cache, id::Vector{UInt8}, rank::Int, world::Int) =
+    check(c.ctx, ccall((:scvx_comm_create, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), c.ctx, id, rank, world), "scvx_comm_create")
+# out_dev: device pointer to world x B x ((K+1)*17+1) doubles (e.g. an AMDGPU.jl ROCArray)
+allgather_trajectories!(b::Batch, out_dev::Ptr{Cdouble}) =
+    check(b.cache.ctx, ccall((:scvx_allgather_trajectories, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), b.h, out_dev), "scvx_allgather_trajectories")
 end

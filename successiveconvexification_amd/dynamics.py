@@ -50,6 +50,10 @@ class IntegratorCache:
             _lib.check(h, self._L.scvx_set_aero_table(h, _p(d), _p(l), _p(t), na, nm, a.aoa0, a.daoa, a.mach0, a.dmach),
                        "scvx_set_aero_table")
 
+    def cproblem(self):
+        """The flat struct scvx_problem this context was created from (what a ccall caller passes by pointer)."""
+        return self._c_prob
+
     def set_npts(self, npts: int):
         _lib.check(self.handle, self._L.scvx_set_nsub(self.handle, int(npts)), "scvx_set_nsub")
 

@@ -1,0 +1,103 @@
+"""The Julia binding's use of the C ABI, executed without Julia: tests/abi_harness.c replays the ccall sequence of
+julia/ScvxAMD.jl on the reference's recipe (rocketland.jl:26-32, the aero problem) and must reproduce the Python-driven
+run bit for bit (same library, same kernels, same data)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "successiveconvexification_amd")
+SRC = os.path.join(ROOT, "tests", "abi_harness.c")
+
+
+def _compile(tmp_path, link=True):
+    exe = str(tmp_path / "abi_harness")
+    cmd = ["gcc", "-O1", "-Wall", "-Wextra", "-Werror", "-std=c11", "-I", os.path.join(ROOT, "include"), SRC]
+    cmd += ["-o", exe, "-L", PKG, "-l:libscvx_hip.so", "-Wl,-rpath," + PKG] if link else ["-c", "-o", exe + ".o"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_harness_compiles_against_the_header(tmp_path):
+    """-m "not gpu": the harness is valid C against include/scvx.h (prototypes, struct, constants), warnings as errors."""
+    _compile(tmp_path, link=False)
+
+
+def test_julia_shim_struct_matches_header():
+    """julia/ScvxAMD.jl's CProblem lists the fields of struct scvx_problem in the same order (names and multiplicity)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "scvx.h")).read()
+    body = hdr[hdr.index("typedef struct scvx_problem {"):hdr.index("} scvx_problem;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    hfields = []
+    for decl in re.findall(r"(?:double|int32_t)\s+([^;]+);", body):
+        for name in decl.split(","):
+            m = re.match(r"\s*(\w+)(?:\[(\d+)\])?", name)
+            hfields.append((m.group(1), int(m.group(2) or 1)))
+    jl = open(os.path.join(ROOT, "julia", "ScvxAMD.jl")).read()
+    sb = jl[jl.index("struct CProblem"):jl.index("\nend", jl.index("struct CProblem"))]
+    jfields = []
+    for name, typ in re.findall(r"(\w+)::(\w+(?:\{\d+,\w+\})?)", sb):
+        n = re.match(r"NTuple\{(\d+),", typ)
+        jfields.append((name, int(n.group(1)) if n else 1))
+    assert jfields == hfields
+
+
+@pytest.mark.gpu
+def test_harness_replays_the_julia_call_sequence_bit_for_bit(tmp_path, aero_tables):
+    from successiveconvexification_amd import _lib, sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.defns import AtmosphericData
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    exe = _compile(tmp_path)
+    d, l, t = aero_tables
+    prob = sp.base_prob_aero_scaled(AtmosphericData(d, l, t))
+    K, nsub, nstep = prob.K, 10, 2
+    cache = IntegratorCache(prob, npts=nsub)
+    cp = cache.cproblem()                       # the flat struct the Python layer hands to scvx_ctx_create
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(bytes(cp))
+        f.write(np.array([d.shape[1], d.shape[0], nsub, nstep], np.int32).tobytes())   # tables are [n_mach][n_aoa], AoA fastest
+        f.write(np.array([-1.0, 1.0 / 90.0, 0.0, 0.025]).tobytes())
+        for tab in (d, l, t):
+            f.write(np.ascontiguousarray(tab, np.float64).tobytes())
+    env = dict(os.environ)
+    r = subprocess.run([exe, fin, fout], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = np.fromfile(fout)
+    nrec = (K + 1) * 17 + 1
+    per_iter = nrec + K * 14 + K * 294 + 3
+    assert out.size == per_iter * (nstep + 1) + 3 * nstep + K * 14 + K * 294 + 14
+
+    b = ScvxBatch(cache, 1).init(None)
+
+    def expect():
+        e, dd = b.linearization()
+        rk, cost, it = b.scalars()
+        return np.concatenate([b.trajectory_record()[0], e.ravel(), dd.ravel(), [rk[0], cost[0], float(it[0])]])
+    pos = 0
+    ref = expect()
+    assert np.array_equal(out[pos:pos + per_iter], ref, equal_nan=True)
+    pos += per_iter
+    for s in range(nstep):
+        st, nu, dj = b.solve_step()
+        ref = expect()
+        assert np.array_equal(out[pos:pos + per_iter], ref, equal_nan=True), s
+        pos += per_iter
+        assert np.array_equal(out[pos:pos + 3], [float(st[0]), nu[0], dj[0]], equal_nan=True)
+        pos += 3
+    # Dynamics.linearize_dynamics / predict_state through the host entry points
+    from successiveconvexification_amd.dynamics import linearize_batch, propagate_batch
+    x, u, s = b.trajectory()
+    e2, d2 = linearize_batch(cache, x, u, s, 1.0 / (K + 1))
+    assert np.array_equal(out[pos:pos + K * 14], e2.ravel()); pos += K * 14
+    assert np.array_equal(out[pos:pos + K * 294], d2.ravel()); pos += K * 294
+    xs = np.zeros((1, 2, 14)); xs[0, 0] = x[0, 3]
+    xp = propagate_batch(cache, xs, u[:, 3:5], s, 1.0 / (K + 1))
+    assert np.array_equal(out[pos:pos + 14], xp[0, 0])
+    b.close(); cache.close()
