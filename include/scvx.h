@@ -50,6 +50,11 @@ extern "C" {
 #define SCVX_ST_SOLVER 3      /* conic solver did not reach tolerance        (rocketland.jl:273-276) */
 #define SCVX_ST_NONFINITE 4   /* NaN/Inf encountered                                              */
 
+/* model_flags: enforce the dynamic-pressure limit 1/2 rho |v_k|^2 <= dpMax at nodes 1..K as the second-order cone
+ * |v_k| <= sqrt(2 dpMax / rho) (fields master.jl:27,30; the constraint is a "todo" at rocketland.jl:211-212).  The
+ * initial velocity must satisfy it. */
+#define SCVX_MODEL_DPMAX 1
+
 /* Flat image of DescentProblem (master.jl:17-71) + the aero scalars of AtmosphericData (master.jl:10-16).
  * Angles in degrees exactly as the reference stores them.  jB is column-major 3x3. */
 typedef struct scvx_problem {
@@ -66,7 +71,7 @@ typedef struct scvx_problem {
     double force_scalar, length_scalar; /* AtmosphericData scalars; ignored when aero_kind == 0 */
     int32_t K, imax;
     int32_t aero_kind; /* 0 = ExoatmosphericData, 1 = AtmosphericData */
-    int32_t reserved;
+    int32_t model_flags; /* SCVX_MODEL_* bits: constraints the reference sketches but never wired up; 0 = the reference's model */
 } scvx_problem;
 
 /* Tunables of the batched conic solver that replaces MOI.optimize! (rocketland.jl:271): a structure-

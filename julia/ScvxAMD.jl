@@ -27,20 +27,20 @@ struct CProblem
     wNu::Cdouble; wID::Cdouble; wDS::Cdouble; wCst::Cdouble; wTviol::Cdouble; nuTol::Cdouble; delTol::Cdouble; tf_guess::Cdouble
     ri::Cdouble; rh0::Cdouble; rh1::Cdouble; rh2::Cdouble; alph::Cdouble; bet::Cdouble
     force_scalar::Cdouble; length_scalar::Cdouble
-    K::Int32; imax::Int32; aero_kind::Int32; reserved::Int32
+    K::Int32; imax::Int32; aero_kind::Int32; model_flags::Int32
 end
 
 t3(v) = (Float64(v[1]), Float64(v[2]), Float64(v[3]))
 t4(v) = (Float64(v[1]), Float64(v[2]), Float64(v[3]), Float64(v[4]))
 
-function CProblem(p::DescentProblem)
+function CProblem(p::DescentProblem; model_flags::Integer=0)   # model_flags = 1: enforce dpMax (SCVX_MODEL_DPMAX)
     aero = p.aero isa AtmosphericData
     CProblem(p.g, p.mdry, p.mwet, p.Tmin, p.Tmax, p.deltaMax, p.thetaMax, p.gammaGs, p.omMax, p.dpMax,
              Tuple(Float64.(vec(p.jB))), p.alpha, p.rho, p.sos, t3(p.rTB), t3(p.rFB), t3(p.rIi), t3(p.rIf), t3(p.vIi), t3(p.vIf),
              t4(p.qBIi), t4(p.qBIf), t3(p.wBi), t3(p.wBf),
              p.wNu, p.wID, p.wDS, p.wCst, p.wTviol, p.nuTol, p.delTol, p.tf_guess, p.ri, p.rh0, p.rh1, p.rh2, p.alph, p.bet,
              aero ? p.aero.force_scalar : 1.0, aero ? p.aero.length_scalar : 1.0,
-             Int32(p.K), Int32(p.imax), Int32(aero ? 1 : 0), Int32(0))
+             Int32(p.K), Int32(p.imax), Int32(aero ? 1 : 0), Int32(model_flags))
 end
 
 check(ctx, rc, what) = rc == 0 || error("$what failed ($rc): " * unsafe_string(ccall((:scvx_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx)))

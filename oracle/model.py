@@ -77,6 +77,7 @@ class DescentProblem:
     alph: float = 2.0
     bet: float = 3.2
     sos: float = 5.0
+    enforce_dp: bool = False   # build extension: enforce 1/2 rho |v|^2 <= dpMax (the reference leaves it as a todo)
 
 
 def normalize_problem(dp: DescentProblem) -> DescentProblem:

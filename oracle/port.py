@@ -14,7 +14,7 @@ class Consts(C.Structure):
                 ("tol", C.c_double), ("accept", C.c_double),
                 ("itan", C.c_double), ("sqcm", C.c_double), ("icos", C.c_double), ("Tmax", C.c_double),
                 ("Tmin", C.c_double), ("omMax", C.c_double), ("mdry", C.c_double), ("wNu", C.c_double),
-                ("mwet", C.c_double),
+                ("mwet", C.c_double), ("vmax", C.c_double),
                 ("rIf", C.c_double * 3), ("vIf", C.c_double * 3), ("qBIf", C.c_double * 4),
                 ("wBi", C.c_double * 3), ("wBf", C.c_double * 3)]
 
@@ -26,6 +26,7 @@ def consts(p: DescentProblem, tol=1e-8, max_iter=60, refine=6, accept=1e-6) -> C
     c.sqcm = np.sqrt((1 - np.cos(np.radians(p.thetaMax))) / 2)  # :64
     c.icos = 1.0 / np.cos(np.radians(p.deltaMax))      # :65
     c.Tmax, c.Tmin, c.omMax, c.mdry, c.wNu, c.mwet = p.Tmax, p.Tmin, p.omMax, p.mdry, p.wNu, p.mwet
+    c.vmax = float(np.sqrt(2.0 * p.dpMax / p.rho)) if getattr(p, "enforce_dp", False) else 0.0
     c.rIf[:] = list(p.rIf); c.vIf[:] = list(p.vIf); c.qBIf[:] = list(p.qBIf)
     c.wBi[:] = list(p.wBi); c.wBf[:] = list(p.wBf)
     return c

@@ -125,7 +125,7 @@ static int port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, cons
                      int nthreads) {
     const int K = C->K;
     scvx::ipm::Layout L;
-    L.init(K);
+    L.init(K, C->vmax > 0.0);
     const size_t nw = L.work_doubles();
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel

@@ -168,5 +168,14 @@ def build(p: DescentProblem, xbar, ubar, endpoint, deriv, rk):
         soc([ix.ang_sp_help[k]] + list(ix.xv[11:14, k]))                                 # :165-167
     for k in range(K + 1):
         soc([ix.mtk[k]] + list(ix.uv[:, k]))                                             # :190-192
+    # dynamic pressure 1/2 rho |v_k|^2 <= dpMax, k = 1..K, as the cone (vmax; v_k) -- fields master.jl:27,30, constraint a
+    # "todo" at rocketland.jl:211-212; only when the problem enables it (build extension)
+    if getattr(p, "enforce_dp", False):
+        vmax = float(np.sqrt(2.0 * p.dpMax / p.rho))
+        for k in range(K):
+            L.add([], [], vmax)
+            for i in range(4, 7):
+                L.add([ix.xv[i, k]], [-1.0], 0.0)
+            q.append(4)
     G, h = L.mat()
     return c, A, b, G, h, l, q, ix

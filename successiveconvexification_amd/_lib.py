@@ -31,7 +31,7 @@ class ScvxProblem(C.Structure):
         ("ri", C.c_double), ("rh0", C.c_double), ("rh1", C.c_double), ("rh2", C.c_double),
         ("alph", C.c_double), ("bet", C.c_double),
         ("force_scalar", C.c_double), ("length_scalar", C.c_double),
-        ("K", C.c_int32), ("imax", C.c_int32), ("aero_kind", C.c_int32), ("reserved", C.c_int32),
+        ("K", C.c_int32), ("imax", C.c_int32), ("aero_kind", C.c_int32), ("model_flags", C.c_int32),
     ]
 
 

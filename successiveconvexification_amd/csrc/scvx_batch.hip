@@ -36,7 +36,7 @@ namespace scvx {
 // only).  A pointer carried in the executor object is reloaded from memory in each non-inlined routine, loses its
 // address space, and every LDS access becomes a flat_load/flat_store that also waits on the global loads and
 // stores in flight (vmcnt) — which serialises the tile arithmetic behind the HBM traffic it is meant to overlap.
-__shared__ __attribute__((aligned(16))) double g_socp_lds[1536];
+__shared__ __attribute__((aligned(16))) double g_socp_lds[1552];
 
 struct WaveEx {
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
@@ -662,13 +662,16 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     C.sqcm = std::sqrt((1.0 - std::cos(p.thetaMax * d2r)) / 2.0);   // :64
     C.icos = 1.0 / std::cos(p.deltaMax * d2r);                      // :65
     C.Tmax = p.Tmax; C.Tmin = p.Tmin; C.omMax = p.omMax; C.mdry = p.mdry; C.wNu = p.wNu; C.mwet = p.mwet;
+    // dynamic pressure 1/2 rho |v|^2 <= dpMax (master.jl:27,30 carry the fields, rocketland.jl:211 leaves the constraint
+    // as a todo): enforced only when the problem asks for it
+    C.vmax = (p.model_flags & SCVX_MODEL_DPMAX) ? std::sqrt(2.0 * p.dpMax / p.rho) : 0.0;
     for (int i = 0; i < 3; i++) { C.rIf[i] = p.rIf[i]; C.vIf[i] = p.vIf[i]; C.wBi[i] = p.wBi[i]; C.wBf[i] = p.wBf[i]; }
     for (int i = 0; i < 4; i++) C.qBIf[i] = p.qBIf[i];
     scvx::TrParams& T = b->tr;
     T.wNu = p.wNu; T.rh0 = p.rh0; T.rh1 = p.rh1; T.rh2 = p.rh2; T.alph = p.alph; T.bet = p.bet; T.ri = p.ri;
     T.nuTol = p.nuTol; T.delTol = p.delTol; T.K = K; T.imax = p.imax;
     scvx::ipm::Layout L;
-    L.init(K);
+    L.init(K, C.vmax > 0.0);
     b->work_stride = (L.work_doubles() + 7) & ~(size_t)7;
     const size_t nB = (size_t)B;
     int rc = 0;

@@ -11,7 +11,8 @@
 //
 // Reduced variables  w = (dx[K+1][14], du[K+1][3], nu[K][14], s, tnu, ttr, ts)   ("var vector", NV)
 // Cone vector layout ("cone vector", NC):
-//     gs[K][3] tilt[K][3] rate[K][4] mass[K] tb[K+1][4] tc[K+1][4] lb[K+1] nu[14K+1] tr[17(K+1)+1] sg[2] rk[1]
+//     gs[K][3] tilt[K][3] rate[K][4] mass[K] tb[K+1][4] tc[K+1][4] lb[K+1] dp[ndp][4] nu[14K+1] tr[17(K+1)+1] sg[2] rk[1]
+//     (dp: the optional dynamic-pressure cones, ndp = K when Consts::vmax > 0, else 0)
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -118,6 +119,7 @@ struct Consts {
     int K, max_iter, refine, pad;
     double tol, accept;   // accept: acceptance band of a floor-limited iterate (status 4), >= tol
     double itan, sqcm, icos, Tmax, Tmin, omMax, mdry, wNu, mwet;
+    double vmax;   // dynamic-pressure limit |v_k| <= sqrt(2 dpMax / rho) (master.jl:27,30; 0 = not enforced, as in the reference)
     double rIf[3], vIf[3], qBIf[4], wBi[3], wBf[3];
 };
 
@@ -127,13 +129,19 @@ struct Consts {
 enum { LINV_SZ = 105 };
 SCVX_HD int linv_row(int i) { return i < 7 ? 15 * i : 15 * (13 - i) + (14 - i); }
 
+// compact per-node inverse of the x-block of Hb: [hm | Hr 3x3 | Hv 3x3 | hq | Hq34 2x2 | Hw 3x3] = 33 doubles
+// (Hv is a multiple of the identity unless the dynamic-pressure cone is enforced); NODE_SZ adds the 3x3 u-block
+enum { HX_M = 0, HX_R = 1, HX_V = 10, HX_Q = 19, HX_Q34 = 20, HX_W = 24, HX_SZ = 33, NODE_SZ = HX_SZ + 9 };
+
 struct Layout {
     int K, nx, nu_, nloc, nv, iS, iTNU, iTTR, iTS;
-    int o_gs, o_tilt, o_rate, o_mass, o_tb, o_tc, o_lb, o_nu, o_tr, o_sg, o_rk, nc;
-    int c_gs, c_tilt, c_rate, c_mass, c_tb, c_tc, c_lb, c_nu, c_tr, c_sg, c_rk, ncones, nsmall;
+    int o_gs, o_tilt, o_rate, o_mass, o_tb, o_tc, o_lb, o_dp, o_nu, o_tr, o_sg, o_rk, nc;
+    int c_gs, c_tilt, c_rate, c_mass, c_tb, c_tc, c_lb, c_dp, c_nu, c_tr, c_sg, c_rk, ncones, nsmall;
+    int ndp;
     int ny;
-    SCVX_HD void init(int K_) {
+    SCVX_HD void init(int K_, bool with_dp = false) {
         K = K_;
+        ndp = with_dp ? K_ : 0;
         nx = 14 * (K + 1);
         nu_ = 3 * (K + 1);
         nloc = nx + nu_ + 14 * K;
@@ -141,10 +149,11 @@ struct Layout {
         nv = nloc + 4;
         ny = 14 * K;
         o_gs = 0; o_tilt = 3 * K; o_rate = 6 * K; o_mass = 10 * K; o_tb = 11 * K;
-        o_tc = o_tb + 4 * (K + 1); o_lb = o_tc + 4 * (K + 1); o_nu = o_lb + (K + 1);
+        o_tc = o_tb + 4 * (K + 1); o_lb = o_tc + 4 * (K + 1); o_dp = o_lb + (K + 1); o_nu = o_dp + 4 * ndp;
         o_tr = o_nu + 14 * K + 1; o_sg = o_tr + 17 * (K + 1) + 1; o_rk = o_sg + 2; nc = o_rk + 1;
         c_gs = 0; c_tilt = K; c_rate = 2 * K; c_mass = 3 * K; c_tb = 4 * K; c_tc = c_tb + K + 1; c_lb = c_tc + K + 1;
-        nsmall = c_lb + K + 1;
+        c_dp = c_lb + K + 1;
+        nsmall = c_dp + ndp;
         c_nu = nsmall; c_tr = nsmall + 1; c_sg = nsmall + 2; c_rk = nsmall + 3; ncones = nsmall + 4;
     }
     // doubles of per-trajectory workspace
@@ -155,7 +164,7 @@ struct Layout {
         n += (size_t)ny * 10;            // y, ry, dy, r2, cy, tmpy, tmpy2, rp, tq0, tq1
         n += (size_t)nc * 8;             // S, Z, lam, Wv, Wibz, tmpc, Wirz, sd
         n += (size_t)ncones;             // Wbeta
-        n += (size_t)(K + 1) * 25 + (size_t)(K + 1) * 9;  // hx, hu
+        n += (size_t)(K + 1) * HX_SZ + (size_t)(K + 1) * 9;  // hx, hu
         n += (size_t)K * (LINV_SZ + 196);  // Linv (packed lower triangle), Nf
         n += (size_t)K * 196;            // At: the state blocks A_k of D transposed (coalesced E' products)
         n += (size_t)ny;                 // tchain
@@ -252,13 +261,11 @@ SCVX_HD void inv2(double a, double b, double d, PO Mi) {  // [[a b],[b d]] SPD
     Mi[0] = i00 * i00 + i10 * i10; Mi[1] = Mi[2] = i10 * i11; Mi[3] = i11 * i11;
 }
 
-// compact per-node inverse of the x-block of Hb: [hm | Hr 3x3 | hv | hq | Hq34 2x2 | Hw 3x3] = 25 doubles
-enum { HX_M = 0, HX_R = 1, HX_V = 10, HX_Q = 11, HX_Q34 = 12, HX_W = 16, HX_SZ = 25 };
 template <class PH>
 SCVX_HD double hxi_entry(PH h, int a, int b) {
     if (a == 0) return b == 0 ? h[HX_M] : 0.0;
     if (a < 4) return (b >= 1 && b < 4) ? h[HX_R + 3 * (a - 1) + (b - 1)] : 0.0;
-    if (a < 7) return a == b ? h[HX_V] : 0.0;
+    if (a < 7) return (b >= 4 && b < 7) ? h[HX_V + 3 * (a - 4) + (b - 4)] : 0.0;
     if (a < 9) return a == b ? h[HX_Q] : 0.0;
     if (a < 11) return (b >= 9 && b < 11) ? h[HX_Q34 + 2 * (a - 9) + (b - 9)] : 0.0;
     return (b >= 11) ? h[HX_W + 3 * (a - 11) + (b - 11)] : 0.0;
@@ -268,7 +275,7 @@ template <class PH>
 SCVX_HD void hxi_apply(PH h, const double* x, double* y) {
     y[0] = h[HX_M] * x[0];
     for (int i = 0; i < 3; i++) y[1 + i] = h[HX_R + 3 * i] * x[1] + h[HX_R + 3 * i + 1] * x[2] + h[HX_R + 3 * i + 2] * x[3];
-    for (int i = 4; i < 7; i++) y[i] = h[HX_V] * x[i];
+    for (int i = 0; i < 3; i++) y[4 + i] = h[HX_V + 3 * i] * x[4] + h[HX_V + 3 * i + 1] * x[5] + h[HX_V + 3 * i + 2] * x[6];
     y[7] = h[HX_Q] * x[7]; y[8] = h[HX_Q] * x[8];
     y[9] = h[HX_Q34] * x[9] + h[HX_Q34 + 1] * x[10];
     y[10] = h[HX_Q34 + 2] * x[9] + h[HX_Q34 + 3] * x[10];
@@ -314,7 +321,7 @@ struct Solver {
     double cur_gate;   // max(pres, relgap) of the current iterate: refinement only pays in the endgame (dres is left out:
                        // an inaccurate solve RAISES it, and must not switch the refinement off)
 
-    SCVX_HD Solver(Ex& e, const Consts& c) : ex(e), C(c) { L.init(c.K); for (int i = 0; i < 32; i++) prof[i] = 0.0; }
+    SCVX_HD Solver(Ex& e, const Consts& c) : ex(e), C(c) { L.init(c.K, c.vmax > 0.0); for (int i = 0; i < 32; i++) prof[i] = 0.0; }
 
     SCVX_HD void carve(gptr w) {
         const int nv = L.nv, ny = L.ny, nc = L.nc, nloc = L.nloc, K = L.K;
@@ -477,6 +484,10 @@ struct Solver {
                 t[0] = af * C.sqcm; t[1] = x[9]; t[2] = x[10];
                 gptr r = out + L.o_rate + 4 * k;
                 r[0] = af * C.omMax; r[1] = x[11]; r[2] = x[12]; r[3] = x[13];
+                if (k < L.ndp) {
+                    gptr d = out + L.o_dp + 4 * k;
+                    d[0] = af * C.vmax; d[1] = x[4]; d[2] = x[5]; d[3] = x[6];
+                }
             }
             if (k >= 1) out[L.o_mass + (k - 1)] = x[0] - af * C.mdry;
             gptr tb = out + L.o_tb + 4 * k;
@@ -516,6 +527,10 @@ struct Solver {
                 gl[9] += t[1]; gl[10] += t[2];
                 cgptr r = z + L.o_rate + 4 * k;
                 gl[11] += r[1]; gl[12] += r[2]; gl[13] += r[3];
+                if (k < L.ndp) {
+                    cgptr d = z + L.o_dp + 4 * k;
+                    gl[4] += d[1]; gl[5] += d[2]; gl[6] += d[3];
+                }
             }
             cgptr tru = z + L.o_tr + 1 + L.nx + 3 * k;
             cgptr tb = z + L.o_tb + 4 * k;
@@ -593,6 +608,7 @@ struct Solver {
         each_small<1>(L.o_mass, L.c_mass, K, f);
         each_small<4>(L.o_tb, L.c_tb, 2 * (K + 1), f);      // tb, tc are adjacent
         each_small<1>(L.o_lb, L.c_lb, K + 1, f);
+        each_small<4>(L.o_dp, L.c_dp, L.ndp, f);
         if (with_sg) { each_small<2>(L.o_sg, L.c_sg, 1, f); each_small<1>(L.o_rk, L.c_rk, 1, f); }
     }
 
@@ -637,7 +653,7 @@ struct Solver {
     // cones are swept cooperatively: reductions first (their scalars enter every element), then one apply sweep.
     // a(v) / J v of a small cone are gathered straight from the variable vector (no cone-shaped temporary).
     // ------------------------------------------------------------------------------------------------
-    enum { G_GS3 = 0, G_RATE = 1, G_MASS = 2, G_T4 = 3, G_LB = 4, G_SG = 5, G_RK = 6 };
+    enum { G_GS3 = 0, G_RATE = 1, G_MASS = 2, G_T4 = 3, G_LB = 4, G_SG = 5, G_RK = 6, G_DP = 7 };
     template <int GRP, int D, class F>
     SCVX_HD void each_small_g(int off0, int c0, int n, F&& f) {
         for (int q = ex.lane(); q < n; q += ex.nlanes())
@@ -652,6 +668,7 @@ struct Solver {
         each_small_g<G_MASS, 1>(L.o_mass, L.c_mass, K, f);
         each_small_g<G_T4, 4>(L.o_tb, L.c_tb, 2 * (K + 1), f);       // tb, tc are adjacent
         each_small_g<G_LB, 1>(L.o_lb, L.c_lb, K + 1, f);
+        each_small_g<G_DP, 4>(L.o_dp, L.c_dp, L.ndp, f);
         each_small_g<G_SG, 2>(L.o_sg, L.c_sg, 1, f);
         each_small_g<G_RK, 1>(L.o_rk, L.c_rk, 1, f);
     }
@@ -686,6 +703,10 @@ struct Solver {
         } else if constexpr (GRP == G_LB) {
             cgptr du = v + L.nx + 3 * q;
             o[0] = uhat[3 * q] * du[0] + uhat[3 * q + 1] * du[1] + uhat[3 * q + 2] * du[2] - af * lb0[q];
+        } else if constexpr (GRP == G_DP) {
+            cgptr dx = v + 14 * q; cdptr xb = xbar + 14 * q;
+            o[0] = af * C.vmax;
+            for (int j = 0; j < 3; j++) o[1 + j] = af * xb[4 + j] + dx[4 + j];
         } else if constexpr (GRP == G_SG) {
             o[0] = v[L.iTS]; o[1] = v[L.iS];
         } else {
@@ -973,7 +994,7 @@ struct Solver {
     // ---- Hb^-1 on a local vector (dx, du, nu); g and out must not alias ----
     // One lane per output ROW: row j of the compact node inverse has at most three entries (hxi_apply's formulas), so
     // every lane loads three coefficients and three inputs that sit next to those of its neighbours.  (One lane per
-    // node, as build_kkt assembles the blocks, reads 51 elements at a stride of 25 doubles: no two lanes share a line.)
+    // node, as build_kkt assembles the blocks, reads 51 elements at a stride of 33 doubles: no two lanes share a line.)
     SCVX_HD_NI void Hb_inv(cgptr g, gptr out) {
         SCVX_T0();
         const int K = L.K;
@@ -982,10 +1003,10 @@ struct Solver {
                [&](int t) {
                    const int k = t / 14, j = t - 14 * k;
                    // first coefficient / first input / number of terms of row j
-                   const int hb = j == 0 ? HX_M : j < 4 ? HX_R + 3 * (j - 1) : j < 7 ? HX_V : j < 9 ? HX_Q
+                   const int hb = j == 0 ? HX_M : j < 4 ? HX_R + 3 * (j - 1) : j < 7 ? HX_V + 3 * (j - 4) : j < 9 ? HX_Q
                                   : j < 11 ? HX_Q34 + 2 * (j - 9) : HX_W + 3 * (j - 11);
-                   const int gb = j == 0 ? 0 : j < 4 ? 1 : j < 9 ? j : j < 11 ? 9 : 11;
-                   const int n = (j == 0 || (j >= 4 && j < 9)) ? 1 : (j == 9 || j == 10) ? 2 : 3;
+                   const int gb = j == 0 ? 0 : j < 4 ? 1 : j < 7 ? 4 : j < 9 ? j : j < 11 ? 9 : 11;
+                   const int n = (j == 0 || j == 7 || j == 8) ? 1 : (j == 9 || j == 10) ? 2 : 3;
                    cgptr h = hx_ + (size_t)k * HX_SZ + hb; cgptr x = g + 14 * k + gb;
                    const int i1 = n > 1 ? 1 : 0, i2 = n > 2 ? 2 : 0;
                    return D6{h[0], n > 1 ? h[i1] : 0.0, n > 2 ? h[i2] : 0.0, x[0], x[i1], x[i2]};
@@ -1223,7 +1244,16 @@ struct Solver {
                 M[5] = M[7] = h11 * v[1] * v[2];
                 M[8] = dtr + b2 + h11 * v[2] * v[2];
                 inv3(M, h + HX_R);
-                h[HX_V] = 1.0 / dtr;
+                // v block: dtr I, plus the dynamic-pressure cone (vmax; v_k) when it is enforced
+                if (k < L.ndp) {
+                    cgptr vd = Wv + L.o_dp + 4 * k;
+                    soc_w2(vd[0], vd[1] * vd[1] + vd[2] * vd[2] + vd[3] * vd[3], Wbeta[L.c_dp + k], h00, h01, h11, b2);
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++) M[3 * a + b] = h11 * vd[1 + a] * vd[1 + b] + (a == b ? dtr + b2 : 0.0);
+                    inv3(M, h + HX_V);
+                } else {
+                    h[HX_V] = h[HX_V + 4] = h[HX_V + 8] = 1.0 / dtr;
+                }
             }
             if (!last) {
                 h[HX_Q] = 1.0 / dtr;
@@ -1298,38 +1328,38 @@ struct Solver {
         double* Dt = Li + 196;          // 294  D_k tile (column-major 14x21: element (i,j) at 14 j + i)
         double* T = Dt + 294;           // 308  [TA | TBm | TBp] = [A_k Hxi_k | Bm_k Hui_k | Bp_k Hui_{k+1}], 14 x 20, row stride 22
         double* Bp = T + 308;           // 42   copy of Bp_k (column-major 14x3) kept across the D tile swap
-        double* Hh = Bp + 42;           // 68   hx_k (25) hu_k (9) | hx_{k+1} (25) hu_{k+1} (9)
-        double* Hd = Hh + 68;           // 196  dense Hxi of the node being multiplied
+        double* Hh = Bp + 42;           // 84   hx_k (33) hu_k (9) | hx_{k+1} (33) hu_{k+1} (9)
+        double* Hd = Hh + 2 * NODE_SZ;           // 196  dense Hxi of the node being multiplied
         constexpr int TS = 22;          // row stride of T (22: conflict-free fragment reads; 20 would be 2-way)
         bool ok = true;
         // All 14x14xK products below go through ex.tile_gemm: FP64 MFMA (v_mfma_f64_16x16x4) on the device — one A and
         // one B element per lane per instruction instead of 2 LDS reads per multiply-add — plain loops on the host.
         // prologue: D_0, hx_0/hu_0 -> LDS; TA_0, TBm_0
         for (int e = ex.lane(); e < 294; e += ex.nlanes()) Dt[e] = D_[e];
-        for (int e = ex.lane(); e < 34; e += ex.nlanes()) Hh[34 + e] = e < 25 ? hx_[e] : hu_[e - 25];
+        for (int e = ex.lane(); e < NODE_SZ; e += ex.nlanes()) Hh[NODE_SZ + e] = e < HX_SZ ? hx_[e] : hu_[e - HX_SZ];
         ex.sync_lds();
-        for (int e = ex.lane(); e < 196; e += ex.nlanes()) Hd[e] = hxi_entry(Hh + 34, e / 14, e % 14);
+        for (int e = ex.lane(); e < 196; e += ex.nlanes()) Hd[e] = hxi_entry(Hh + NODE_SZ, e / 14, e % 14);
         ex.sync_lds();
         ex.tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);          // TA_0 = A_0 Hxi_0
         for (int q = ex.lane(); q < 42; q += ex.nlanes()) {
             const int i = q / 3, c = q - 3 * i;
-            const double* h = Hh + 34 + 25;
+            const double* h = Hh + NODE_SZ + HX_SZ;
             T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
         }
         ex.sync_lds();
-        // the compact node inverses (34 doubles) are requested one segment ahead as well: lane e holds element e of node
-        // k + 1 while segment k - 1 is processed (register-prefetching executors have at least 34 lanes)
+        // the compact node inverses (42 doubles) are requested one segment ahead as well: lane e holds element e of node
+        // k + 1 while segment k - 1 is processed (register-prefetching executors have at least 42 lanes)
         auto node_elem = [&](int node, int e) -> double {
-            return e < 25 ? hx_[(size_t)node * HX_SZ + e] : hu_[9 * node + (e - 25)];
+            return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[9 * node + (e - HX_SZ)];
         };
         double hn = 0.0;
-        if (Ex::kPrefetchRegs > 0 && ex.lane() < 34) hn = node_elem(1, ex.lane());
+        if (Ex::kPrefetchRegs > 0 && ex.lane() < NODE_SZ) hn = node_elem(1, ex.lane());
         for (int k = 0; k < K; k++) {
             SCVX_TS(ta_);
             // prefetch the next segment's tile
             constexpr int NPRE = Ex::kPrefetchRegs;
             double hn2 = 0.0;
-            if (NPRE > 0 && ex.lane() < 34) hn2 = node_elem(k + 2 <= K ? k + 2 : K, ex.lane());
+            if (NPRE > 0 && ex.lane() < NODE_SZ) hn2 = node_elem(k + 2 <= K ? k + 2 : K, ex.lane());
             double pre[NPRE > 0 ? NPRE : 1];
             cgptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
             if (NPRE > 0) {
@@ -1337,22 +1367,22 @@ struct Solver {
                 for (int q = 0; q < NPRE; q++) { const int e = ex.lane() + ex.nlanes() * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
             }
             // node inverses: slot 0 <- slot 1 (k), slot 1 <- k+1, dense tile of k+1
-            for (int e = ex.lane(); e < 34; e += ex.nlanes()) {
+            for (int e = ex.lane(); e < NODE_SZ; e += ex.nlanes()) {
                 const double nk1 = NPRE > 0 ? hn : node_elem(k + 1, e);
-                Hh[e] = Hh[34 + e];
-                Hh[34 + e] = nk1;
+                Hh[e] = Hh[NODE_SZ + e];
+                Hh[NODE_SZ + e] = nk1;
             }
             hn = hn2;
             ex.sync_lds();
             for (int e = ex.lane(); e < 196 + 42; e += ex.nlanes()) {
                 if (e < 196) {
                     const int i = e / 14, j = e - 14 * i;
-                    const double h = hxi_entry(Hh + 34, i, j);
+                    const double h = hxi_entry(Hh + NODE_SZ, i, j);
                     Hd[e] = h;
                     M[e] = h + (i == j ? hnui_ : 0.0);   // pivot tile starts from Hxi_{k+1} + hnui I
                 } else {  // TBp_k = Bp_k Hui_{k+1}
                     const int q = e - 196, i = q / 3, c = q - 3 * i;
-                    const double* h = Hh + 34 + 25;
+                    const double* h = Hh + NODE_SZ + HX_SZ;
                     T[TS * i + 17 + c] = Dt[14 * 17 + i] * h[c] + Dt[14 * 18 + i] * h[3 + c] + Dt[14 * 19 + i] * h[6 + c];
                 }
             }
@@ -1396,7 +1426,7 @@ struct Solver {
                 ex.tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
                 for (int q = ex.lane(); q < 42; q += ex.nlanes()) {
                     const int i = q / 3, c = q - 3 * i;
-                    const double* h = Hh + 34 + 25;
+                    const double* h = Hh + NODE_SZ + HX_SZ;
                     T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
                 }
                 ex.sync_lds();

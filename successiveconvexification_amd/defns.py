@@ -84,6 +84,7 @@ class DescentProblem:
     alph: float = 2.0
     bet: float = 3.2
     sos: float = 5.0
+    model_flags: int = 0   # not a reference field: 1 (SCVX_MODEL_DPMAX) enforces the dpMax / rho constraint the reference leaves as a todo
 
     def to_c(self) -> ScvxProblem:
         s = ScvxProblem()
@@ -98,6 +99,7 @@ class DescentProblem:
             assert a.shape == (n,), name
             getattr(s, name)[:] = list(a)
         s.K, s.imax = int(self.K), int(self.imax)
+        s.model_flags = int(getattr(self, "model_flags", 0))
         if isinstance(self.aero, AtmosphericData):
             s.aero_kind = 1
             s.force_scalar, s.length_scalar = float(self.aero.force_scalar), float(self.aero.length_scalar)

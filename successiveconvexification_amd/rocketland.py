@@ -2,6 +2,7 @@
 
     create_initial(problem, cache) -> ProblemIteration            rocketland.jl:34-39
     run_iters(iprob, niters, cache) -> (trajectories, tfs)        rocketland.jl:420-430
+    plot_solution_data(ip) / dump_solution(ip, path)              rocketland.jl:454-478 (the arrays plot_solution draws)
     solve_step(iteration, cache) -> (ProblemIteration, |nu|, dJ)  rocketland.jl:226-321
     solve_problem(iprob, cache) -> (ProblemIteration, cnu, cdel)  rocketland.jl:432-443
 The recipe of rocketland.jl:26-32 reads the same here:
@@ -63,3 +64,48 @@ def run_iters(iprob: DescentProblem, niters: int, cache: IntegratorCache = None)
         tfs.append(ip.sigma)
         trjs.append(np.stack([pt.state[1:4] for pt in ip.about], axis=1))
     return trjs, tfs
+
+
+# ---- plot_solution (rocketland.jl:454-478) without a plotting library ------------------------------------------------
+def body_axis(q):
+    """Dynamics.DCM(q) * [1, 0, 0] (dynamics.jl:29-44): first column of the body->inertial rotation, q scalar-first."""
+    q0, q1, q2, q3 = (np.asarray(q, float)[..., i] for i in range(4))
+    return np.stack([1 - 2 * (q2 * q2 + q3 * q3), 2 * (q1 * q2 + q0 * q3), 2 * (q1 * q3 - q0 * q2)], axis=-1)
+
+
+def plot_solution_data(ip: ProblemIteration) -> dict:
+    """Everything Rocketland.plot_solution computes before it calls Plots.jl, under the names it uses:
+        xs [K+1][2] = (r_y, r_z), ys [K+1][2] = (r_up, r_up)      the two trajectory panels (layout = 2)
+        xlims = (tmin, tmax), pmin, pmax                           its axis limits (tmin/tmax over r_up and r_y, pmin/pmax over r_up and r_z)
+        thr [K+1] = |u| / Tmax                                      the throttle it prints
+        dp [K+1] = (C(q) e1) . v / |v|                              the cos(angle of attack) it prints per node
+        xls, yls [K+1][2][2]                                        the attitude tick of every node: from r to r + C(q) e1 / 3
+    """
+    X = np.stack([pt.state for pt in ip.about])
+    U = np.stack([pt.control for pt in ip.about])
+    up, ry, rz = X[:, 1], X[:, 2], X[:, 3]
+    dv = body_axis(X[:, 7:11])
+    v = X[:, 4:7]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        dp = np.sum(dv * v, axis=1) / np.linalg.norm(v, axis=1)
+    xls = np.stack([np.stack([ry, rz], 1), np.stack([ry + dv[:, 1] / 3, rz + dv[:, 2] / 3], 1)], axis=1)
+    yls = np.stack([np.stack([up, up], 1), np.stack([up + dv[:, 0] / 3, up + dv[:, 0] / 3], 1)], axis=1)
+    return dict(xs=np.stack([ry, rz], 1), ys=np.stack([up, up], 1),
+                xlims=(float(min(up.min(), ry.min())), float(max(up.max(), ry.max()))),
+                pmin=float(min(up.min(), rz.min())), pmax=float(max(up.max(), rz.max())),
+                thr=np.linalg.norm(U, axis=1) / ip.problem.Tmax, dp=dp, xls=xls, yls=yls, sigma=float(ip.sigma))
+
+
+def dump_solution(ip: ProblemIteration, path: str) -> str:
+    """Writes plot_solution_data(ip) to `path`: .npz (all arrays) or .csv (one row per node: k, r_up, r_y, r_z, thr, dp and
+    the attitude tick end points) -- enough to redraw the reference's figure with any tool."""
+    d = plot_solution_data(ip)
+    if path.endswith(".npz"):
+        np.savez(path, **{k: np.asarray(v) for k, v in d.items()})
+    else:
+        K1 = d["xs"].shape[0]
+        tab = np.column_stack([np.arange(K1), d["ys"][:, 0], d["xs"][:, 0], d["xs"][:, 1], d["thr"], d["dp"],
+                               d["yls"][:, 1, 0], d["xls"][:, 1, 0], d["xls"][:, 1, 1]])
+        np.savetxt(path, tab, delimiter=",", comments="",
+                   header="k,r_up,r_y,r_z,thr,cos_aoa,tick_up,tick_y,tick_z   # sigma=%.17g xlims=%s" % (d["sigma"], d["xlims"]))
+    return path

@@ -79,7 +79,7 @@ def test_product_and_oracle_problem_definitions_agree():
     from successiveconvexification_amd import sample_problems as sp
     po, pp = model.base_prob_scaled(), sp.base_prob_scaled
     for f in fields(po):
-        if f.name == "aero":
+        if f.name in ("aero", "enforce_dp"):   # enforce_dp (oracle) = model_flags bit 0 (product): build extension
             continue
         a, b = getattr(po, f.name), getattr(pp, f.name)
         assert np.all(np.asarray(a) == np.asarray(b)), f.name
@@ -138,3 +138,37 @@ def test_bench_roofline_byte_model_matches_survey():
     assert bench.HBM_PEAK == 8.0e12
     t = bench.k1_measured_traffic(8192)
     assert t is None or 0.9 < t["bytes"] / (bench.k1_alg_bytes(50) * 8192) < 1.2  # PMC: no wasted re-reads
+
+
+def test_plot_solution_data_matches_the_reference_formulas(tmp_path):
+    """rocketland.jl:454-478 restated literally (per node, scalar code) against the vectorised dump."""
+    from successiveconvexification_amd import rocketland as R, sample_problems as sp
+    from successiveconvexification_amd.defns import LinPoint, ProblemIteration
+    rng = np.random.default_rng(3)
+    about = []
+    for k in range(7):
+        x = rng.normal(size=14)
+        x[7:11] /= np.linalg.norm(x[7:11])
+        about.append(LinPoint(x, rng.normal(size=3)))
+    ip = ProblemIteration(sp.base_prob_scaled, None, 1.25, about, [], None, 3, 1.0, 0.0)
+    d = R.plot_solution_data(ip)
+
+    def DCM(q):  # dynamics.jl:29-44
+        q0, q1, q2, q3 = q
+        return np.array([[1 - 2 * (q2**2 + q3**2), 2 * (q1 * q2 - q0 * q3), 2 * (q1 * q3 + q0 * q2)],
+                         [2 * (q1 * q2 + q0 * q3), 1 - 2 * (q1**2 + q3**2), 2 * (q2 * q3 - q0 * q1)],
+                         [2 * (q1 * q3 - q0 * q2), 2 * (q2 * q3 + q0 * q1), 1 - 2 * (q1**2 + q2**2)]])
+    for k, pt in enumerate(about):
+        dv = DCM(pt.state[7:11]) @ np.array([1.0, 0, 0])
+        assert d["dp"][k] == pytest.approx(dv @ pt.state[4:7] / np.linalg.norm(pt.state[4:7]), rel=1e-13)
+        assert d["thr"][k] == pytest.approx(np.linalg.norm(pt.control) / sp.base_prob_scaled.Tmax, rel=1e-13)
+        assert np.allclose(d["xls"][k], [[pt.state[2], pt.state[3]], [pt.state[2] + dv[1] / 3, pt.state[3] + dv[2] / 3]], rtol=0, atol=1e-15)
+        assert np.allclose(d["yls"][k], [[pt.state[1], pt.state[1]], [pt.state[1] + dv[0] / 3, pt.state[1] + dv[0] / 3]], rtol=0, atol=1e-15)
+        assert np.array_equal(d["xs"][k], [pt.state[2], pt.state[3]]) and np.array_equal(d["ys"][k], [pt.state[1], pt.state[1]])
+    up = np.array([pt.state[1] for pt in about]); ry = np.array([pt.state[2] for pt in about])
+    assert d["xlims"] == (min(up.min(), ry.min()), max(up.max(), ry.max()))
+    f = R.dump_solution(ip, str(tmp_path / "sol.csv"))
+    tab = np.loadtxt(f, delimiter=",", skiprows=1)
+    assert tab.shape == (7, 9) and np.array_equal(tab[:, 4], d["thr"])
+    z = np.load(R.dump_solution(ip, str(tmp_path / "sol.npz")))
+    assert np.array_equal(z["dp"], d["dp"]) and float(z["sigma"]) == 1.25

@@ -573,3 +573,41 @@ def test_native_rccl_allgather_world_of_one():
     assert L.scvx_comm_create(c.handle, ident, 0, 1) == -3     # one communicator per context
     assert L.scvx_comm_destroy(c.handle) == 0
     b.close(); c.close()
+
+
+def test_dynamic_pressure_cone_on_device_matches_independent_oracle():
+    """SCVX_MODEL_DPMAX: the optional cone |v_k| <= sqrt(2 dpMax / rho) on the device vs the independent oracle (explicit
+    rows in oracle/socp.py), binding on a run of nodes; two solve_steps keep it satisfied."""
+    from dataclasses import replace
+    from oracle import model, scvx as oscvx
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    p0 = model.base_prob_scaled()
+    vm = 0.2255
+    dpmax = 0.5 * p0.rho * vm**2
+    po = replace(p0, enforce_dp=True, dpMax=dpmax)
+    pp = replace(sp.base_prob_scaled, dpMax=dpmax, model_flags=1)
+    c = IntegratorCache(pp, npts=10)
+    b = ScvxBatch(c, 2).init(None)
+    xb, ub, sg = b.trajectory()
+    x, u, snew, nu = b.socp_solve()
+    st, its, merit, pobj = b.solver_stats()
+    assert np.all(st == 0) and merit.max() < 1e-8
+    it = oscvx.create_initial(po, 10)
+    sol, ix = oscvx.solve_socp(it)
+    z = sol.x
+    assert np.abs(x[0] - z[ix.xv].T).max() < 2e-5 and np.abs(u[0] - z[ix.uv].T).max() < 2e-5
+    speed = np.linalg.norm(x[0, :po.K, 4:7], axis=1)
+    assert speed.max() < vm + 1e-8 and (speed > vm - 1e-6).sum() >= 10
+    for _ in range(2):
+        stt, _, _ = b.solve_step()
+        assert np.all((stt == 1) | (stt == 2))
+    xs, _, _ = b.trajectory()
+    assert np.linalg.norm(xs[:, :po.K, 4:7], axis=-1).max() < vm + 1e-7
+    # flag off: the same problem data gives the unconstrained optimum (faster than vm)
+    c0 = IntegratorCache(replace(sp.base_prob_scaled, dpMax=dpmax), npts=10)
+    b0 = ScvxBatch(c0, 1).init(None)
+    x0, _, _, _ = b0.socp_solve()
+    assert np.linalg.norm(x0[0, :po.K, 4:7], axis=1).max() > vm + 1e-3
+    b.close(); c.close(); b0.close(); c0.close()

@@ -109,3 +109,29 @@ def test_scvx_loop_reproduces_reference_logic():
     assert it1.sigma == pytest.approx(it.sigma + it1.last["dsr"])
     assert cnu == pytest.approx(np.linalg.norm(it1.last["nur"]))
     assert it1.cost == pytest.approx(it1.last["jK"])
+
+
+def test_dynamic_pressure_cone_twin_matches_independent_oracle():
+    """Build extension: 1/2 rho |v_k|^2 <= dpMax as the cone (vmax; v_k), k = 1..K.  The reference
+    carries dpMax / rho (master.jl:27,30) and leaves the constraint as a todo (rocketland.jl:211-212).  With vmax set
+    between the initial speed and the unconstrained peak the cone binds on a run of nodes; the structured solver (the
+    device core on the host) and the independent IPM on the explicit rows agree, and with the flag off nothing changes."""
+    from dataclasses import replace
+    from oracle import model, port, scvx as oscvx
+    p0 = model.base_prob_scaled()
+    vm = 0.2255                                   # |vIi| = 0.2236 < vm < 0.2318 = unconstrained peak speed
+    p = replace(p0, enforce_dp=True, dpMax=0.5 * p0.rho * vm**2)
+    it = oscvx.create_initial(p, 10)
+    sol, ix = oscvx.solve_socp(it)
+    assert sol.status == "optimal"
+    speed = np.linalg.norm(sol.x[ix.xv].T[:p.K, 4:7], axis=1)
+    assert speed.max() < vm + 1e-8 and (speed > vm - 1e-6).sum() >= 10      # the cone is active on many nodes
+    tw = port.socp(p, it.x[None], it.u[None], it.endpoint[None], it.deriv[None], 100.0)
+    assert tw["status"][0] == 0 and tw["merit"][0] < 1e-8
+    x, u = it.x + tw["dx"][0], it.u + tw["du"][0]
+    assert np.linalg.norm(x[:p.K, 4:7], axis=1).max() < vm + 1e-8
+    assert np.abs(x - sol.x[ix.xv].T).max() < 2e-5 and np.abs(u - sol.x[ix.uv].T).max() < 2e-5
+    # unconstrained optimum really violates it
+    it0 = oscvx.create_initial(p0, 10)
+    tw0 = port.socp(p0, it0.x[None], it0.u[None], it0.endpoint[None], it0.deriv[None], 100.0)
+    assert np.linalg.norm((it0.x + tw0["dx"][0])[:p.K, 4:7], axis=1).max() > vm + 1e-3
