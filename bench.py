@@ -368,6 +368,31 @@ def main():
             line["roofline_k1_by_npts"] = k1_by_npts(cache, batch, torch, K, B, args.npts)
         if world == 1 and not args.no_traj_check:
             line["traj_linf_vs_oracle"] = traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts)
+        if world == 1 and not args.no_traj_check:
+            # NOT the headline: the same loop with scvx_solver_opts.reuse_inactive_tr (a conic solve whose optimum is
+            # provably unchanged after a rejected step is skipped).  Reported beside `value`, never instead of it.
+            batch.close()
+            b2 = ScvxBatch(cache, B, reuse_inactive_tr=True).init(shard.ic)
+            cnt = [0]
+
+            def run2(n):
+                for _ in range(n):
+                    if not args.no_reset and cnt[0] and cnt[0] % period == 0:
+                        b2.reset()
+                    b2.solve_step_async()
+                    cnt[0] += 1
+            run2(args.warmup)
+            cache.synchronize()
+            t2 = time.perf_counter()
+            run2(args.steps)
+            cache.synchronize()
+            t2 = time.perf_counter() - t2
+            line["with_reuse_inactive_tr"] = {
+                "value": B * args.steps / t2, "unit": "traj-iter/s", "ms_per_step": 1e3 * t2 / args.steps,
+                "note": "opt-in shortcut, off in the headline: after a rejected step the conic solve is skipped when the optimum "
+                        "just found lies strictly inside the halved radius (it is then the new optimum too); every solve_step "
+                        "still runs its propagation, trust-region test and re-linearisation"}
+            b2.close()
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.npts, args.seed, period)
         print(json.dumps(line), flush=True)

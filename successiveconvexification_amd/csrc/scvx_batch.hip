@@ -308,10 +308,19 @@ struct BlockEx {
 template <class Ex>
 __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t work_stride, const double* x, const double* u,
                                           const double* endpoint, const double* deriv, const double* rk, const double* ic,
-                                          const int* active, double* work, double* sol, double* nu, double* info) {
+                                          const int* active, double* work, double* sol, double* nu, double* info,
+                                          const int* step_status, double* ttr) {
     const int b = blockIdx.x;
     if (b >= B) return;
     if (active && !active[b]) return;
+    // Opt-in shortcut (scvx_solver_opts.reuse_inactive_tr): after a REJECTED step the subproblem is the same one with a
+    // halved radius (rocketland.jl:299-301 keeps about / dynam).  If the optimum just found lies strictly inside the new
+    // radius, the radius row is inactive with a zero multiplier and that optimum still satisfies every KKT condition of
+    // the new subproblem: the solve would return it again.  sol / nu / info are left as they are; iters = 0 marks it.
+    if (C.pad && step_status[b] == SCVX_ST_REJECTED && ttr[b] <= (1.0 - 1e-6) * rk[b]) {
+        if (threadIdx.x == 0) info[4 * b + 1] = 0.0;
+        return;
+    }
     const int K = C.K;
     Ex ex;
     ipm::Solver<Ex> S(ex, C);
@@ -331,6 +340,7 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t wo
         info[4 * b + 1] = (double)r.iters;
         info[4 * b + 2] = r.merit;
         info[4 * b + 3] = r.pobj;
+        ttr[b] = S.V[S.L.iTTR];   // the trust-region norm bound at the optimum (Jtr of build_model)
 #if defined(SCVX_IPM_PROF)
         if (b == 0) for (int i = 0; i < 32; i++) work[i] = S.prof[i];  // diagnostic build: section cycles of trajectory 0
 #endif
@@ -347,8 +357,9 @@ __global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_kernel(ipm::Consts C, in
                                                   const double* __restrict__ rk, const double* __restrict__ ic,
                                                   const int* __restrict__ active, double* __restrict__ work,
                                                   double* __restrict__ sol, double* __restrict__ nu,
-                                                  double* __restrict__ info) {
-    socp_body<WaveEx>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info);
+                                                  double* __restrict__ info, const int* __restrict__ step_status,
+                                                  double* __restrict__ ttr) {
+    socp_body<WaveEx>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr);
 }
 
 // NW wavefronts per trajectory (batches that cannot fill the chip with one wavefront each)
@@ -359,8 +370,9 @@ __global__ __launch_bounds__(64 * NW) void socp_block_kernel(ipm::Consts C, int 
                                                   const double* __restrict__ rk, const double* __restrict__ ic,
                                                   const int* __restrict__ active, double* __restrict__ work,
                                                   double* __restrict__ sol, double* __restrict__ nu,
-                                                  double* __restrict__ info) {
-    socp_body<BlockEx<NW>>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info);
+                                                  double* __restrict__ info, const int* __restrict__ step_status,
+                                                  double* __restrict__ ttr) {
+    socp_body<BlockEx<NW>>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr);
 }
 
 // cand = about + step (x, u in one contiguous [B][(K+1)*17+1] trajectory record, sigma last)
@@ -499,6 +511,7 @@ struct scvx_batch {
     double *cx = nullptr, *cu = nullptr, *csigma = nullptr;       // split views of cand
     double *endpoint = nullptr, *deriv = nullptr, *xprop = nullptr, *nu = nullptr;
     double *rk = nullptr, *cost = nullptr, *ic = nullptr, *info = nullptr, *out = nullptr, *work = nullptr;
+    double *ttr = nullptr;   // trust-region norm bound at the last optimum (reuse_inactive_tr)
     int *iter = nullptr, *status = nullptr;
     int *active = nullptr;   // 0 once a trajectory has failed (solver / non-finite): never stepped again
     int *live = nullptr;     // active and not yet converged: the trajectories scvx_solve still steps
@@ -558,7 +571,7 @@ int socp_waves(int B) {
 template <int NW>
 void launch_socp_block(scvx_batch* b, const int* mask) {
     hipLaunchKernelGGL(scvx::socp_block_kernel<NW>, dim3(b->B), dim3(64 * NW), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x,
-                       b->u, b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info);
+                       b->u, b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr);
 }
 
 int enqueue_socp(scvx_batch* b, const int* mask) {
@@ -567,7 +580,7 @@ int enqueue_socp(scvx_batch* b, const int* mask) {
     else if (w == 2) launch_socp_block<2>(b, mask);
     else
         hipLaunchKernelGGL(scvx::socp_kernel, dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
-                           b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info);
+                           b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr);
     SCVX_HIP(b->ctx, hipGetLastError());
     return SCVX_OK;
 }
@@ -636,6 +649,7 @@ int scvx_solver_default_opts(scvx_solver_opts* o) {
     o->refine = 6;
     o->tol = 1e-8;
     o->accept_tol = 1e-6;
+    o->reuse_inactive_tr = 0;
     return SCVX_OK;
 }
 
@@ -658,6 +672,7 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     const double d2r = M_PI / 180.0;
     C.K = K; C.max_iter = b->opts.max_iter; C.refine = b->opts.refine; C.pad = 0; C.tol = b->opts.tol;
     C.accept = b->opts.accept_tol;
+    C.pad = b->opts.reuse_inactive_tr;
     C.itan = 1.0 / std::tan(p.gammaGs * d2r);                       // rocketland.jl:63
     C.sqcm = std::sqrt((1.0 - std::cos(p.thetaMax * d2r)) / 2.0);   // :64
     C.icos = 1.0 / std::cos(p.deltaMax * d2r);                      // :65
@@ -694,6 +709,7 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     rc |= dmalloc(ctx, &b->ic, nB * 6);
     rc |= dmalloc(ctx, &b->info, nB * 4);
     rc |= dmalloc(ctx, &b->out, nB * 2);
+    rc |= dmalloc(ctx, &b->ttr, nB);
     rc |= dmalloc(ctx, &b->work, nB * b->work_stride);
     rc |= dmalloc(ctx, &b->iter, nB);
     rc |= dmalloc(ctx, &b->status, nB);
@@ -712,7 +728,7 @@ void scvx_batch_destroy(scvx_batch* b) {
     (void)hipSetDevice(b->device);
     for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
     void* ptrs[] = {b->traj0, b->traj, b->cand, b->sol, b->x, b->u, b->sigma, b->cx, b->cu, b->csigma, b->endpoint, b->deriv, b->xprop,
-                    b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active, b->live};
+                    b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active, b->live, b->ttr};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete b;
@@ -727,6 +743,7 @@ int scvx_batch_set_solver(scvx_batch* b, const scvx_solver_opts* o) {
     b->C.refine = o->refine;
     b->C.tol = o->tol;
     b->C.accept = o->accept_tol;
+    b->C.pad = o->reuse_inactive_tr ? 1 : 0;
     return SCVX_OK;
 }
 
@@ -774,6 +791,7 @@ int scvx_batch_init(scvx_batch* b, const double* ic) {
     SCVX_HIP(ctx, hipMemcpyAsync(b->live, hact.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     SCVX_HIP(ctx, hipMemsetAsync(b->out, 0, (size_t)B * 16, st));
     SCVX_HIP(ctx, hipMemsetAsync(b->info, 0, (size_t)B * 32, st));
+    SCVX_HIP(ctx, hipMemsetAsync(b->ttr, 0x7f, (size_t)B * 8, st));   // a huge finite value: nothing to reuse yet
     rc = split_views(b, b->traj, b->x, b->u, b->sigma);
     if (rc) return rc;
     SCVX_HIP(ctx, scvx::launch_linearize(ctx, B, K, b->x, b->u, b->sigma, 1.0 / (K + 1), b->endpoint, b->deriv, st));
@@ -868,6 +886,7 @@ int scvx_batch_set_trajectory(scvx_batch* b, const double* traj) {
     if (!traj) return fail(b->ctx, SCVX_ERR_ARG, "null buffer");
     scvx_ctx* ctx = b->ctx;
     SCVX_HIP(ctx, hipMemcpyAsync(b->traj, traj, (size_t)b->B * b->nrec * 8, hipMemcpyHostToDevice, ctx->stream));
+    SCVX_HIP(ctx, hipMemsetAsync(b->ttr, 0x7f, (size_t)b->B * 8, ctx->stream));   // a new iterate: no optimum to reuse
     rc = split_views(b, b->traj, b->x, b->u, b->sigma);
     if (rc) return rc;
     SCVX_HIP(ctx, scvx::launch_linearize(ctx, b->B, b->K, b->x, b->u, b->sigma, 1.0 / (b->K + 1), b->endpoint, b->deriv,

@@ -611,3 +611,33 @@ def test_dynamic_pressure_cone_on_device_matches_independent_oracle():
     x0, _, _, _ = b0.socp_solve()
     assert np.linalg.norm(x0[0, :po.K, 4:7], axis=1).max() > vm + 1e-3
     b.close(); c.close(); b0.close(); c0.close()
+
+
+def test_reuse_of_the_optimum_across_rejected_steps_changes_nothing():
+    """scvx_solver_opts.reuse_inactive_tr: a complete solve_problem with and without the shortcut.  Same accept / reject
+    sequence, same radius schedule, trajectories equal to solver accuracy; the skipped solves are visible (iters = 0)."""
+    from oracle import model
+    po = model.base_prob_scaled()
+    B = 16
+    ic = model.disperse_ics(po, B, 20261004)
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    c = IntegratorCache(sp.base_prob_scaled, npts=10)
+    a = ScvxBatch(c, B).init(ic)
+    r = ScvxBatch(c, B, reuse_inactive_tr=True).init(ic)
+    skipped = 0
+    for n in range(po.imax - 1):
+        sa, nua, dja = a.solve_step()
+        sr, nur, djr = r.solve_step()
+        assert np.array_equal(sa, sr), n
+        assert np.array_equal(a.scalars()[0], r.scalars()[0])          # radius schedule
+        assert np.allclose(nua, nur, rtol=0, atol=1e-7)
+        its = r.solver_stats()[1]
+        skipped += int((its == 0).sum())
+        assert np.all(a.solver_stats()[1] > 0)
+    xa, ua, sga = a.trajectory()
+    xr, ur, sgr = r.trajectory()
+    assert np.abs(xa - xr).max() < 1e-6 and np.abs(ua - ur).max() < 1e-6 and np.abs(sga - sgr).max() < 1e-6
+    assert skipped >= 4 * B, skipped     # the sample problem's rejection run: most of its re-solves are repeats
+    a.close(); r.close(); c.close()
