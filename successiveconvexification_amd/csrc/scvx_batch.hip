@@ -349,7 +349,11 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t wo
 
 // one wavefront per trajectory (large batches: the chip is filled by trajectories)
 #ifndef SCVX_K4_OCC
-#define SCVX_K4_OCC 3   // wavefronts per SIMD the single-wavefront solver is compiled for
+// Wavefronts per SIMD the single-wavefront solver is compiled for.  Measured (profiles/r02_k4_sections.md): 2 and 3 give
+// the same throughput at B = 8192 (143 vs 142 ms per solve of the batch: the kernel runs at the HBM streaming rate either
+// way), 2 is 4 % faster below 3,072 trajectories, and at 2 (<= 256 VGPRs) nothing spills -- at 3 (168 VGPRs) 147
+// registers did.  4 (128 VGPRs) is 17 % slower, 1 is 40 % slower at the full batch.
+#define SCVX_K4_OCC 2
 #endif
 __global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_kernel(ipm::Consts C, int B, size_t work_stride,
                                                   const double* __restrict__ x, const double* __restrict__ u,

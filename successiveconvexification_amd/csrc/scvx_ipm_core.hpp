@@ -317,11 +317,18 @@ struct Solver {
     double q_tr[2], q_nu[2], q_sg[4], h00s;   // (v0, |v1|^2) of the two big cones; (v0, v1, b2, h01 v1 / h00) of the 2-cone (ts; s)
     double css, cst, csn, cts, ctt, ctn, cns, cnt_, pny;
     double bigvz[2];  // <v, W dz>_1 of the two big cones (corr_dir_pass -> update_pass)
-    double prof[32];
+#if defined(SCVX_IPM_PROF)
+    double prof[32];   // in-kernel section timers (diagnostic builds)
+#endif
     double cur_gate;   // max(pres, relgap) of the current iterate: refinement only pays in the endgame (dres is left out:
                        // an inaccurate solve RAISES it, and must not switch the refinement off)
 
-    SCVX_HD Solver(Ex& e, const Consts& c) : ex(e), C(c) { L.init(c.K, c.vmax > 0.0); for (int i = 0; i < 32; i++) prof[i] = 0.0; }
+    SCVX_HD Solver(Ex& e, const Consts& c) : ex(e), C(c) {
+        L.init(c.K, c.vmax > 0.0);
+#if defined(SCVX_IPM_PROF)
+        for (int i = 0; i < 32; i++) prof[i] = 0.0;
+#endif
+    }
 
     SCVX_HD void carve(gptr w) {
         const int nv = L.nv, ny = L.ny, nc = L.nc, nloc = L.nloc, K = L.K;
