@@ -159,8 +159,8 @@ def k1_by_npts(cache, batch, torch, K, B, default_npts):
     e = torch.empty((B, K, 14), dtype=torch.float64, device="cuda")
     d = torch.empty((B, K, 21, 14), dtype=torch.float64, device="cuda")
     L, out = cache._L, {}
-    ts = torch.cuda.Stream()            # a real stream handle: torch's default stream is handle 0, which the library
-    cache.set_stream(ts.cuda_stream)    # replaces by its own stream, where torch's events would not see the kernel
+    ts = torch.cuda.Stream()            # torch's events only see kernels on a torch stream: run K1 on one for this leg
+    cache.set_stream(ts.cuda_stream)
     torch.cuda.synchronize()
     for npts in (1, 2, 4, 10):
         cache.set_npts(npts)
@@ -180,9 +180,32 @@ def k1_by_npts(cache, batch, torch, K, B, default_npts):
         ms = t0.elapsed_time(t1) / 5
         out[str(npts)] = {"ms": ms, "achieved_GBps": k1_alg_bytes(K) * B / (ms * 1e-3) / 1e9,
                           "frac": k1_alg_bytes(K) * B / (ms * 1e-3) / HBM_PEAK}
+    # fp32 entry point (scvx_linearize_f32: column-per-lane kernel in float arithmetic, float arrays): SURVEY 8d's fp32 row
+    xf, uf, sf = xd.float(), ud.float(), sd.float()
+    ef = torch.empty((B, K, 14), dtype=torch.float32, device="cuda")
+    df = torch.empty((B, K, 21, 14), dtype=torch.float32, device="cuda")
+    out32 = {}
+    for npts in (1, 2, 4, 10):
+        cache.set_npts(npts)
+
+        def call32():
+            return L.scvx_linearize_f32(cache.handle, B, K, C.c_void_p(xf.data_ptr()), C.c_void_p(uf.data_ptr()),
+                                        C.c_void_p(sf.data_ptr()), C.c_float(1.0 / (K + 1)), C.c_void_p(ef.data_ptr()),
+                                        C.c_void_p(df.data_ptr()))
+        for _ in range(2):
+            assert call32() == 0
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record(ts)
+        for _ in range(5):
+            call32()
+        t1.record(ts)
+        torch.cuda.synchronize()
+        ms = t0.elapsed_time(t1) / 5
+        out32[str(npts)] = {"ms": ms, "achieved_GBps": k1_alg_bytes(K, s=4) * B / (ms * 1e-3) / 1e9,
+                            "frac": k1_alg_bytes(K, s=4) * B / (ms * 1e-3) / HBM_PEAK}
     cache.set_npts(default_npts)
-    cache.set_stream(torch.cuda.current_stream().cuda_stream)
-    return out
+    cache.set_stream(None)   # back to the context's own stream
+    return out, out32
 
 
 SOCP_ALG_BYTES = 137 * 1024  # K4 reads the linearisation and the iterate, writes the solution (per trajectory)
@@ -365,7 +388,7 @@ def main():
                                        "frozen_trajectories": int(np.sum(act_f == 0))},
         }
         if world == 1 and not args.no_k1_sweep:
-            line["roofline_k1_by_npts"] = k1_by_npts(cache, batch, torch, K, B, args.npts)
+            line["roofline_k1_by_npts"], line["roofline_k1_f32_by_npts"] = k1_by_npts(cache, batch, torch, K, B, args.npts)
         if world == 1 and not args.no_traj_check:
             line["traj_linf_vs_oracle"] = traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts)
         if world == 1 and not args.no_traj_check:

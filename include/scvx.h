@@ -130,6 +130,20 @@ int scvx_propagate_f64(scvx_ctx *ctx, int B, int K, const double *x_dev, const d
 int scvx_propagate_f64_host(scvx_ctx *ctx, int B, int K, const double *x, const double *u,
                             const double *sigma, double dt, double *xnext);
 
+/* fp32 forms of the two discretisation entry points (SURVEY.md 8b "_f64/_f32"; BASELINE configs[3-4] name fp32): the
+ * same layouts in float, float arithmetic throughout (RK4 state + sensitivity columns), tables read from the same
+ * double coefficients.  Stated tolerance against the fp64 path: 2e-5 relative on endpoint, 2e-4 on derivative at
+ * npts = 10 (tests/test_gpu_discretize.py).  The conic solve has no fp32 form: its block-tridiagonal factor needs double
+ * (cond(S) * eps_float ~ 1, DESIGN.md "fp32"), so the SCvx loop itself always runs in fp64. */
+int scvx_linearize_f32(scvx_ctx *ctx, int B, int K, const float *x_dev, const float *u_dev,
+                       const float *sigma_dev, float dt, float *endpoint_dev, float *deriv_dev);
+int scvx_linearize_f32_host(scvx_ctx *ctx, int B, int K, const float *x, const float *u,
+                            const float *sigma, float dt, float *endpoint, float *deriv);
+int scvx_propagate_f32(scvx_ctx *ctx, int B, int K, const float *x_dev, const float *u_dev,
+                       const float *sigma_dev, float dt, float *xnext_dev);
+int scvx_propagate_f32_host(scvx_ctx *ctx, int B, int K, const float *x, const float *u,
+                            const float *sigma, float dt, float *xnext);
+
 /* ---- batched SCvx: create_initial / solve_step / solve_problem ------------------------------ */
 int scvx_solver_default_opts(scvx_solver_opts *o);
 int scvx_batch_create(scvx_ctx *ctx, int B, scvx_batch **out);

@@ -12,6 +12,7 @@ _DEFAULT_LIB_PATH = LIB_PATH
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
+_fp = C.POINTER(C.c_float)
 
 
 class ScvxProblem(C.Structure):
@@ -57,6 +58,10 @@ SIGNATURES = {
     "scvx_linearize_f64_host": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp]),
     "scvx_propagate_f64": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
     "scvx_propagate_f64_host": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp]),
+    "scvx_linearize_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_float, _vp, _vp]),
+    "scvx_linearize_f32_host": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_float, _fp, _fp]),
+    "scvx_propagate_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_float, _vp]),
+    "scvx_propagate_f32_host": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_float, _fp]),
     "scvx_solver_default_opts": (C.c_int, [C.POINTER(ScvxSolverOpts)]),
     "scvx_batch_create": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "scvx_batch_destroy": (None, [_vp]),

@@ -234,6 +234,73 @@ int scvx_propagate_f64(scvx_ctx* ctx, int B, int K, const double* x_dev, const d
     return SCVX_OK;
 }
 
+int scvx_linearize_f32(scvx_ctx* ctx, int B, int K, const float* x_dev, const float* u_dev, const float* sigma_dev, float dt,
+                       float* endpoint_dev, float* deriv_dev) {
+    int rc = check_disc(ctx, B, K, x_dev, u_dev, sigma_dev, endpoint_dev);
+    if (rc) return rc;
+    if (B > 0 && !deriv_dev) return fail(ctx, SCVX_ERR_ARG, "null buffer");
+    SCVX_HIP(ctx, hipSetDevice(ctx->device));
+    SCVX_HIP(ctx, scvx::launch_linearize_f32(ctx, B, K, x_dev, u_dev, sigma_dev, dt, endpoint_dev, deriv_dev, ctx->stream));
+    return SCVX_OK;
+}
+
+int scvx_propagate_f32(scvx_ctx* ctx, int B, int K, const float* x_dev, const float* u_dev, const float* sigma_dev, float dt,
+                       float* xnext_dev) {
+    int rc = check_disc(ctx, B, K, x_dev, u_dev, sigma_dev, xnext_dev);
+    if (rc) return rc;
+    SCVX_HIP(ctx, hipSetDevice(ctx->device));
+    SCVX_HIP(ctx, scvx::launch_propagate_f32(ctx, B, K, x_dev, u_dev, sigma_dev, dt, xnext_dev, ctx->stream));
+    return SCVX_OK;
+}
+
+namespace {
+struct DevBufF {
+    float* p = nullptr;
+    ~DevBufF() {
+        if (p) (void)hipFree(p);
+    }
+};
+}  // namespace
+
+static int disc_host_f32(scvx_ctx* ctx, int B, int K, const float* x, const float* u, const float* sigma, float dt,
+                         float* endpoint, float* deriv, bool with_deriv) {
+    int rc = check_disc(ctx, B, K, x, u, sigma, endpoint);
+    if (rc) return rc;
+    if (B == 0) return SCVX_OK;
+    if (with_deriv && !deriv) return fail(ctx, SCVX_ERR_ARG, "null buffer");
+    SCVX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nx = (size_t)B * (K + 1) * 14, nu = (size_t)B * (K + 1) * 3, ne = (size_t)B * K * 14,
+                 nd = (size_t)B * K * 294;
+    DevBufF dx, du, ds, de, dd;
+    SCVX_HIP(ctx, hipMalloc(&dx.p, nx * 4));
+    SCVX_HIP(ctx, hipMalloc(&du.p, nu * 4));
+    SCVX_HIP(ctx, hipMalloc(&ds.p, (size_t)B * 4));
+    SCVX_HIP(ctx, hipMalloc(&de.p, ne * 4));
+    if (with_deriv) SCVX_HIP(ctx, hipMalloc(&dd.p, nd * 4));
+    hipStream_t st = ctx->stream;
+    SCVX_HIP(ctx, hipMemcpyAsync(dx.p, x, nx * 4, hipMemcpyHostToDevice, st));
+    SCVX_HIP(ctx, hipMemcpyAsync(du.p, u, nu * 4, hipMemcpyHostToDevice, st));
+    SCVX_HIP(ctx, hipMemcpyAsync(ds.p, sigma, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    if (with_deriv)
+        SCVX_HIP(ctx, scvx::launch_linearize_f32(ctx, B, K, dx.p, du.p, ds.p, dt, de.p, dd.p, st));
+    else
+        SCVX_HIP(ctx, scvx::launch_propagate_f32(ctx, B, K, dx.p, du.p, ds.p, dt, de.p, st));
+    SCVX_HIP(ctx, hipMemcpyAsync(endpoint, de.p, ne * 4, hipMemcpyDeviceToHost, st));
+    if (with_deriv) SCVX_HIP(ctx, hipMemcpyAsync(deriv, dd.p, nd * 4, hipMemcpyDeviceToHost, st));
+    SCVX_HIP(ctx, hipStreamSynchronize(st));
+    return SCVX_OK;
+}
+
+int scvx_linearize_f32_host(scvx_ctx* ctx, int B, int K, const float* x, const float* u, const float* sigma, float dt,
+                            float* endpoint, float* deriv) {
+    return disc_host_f32(ctx, B, K, x, u, sigma, dt, endpoint, deriv, true);
+}
+
+int scvx_propagate_f32_host(scvx_ctx* ctx, int B, int K, const float* x, const float* u, const float* sigma, float dt,
+                            float* xnext) {
+    return disc_host_f32(ctx, B, K, x, u, sigma, dt, xnext, nullptr, false);
+}
+
 namespace {
 struct DevBuf {
     double* p = nullptr;

@@ -27,58 +27,82 @@ struct DynParams {
     const double* clift;
 };
 
-// Everything one RK stage needs about the state trajectory, evaluated once per stage per lane.
-template <bool AERO>
-struct Stage {
-    double g[14];      // un-scaled RHS
-    double C[9];       // DCM, row-major
-    double invm;
-    double am[3];      // d vdot / d m
-    double Dq[12];     // d vdot / d q   (3x4 row-major)
-    double Dv[AERO ? 9 : 1];  // d vdot / d v (aero only)
-    double Mw[9];      // d wdot / d w
+// The device functions below are templates on the arithmetic type R: double is the reference precision (and what the
+// SCvx loop uses); float backs the scvx_*_f32 entry points (BASELINE configs[3-4] name fp32).  DynP<R> is DynParams with
+// every constant converted once per kernel, so that no expression silently promotes to double in the float build.
+template <typename R>
+struct DynP {
+    R alpha, g0, sos;
+    R J[9], Jinv[9], rTB[3], JrT[9];
+    int aero, n_aoa, n_mach;
+    R aoa0, inv_daoa, mach0, inv_dmach, force_scalar;
+    const double* cdrag;   // prefiltered coefficients stay double in memory (shared by both precisions, cache-resident)
+    const double* clift;
+    __device__ __forceinline__ explicit DynP(const DynParams& p)
+        : alpha((R)p.alpha), g0((R)p.g0), sos((R)p.sos), aero(p.aero), n_aoa(p.n_aoa), n_mach(p.n_mach), aoa0((R)p.aoa0),
+          inv_daoa((R)p.inv_daoa), mach0((R)p.mach0), inv_dmach((R)p.inv_dmach), force_scalar((R)p.force_scalar),
+          cdrag(p.cdrag), clift(p.clift) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) { J[i] = (R)p.J[i]; Jinv[i] = (R)p.Jinv[i]; JrT[i] = (R)p.JrT[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; i++) rTB[i] = (R)p.rTB[i];
+    }
 };
 
-__device__ __forceinline__ void bspline_weights(double t, int n, int& i0, double w[4], double dw[4]) {
+// Everything one RK stage needs about the state trajectory, evaluated once per stage per lane.
+template <bool AERO, typename R = double>
+struct Stage {
+    R g[14];      // un-scaled RHS
+    R C[9];       // DCM, row-major
+    R invm;
+    R am[3];      // d vdot / d m
+    R Dq[12];     // d vdot / d q   (3x4 row-major)
+    R Dv[AERO ? 9 : 1];  // d vdot / d v (aero only)
+    R Mw[9];      // d wdot / d w
+};
+
+template <typename R>
+__device__ __forceinline__ void bspline_weights(R t, int n, int& i0, R w[4], R dw[4]) {
     int i = (int)floor(t);
     i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
-    double d = t - (double)i;
-    double d2 = d * d, d3 = d2 * d;
-    const double s = 1.0 / 6.0;
-    w[0] = (1.0 - 3.0 * d + 3.0 * d2 - d3) * s;
-    w[1] = (4.0 - 6.0 * d2 + 3.0 * d3) * s;
-    w[2] = (1.0 + 3.0 * d + 3.0 * d2 - 3.0 * d3) * s;
+    R d = t - R(i);
+    R d2 = d * d, d3 = d2 * d;
+    const R s = R(1.0) / R(6.0);
+    w[0] = (R(1.0) - R(3.0) * d + R(3.0) * d2 - d3) * s;
+    w[1] = (R(4.0) - R(6.0) * d2 + R(3.0) * d3) * s;
+    w[2] = (R(1.0) + R(3.0) * d + R(3.0) * d2 - R(3.0) * d3) * s;
     w[3] = d3 * s;
-    dw[0] = (-3.0 + 6.0 * d - 3.0 * d2) * s;
-    dw[1] = (-12.0 * d + 9.0 * d2) * s;
-    dw[2] = (3.0 + 6.0 * d - 9.0 * d2) * s;
-    dw[3] = (3.0 * d2) * s;
+    dw[0] = (-R(3.0) + R(6.0) * d - R(3.0) * d2) * s;
+    dw[1] = (-R(12.0) * d + R(9.0) * d2) * s;
+    dw[2] = (R(3.0) + R(6.0) * d - R(9.0) * d2) * s;
+    dw[3] = (R(3.0) * d2) * s;
     i0 = i;
 }
 
 // drag and lift tables at (aoa, mach): value, d/daoa, d/dmach each; Flat() extrapolation.
-__device__ __forceinline__ void aero_tables(const DynParams& p, double aoa, double mach, double td[3], double tl[3]) {
+template <typename R>
+__device__ __forceinline__ void aero_tables(const DynP<R>& p, R aoa, R mach, R td[3], R tl[3]) {
     const int na = p.n_aoa, nm = p.n_mach;
-    double ta = (aoa - p.aoa0) * p.inv_daoa, tm = (mach - p.mach0) * p.inv_dmach;
+    R ta = (aoa - p.aoa0) * p.inv_daoa, tm = (mach - p.mach0) * p.inv_dmach;
     bool fa = false, fm = false;
-    if (ta < 0.0) { ta = 0.0; fa = true; }
-    if (ta > (double)(na - 1)) { ta = (double)(na - 1); fa = true; }
-    if (tm < 0.0) { tm = 0.0; fm = true; }
-    if (tm > (double)(nm - 1)) { tm = (double)(nm - 1); fm = true; }
+    if (ta < R(0.0)) { ta = R(0.0); fa = true; }
+    if (ta > R(na - 1)) { ta = R(na - 1); fa = true; }
+    if (tm < R(0.0)) { tm = R(0.0); fm = true; }
+    if (tm > (R)(nm - 1)) { tm = (R)(nm - 1); fm = true; }
     int ia, im;
-    double wa[4], dwa[4], wm[4], dwm[4];
+    R wa[4], dwa[4], wm[4], dwm[4];
     bspline_weights(ta, na, ia, wa, dwa);
     bspline_weights(tm, nm, im, wm, dwm);
     const int lda = na + 2;
-    double vd = 0, vda = 0, vdm = 0, vl = 0, vla = 0, vlm = 0;
+    R vd = 0, vda = 0, vdm = 0, vl = 0, vla = 0, vlm = 0;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         const double* rd = p.cdrag + (size_t)(im + b) * lda + ia;
         const double* rl = p.clift + (size_t)(im + b) * lda + ia;
-        double sd = 0, sda = 0, sl = 0, sla = 0;
+        R sd = 0, sda = 0, sl = 0, sla = 0;
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-            double cd = rd[a], cl = rl[a];
+            const R cd = (R)rd[a], cl = (R)rl[a];
             sd = fma(wa[a], cd, sd);
             sda = fma(dwa[a], cd, sda);
             sl = fma(wa[a], cl, sl);
@@ -92,69 +116,69 @@ __device__ __forceinline__ void aero_tables(const DynParams& p, double aoa, doub
         vlm = fma(dwm[b], sl, vlm);
     }
     td[0] = vd;
-    td[1] = fa ? 0.0 : vda * p.inv_daoa;
-    td[2] = fm ? 0.0 : vdm * p.inv_dmach;
+    td[1] = fa ? R(0.0) : vda * p.inv_daoa;
+    td[2] = fm ? R(0.0) : vdm * p.inv_dmach;
     tl[0] = vl;
-    tl[1] = fa ? 0.0 : vla * p.inv_daoa;
-    tl[2] = fm ? 0.0 : vlm * p.inv_dmach;
+    tl[1] = fa ? R(0.0) : vla * p.inv_daoa;
+    tl[2] = fm ? R(0.0) : vlm * p.inv_dmach;
 }
 
 // F[3] and (JAC) dF/d(q0..q3, v1..v3) as 3x7 row-major.
-template <bool JAC>
-__device__ __forceinline__ void aero_force(const DynParams& p, const double* q, const double* v, const double* C,
-                                           double F[3], double dF[21]) {
-    F[0] = F[1] = F[2] = 0.0;
+template <bool JAC, typename R>
+__device__ __forceinline__ void aero_force(const DynP<R>& p, const R* q, const R* v, const R* C,
+                                           R F[3], R dF[21]) {
+    F[0] = F[1] = F[2] = R(0.0);
     if (JAC) {
 #pragma unroll
-        for (int i = 0; i < 21; i++) dF[i] = 0.0;
+        for (int i = 0; i < 21; i++) dF[i] = R(0.0);
     }
-    const double bv[3] = {C[0], C[3], C[6]};
-    const double vn2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-    const double vn = sqrt(vn2);
-    if (!(vn > 0.0)) return;
-    const double ivn = 1.0 / vn;
-    const double c = bv[0] * v[0] + bv[1] * v[1] + bv[2] * v[2];
-    const double mach = vn / p.sos;
-    double arg = c / (mach * p.sos);
+    const R bv[3] = {C[0], C[3], C[6]};
+    const R vn2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const R vn = sqrt(vn2);
+    if (!(vn > R(0.0))) return;
+    const R ivn = R(1.0) / vn;
+    const R c = bv[0] * v[0] + bv[1] * v[1] + bv[2] * v[2];
+    const R mach = vn / p.sos;
+    R arg = c / (mach * p.sos);
     bool clamped = false;
-    if (arg < -1.0) { arg = -1.0; clamped = true; }
-    if (arg > 1.0) { arg = 1.0; clamped = true; }
-    double td[3], tl[3];
+    if (arg < -R(1.0)) { arg = -R(1.0); clamped = true; }
+    if (arg > R(1.0)) { arg = R(1.0); clamped = true; }
+    R td[3], tl[3];
     aero_tables(p, arg, mach, td, tl);
-    const double fs = p.force_scalar;
-    const double drag = td[0] * fs, lift = tl[0] * fs;
+    const R fs = p.force_scalar;
+    const R drag = td[0] * fs, lift = tl[0] * fs;
     // liftd = (bv x v) x v = c v - |v|^2 bv
-    double ld[3];
+    R ld[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) ld[i] = c * v[i] - vn2 * bv[i];
-    const double ln = sqrt(ld[0] * ld[0] + ld[1] * ld[1] + ld[2] * ld[2]);
-    const bool has_lift = ln > 0.0;
-    const double iln = has_lift ? 1.0 / ln : 0.0;
-    double l[3];
+    const R ln = sqrt(ld[0] * ld[0] + ld[1] * ld[1] + ld[2] * ld[2]);
+    const bool has_lift = ln > R(0.0);
+    const R iln = has_lift ? R(1.0) / ln : R(0.0);
+    R l[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         l[i] = ld[i] * iln;
-        F[i] = drag * v[i] * ivn + (has_lift ? lift * l[i] : 0.0);
+        F[i] = drag * v[i] * ivn + (has_lift ? lift * l[i] : R(0.0));
     }
     if (!JAC) return;
-    const double dbv[12] = {0.0, 0.0, -4.0 * q[2], -4.0 * q[3],
-                            2.0 * q[3], 2.0 * q[2], 2.0 * q[1], 2.0 * q[0],
-                            -2.0 * q[2], 2.0 * q[3], -2.0 * q[0], 2.0 * q[1]};
-    double dc[4];  // d c / d q
+    const R dbv[12] = {R(0.0), R(0.0), -R(4.0) * q[2], -R(4.0) * q[3],
+                            R(2.0) * q[3], R(2.0) * q[2], R(2.0) * q[1], R(2.0) * q[0],
+                            -R(2.0) * q[2], R(2.0) * q[3], -R(2.0) * q[0], R(2.0) * q[1]};
+    R dc[4];  // d c / d q
 #pragma unroll
     for (int j = 0; j < 4; j++) dc[j] = dbv[j] * v[0] + dbv[4 + j] * v[1] + dbv[8 + j] * v[2];
-    double darg[7], dmach[7];
+    R darg[7], dmach[7];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        darg[j] = clamped ? 0.0 : dc[j] * ivn;
-        dmach[j] = 0.0;
+        darg[j] = clamped ? R(0.0) : dc[j] * ivn;
+        dmach[j] = R(0.0);
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-        darg[4 + j] = clamped ? 0.0 : (bv[j] * ivn - c * v[j] * ivn * ivn * ivn);
+        darg[4 + j] = clamped ? R(0.0) : (bv[j] * ivn - c * v[j] * ivn * ivn * ivn);
         dmach[4 + j] = v[j] * ivn / p.sos;
     }
-    double ddrag[7], dlift[7];
+    R ddrag[7], dlift[7];
 #pragma unroll
     for (int j = 0; j < 7; j++) {
         ddrag[j] = fs * (td[1] * darg[j] + td[2] * dmach[j]);
@@ -166,59 +190,60 @@ __device__ __forceinline__ void aero_force(const DynParams& p, const double* q, 
         for (int j = 0; j < 7; j++) dF[i * 7 + j] = ddrag[j] * v[i] * ivn;
 #pragma unroll
         for (int j = 0; j < 3; j++)
-            dF[i * 7 + 4 + j] += drag * ((i == j ? ivn : 0.0) - v[i] * v[j] * ivn * ivn * ivn);
+            dF[i * 7 + 4 + j] += drag * ((i == j ? ivn : R(0.0)) - v[i] * v[j] * ivn * ivn * ivn);
     }
     if (has_lift) {
-        double dld[21];
+        R dld[21];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) dld[i * 7 + j] = v[i] * dc[j] - vn2 * dbv[i * 4 + j];
 #pragma unroll
-            for (int j = 0; j < 3; j++) dld[i * 7 + 4 + j] = (i == j ? c : 0.0) + v[i] * bv[j] - 2.0 * bv[i] * v[j];
+            for (int j = 0; j < 3; j++) dld[i * 7 + 4 + j] = (i == j ? c : R(0.0)) + v[i] * bv[j] - R(2.0) * bv[i] * v[j];
         }
 #pragma unroll
         for (int j = 0; j < 7; j++) {
-            const double proj = l[0] * dld[j] + l[1] * dld[7 + j] + l[2] * dld[14 + j];
+            const R proj = l[0] * dld[j] + l[1] * dld[7 + j] + l[2] * dld[14 + j];
 #pragma unroll
             for (int i = 0; i < 3; i++) dF[i * 7 + j] += dlift[j] * l[i] + lift * (dld[i * 7 + j] - l[i] * proj) * iln;
         }
     }
 }
 
-__device__ __forceinline__ void dcm(const double* q, double* C) {
-    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-    C[0] = 1.0 - 2.0 * (q2 * q2 + q3 * q3);
-    C[1] = 2.0 * (q1 * q2 - q0 * q3);
-    C[2] = 2.0 * (q1 * q3 + q0 * q2);
-    C[3] = 2.0 * (q1 * q2 + q0 * q3);
-    C[4] = 1.0 - 2.0 * (q1 * q1 + q3 * q3);
-    C[5] = 2.0 * (q2 * q3 - q0 * q1);
-    C[6] = 2.0 * (q1 * q3 - q0 * q2);
-    C[7] = 2.0 * (q2 * q3 + q0 * q1);
-    C[8] = 1.0 - 2.0 * (q1 * q1 + q2 * q2);
+template <typename R>
+__device__ __forceinline__ void dcm(const R* q, R* C) {
+    const R q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    C[0] = R(1.0) - R(2.0) * (q2 * q2 + q3 * q3);
+    C[1] = R(2.0) * (q1 * q2 - q0 * q3);
+    C[2] = R(2.0) * (q1 * q3 + q0 * q2);
+    C[3] = R(2.0) * (q1 * q2 + q0 * q3);
+    C[4] = R(1.0) - R(2.0) * (q1 * q1 + q3 * q3);
+    C[5] = R(2.0) * (q2 * q3 - q0 * q1);
+    C[6] = R(2.0) * (q1 * q3 - q0 * q2);
+    C[7] = R(2.0) * (q2 * q3 + q0 * q1);
+    C[8] = R(1.0) - R(2.0) * (q1 * q1 + q2 * q2);
 }
 
 // RHS only (K2 propagate and the state part of K1).
-template <bool AERO>
-__device__ __forceinline__ void rhs_only(const DynParams& p, const double* x, const double* u, double* g) {
-    const double* v = x + 4;
-    const double* q = x + 7;
-    const double* w = x + 11;
-    double C[9], F[3] = {0.0, 0.0, 0.0};
+template <bool AERO, typename R>
+__device__ __forceinline__ void rhs_only(const DynP<R>& p, const R* x, const R* u, R* g) {
+    const R* v = x + 4;
+    const R* q = x + 7;
+    const R* w = x + 11;
+    R C[9], F[3] = {R(0.0), R(0.0), R(0.0)};
     dcm(q, C);
-    if (AERO) aero_force<false>(p, q, v, C, F, nullptr);
-    const double invm = 1.0 / x[0];
+    if (AERO) aero_force<false, R>(p, q, v, C, F, nullptr);
+    const R invm = R(1.0) / x[0];
     g[0] = -p.alpha * sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
     g[1] = v[0]; g[2] = v[1]; g[3] = v[2];
 #pragma unroll
     for (int i = 0; i < 3; i++) g[4 + i] = (C[3 * i] * u[0] + C[3 * i + 1] * u[1] + C[3 * i + 2] * u[2] + F[i]) * invm;
     g[4] -= p.g0;
-    g[7] = 0.5 * (-w[0] * q[1] - w[1] * q[2] - w[2] * q[3]);
-    g[8] = 0.5 * (w[0] * q[0] + w[2] * q[2] - w[1] * q[3]);
-    g[9] = 0.5 * (w[1] * q[0] - w[2] * q[1] + w[0] * q[3]);
-    g[10] = 0.5 * (w[2] * q[0] + w[1] * q[1] - w[0] * q[2]);
-    double Jw[3], t[3];
+    g[7] = R(0.5) * (-w[0] * q[1] - w[1] * q[2] - w[2] * q[3]);
+    g[8] = R(0.5) * (w[0] * q[0] + w[2] * q[2] - w[1] * q[3]);
+    g[9] = R(0.5) * (w[1] * q[0] - w[2] * q[1] + w[0] * q[3]);
+    g[10] = R(0.5) * (w[2] * q[0] + w[1] * q[1] - w[0] * q[2]);
+    R Jw[3], t[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) Jw[i] = p.J[3 * i] * w[0] + p.J[3 * i + 1] * w[1] + p.J[3 * i + 2] * w[2];
     t[0] = (p.rTB[1] * u[2] - p.rTB[2] * u[1]) - (w[1] * Jw[2] - w[2] * Jw[1]);
@@ -229,53 +254,53 @@ __device__ __forceinline__ void rhs_only(const DynParams& p, const double* x, co
 }
 
 // RHS + the structural non-zeros of df/dx at (x,u).
-template <bool AERO>
-__device__ __forceinline__ void stage_eval(const DynParams& p, const double* x, const double* u, Stage<AERO>& s) {
-    const double* v = x + 4;
-    const double* q = x + 7;
-    const double* w = x + 11;
+template <bool AERO, typename R>
+__device__ __forceinline__ void stage_eval(const DynP<R>& p, const R* x, const R* u, Stage<AERO, R>& s) {
+    const R* v = x + 4;
+    const R* q = x + 7;
+    const R* w = x + 11;
     dcm(q, s.C);
-    double F[3] = {0.0, 0.0, 0.0};
-    double dF[AERO ? 21 : 1];
+    R F[3] = {R(0.0), R(0.0), R(0.0)};
+    R dF[AERO ? 21 : 1];
     if (AERO) aero_force<true>(p, q, v, s.C, F, dF);
-    const double invm = 1.0 / x[0];
+    const R invm = R(1.0) / x[0];
     s.invm = invm;
     s.g[0] = -p.alpha * sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
     s.g[1] = v[0]; s.g[2] = v[1]; s.g[3] = v[2];
-    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-    const double u1 = u[0], u2 = u[1], u3 = u[2];
+    const R q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const R u1 = u[0], u2 = u[1], u3 = u[2];
     // d(C u)/dq, 3x4 row-major
-    double D[12];
-    D[0] = 2.0 * (-q3 * u2 + q2 * u3);
-    D[4] = 2.0 * (q3 * u1 - q1 * u3);
-    D[8] = 2.0 * (-q2 * u1 + q1 * u2);
-    D[1] = 2.0 * (q2 * u2 + q3 * u3);
-    D[5] = 2.0 * (q2 * u1 - 2.0 * q1 * u2 - q0 * u3);
-    D[9] = 2.0 * (q3 * u1 + q0 * u2 - 2.0 * q1 * u3);
-    D[2] = 2.0 * (-2.0 * q2 * u1 + q1 * u2 + q0 * u3);
-    D[6] = 2.0 * (q1 * u1 + q3 * u3);
-    D[10] = 2.0 * (-q0 * u1 + q3 * u2 - 2.0 * q2 * u3);
-    D[3] = 2.0 * (-2.0 * q3 * u1 - q0 * u2 + q1 * u3);
-    D[7] = 2.0 * (q0 * u1 - 2.0 * q3 * u2 + q2 * u3);
-    D[11] = 2.0 * (q1 * u1 + q2 * u2);
+    R D[12];
+    D[0] = R(2.0) * (-q3 * u2 + q2 * u3);
+    D[4] = R(2.0) * (q3 * u1 - q1 * u3);
+    D[8] = R(2.0) * (-q2 * u1 + q1 * u2);
+    D[1] = R(2.0) * (q2 * u2 + q3 * u3);
+    D[5] = R(2.0) * (q2 * u1 - R(2.0) * q1 * u2 - q0 * u3);
+    D[9] = R(2.0) * (q3 * u1 + q0 * u2 - R(2.0) * q1 * u3);
+    D[2] = R(2.0) * (-R(2.0) * q2 * u1 + q1 * u2 + q0 * u3);
+    D[6] = R(2.0) * (q1 * u1 + q3 * u3);
+    D[10] = R(2.0) * (-q0 * u1 + q3 * u2 - R(2.0) * q2 * u3);
+    D[3] = R(2.0) * (-R(2.0) * q3 * u1 - q0 * u2 + q1 * u3);
+    D[7] = R(2.0) * (q0 * u1 - R(2.0) * q3 * u2 + q2 * u3);
+    D[11] = R(2.0) * (q1 * u1 + q2 * u2);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const double acc = (s.C[3 * i] * u1 + s.C[3 * i + 1] * u2 + s.C[3 * i + 2] * u3 + F[i]) * invm;
+        const R acc = (s.C[3 * i] * u1 + s.C[3 * i + 1] * u2 + s.C[3 * i + 2] * u3 + F[i]) * invm;
         s.g[4 + i] = acc;
         s.am[i] = -acc * invm;
 #pragma unroll
-        for (int j = 0; j < 4; j++) s.Dq[4 * i + j] = (D[4 * i + j] + (AERO ? dF[7 * i + j] : 0.0)) * invm;
+        for (int j = 0; j < 4; j++) s.Dq[4 * i + j] = (D[4 * i + j] + (AERO ? dF[7 * i + j] : R(0.0))) * invm;
         if (AERO) {
 #pragma unroll
             for (int j = 0; j < 3; j++) s.Dv[3 * i + j] = dF[7 * i + 4 + j] * invm;
         }
     }
     s.g[4] -= p.g0;
-    s.g[7] = 0.5 * (-w[0] * q1 - w[1] * q2 - w[2] * q3);
-    s.g[8] = 0.5 * (w[0] * q0 + w[2] * q2 - w[1] * q3);
-    s.g[9] = 0.5 * (w[1] * q0 - w[2] * q1 + w[0] * q3);
-    s.g[10] = 0.5 * (w[2] * q0 + w[1] * q1 - w[0] * q2);
-    double Jw[3], t[3];
+    s.g[7] = R(0.5) * (-w[0] * q1 - w[1] * q2 - w[2] * q3);
+    s.g[8] = R(0.5) * (w[0] * q0 + w[2] * q2 - w[1] * q3);
+    s.g[9] = R(0.5) * (w[1] * q0 - w[2] * q1 + w[0] * q3);
+    s.g[10] = R(0.5) * (w[2] * q0 + w[1] * q1 - w[0] * q2);
+    R Jw[3], t[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) Jw[i] = p.J[3 * i] * w[0] + p.J[3 * i + 1] * w[1] + p.J[3 * i + 2] * w[2];
     t[0] = (p.rTB[1] * u3 - p.rTB[2] * u2) - (w[1] * Jw[2] - w[2] * Jw[1]);
@@ -284,7 +309,7 @@ __device__ __forceinline__ void stage_eval(const DynParams& p, const double* x, 
 #pragma unroll
     for (int i = 0; i < 3; i++) s.g[11 + i] = p.Jinv[3 * i] * t[0] + p.Jinv[3 * i + 1] * t[1] + p.Jinv[3 * i + 2] * t[2];
     // T = [w]x J - [Jw]x ; Mw = -Jinv T
-    double T[9];
+    R T[9];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         T[0 + j] = -w[2] * p.J[3 + j] + w[1] * p.J[6 + j];
@@ -303,19 +328,19 @@ __device__ __forceinline__ void stage_eval(const DynParams& p, const double* x, 
 
 // d/dt of one sensitivity column c (14 values):  sigma * (A c + Bu * wc) + gsel * g
 // wc[3] = FOH weight of this column's control component (zero for state / sigma columns).
-template <bool AERO>
-__device__ __forceinline__ void column_deriv(const DynParams& p, const Stage<AERO>& s, const double* x, const double* u,
-                                             const double* c, const double* wc, double gsel, double sigma, double* dc) {
-    const double* q = x + 7;
-    const double* w = x + 11;
-    const double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-    const double iun = un > 0.0 ? 1.0 / un : 0.0;
-    double a[14];
+template <bool AERO, typename R>
+__device__ __forceinline__ void column_deriv(const DynP<R>& p, const Stage<AERO, R>& s, const R* x, const R* u,
+                                             const R* c, const R* wc, R gsel, R sigma, R* dc) {
+    const R* q = x + 7;
+    const R* w = x + 11;
+    const R un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    const R iun = un > R(0.0) ? R(1.0) / un : R(0.0);
+    R a[14];
     a[0] = -p.alpha * iun * (u[0] * wc[0] + u[1] * wc[1] + u[2] * wc[2]);
     a[1] = c[4]; a[2] = c[5]; a[3] = c[6];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        double t = s.am[i] * c[0];
+        R t = s.am[i] * c[0];
         t = fma(s.Dq[4 * i], c[7], t);
         t = fma(s.Dq[4 * i + 1], c[8], t);
         t = fma(s.Dq[4 * i + 2], c[9], t);
@@ -328,15 +353,15 @@ __device__ __forceinline__ void column_deriv(const DynParams& p, const Stage<AER
         t = fma((s.C[3 * i] * wc[0] + s.C[3 * i + 1] * wc[1] + s.C[3 * i + 2] * wc[2]), s.invm, t);
         a[4 + i] = t;
     }
-    const double cq0 = c[7], cq1 = c[8], cq2 = c[9], cq3 = c[10];
-    const double cw0 = c[11], cw1 = c[12], cw2 = c[13];
-    a[7] = 0.5 * (-w[0] * cq1 - w[1] * cq2 - w[2] * cq3 - q[1] * cw0 - q[2] * cw1 - q[3] * cw2);
-    a[8] = 0.5 * (w[0] * cq0 + w[2] * cq2 - w[1] * cq3 + q[0] * cw0 - q[3] * cw1 + q[2] * cw2);
-    a[9] = 0.5 * (w[1] * cq0 - w[2] * cq1 + w[0] * cq3 + q[3] * cw0 + q[0] * cw1 - q[1] * cw2);
-    a[10] = 0.5 * (w[2] * cq0 + w[1] * cq1 - w[0] * cq2 - q[2] * cw0 + q[1] * cw1 + q[0] * cw2);
+    const R cq0 = c[7], cq1 = c[8], cq2 = c[9], cq3 = c[10];
+    const R cw0 = c[11], cw1 = c[12], cw2 = c[13];
+    a[7] = R(0.5) * (-w[0] * cq1 - w[1] * cq2 - w[2] * cq3 - q[1] * cw0 - q[2] * cw1 - q[3] * cw2);
+    a[8] = R(0.5) * (w[0] * cq0 + w[2] * cq2 - w[1] * cq3 + q[0] * cw0 - q[3] * cw1 + q[2] * cw2);
+    a[9] = R(0.5) * (w[1] * cq0 - w[2] * cq1 + w[0] * cq3 + q[3] * cw0 + q[0] * cw1 - q[1] * cw2);
+    a[10] = R(0.5) * (w[2] * cq0 + w[1] * cq1 - w[0] * cq2 - q[2] * cw0 + q[1] * cw1 + q[0] * cw2);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        double t = s.Mw[3 * i] * cw0;
+        R t = s.Mw[3 * i] * cw0;
         t = fma(s.Mw[3 * i + 1], cw1, t);
         t = fma(s.Mw[3 * i + 2], cw2, t);
         t = fma(p.JrT[3 * i], wc[0], t);
@@ -353,9 +378,9 @@ __device__ __forceinline__ void column_deriv(const DynParams& p, const Stage<AER
 //   g[14] | C[9] | invm | am[3] | Dq[12] | Mw[9] | q[4] | w[3] | ku[3] = -alpha u/|u| | (aero) Dv[9]
 template <bool AERO> struct StageRec { static constexpr int N = AERO ? 67 : 58; };
 
-template <bool AERO>
-__device__ __forceinline__ void stage_publish(const DynParams& p, const Stage<AERO>& s, const double* x, const double* u,
-                                              double* rec, int stride) {
+template <bool AERO, typename R>
+__device__ __forceinline__ void stage_publish(const DynP<R>& p, const Stage<AERO, R>& s, const R* x, const R* u,
+                                              R* rec, int stride) {
     int o = 0;
 #pragma unroll
     for (int i = 0; i < 14; i++) rec[(o++) * stride] = s.g[i];
@@ -372,8 +397,8 @@ __device__ __forceinline__ void stage_publish(const DynParams& p, const Stage<AE
     for (int i = 0; i < 4; i++) rec[(o++) * stride] = x[7 + i];
 #pragma unroll
     for (int i = 0; i < 3; i++) rec[(o++) * stride] = x[11 + i];
-    const double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-    const double k = un > 0.0 ? -p.alpha / un : 0.0;
+    const R un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    const R k = un > R(0.0) ? -p.alpha / un : R(0.0);
 #pragma unroll
     for (int i = 0; i < 3; i++) rec[(o++) * stride] = k * u[i];
     if (AERO) {
@@ -383,56 +408,56 @@ __device__ __forceinline__ void stage_publish(const DynParams& p, const Stage<AE
 }
 
 // d/dt of one sensitivity column from a published stage record (same arithmetic as column_deriv)
-template <bool AERO>
-__device__ __forceinline__ void column_deriv_rec(const DynParams& p, const double* rec, int stride, const double* c,
-                                                 const double* wc, double gsel, double sigma, double* dc) {
+template <bool AERO, typename R>
+__device__ __forceinline__ void column_deriv_rec(const DynP<R>& p, const R* rec, int stride, const R* c,
+                                                 const R* wc, R gsel, R sigma, R* dc) {
     // the whole record into registers first: 58 (67) independent LDS reads in flight, one wait — read one at a
     // time each multiply-add would expose a full LDS latency with only two waves per SIMD to hide it
     constexpr int NR = StageRec<AERO>::N;
-    double rr[NR];
+    R rr[NR];
 #pragma unroll
     for (int i = 0; i < NR; i++) rr[i] = rec[i * stride];
-    auto R = [&](int i) { return rr[i]; };
+    auto RR = [&](int i) { return rr[i]; };
     const int oC = 14, oInvm = 23, oAm = 24, oDq = 27, oMw = 39, oQ = 48, oW = 52, oKu = 55, oDv = 58;
-    double a[14];
-    a[0] = R(oKu) * wc[0] + R(oKu + 1) * wc[1] + R(oKu + 2) * wc[2];
+    R a[14];
+    a[0] = RR(oKu) * wc[0] + RR(oKu + 1) * wc[1] + RR(oKu + 2) * wc[2];
     a[1] = c[4]; a[2] = c[5]; a[3] = c[6];
-    const double invm = R(oInvm);
+    const R invm = RR(oInvm);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        double t = R(oAm + i) * c[0];
-        t = fma(R(oDq + 4 * i), c[7], t);
-        t = fma(R(oDq + 4 * i + 1), c[8], t);
-        t = fma(R(oDq + 4 * i + 2), c[9], t);
-        t = fma(R(oDq + 4 * i + 3), c[10], t);
+        R t = RR(oAm + i) * c[0];
+        t = fma(RR(oDq + 4 * i), c[7], t);
+        t = fma(RR(oDq + 4 * i + 1), c[8], t);
+        t = fma(RR(oDq + 4 * i + 2), c[9], t);
+        t = fma(RR(oDq + 4 * i + 3), c[10], t);
         if (AERO) {
-            t = fma(R(oDv + 3 * i), c[4], t);
-            t = fma(R(oDv + 3 * i + 1), c[5], t);
-            t = fma(R(oDv + 3 * i + 2), c[6], t);
+            t = fma(RR(oDv + 3 * i), c[4], t);
+            t = fma(RR(oDv + 3 * i + 1), c[5], t);
+            t = fma(RR(oDv + 3 * i + 2), c[6], t);
         }
-        t = fma((R(oC + 3 * i) * wc[0] + R(oC + 3 * i + 1) * wc[1] + R(oC + 3 * i + 2) * wc[2]), invm, t);
+        t = fma((RR(oC + 3 * i) * wc[0] + RR(oC + 3 * i + 1) * wc[1] + RR(oC + 3 * i + 2) * wc[2]), invm, t);
         a[4 + i] = t;
     }
-    const double q0 = R(oQ), q1 = R(oQ + 1), q2 = R(oQ + 2), q3 = R(oQ + 3);
-    const double w0 = R(oW), w1 = R(oW + 1), w2 = R(oW + 2);
-    const double cq0 = c[7], cq1 = c[8], cq2 = c[9], cq3 = c[10];
-    const double cw0 = c[11], cw1 = c[12], cw2 = c[13];
-    a[7] = 0.5 * (-w0 * cq1 - w1 * cq2 - w2 * cq3 - q1 * cw0 - q2 * cw1 - q3 * cw2);
-    a[8] = 0.5 * (w0 * cq0 + w2 * cq2 - w1 * cq3 + q0 * cw0 - q3 * cw1 + q2 * cw2);
-    a[9] = 0.5 * (w1 * cq0 - w2 * cq1 + w0 * cq3 + q3 * cw0 + q0 * cw1 - q1 * cw2);
-    a[10] = 0.5 * (w2 * cq0 + w1 * cq1 - w0 * cq2 - q2 * cw0 + q1 * cw1 + q0 * cw2);
+    const R q0 = RR(oQ), q1 = RR(oQ + 1), q2 = RR(oQ + 2), q3 = RR(oQ + 3);
+    const R w0 = RR(oW), w1 = RR(oW + 1), w2 = RR(oW + 2);
+    const R cq0 = c[7], cq1 = c[8], cq2 = c[9], cq3 = c[10];
+    const R cw0 = c[11], cw1 = c[12], cw2 = c[13];
+    a[7] = R(0.5) * (-w0 * cq1 - w1 * cq2 - w2 * cq3 - q1 * cw0 - q2 * cw1 - q3 * cw2);
+    a[8] = R(0.5) * (w0 * cq0 + w2 * cq2 - w1 * cq3 + q0 * cw0 - q3 * cw1 + q2 * cw2);
+    a[9] = R(0.5) * (w1 * cq0 - w2 * cq1 + w0 * cq3 + q3 * cw0 + q0 * cw1 - q1 * cw2);
+    a[10] = R(0.5) * (w2 * cq0 + w1 * cq1 - w0 * cq2 - q2 * cw0 + q1 * cw1 + q0 * cw2);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        double t = R(oMw + 3 * i) * cw0;
-        t = fma(R(oMw + 3 * i + 1), cw1, t);
-        t = fma(R(oMw + 3 * i + 2), cw2, t);
+        R t = RR(oMw + 3 * i) * cw0;
+        t = fma(RR(oMw + 3 * i + 1), cw1, t);
+        t = fma(RR(oMw + 3 * i + 2), cw2, t);
         t = fma(p.JrT[3 * i], wc[0], t);
         t = fma(p.JrT[3 * i + 1], wc[1], t);
         t = fma(p.JrT[3 * i + 2], wc[2], t);
         a[11 + i] = t;
     }
 #pragma unroll
-    for (int i = 0; i < 14; i++) dc[i] = fma(sigma, a[i], gsel * R(i));
+    for (int i = 0; i < 14; i++) dc[i] = fma(sigma, a[i], gsel * RR(i));
 }
 
 }  // namespace scvx

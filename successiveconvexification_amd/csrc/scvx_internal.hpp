@@ -32,6 +32,12 @@ hipError_t launch_linearize(const scvx_ctx* ctx, int B, int K, const double* x, 
 hipError_t launch_propagate(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
                             double dt, double* xnext, hipStream_t st);
 
+// fp32 forms (column-per-lane kernel / one thread per segment, float arithmetic): scvx_linearize_f32, scvx_propagate_f32
+hipError_t launch_linearize_f32(const scvx_ctx* ctx, int B, int K, const float* x, const float* u, const float* sigma,
+                                float dt, float* endpoint, float* deriv, hipStream_t st);
+hipError_t launch_propagate_f32(const scvx_ctx* ctx, int B, int K, const float* x, const float* u, const float* sigma,
+                                float dt, float* xnext, hipStream_t st);
+
 inline int fail(scvx_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return code;

@@ -62,7 +62,7 @@ class IntegratorCache:
         return self._L.scvx_get_nsub(self.handle)
 
     def set_stream(self, stream_handle):
-        _lib.check(self.handle, self._L.scvx_set_stream(self.handle, C.c_void_p(stream_handle)), "scvx_set_stream")
+        _lib.check(self.handle, self._L.scvx_set_stream(self.handle, C.c_void_p(stream_handle or 0)), "scvx_set_stream")
 
     def synchronize(self):
         _lib.check(self.handle, self._L.scvx_synchronize(self.handle), "scvx_synchronize")
@@ -106,6 +106,40 @@ def propagate_batch(cache: IntegratorCache, x, u, sigma, dt):
     e = np.empty((B, K, 14))
     _lib.check(cache.handle, cache._L.scvx_propagate_f64_host(cache.handle, B, K, _p(x), _p(u), _p(sigma), float(dt),
                                                               _p(e)), "scvx_propagate_f64_host")
+    return e
+
+
+def _pf(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def linearize_batch_f32(cache: IntegratorCache, x, u, sigma, dt):
+    """fp32 form (scvx_linearize_f32_host): float arrays in and out, float arithmetic on the device."""
+    x = np.ascontiguousarray(x, np.float32)
+    u = np.ascontiguousarray(u, np.float32)
+    sigma = np.ascontiguousarray(sigma, np.float32)
+    B, K1, nx = x.shape
+    K = K1 - 1
+    if nx != 14 or u.shape != (B, K1, 3) or sigma.shape != (B,):
+        raise ValueError("shape mismatch: x [B][K+1][14], u [B][K+1][3], sigma [B]")
+    e = np.empty((B, K, 14), np.float32)
+    d = np.empty((B, K, 21, 14), np.float32)
+    _lib.check(cache.handle, cache._L.scvx_linearize_f32_host(cache.handle, B, K, _pf(x), _pf(u), _pf(sigma), float(dt),
+                                                              _pf(e), _pf(d)), "scvx_linearize_f32_host")
+    return e, d
+
+
+def propagate_batch_f32(cache: IntegratorCache, x, u, sigma, dt):
+    x = np.ascontiguousarray(x, np.float32)
+    u = np.ascontiguousarray(u, np.float32)
+    sigma = np.ascontiguousarray(sigma, np.float32)
+    B, K1, nx = x.shape
+    K = K1 - 1
+    if nx != 14 or u.shape != (B, K1, 3) or sigma.shape != (B,):
+        raise ValueError("shape mismatch: x [B][K+1][14], u [B][K+1][3], sigma [B]")
+    e = np.empty((B, K, 14), np.float32)
+    _lib.check(cache.handle, cache._L.scvx_propagate_f32_host(cache.handle, B, K, _pf(x), _pf(u), _pf(sigma), float(dt),
+                                                              _pf(e)), "scvx_propagate_f32_host")
     return e
 
 

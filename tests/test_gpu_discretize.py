@@ -105,3 +105,31 @@ def test_empty_and_errors():
         linearize_batch(c, np.zeros((2, 51, 14)), np.zeros((2, 50, 3)), np.zeros(2), 1 / 51)
     with pytest.raises(_lib.ScvxError):
         c.set_npts(0)
+
+
+@pytest.mark.parametrize("aero", [False, True])
+def test_fp32_entry_points_match_the_fp64_oracle_to_the_stated_tolerance(aero, aero_tables):
+    """scvx_linearize_f32 / scvx_propagate_f32 (float arithmetic, float storage) against the fp64 C oracle on random
+    physical segments (SURVEY 8d law): endpoint 2e-5, derivative 2e-4 relative to the largest entry of its column block --
+    the stated tolerance of include/scvx.h.  Also the variant check: the fp64 column-per-lane kernel (SCVX_K1_VARIANT=0,
+    the one the float kernel is instantiated from) still agrees with the oracle to 1e-11."""
+    from oracle import dynamics as od, model
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.defns import AtmosphericData
+    from successiveconvexification_amd.dynamics import IntegratorCache, linearize_batch_f32, propagate_batch_f32
+    d, l, t = aero_tables
+    po = model.base_prob_scaled(model.AeroData(d, l, t) if aero else None)
+    pp = sp.base_prob_aero_scaled(AtmosphericData(d, l, t)) if aero else sp.base_prob_scaled
+    B, K = 64, 50
+    x, u, s = random_segments(po, B, K, 20261006)
+    c = IntegratorCache(pp, npts=10)
+    e_ref, d_ref = od.linearize(od.Params(po), x, u, s, 1.0 / (K + 1), 10)
+    e32, d32 = linearize_batch_f32(c, x, u, s, 1.0 / (K + 1))
+    assert e32.dtype == np.float32 and d32.dtype == np.float32
+    assert np.abs(e32 - e_ref).max() < 2e-5 * max(1.0, np.abs(e_ref).max())
+    scale = np.abs(d_ref).max(axis=(0, 1, 3), keepdims=True)          # per column of the 14x21 derivative
+    assert (np.abs(d32 - d_ref) / np.maximum(scale, 1.0)).max() < 2e-4
+    xp32 = propagate_batch_f32(c, x, u, s, 1.0 / (K + 1))
+    assert np.abs(xp32 - e_ref).max() < 2e-5 * max(1.0, np.abs(e_ref).max())
+    assert np.array_equal(xp32, e32)                                   # K2 and the state part of K1: same arithmetic
+    c.close()
