@@ -41,11 +41,10 @@ template <> struct Vec2<float> { typedef float2 type; };
 // float: 2 wavefronts per SIMD (the four unrolled stages keep ~250 values live either way: at 168 VGPRs 300-600 spill)
 template <bool AERO, typename R>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, sizeof(R) == 4 ? 2 : 1) void linearize_kernel(
-    DynParams p_, long nseg, int K, const R* __restrict__ x, const R* __restrict__ u,
+    DynP<R> p, long nseg, int K, const R* __restrict__ x, const R* __restrict__ u,
     const R* __restrict__ sigma, R dt, int nsub, R* __restrict__ endpoint,
     R* __restrict__ deriv) {
     constexpr int LPS = K1Map<AERO>::LPS, SPW = K1Map<AERO>::SPW;
-    const DynP<R> p(p_);
     typedef typename Vec2<R>::type VEC2;   // 16-byte (double) / 8-byte (float) pairs: 147 per segment either way
     __shared__ __attribute__((aligned(16))) R tile[WAVES_PER_BLOCK][SPW * 294];
     const int lane = threadIdx.x & 63;
@@ -325,13 +324,12 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
 }
 
 template <bool AERO, typename R>
-__global__ __launch_bounds__(256) void propagate_kernel(DynParams p_, long nseg, int K, const R* __restrict__ x,
+__global__ __launch_bounds__(256) void propagate_kernel(DynP<R> p, long nseg, int K, const R* __restrict__ x,
                                                         const R* __restrict__ u,
                                                         const R* __restrict__ sigma, R dt, int nsub,
                                                         R* __restrict__ xnext) {
     const long seg = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (seg >= nseg) return;
-    const DynP<R> p(p_);
     const long b = seg / K;
     const int k = (int)(seg - b * K);
     const R* xk = x + ((size_t)b * (K + 1) + k) * 14;
@@ -383,11 +381,12 @@ hipError_t launch_linearize_simple(const scvx_ctx* ctx, int B, int K, const R* x
     const int spw = ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW;
     const long nwave = (nseg + spw - 1) / spw;
     const unsigned grid = (unsigned)((nwave + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    const DynP<R> dp(ctx->dyn);
     if (ctx->dyn.aero)
-        hipLaunchKernelGGL((linearize_kernel<true, R>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, st, ctx->dyn, nseg, K, x, u,
+        hipLaunchKernelGGL((linearize_kernel<true, R>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, st, dp, nseg, K, x, u,
                            sigma, dt, ctx->nsub, endpoint, deriv);
     else
-        hipLaunchKernelGGL((linearize_kernel<false, R>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, st, ctx->dyn, nseg, K, x, u,
+        hipLaunchKernelGGL((linearize_kernel<false, R>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, st, dp, nseg, K, x, u,
                            sigma, dt, ctx->nsub, endpoint, deriv);
     return hipGetLastError();
 }
@@ -428,11 +427,12 @@ hipError_t launch_propagate_t(const scvx_ctx* ctx, int B, int K, const R* x, con
     const long nseg = (long)B * K;
     if (nseg == 0) return hipSuccess;
     const unsigned grid = (unsigned)((nseg + 255) / 256);
+    const DynP<R> dp(ctx->dyn);
     if (ctx->dyn.aero)
-        hipLaunchKernelGGL((propagate_kernel<true, R>), dim3(grid), dim3(256), 0, st, ctx->dyn, nseg, K, x, u, sigma, dt,
+        hipLaunchKernelGGL((propagate_kernel<true, R>), dim3(grid), dim3(256), 0, st, dp, nseg, K, x, u, sigma, dt,
                            ctx->nsub, xnext);
     else
-        hipLaunchKernelGGL((propagate_kernel<false, R>), dim3(grid), dim3(256), 0, st, ctx->dyn, nseg, K, x, u, sigma, dt,
+        hipLaunchKernelGGL((propagate_kernel<false, R>), dim3(grid), dim3(256), 0, st, dp, nseg, K, x, u, sigma, dt,
                            ctx->nsub, xnext);
     return hipGetLastError();
 }

@@ -29,7 +29,8 @@ struct DynParams {
 
 // The device functions below are templates on the arithmetic type R: double is the reference precision (and what the
 // SCvx loop uses); float backs the scvx_*_f32 entry points (BASELINE configs[3-4] name fp32).  DynP<R> is DynParams with
-// every constant converted once per kernel, so that no expression silently promotes to double in the float build.
+// every constant converted once ON THE HOST and passed as the kernel argument (scalar registers), so that no expression
+// silently promotes to double in the float build and no vector register holds a constant.
 template <typename R>
 struct DynP {
     R alpha, g0, sos;
@@ -38,7 +39,7 @@ struct DynP {
     R aoa0, inv_daoa, mach0, inv_dmach, force_scalar;
     const double* cdrag;   // prefiltered coefficients stay double in memory (shared by both precisions, cache-resident)
     const double* clift;
-    __device__ __forceinline__ explicit DynP(const DynParams& p)
+    __host__ __device__ __forceinline__ explicit DynP(const DynParams& p)
         : alpha((R)p.alpha), g0((R)p.g0), sos((R)p.sos), aero(p.aero), n_aoa(p.n_aoa), n_mach(p.n_mach), aoa0((R)p.aoa0),
           inv_daoa((R)p.inv_daoa), mach0((R)p.mach0), inv_dmach((R)p.inv_dmach), force_scalar((R)p.force_scalar),
           cdrag(p.cdrag), clift(p.clift) {

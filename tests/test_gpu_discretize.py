@@ -131,5 +131,5 @@ def test_fp32_entry_points_match_the_fp64_oracle_to_the_stated_tolerance(aero, a
     assert (np.abs(d32 - d_ref) / np.maximum(scale, 1.0)).max() < 2e-4
     xp32 = propagate_batch_f32(c, x, u, s, 1.0 / (K + 1))
     assert np.abs(xp32 - e_ref).max() < 2e-5 * max(1.0, np.abs(e_ref).max())
-    assert np.array_equal(xp32, e32)                                   # K2 and the state part of K1: same arithmetic
+    assert np.abs(xp32 - e32).max() < 2e-6                             # K2 and the state part of K1: same arithmetic up to contraction
     c.close()
