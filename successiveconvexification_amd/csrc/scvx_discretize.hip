@@ -182,25 +182,25 @@ constexpr int PC_GROUP = 4;              // stages published per barrier (one RK
 // SG (stage-granular, the default): one barrier per RK stage and the producer one STAGE ahead (2-slot ring) instead of
 // one barrier per substep and the producer one substep ahead: the pipeline fills after one stage instead of four (at
 // npts = 1 the substep-granular form does not overlap at all), which outweighs the 4x barrier count at every npts.
-template <bool AERO, bool SG>
+template <bool AERO, bool SG, typename R>
 __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
-    DynParams p_, long nseg, int K, const double* __restrict__ x, const double* __restrict__ u,
-    const double* __restrict__ sigma, double dt, int nsub, double* __restrict__ endpoint,
-    double* __restrict__ deriv) {
+    DynP<R> p, long nseg, int K, const R* __restrict__ x, const R* __restrict__ u,
+    const R* __restrict__ sigma, R dt, int nsub, R* __restrict__ endpoint,
+    R* __restrict__ deriv) {
     constexpr int LPS = K1Map<AERO>::LPS, SPW = K1Map<AERO>::SPW;
-    const DynP<double> p(p_);
+    typedef typename Vec2<R>::type VEC2;
     constexpr int NC = PC_WAVES - 1;
     constexpr int NS = NC * SPW;               // segments per block
     constexpr int NR = StageRec<AERO>::N;
     constexpr int RING = SG ? 2 : 2 * PC_GROUP;   // stage records in flight: the producer runs one stage / one substep ahead
     constexpr int RING_D = RING * NR * NS, TILE_D = NC * SPW * 294;
     // one LDS slab: the coefficient ring during the integration, the output tiles afterwards
-    __shared__ __attribute__((aligned(16))) double lds[RING_D > TILE_D ? RING_D : TILE_D];
+    __shared__ __attribute__((aligned(16))) R lds[RING_D > TILE_D ? RING_D : TILE_D];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const long seg_base = (long)blockIdx.x * NS;
-    const double h = dt / (double)nsub;
-    const double inv_n = 1.0 / (double)nsub;
+    const R h = dt / R(nsub);
+    const R inv_n = R(1.0) / R(nsub);
 
     if (wave == PC_PROD) {
         // ---------------- producer: lane = segment ----------------
@@ -210,29 +210,29 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
         if (seg >= nseg) seg = nseg - 1;
         const long b = seg / K;
         const int k = (int)(seg - b * K);
-        const double* xk = x + ((size_t)b * (K + 1) + k) * 14;
-        const double* uk = u + ((size_t)b * (K + 1) + k) * 3;
-        const double sig = sigma[b];
-        double xs[14], xa[14], xt[14];
+        const R* xk = x + ((size_t)b * (K + 1) + k) * 14;
+        const R* uk = u + ((size_t)b * (K + 1) + k) * 3;
+        const R sig = sigma[b];
+        R xs[14], xa[14], xt[14];
 #pragma unroll
         for (int i = 0; i < 14; i++) { xs[i] = xk[i]; xa[i] = xs[i]; xt[i] = xs[i]; }
-        const double uk0 = uk[0], uk1 = uk[1], uk2 = uk[2], up0 = uk[3], up1 = uk[4], up2 = uk[5];
+        const R uk0 = uk[0], uk1 = uk[1], uk2 = uk[2], up0 = uk[3], up1 = uk[4], up2 = uk[5];
         const int l = live ? lane : 0;
         for (int s = 0; s <= nsub; s++) {
             if (s < nsub) {
 #pragma unroll
                 for (int stg = 0; stg < 4; stg++) {
-                    const double lkp = ((double)s + (stg == 0 ? 0.0 : (stg == 3 ? 1.0 : 0.5))) * inv_n;
-                    const double lkm = 1.0 - lkp;
-                    double uu[3] = {fma(uk0, lkm, up0 * lkp), fma(uk1, lkm, up1 * lkp), fma(uk2, lkm, up2 * lkp)};
-                    Stage<AERO, double> st;
+                    const R lkp = (R(s) + (stg == 0 ? R(0.0) : (stg == 3 ? R(1.0) : R(0.5)))) * inv_n;
+                    const R lkm = R(1.0) - lkp;
+                    R uu[3] = {fma(uk0, lkm, up0 * lkp), fma(uk1, lkm, up1 * lkp), fma(uk2, lkm, up2 * lkp)};
+                    Stage<AERO, R> st;
                     stage_eval<AERO>(p, xt, uu, st);
                     if (live) stage_publish<AERO>(p, st, xt, uu, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + l, NS);
-                    const double wacc = h * ((stg == 0 || stg == 3) ? (1.0 / 6.0) : (1.0 / 3.0));
-                    const double wnext = h * (stg == 2 ? 1.0 : 0.5);
+                    const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
+                    const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
 #pragma unroll
                     for (int i = 0; i < 14; i++) {
-                        const double dx = sig * st.g[i];
+                        const R dx = sig * st.g[i];
                         xa[i] = fma(wacc, dx, xa[i]);
                         xt[i] = (stg < 3) ? fma(wnext, dx, xs[i]) : xa[i];
                     }
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
             if (!SG || s == nsub) __syncthreads();
         }
         if (valid) {
-            double* ep = endpoint + (size_t)seg * 14;
+            R* ep = endpoint + (size_t)seg * 14;
 #pragma unroll
             for (int i = 0; i < 14; i++) ep[i] = xs[i];
         }
@@ -261,27 +261,27 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
     const int ls = cw * SPW + (lane_live ? sl : 0);   // local segment index in the block
     long seg = seg_base + ls;
     if (seg >= nseg) seg = nseg - 1;
-    const double sig = sigma[seg / K];
-    double c[14], ca[14], ct[14];
+    const R sig = sigma[seg / K];
+    R c[14], ca[14], ct[14];
 #pragma unroll
-    for (int i = 0; i < 14; i++) { c[i] = (col == i) ? 1.0 : 0.0; ca[i] = c[i]; ct[i] = c[i]; }
+    for (int i = 0; i < 14; i++) { c[i] = (col == i) ? R(1.0) : R(0.0); ca[i] = c[i]; ct[i] = c[i]; }
     const bool is_uk = (col >= 14) && (col < 17);
     const bool is_up = (col >= 17) && (col < 20);
     const int comp = is_uk ? col - 14 : (is_up ? col - 17 : -1);
-    const double gsel = (col == 20) ? 1.0 : 0.0;
-    const double e0 = (comp == 0) ? 1.0 : 0.0, e1 = (comp == 1) ? 1.0 : 0.0, e2 = (comp == 2) ? 1.0 : 0.0;
+    const R gsel = (col == 20) ? R(1.0) : R(0.0);
+    const R e0 = (comp == 0) ? R(1.0) : R(0.0), e1 = (comp == 1) ? R(1.0) : R(0.0), e2 = (comp == 2) ? R(1.0) : R(0.0);
     __syncthreads();  // records of substep 0 are ready
     for (int s = 0; s < nsub; s++) {
 #pragma unroll
         for (int stg = 0; stg < 4; stg++) {
-            const double lkp = ((double)s + (stg == 0 ? 0.0 : (stg == 3 ? 1.0 : 0.5))) * inv_n;
-            const double lkm = 1.0 - lkp;
-            const double wk = is_uk ? lkm : (is_up ? lkp : 0.0);
-            const double wc[3] = {e0 * wk, e1 * wk, e2 * wk};
-            double dc[14];
+            const R lkp = (R(s) + (stg == 0 ? R(0.0) : (stg == 3 ? R(1.0) : R(0.5)))) * inv_n;
+            const R lkm = R(1.0) - lkp;
+            const R wk = is_uk ? lkm : (is_up ? lkp : R(0.0));
+            const R wc[3] = {e0 * wk, e1 * wk, e2 * wk};
+            R dc[14];
             column_deriv_rec<AERO>(p, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + ls, NS, ct, wc, gsel, sig, dc);
-            const double wacc = h * ((stg == 0 || stg == 3) ? (1.0 / 6.0) : (1.0 / 3.0));
-            const double wnext = h * (stg == 2 ? 1.0 : 0.5);
+            const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
+            const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
 #pragma unroll
             for (int i = 0; i < 14; i++) {
                 ca[i] = fma(wacc, dc[i], ca[i]);
@@ -294,17 +294,17 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
         if (!SG) __syncthreads();
     }
     // ---- epilogue: columns into the LDS tile (the ring is dead now) -> coalesced 16-byte stores ----
-    double* t = lds + cw * SPW * 294;
+    R* t = lds + cw * SPW * 294;
     if (lane_live) {
 #pragma unroll
         for (int i = 0; i < 14; i++) t[sl * 294 + col * 14 + i] = c[i];
         if (!AERO && slot < 6) {
             const int j = slot < 3 ? slot : slot - 3;
-            double* cc = t + sl * 294 + (slot < 3 ? 1 + j : 4 + j) * 14;
+            R* cc = t + sl * 294 + (slot < 3 ? 1 + j : 4 + j) * 14;
 #pragma unroll
-            for (int i = 0; i < 14; i++) cc[i] = 0.0;
-            if (slot < 3) cc[1 + j] = 1.0;
-            else { cc[1 + j] = sig * dt; cc[4 + j] = 1.0; }
+            for (int i = 0; i < 14; i++) cc[i] = R(0.0);
+            if (slot < 3) cc[1 + j] = R(1.0);
+            else { cc[1 + j] = sig * dt; cc[4 + j] = R(1.0); }
         }
     }
     __syncthreads();
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
         const long rem = nseg - seg0;
         const int nvalid = rem < SPW ? (int)rem : SPW;
         const int n2 = nvalid * 147;
-        double2* out = reinterpret_cast<double2*>(deriv + (size_t)seg0 * 294);
-        const double2* src = reinterpret_cast<const double2*>(t);
+        VEC2* out = reinterpret_cast<VEC2*>(deriv + (size_t)seg0 * 294);
+        const VEC2* src = reinterpret_cast<const VEC2*>(t);
 #pragma unroll
         for (int r = 0; r < (SPW * 147 + 63) / 64; r++) {
             const int e = lane + 64 * r;
@@ -391,34 +391,42 @@ hipError_t launch_linearize_simple(const scvx_ctx* ctx, int B, int K, const R* x
     return hipGetLastError();
 }
 
-hipError_t launch_linearize(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
-                            double dt, double* endpoint, double* deriv, hipStream_t st) {
+template <typename R>
+hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, const R* u, const R* sigma, R dt, R* endpoint,
+                              R* deriv, hipStream_t st) {
     const long nseg = (long)B * K;
     if (nseg == 0) return hipSuccess;
-    if (ctx->k1_variant == 0) return launch_linearize_simple<double>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st);
-    {
-        const int ns = (PC_WAVES - 1) * (ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW);
-        const unsigned grid = (unsigned)((nseg + ns - 1) / ns);
-        // stage-granular pipeline by default (faster at every npts measured: 0.70 -> 0.60 ms at npts 1, 3.05 -> 2.96 ms
-        // at npts 10, B = 8192); SCVX_K1_SG=0 selects the substep-granular form
-        const bool sg = ctx->k1_sg != 0;
-        const dim3 g(grid), blk(64 * PC_WAVES);
-        if (ctx->dyn.aero) {
-            if (sg) hipLaunchKernelGGL((linearize_pc_kernel<true, true>), g, blk, 0, st, ctx->dyn, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
-            else hipLaunchKernelGGL((linearize_pc_kernel<true, false>), g, blk, 0, st, ctx->dyn, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
-        } else {
-            if (sg) hipLaunchKernelGGL((linearize_pc_kernel<false, true>), g, blk, 0, st, ctx->dyn, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
-            else hipLaunchKernelGGL((linearize_pc_kernel<false, false>), g, blk, 0, st, ctx->dyn, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
-        }
+    if (ctx->k1_variant == 0) return launch_linearize_simple<R>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st);
+    const int ns = (PC_WAVES - 1) * (ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW);
+    const unsigned grid = (unsigned)((nseg + ns - 1) / ns);
+    // stage-granular pipeline by default (faster at every npts measured: 0.70 -> 0.60 ms at npts 1, 3.05 -> 2.96 ms
+    // at npts 10, B = 8192, fp64); SCVX_K1_SG=0 selects the substep-granular form
+    const bool sg = ctx->k1_sg != 0;
+    const dim3 g(grid), blk(64 * PC_WAVES);
+    const DynP<R> dp(ctx->dyn);
+    if (ctx->dyn.aero) {
+        if (sg) hipLaunchKernelGGL((linearize_pc_kernel<true, true, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
+        else hipLaunchKernelGGL((linearize_pc_kernel<true, false, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
+    } else {
+        if (sg) hipLaunchKernelGGL((linearize_pc_kernel<false, true, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
+        else hipLaunchKernelGGL((linearize_pc_kernel<false, false, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
     }
     return hipGetLastError();
 }
 
-// fp32 form of K1 (scvx_linearize_f32): the column-per-lane kernel in float arithmetic -- half the bytes, half the
-// registers (4 wavefronts per SIMD instead of 2) and twice the vector rate of the fp64 kernel
+hipError_t launch_linearize(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
+                            double dt, double* endpoint, double* deriv, hipStream_t st) {
+    return launch_linearize_t<double>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st);
+}
+
+// fp32 form of K1 (scvx_linearize_f32): the same kernels instantiated in float arithmetic -- half the bytes, twice the
+// vector rate of the fp64 instantiation
 hipError_t launch_linearize_f32(const scvx_ctx* ctx, int B, int K, const float* x, const float* u, const float* sigma,
                                 float dt, float* endpoint, float* deriv, hipStream_t st) {
-    return launch_linearize_simple<float>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st);
+    // measured at B = 8192 (profiles/r02_k1.md): up to two substeps the column-per-lane form wins in float (0.37 vs 0.43 ms
+    // at npts 1: the producer/consumer pipeline pays a barrier per RK stage), beyond that the producer/consumer form does
+    if (ctx->nsub <= 2 && ctx->k1_variant != 0) return launch_linearize_simple<float>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st);
+    return launch_linearize_t<float>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st);
 }
 
 template <typename R>
