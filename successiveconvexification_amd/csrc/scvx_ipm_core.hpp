@@ -168,7 +168,7 @@ struct Layout {
         n += (size_t)K * (LINV_SZ + 196);  // Linv (packed lower triangle), Nf
         n += (size_t)K * 196;            // At: the state blocks A_k of D transposed (coalesced E' products)
         n += (size_t)ny;                 // tchain
-        n += (size_t)(nloc + ny) * 3;    // ls,ys, ltr,ytr, lnu,ynu
+        n += (size_t)ny * 4 + nloc;      // ys, ytr, ynu, rtr, ptl
         n += (size_t)nloc * 2;           // tmpl, tmpl2
         n += (size_t)3 * (K + 1);        // uhat
         n += (size_t)(K + 1);            // lb0
@@ -309,7 +309,8 @@ struct Solver {
     gptr Wbeta;
     gptr hx, hu;
     gptr Linv, Nf, tchain, At;
-    gptr ls, ys, ltr, ytr, lnu, ynu;
+    gptr ys, ytr, ynu;   // the three border multipliers  S y = Sg, E Hb^-1 Ptr, hnui Pnu
+    gptr ptl, rtr;       // ptl = Hb^-1 Ptr (local, zero on nu),  rtr = E ptl
     gptr tmpl, tmpl2;
     gptr uhat, lb0;
     // per-factorisation scalars
@@ -342,7 +343,7 @@ struct Solver {
         hx = w; w += (size_t)(K + 1) * HX_SZ; hu = w; w += (size_t)(K + 1) * 9;
         Linv = w; w += (size_t)K * LINV_SZ; Nf = w; w += (size_t)K * 196; At = w; w += (size_t)K * 196;
         tchain = w; w += ny;
-        ls = w; w += nloc; ys = w; w += ny; ltr = w; w += nloc; ytr = w; w += ny; lnu = w; w += nloc; ynu = w; w += ny;
+        ys = w; w += ny; ytr = w; w += ny; ynu = w; w += ny; rtr = w; w += ny; ptl = w; w += nloc;
         tmpl = w; w += nloc; tmpl2 = w; w += nloc;
         uhat = w; w += 3 * (K + 1); lb0 = w; w += (K + 1);
     }
@@ -428,12 +429,15 @@ struct Solver {
     // g = E_loc' y on the local part (dx, du, nu); returns Sg . y (the s entry) to every lane.
     // mode 1: g = base - E_loc' y;  mode 2: g = E_loc' y - base  (base may be g itself: each entry is read and written by
     // the same lane)
-    SCVX_HD_NI double Et_apply(cgptr yy, gptr g, cgptr base = nullptr, int mode = 0) {
+    // pc / pn (mode 1 only): base - pc Ptr - pn Pnu - E_loc' y, the right-hand side of a solve's final Hb^-1 (kkt_solve)
+    SCVX_HD_NI double Et_apply(cgptr yy, gptr g, cgptr base = nullptr, int mode = 0, double pc = 0.0, double pn = 0.0) {
         SCVX_T0();
         const int K = L.K;
+        const bool corr = pc != 0.0 || pn != 0.0;
+        cgptr Pt = Wv + L.o_tr + 1; cgptr Pn = Wv + L.o_nu + 1;
         for (int t = ex.lane(); t < L.nx; t += ex.nlanes()) {
             const int k = t / 14, j = t - 14 * k;
-            const double b0 = mode ? base[t] : 0.0;   // loaded with the batch below
+            const double b0 = mode ? base[t] - (corr ? pc * Pt[t] : 0.0) : 0.0;   // loaded with the batch below
             double a = 0;
             if (k < K) {
                 cgptr col = At + (size_t)k * 196 + j;   // A_k' row-major: lanes j read consecutive doubles
@@ -446,7 +450,7 @@ struct Solver {
         }
         for (int t = ex.lane(); t < L.nu_; t += ex.nlanes()) {
             const int k = t / 3, c = t - 3 * k;
-            const double b0 = mode ? base[L.nx + t] : 0.0;
+            const double b0 = mode ? base[L.nx + t] - (corr ? pc * Pt[L.nx + t] : 0.0) : 0.0;
             double a = 0;
             if (k < K) {
                 cgptr col = D + (size_t)k * 294 + 14 * (14 + c);
@@ -464,6 +468,10 @@ struct Solver {
         double sg = 0;
         {
             const cgptr D_ = D; cgptr bn = mode ? base + L.nx + L.nu_ : yy; const gptr gn = g + L.nx + L.nu_;
+            if (corr)
+                stream(0, 14 * K, [&](int r) { const int k = r / 14, i = r - 14 * k; return D4{yy[r], bn[r], D_[(size_t)k * 294 + 14 * 20 + i], Pn[r]}; },
+                       [&](int r, const D4& w) { gn[r] = (w.b - pn * w.d) - w.a; sg += w.c * w.a; });
+            else
             stream(0, 14 * K, [&](int r) { const int k = r / 14, i = r - 14 * k; return D3{yy[r], bn[r], D_[(size_t)k * 294 + 14 * 20 + i]}; },
                    [&](int r, const D3& w) { gn[r] = mode == 0 ? w.a : (mode == 1 ? w.b - w.a : w.a - w.b); sg += w.c * w.a; });
         }
@@ -1133,42 +1141,6 @@ struct Solver {
         }
         ex.sync();
     }
-    // g_q = E_loc' y_q on (dx, du) for N vectors with one pass over D / At; the nu block of E_loc' y is y itself
-    template <int N>
-    SCVX_HD_NI void Et_applyN(const cgptr (&y)[N], const gptr (&g)[N]) {
-        const int K = L.K;
-        const cgptr D = this->D;
-        const cgptr At = this->At;
-        for (int t = ex.lane(); t < L.nx; t += ex.nlanes()) {
-            const int k = t / 14, j = t - 14 * k;
-            double a[N];
-            for (int q = 0; q < N; q++) a[q] = 0;
-            if (k < K) {
-                cgptr col = At + (size_t)k * 196 + j;
-                SCVX_UNROLL
-                for (int i = 0; i < 14; i++) { const double c = col[14 * i]; for (int q = 0; q < N; q++) a[q] += c * y[q][14 * k + i]; }
-            }
-            if (k > 0) for (int q = 0; q < N; q++) a[q] -= y[q][14 * (k - 1) + j];
-            for (int q = 0; q < N; q++) g[q][t] = a[q];
-        }
-        for (int t = ex.lane(); t < L.nu_; t += ex.nlanes()) {
-            const int k = t / 3, c = t - 3 * k;
-            double a[N];
-            for (int q = 0; q < N; q++) a[q] = 0;
-            if (k < K) {
-                cgptr col = D + (size_t)k * 294 + 14 * (14 + c);
-                SCVX_UNROLL
-                for (int i = 0; i < 14; i++) { const double cc = col[i]; for (int q = 0; q < N; q++) a[q] += cc * y[q][14 * k + i]; }
-            }
-            if (k > 0) {
-                cgptr col = D + (size_t)(k - 1) * 294 + 14 * (17 + c);
-                SCVX_UNROLL
-                for (int i = 0; i < 14; i++) { const double cc = col[i]; for (int q = 0; q < N; q++) a[q] += cc * y[q][14 * (k - 1) + i]; }
-            }
-            for (int q = 0; q < N; q++) g[q][L.nx + t] = a[q];
-        }
-        ex.sync();
-    }
     // out0 = E v0, out1 = E v1 + add1 (both without the s column) with one pass over D
     SCVX_HD_NI void E_apply2(cgptr v0, cgptr v1, gptr out0, gptr out1, cgptr add1) {
         SCVX_T0();
@@ -1187,15 +1159,6 @@ struct Solver {
         }
         ex.sync();
         SCVX_T1(1);
-    }
-
-    // The equality right-hand side is rsign * ryv (ryv may be null).
-    SCVX_HD_NI void band_solve(cgptr gl, cgptr ryv, double rsign, gptr dl, gptr dyv) {
-        Hb_inv(gl, tmpl);
-        (void)E_apply(tmpl, tmpy, false, ryv, -rsign);      // E Hb^-1 g - r
-        S_solve(tmpy, dyv);
-        (void)Et_apply(dyv, tmpl2, gl, 1);                  // g - E' y
-        Hb_inv(tmpl2, dl);
     }
 
     // ---- factorisation for the current scaling (Wv, Wbeta) ----
@@ -1451,11 +1414,14 @@ struct Solver {
         ex.sync();   // the factors written above are read back (by other lanes) in the border solves
         SCVX_TE(tC_, 6);
         SCVX_TS(tB_);
-        // border solves: three banded systems [Hb E'; E 0][l; y] = [g; r] sharing every matrix read
-        //   s  : g = 0,            r = -Sg   ->  S y = +Sg
-        //   tr : g = (Ptr, 0, 0),  r = 0     ->  S y = E_loc Hb^-1 g
-        //   nu : g = (0, 0, Pnu),  r = 0     ->  S y = hnui Pnu          (E_loc is the identity on the nu block)
-        // and, with_pred, a fourth one on the same sweeps:  g = gx, r = -ry  (the predictor's banded solve)
+        // border: three banded systems [Hb E'; E 0][l; y] = [g; r] sharing every matrix read
+        //   s  : g = 0,            r = -Sg   ->  S ys  = +Sg
+        //   tr : g = (Ptr, 0, 0),  r = 0     ->  S ytr = E_loc Hb^-1 Ptr =: rtr
+        //   nu : g = (0, 0, Pnu),  r = 0     ->  S ynu = hnui Pnu        (E_loc is the identity on the nu block)
+        // and, with_pred, a fourth one on the same sweeps: the y of the predictor's banded solve, S dy = E Hb^-1 gx + ry.
+        // Only the multipliers y are kept.  The local parts l = Hb^-1 (g - E'y) of the border solutions are never
+        // formed: every border coefficient is an inner product in y-space (below), and a solve applies its border
+        // correction to dy and to the right-hand side BEFORE its single final  Hb^-1 (g - E'dy)  (kkt_solve).
         {
             const int nxu = L.nx + L.nu_;
             const gptr g_tr = r1;     // nloc: Ptr on (dx,du), 0 on nu   (r1: refinement scratch, idle here)
@@ -1464,12 +1430,12 @@ struct Solver {
                 stream<8>(0, L.nloc, [&](int i) { return i < nxu ? wt[i] : 0.0; }, [&](int i, double v) { g_tr[i] = v; });
             }
             ex.sync();
-            Hb_inv(g_tr, tmpl);
+            Hb_inv(g_tr, ptl);
             if (with_pred) {
                 Hb_inv(gx, cw);
-                E_apply2(tmpl, cw, tmpy2, rp, ry);                 // r_tr, r_pred = E Hb^-1 gx + ry
+                E_apply2(ptl, cw, rtr, rp, ry);                    // rtr, r_pred = E Hb^-1 gx + ry
             } else {
-                E_apply(tmpl, tmpy2, false);                       // r_tr
+                E_apply(ptl, rtr, false);                          // rtr
             }
             {
                 gptr ty = tmpy; gptr r2_ = r2; cgptr wn = Wv + L.o_nu + 1;
@@ -1478,58 +1444,37 @@ struct Solver {
             }
             ex.sync();
             if (with_pred) {
-                const cgptr rr[4] = {tmpy, tmpy2, r2, rp};
+                const cgptr rr[4] = {tmpy, rtr, r2, rp};
                 const gptr xx[4] = {ys, ytr, ynu, dy};
                 const gptr tt4[4] = {tchain, cy, tq0, tq1};
                 S_solveN<4>(rr, xx, tt4);
-                const cgptr yy[4] = {ys, ytr, ynu, dy};
-                const gptr gg[4] = {tmpl, tmpl2, tmpv, cw};
-                Et_applyN<4>(yy, gg);
             } else {
-                const cgptr rr[3] = {tmpy, tmpy2, r2};
+                const cgptr rr[3] = {tmpy, rtr, r2};
                 const gptr xx[3] = {ys, ytr, ynu};
                 const gptr tt3[3] = {tchain, cy, tq0};
                 S_solveN<3>(rr, xx, tt3);
-                const cgptr yy[3] = {ys, ytr, ynu};
-                const gptr gg[3] = {tmpl, tmpl2, tmpv};
-                Et_applyN<3>(yy, gg);
             }
-            // l = Hb^-1 (g - E' y): assemble the right-hand sides in place, then invert
-            {
-                gptr t0 = tmpl; gptr t1 = tmpl2; gptr t2 = tmpv;
-                cgptr y0 = ys; cgptr y1 = ytr; cgptr y2 = ynu; cgptr wn = Wv + L.o_nu + 1;
-                stream(0, L.nloc, [&](int i) {
-                           const bool isnu = i >= nxu;
-                           return D5{isnu ? y0[i - nxu] : t0[i], isnu ? y1[i - nxu] : t1[i], isnu ? y2[i - nxu] : t2[i],
-                                     g_tr[i], isnu ? wn[i - nxu] : 0.0};
-                       },
-                       [&](int i, const D5& v) { t0[i] = -v.a; t1[i] = v.d - v.b; t2[i] = v.e - v.c; });
-                if (with_pred) {
-                    gptr t3 = cw; cgptr y3 = dy; cgptr g3 = gx;
-                    stream(0, L.nloc, [&](int i) { return D2{i >= nxu ? y3[i - nxu] : t3[i], g3[i]}; },
-                           [&](int i, const D2& v) { t3[i] = v.b - v.a; });
-                }
-            }
-            ex.sync();
-            Hb_inv(tmpl, ls);
-            Hb_inv(tmpl2, ltr);
-            Hb_inv(tmpv, lnu);
-            if (with_pred) Hb_inv(cw, dw);
         }
-        // border coefficients
+        // border coefficients, all in y-space (Sg = the sigma column of E, Pnu = v1 of the nu cone, rtr = E Hb^-1 Ptr):
+        //   <Ptr, ls>  = -<rtr, ys>          <Ptr, ltr> = <Ptr, ptl> - <rtr, ytr>      <Ptr, lnu> = -<rtr, ynu>
+        //   <Pnu, ls>  = -hnui <Pnu, ys>     <Pnu, ltr> = -hnui <Pnu, ytr>             <Pnu, ynu> = pny
         {
-            double a = 0, b = 0, c = 0;
+            double a[9];
+            for (int q = 0; q < 9; q++) a[q] = 0.0;
             {
-                cgptr y0 = ys; cgptr y1 = ytr; cgptr y2 = ynu;
-                stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D4{D_[(size_t)k * 294 + 14 * 20 + i], y0[r], y1[r], y2[r]}; },
-                       [&](int, const D4& v) { a += v.a * v.b; b += v.a * v.c; c += v.a * v.d; });
+                cgptr y0 = ys; cgptr y1 = ytr; cgptr y2 = ynu; cgptr rt = rtr; cgptr wn = Wv + L.o_nu + 1;
+                stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D6{D_[(size_t)k * 294 + 14 * 20 + i], y0[r], y1[r], y2[r], rt[r], wn[r]}; },
+                       [&](int, const D6& v) {
+                           a[0] += v.a * v.b; a[1] += v.a * v.c; a[2] += v.a * v.d;
+                           a[3] += v.e * v.b; a[4] += v.e * v.c; a[5] += v.e * v.d;
+                           a[6] += v.f * v.b; a[7] += v.f * v.c; a[8] += v.f * v.d;
+                       });
             }
-            css = ex.sum(a); cst = -ex.sum(b); csn = -ex.sum(c);
-            cgptr Ptr = Wv + L.o_tr + 1; const int nt = L.nx + L.nu_;
-            cts = dot(Ptr, ls, nt); ctt = -dot(Ptr, ltr, nt); ctn = -dot(Ptr, lnu, nt);
-            cgptr Pnu = Wv + L.o_nu + 1; const int o = L.nx + L.nu_;
-            cns = dot(Pnu, ls + o, L.ny); cnt_ = -dot(Pnu, ltr + o, L.ny);
-            pny = dot(Pnu, ynu, L.ny);   // <Pnu, lnu> = hnui (|Pnu|^2 - pny): the |Pnu|^2 part is cancelled in closed form (kkt_solve)
+            for (int q = 0; q < 9; q++) a[q] = ex.sum(a[q]);
+            const double ptp = dot(Wv + L.o_tr + 1, ptl, L.nx + L.nu_);
+            css = a[0]; cst = -a[1]; csn = -a[2];
+            cts = -a[3]; ctt = -ptp + a[4]; ctn = a[5];
+            cns = -hnui_ * a[6]; cnt_ = hnui_ * a[7]; pny = a[8];
         }
         SCVX_TE(tB_, 7);
         return ex.all(ok);
@@ -1538,16 +1483,24 @@ struct Solver {
     // full reduced KKT: [H E'; E 0][dwv; dyv] = [g; ryv]  (g var-shaped incl. 4 globals)
     // have_band: (dwv, dyv) already hold the banded solution for (g, rsign ryv) (build_kkt(with_pred))
     SCVX_HD_NI void kkt_solve(cgptr g, cgptr ryv, gptr dwv, gptr dyv, double rsign = 1.0, bool have_band = false) {
-        if (!have_band) band_solve(g, ryv, rsign, dwv, dyv);
-        double a = 0;
+        // banded multiplier: S dy = E Hb^-1 g - rsign ryv   (have_band: build_kkt(true) left it in dyv)
+        if (!have_band) {
+            Hb_inv(g, tmpl);
+            (void)E_apply(tmpl, tmpy, false, ryv, -rsign);
+            S_solve(tmpy, dyv);
+        }
+        // inner products of the banded LOCAL solution dl = Hb^-1 (g - E'dy) with Sg / Ptr / Pnu, without forming dl:
+        //   <Ptr, dl> = <ptl, g> - <rtr, dy>,   <Pnu, dl_nu> = hnui (<Pnu, g_nu> - <Pnu, dy>)
+        double a = 0, bt = 0, bn = 0, gn = 0;
         {
-            const cgptr D_ = D;
-            stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D2{D_[(size_t)k * 294 + 14 * 20 + i], dyv[r]}; },
-                   [&](int, const D2& v) { a += v.a * v.b; });
+            const cgptr D_ = D; cgptr rt = rtr; cgptr wn = Wv + L.o_nu + 1; cgptr gnu = g + L.nx + L.nu_;
+            stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D5{D_[(size_t)k * 294 + 14 * 20 + i], dyv[r], rt[r], wn[r], gnu[r]}; },
+                   [&](int, const D5& v) { a += v.a * v.b; bt += v.c * v.b; bn += v.d * v.b; gn += v.d * v.e; });
         }
         const double c0s = ex.sum(a);
-        const double c0t = dot(Wv + L.o_tr + 1, dwv, L.nx + L.nu_);
-        const double c0n = dot(Wv + L.o_nu + 1, dwv + L.nx + L.nu_, L.ny);
+        bt = ex.sum(bt); bn = ex.sum(bn); gn = ex.sum(gn);
+        const double c0t = dot(ptl, g, L.nx + L.nu_) - bt;
+        const double c0n = hnui * (gn - bn);
         // ---- border: three unknowns (s, ctr, cnu), the heads of the cones eliminated in closed form ----
         // With W^-2 = [[h00, h01 v1'], [h01 v1, b2 I + h11 v1 v1']] a cone whose head t appears in no other row gives
         //     h00 t + h01 pi = g_t,   c = h01 t + h11 pi = kappa + sigma pi,   pi = <v1, l>,
@@ -1593,14 +1546,15 @@ struct Solver {
         const double tnu_ = (g[L.iTNU] - h01n * pi_n) / h00n;
         const double ts_ = g[L.iTS] / h00s - q_sg[3] * s_;
         ex.sync();
-        {
-            cgptr a0 = ls; cgptr a1 = ltr; cgptr a2 = lnu;
-            stream(0, L.nloc, [&](int i) { return D4{dwv[i], a0[i], a1[i], a2[i]}; },
-                   [&](int i, const D4& v) { dwv[i] = v.a + v.b * s_ - v.c * ctr - v.d * cnu; });
+        {   // the border correction in y-space ...
             cgptr b0 = ys; cgptr b1 = ytr; cgptr b2 = ynu;
             stream(0, L.ny, [&](int i) { return D4{dyv[i], b0[i], b1[i], b2[i]}; },
                    [&](int i, const D4& v) { dyv[i] = v.a + v.b * s_ - v.c * ctr - v.d * cnu; });
         }
+        ex.sync();
+        // ... and the local step in one go:  dw = Hb^-1 (g - Ptr ctr - Pnu cnu - E'dy)
+        (void)Et_apply(dyv, tmpl2, g, 1, ctr, cnu);
+        Hb_inv(tmpl2, dwv);
         if (ex.lane() == 0) { dwv[L.iS] = s_; dwv[L.iTS] = ts_; dwv[L.iTNU] = tnu_; dwv[L.iTTR] = ttr_; }
         ex.sync();
     }
