@@ -133,3 +133,38 @@ def test_fp32_entry_points_match_the_fp64_oracle_to_the_stated_tolerance(aero, a
     assert np.abs(xp32 - e_ref).max() < 2e-5 * max(1.0, np.abs(e_ref).max())
     assert np.abs(xp32 - e32).max() < 2e-6                             # K2 and the state part of K1: same arithmetic up to contraction
     c.close()
+
+
+@pytest.mark.parametrize("aero", [False, True])
+def test_closed_form_columns_of_the_linearisation_are_exact(aero, aero_tables):
+    """Structure of A_k = d x_{k+1} / d x_k the model implies: nothing depends on position, and without aerodynamics
+    nothing but r' = sigma v depends on velocity, so d/dr_k = [0; I; 0; 0; 0] always and d/dv_k = [0; sigma dt I; I; 0; 0]
+    for the exo model -- EXACTLY (the exo kernel writes them in closed form, the aero kernel integrates zeros), for both
+    K1 variants.  (Skipping these columns in the conic solver's E / E' products was tried: -6 % bytes, +9 % time -- the
+    lane-dependent selects stop the loads of a row from batching; profiles/README.md.)"""
+    import os
+    from oracle import model
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.defns import AtmosphericData
+    from successiveconvexification_amd.dynamics import IntegratorCache, linearize_batch
+    d, l, t = aero_tables
+    po = model.base_prob_scaled(model.AeroData(d, l, t) if aero else None)
+    pp = sp.base_prob_aero_scaled(AtmosphericData(d, l, t)) if aero else sp.base_prob_scaled
+    B, K = 40, 50
+    x, u, s = random_segments(po, B, K, 20261007)
+    dt = 1.0 / (K + 1)
+    for variant in ("1", "0"):
+        os.environ["SCVX_K1_VARIANT"] = variant
+        try:
+            c = IntegratorCache(pp, npts=10)
+            e, D = linearize_batch(c, x, u, s, dt)       # D [B][K][21][14]: D[b, k, col, row]
+            c.close()
+        finally:
+            os.environ.pop("SCVX_K1_VARIANT", None)
+        eye = np.zeros((3, 14)); eye[np.arange(3), 1 + np.arange(3)] = 1.0
+        assert np.array_equal(D[:, :, 1:4, :], np.broadcast_to(eye, (B, K, 3, 14))), variant
+        if not aero:
+            want = np.zeros((B, K, 3, 14))
+            want[:, :, np.arange(3), 4 + np.arange(3)] = 1.0
+            want[:, :, np.arange(3), 1 + np.arange(3)] = (s * dt)[:, None, None]
+            assert np.array_equal(D[:, :, 4:7, :], want), variant
