@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: total trajectories, split over the ranks")
     ap.add_argument("--npts", type=int, default=10, help="RK4 substeps per segment (Dynamics.rk4 npts)")
     ap.add_argument("--seed", type=int, default=20261004)
+    ap.add_argument("--aero", action="store_true", help="SampleProblems.base_prob_aero_scaled (lift_drag tables): BASELINE configs[2] model; NOT the headline workload")
     ap.add_argument("--no-reset", action="store_true", help="do not return to create_initial every imax-1 steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traj-check", action="store_true", help="skip the B=1 full-solve parity figure (profiling runs)")
@@ -253,7 +254,12 @@ def main():
     from successiveconvexification_amd.batch import ScvxBatch
     from successiveconvexification_amd.dynamics import IntegratorCache
 
-    p = sp.base_prob_scaled
+    if args.aero:
+        from successiveconvexification_amd.defns import AtmosphericData
+        z = np.load(os.path.join(ROOT, "tests", "golden", "lift_drag_tables.npz"))   # the reference's aero/lift_drag.csv, repacked
+        p = sp.base_prob_aero_scaled(AtmosphericData(z["drag"], z["lift"], z["torque"]))
+    else:
+        p = sp.base_prob_scaled
     K = p.K
     scaling = "strong" if args.global_batch else "weak"
     shard = mc.Shard(p, args.global_batch or args.batch, args.seed, rank, world, scaling)
@@ -350,8 +356,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "6-DoF K=50 SCvx, Monte-Carlo dispersed ICs (BASELINE configs[3] shape, SURVEY 8d law, seed %d), "
-                            "SampleProblems.base_prob normalised (exo), fp64; solve_problem mix: create_initial again every "
-                            "%d steps%s" % (args.seed, period, " (disabled)" if args.no_reset else ""),
+                            "SampleProblems.%s, fp64; solve_problem mix: create_initial again every "
+                            "%d steps%s" % (args.seed, "base_prob_aero normalised (lift_drag tables)" if args.aero else "base_prob normalised (exo)",
+                                            period, " (disabled)" if args.no_reset else ""),
                 "K": K, "batch_per_gpu": B, "global_batch": shard.global_batch, "rk4_npts": args.npts,
                 "solver": "interior-point (NT scaling): optimal = merit < 1e-8; a solve that stops on its numerical floor "
                           "below 1e-6 is reported as almost-optimal (solver status 4) and counted separately",
@@ -389,7 +396,7 @@ def main():
         }
         if world == 1 and not args.no_k1_sweep:
             line["roofline_k1_by_npts"], line["roofline_k1_f32_by_npts"] = k1_by_npts(cache, batch, torch, K, B, args.npts)
-        if world == 1 and not args.no_traj_check:
+        if world == 1 and not args.no_traj_check and not args.aero:
             line["traj_linf_vs_oracle"] = traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts)
         if world == 1 and not args.no_traj_check:
             # NOT the headline: the same loop with scvx_solver_opts.reuse_inactive_tr (a conic solve whose optimum is
@@ -416,7 +423,7 @@ def main():
                         "just found lies strictly inside the halved radius (it is then the new optimum too); every solve_step "
                         "still runs its propagation, trust-region test and re-linearisation"}
             b2.close()
-        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
+        if not args.no_cpu_baseline and world == 1 and not args.aero:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.npts, args.seed, period)
         print(json.dumps(line), flush=True)
     if dist is not None:

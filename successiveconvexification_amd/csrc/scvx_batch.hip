@@ -628,7 +628,8 @@ int enqueue_step(scvx_batch* b, const int* mask) {
     rc = split_views(b, b->traj, b->x, b->u, b->sigma);
     if (rc) return rc;
     if ((rc = mark(b))) return rc;
-    SCVX_HIP(ctx, scvx::launch_linearize(ctx, b->B, b->K, b->x, b->u, b->sigma, dt, b->endpoint, b->deriv, st));
+    // rocketland.jl:318; a rejected step returns before it (:301, about / dynam kept): those trajectories are skipped
+    SCVX_HIP(ctx, scvx::launch_linearize(ctx, b->B, b->K, b->x, b->u, b->sigma, dt, b->endpoint, b->deriv, st, b->status));
     if ((rc = mark(b))) return rc;
     return SCVX_OK;
 }

@@ -34,6 +34,19 @@ __device__ __forceinline__ int exo_slot_to_col(int slot) {  // 0 -> m, 1..7 -> q
     return slot == 0 ? 0 : slot + 6;
 }
 
+// solve_step re-linearises after the trust-region test, but a REJECTED step keeps about / dynam (rocketland.jl:299-301) and
+// a frozen trajectory never changes: `skip` = the per-trajectory step status (>= SCVX_ST_REJECTED: unchanged iterate).  A
+// block whose segments all belong to such trajectories returns at once (uniform for the block: before any barrier).
+__device__ __forceinline__ bool block_unchanged(const int* skip, long seg0, int nseg_block, long nseg, int K) {
+    if (!skip || seg0 >= nseg) return false;
+    long seg1 = seg0 + nseg_block - 1;
+    if (seg1 >= nseg) seg1 = nseg - 1;
+    const long b0 = seg0 / K, b1 = seg1 / K;
+    for (long b = b0; b <= b1; b++)
+        if (skip[b] < SCVX_ST_REJECTED) return false;
+    return true;
+}
+
 template <typename R> struct Vec2;
 template <> struct Vec2<double> { typedef double2 type; };
 template <> struct Vec2<float> { typedef float2 type; };
@@ -43,9 +56,10 @@ template <bool AERO, typename R>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, sizeof(R) == 4 ? 2 : 1) void linearize_kernel(
     DynP<R> p, long nseg, int K, const R* __restrict__ x, const R* __restrict__ u,
     const R* __restrict__ sigma, R dt, int nsub, R* __restrict__ endpoint,
-    R* __restrict__ deriv) {
+    R* __restrict__ deriv, const int* __restrict__ skip) {
     constexpr int LPS = K1Map<AERO>::LPS, SPW = K1Map<AERO>::SPW;
     typedef typename Vec2<R>::type VEC2;   // 16-byte (double) / 8-byte (float) pairs: 147 per segment either way
+    if (block_unchanged(skip, (long)blockIdx.x * WAVES_PER_BLOCK * SPW, WAVES_PER_BLOCK * SPW, nseg, K)) return;
     __shared__ __attribute__((aligned(16))) R tile[WAVES_PER_BLOCK][SPW * 294];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -186,10 +200,11 @@ template <bool AERO, bool SG, typename R>
 __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
     DynP<R> p, long nseg, int K, const R* __restrict__ x, const R* __restrict__ u,
     const R* __restrict__ sigma, R dt, int nsub, R* __restrict__ endpoint,
-    R* __restrict__ deriv) {
+    R* __restrict__ deriv, const int* __restrict__ skip) {
     constexpr int LPS = K1Map<AERO>::LPS, SPW = K1Map<AERO>::SPW;
     typedef typename Vec2<R>::type VEC2;
     constexpr int NC = PC_WAVES - 1;
+    if (block_unchanged(skip, (long)blockIdx.x * (NC * SPW), NC * SPW, nseg, K)) return;
     constexpr int NS = NC * SPW;               // segments per block
     constexpr int NR = StageRec<AERO>::N;
     constexpr int RING = SG ? 2 : 2 * PC_GROUP;   // stage records in flight: the producer runs one stage / one substep ahead
@@ -375,7 +390,7 @@ __global__ __launch_bounds__(256) void propagate_kernel(DynP<R> p, long nseg, in
 
 template <typename R>
 hipError_t launch_linearize_simple(const scvx_ctx* ctx, int B, int K, const R* x, const R* u, const R* sigma, R dt,
-                                   R* endpoint, R* deriv, hipStream_t st) {
+                                   R* endpoint, R* deriv, hipStream_t st, const int* skip = nullptr) {
     const long nseg = (long)B * K;
     if (nseg == 0) return hipSuccess;
     const int spw = ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW;
@@ -384,19 +399,19 @@ hipError_t launch_linearize_simple(const scvx_ctx* ctx, int B, int K, const R* x
     const DynP<R> dp(ctx->dyn);
     if (ctx->dyn.aero)
         hipLaunchKernelGGL((linearize_kernel<true, R>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, st, dp, nseg, K, x, u,
-                           sigma, dt, ctx->nsub, endpoint, deriv);
+                           sigma, dt, ctx->nsub, endpoint, deriv, skip);
     else
         hipLaunchKernelGGL((linearize_kernel<false, R>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, st, dp, nseg, K, x, u,
-                           sigma, dt, ctx->nsub, endpoint, deriv);
+                           sigma, dt, ctx->nsub, endpoint, deriv, skip);
     return hipGetLastError();
 }
 
 template <typename R>
 hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, const R* u, const R* sigma, R dt, R* endpoint,
-                              R* deriv, hipStream_t st) {
+                              R* deriv, hipStream_t st, const int* skip = nullptr) {
     const long nseg = (long)B * K;
     if (nseg == 0) return hipSuccess;
-    if (ctx->k1_variant == 0) return launch_linearize_simple<R>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st);
+    if (ctx->k1_variant == 0) return launch_linearize_simple<R>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st, skip);
     const int ns = (PC_WAVES - 1) * (ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW);
     const unsigned grid = (unsigned)((nseg + ns - 1) / ns);
     // stage-granular pipeline by default (faster at every npts measured: 0.70 -> 0.60 ms at npts 1, 3.05 -> 2.96 ms
@@ -405,18 +420,18 @@ hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, con
     const dim3 g(grid), blk(64 * PC_WAVES);
     const DynP<R> dp(ctx->dyn);
     if (ctx->dyn.aero) {
-        if (sg) hipLaunchKernelGGL((linearize_pc_kernel<true, true, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
-        else hipLaunchKernelGGL((linearize_pc_kernel<true, false, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
+        if (sg) hipLaunchKernelGGL((linearize_pc_kernel<true, true, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+        else hipLaunchKernelGGL((linearize_pc_kernel<true, false, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
     } else {
-        if (sg) hipLaunchKernelGGL((linearize_pc_kernel<false, true, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
-        else hipLaunchKernelGGL((linearize_pc_kernel<false, false, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv);
+        if (sg) hipLaunchKernelGGL((linearize_pc_kernel<false, true, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+        else hipLaunchKernelGGL((linearize_pc_kernel<false, false, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_linearize(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
-                            double dt, double* endpoint, double* deriv, hipStream_t st) {
-    return launch_linearize_t<double>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st);
+                            double dt, double* endpoint, double* deriv, hipStream_t st, const int* skip) {
+    return launch_linearize_t<double>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st, skip);
 }
 
 // fp32 form of K1 (scvx_linearize_f32): the same kernels instantiated in float arithmetic -- half the bytes, twice the

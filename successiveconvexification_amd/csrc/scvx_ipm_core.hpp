@@ -1748,6 +1748,9 @@ struct Solver {
         SCVX_DBG("shifted: |S|^2 %.12e |Z|^2 %.12e\n", dot(S, S, L.nc), dot(Z, Z, L.nc));
 
         double best_merit = INFINITY; int best_it = 0;
+        // The best iterate is kept without a copy: V and Vbest are two buffers; while the current iterate IS the best one
+        // (best_in_V) the next iterate is written into the other buffer and the two pointers trade places.
+        bool best_in_V = false;
         const int degree = L.ncones;
         for (int it = 1; it <= C.max_iter; it++) {
             res.iters = it;
@@ -1781,7 +1784,7 @@ struct Solver {
             cur_gate = pres > relgap ? pres : relgap;
             if (merit < best_merit) {
                 best_merit = merit; best_it = it; res.pobj = pobj;
-                copy(Vbest, V, L.nv);
+                best_in_V = true;
                 ex.sync();
             }
             if (pres < C.tol && dres < C.tol && relgap < C.tol) { res.status = 0; break; }
@@ -1815,14 +1818,15 @@ struct Solver {
             if (alpha < 1e-9) { res.status = stop_status(2); break; }
             update_pass(alpha);   // S, Z (reads the old V)
             {
-                gptr V_ = V; cgptr dw_ = dw; gptr y_ = y; cgptr dy_ = dy;
-                stream(0, L.nv, [&](int i) { return D2{V_[i], dw_[i]}; }, [&](int i, const D2& v) { V_[i] = v.a + alpha * v.b; });
+                cgptr V_ = V; const gptr Vn = best_in_V ? Vbest : V; cgptr dw_ = dw; gptr y_ = y; cgptr dy_ = dy;
+                stream(0, L.nv, [&](int i) { return D2{V_[i], dw_[i]}; }, [&](int i, const D2& v) { Vn[i] = v.a + alpha * v.b; });
+                if (best_in_V) { Vbest = V; V = Vn; best_in_V = false; }   // Vbest now holds the best iterate, V the new one
                 stream(0, L.ny, [&](int i) { return D2{y_[i], dy_[i]}; }, [&](int i, const D2& v) { y_[i] = v.a + alpha * v.b; });
             }
             ex.sync();
         }
         res.merit = best_merit;
-        if (best_it > 0) { copy(V, Vbest, L.nv); ex.sync(); }
+        if (best_it > 0 && !best_in_V) V = Vbest;   // the caller reads the solution through V
         SCVX_TE(tTot_, 15);
         return res;
     }
