@@ -49,6 +49,7 @@ extern "C" {
 #define SCVX_ST_REJECTED 2    /* rho < rh0: iterate kept, radius shrunk, dJ=Inf (rocketland.jl:299-301) */
 #define SCVX_ST_SOLVER 3      /* conic solver did not reach tolerance        (rocketland.jl:273-276) */
 #define SCVX_ST_NONFINITE 4   /* NaN/Inf encountered                                              */
+#define SCVX_ST_INFEASIBLE 5  /* the subproblem has no feasible point: a boundary value violates a path cone (solver status 5) */
 
 /* model_flags: enforce the dynamic-pressure limit 1/2 rho |v_k|^2 <= dpMax at nodes 1..K as the second-order cone
  * |v_k| <= sqrt(2 dpMax / rho) (fields master.jl:27,30; the constraint is a "todo" at rocketland.jl:211-212).  The
@@ -187,7 +188,8 @@ int scvx_batch_set_scalars(scvx_batch *b, const double *rk, const double *cost, 
 int scvx_batch_get_flags(scvx_batch *b, int32_t *status, int32_t *active, int32_t *live);
 int scvx_batch_set_flags(scvx_batch *b, const int32_t *status, const int32_t *active, const int32_t *live);
 /* last SOCP solve, per trajectory: solver status (0 optimal: merit < tol; 4 almost optimal: numerical floor with
- * tol <= merit < accept_tol; 1 iteration cap; 2 numerical floor / KKT breakdown at merit >= accept_tol; 3 non-finite),
+ * tol <= merit < accept_tol; 1 iteration cap; 2 numerical floor / KKT breakdown at merit >= accept_tol; 3 non-finite;
+ * 5 infeasible: a fixed boundary value (rIi, vIi, wBi) violates the glideslope / rate / dynamic-pressure cone of node 1),
  * interior-point iterations, final merit max(pres, dres, relgap) of the returned iterate, its objective */
 int scvx_batch_get_solver_stats(scvx_batch *b, int32_t *status, int32_t *iters, double *merit, double *pobj);
 

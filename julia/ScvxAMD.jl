@@ -151,7 +151,7 @@ function create_batch(problem::DescentProblem, cache::Cache; ics::Union{Nothing,
 end
 create_initial(problem::DescentProblem, cache::Cache) = iteration(create_batch(problem, cache))
 
-const STATUS_NAME = Dict(3 => "SLOW_PROGRESS", 4 => "NUMERICAL_ERROR")
+const STATUS_NAME = Dict(3 => "SLOW_PROGRESS", 4 => "NUMERICAL_ERROR", 5 => "INFEASIBLE")
 
 # one solve_step of every trajectory of a batch: (status, ||nu||, dJ) vectors
 function step!(b::Batch)
@@ -163,7 +163,7 @@ end
 # solve_step(iteration, cache) -> (ProblemIteration, ||nu||, dJ)     (rocketland.jl:226-321)
 function solve_step(iter::Iteration, cache::Cache=iter.cache)
     st, nu, dj = step!(iter.model)
-    st[1] in (3, 4) && error("Non-optimal result $(STATUS_NAME[st[1]]) exiting")   # rocketland.jl:273-276
+    st[1] in (3, 4, 5) && error("Non-optimal result $(STATUS_NAME[st[1]]) exiting")   # rocketland.jl:273-276
     return iteration(iter.model), nu[1], dj[1]
 end
 

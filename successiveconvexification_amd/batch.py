@@ -20,7 +20,7 @@ def _pi(a):
     return a.ctypes.data_as(_ip)
 
 
-STATUS = {0: "converged", 1: "running", 2: "rejected", 3: "solver", 4: "nonfinite"}
+STATUS = {0: "converged", 1: "running", 2: "rejected", 3: "solver", 4: "nonfinite", 5: "infeasible"}
 
 
 class ScvxBatch:

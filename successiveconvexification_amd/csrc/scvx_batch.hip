@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
     bool accept = false;
     double next_rk = rk[b], dJ = INFINITY;
     if (sstat != 0 && sstat != 4) {   // 4 = almost optimal, inside the solver's acceptance band (scvx_solver_opts.accept_tol)
-        st = (sstat == 3) ? SCVX_ST_NONFINITE : SCVX_ST_SOLVER;  // rocketland.jl:273-276: error(...)
+        st = sstat == 3 ? SCVX_ST_NONFINITE : (sstat == 5 ? SCVX_ST_INFEASIBLE : SCVX_ST_SOLVER);  // rocketland.jl:273-276: error(...)
     } else if (!(jK == jK) || !(lK == lK)) {
         st = SCVX_ST_NONFINITE;
     } else {
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
     if (threadIdx.x == 0) {
         const int it = iter[b] + 1;
         iter[b] = it;
-        if (st == SCVX_ST_SOLVER || st == SCVX_ST_NONFINITE) {
+        if (st == SCVX_ST_SOLVER || st == SCVX_ST_NONFINITE || st == SCVX_ST_INFEASIBLE) {
             active[b] = 0;   // frozen: the reference stops with an error here
             live[b] = 0;
         } else {

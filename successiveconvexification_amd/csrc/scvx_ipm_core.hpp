@@ -38,6 +38,8 @@
 //     1 iteration cap    best iterate returned, merit >= accept
 //     2 stalled          numerical floor / KKT breakdown with merit >= accept
 //     3 non-finite
+//     5 infeasible       a boundary value fixed by rocketland.jl:109-115 violates a path cone of node 1 (no interior
+//                        point exists; an interior-point iteration would only diverge)
 //     4 almost optimal   stopped on the numerical floor with tol <= merit < accept (MOI's ALMOST_OPTIMAL band; the
 //                        reference treats anything but OPTIMAL as an error, rocketland.jl:273-276 -- set accept = tol
 //                        to get exactly that)
@@ -1698,6 +1700,16 @@ struct Solver {
         }
         ex.sync();
         Result res; res.status = 1; res.iters = 0; res.merit = INFINITY; res.pobj = 0;
+        // Infeasibility that needs no iteration to detect: at node 1 the reference fixes r, v and w (rocketland.jl:109-113) and
+        // applies the glideslope and rate cones there (:142-167, k = 1..K): constants against constants.  (The dynamic-
+        // pressure extension adds |vIi| <= vmax.)  A violated one has no strictly feasible point.
+        {
+            const double r1 = ic[0], r2 = ic[1], r3 = ic[2];
+            bool bad = sqrt(r2 * r2 + r3 * r3) > r1 * C.itan * (1.0 + 1e-12) + 1e-14;
+            bad = bad || sqrt(C.wBi[0] * C.wBi[0] + C.wBi[1] * C.wBi[1] + C.wBi[2] * C.wBi[2]) > C.omMax * (1.0 + 1e-12);
+            if (C.vmax > 0.0) bad = bad || sqrt(ic[3] * ic[3] + ic[4] * ic[4] + ic[5] * ic[5]) > C.vmax * (1.0 + 1e-12);
+            if (bad) { res.status = 5; return res; }
+        }
         cur_gate = INFINITY;
         // ---- initial point (CVXOPT conelp style, W = I): two least-squares problems on one factorisation ----
         //   primal:  min ||s||  s.t. E w = e, s = a(w)        -> w, s     (the cost does not enter)

@@ -36,8 +36,8 @@ def create_initial(problem: DescentProblem, linear_cache: IntegratorCache) -> Pr
 def solve_step(iteration: ProblemIteration, linear_cache: IntegratorCache):
     batch = iteration.model
     st, nu, dj = batch.solve_step()
-    if st[0] in (3, 4):  # rocketland.jl:273-276
-        raise RuntimeError(f"Non-optimal result {'NUMERICAL_ERROR' if st[0] == 4 else 'SLOW_PROGRESS'} exiting")
+    if st[0] in (3, 4, 5):  # rocketland.jl:273-276
+        raise RuntimeError("Non-optimal result %s exiting" % {3: "SLOW_PROGRESS", 4: "NUMERICAL_ERROR", 5: "INFEASIBLE"}[int(st[0])])
     return _snapshot(iteration.problem, linear_cache, batch), float(nu[0]), float(dj[0])
 
 

@@ -81,7 +81,7 @@ int main(int argc, char **argv) {
         int32_t st;
         double nu, dj;
         CHECK(ctx, scvx_solve_step(b, &st, &nu, &dj));
-        if (st == 3 || st == 4) { fprintf(stderr, "Non-optimal result exiting (status %d)\n", st); return 3; }   /* rocketland.jl:273-276 */
+        if (st == 3 || st == 4 || st == 5) { fprintf(stderr, "Non-optimal result exiting (status %d)\n", st); return 3; }   /* rocketland.jl:273-276 */
         if (dump_iteration(ctx, b, K, fo)) return 2;
         double o[3] = {(double)st, nu, dj};
         fwrite(o, 8, 3, fo);

@@ -641,3 +641,29 @@ def test_reuse_of_the_optimum_across_rejected_steps_changes_nothing():
     assert np.abs(xa - xr).max() < 1e-6 and np.abs(ua - ur).max() < 1e-6 and np.abs(sga - sgr).max() < 1e-6
     assert skipped >= 4 * B, skipped     # the sample problem's rejection run: most of its re-solves are repeats
     a.close(); r.close(); c.close()
+
+
+def test_infeasible_boundary_value_gets_its_own_status():
+    """An initial position outside the glideslope cone (a constant row against a constant bound at node 1): solver status 5
+    without iterating, SCVX_ST_INFEASIBLE for the trajectory, which is frozen; its neighbours are unaffected."""
+    from oracle import model
+    po = model.base_prob_scaled()
+    B = 4
+    ic = model.disperse_ics(po, B, 20261004)
+    c, good = _setup(B, ic)
+    st_g, nu_g, _ = good.solve_step()
+    xg = good.trajectory()[0]
+    good.close()
+    bad = ic.copy()
+    bad[1, 1] = 5.0          # |(r_y, r_z)| = 5 > r_up / tan(20 deg) = 2.75
+    c2, b = _setup(B, bad)
+    x0 = b.trajectory()[0].copy()
+    st, nu, dj = b.solve_step()
+    sst, its, _, _ = b.solver_stats()
+    assert st[1] == 5 and sst[1] == 5 and its[1] == 0
+    keep = [0, 2, 3]
+    assert np.array_equal(st[keep], st_g[keep]) and np.abs(b.trajectory()[0][keep] - xg[keep]).max() < 1e-9
+    assert np.array_equal(b.trajectory()[0][1], x0[1])          # frozen
+    st2, _, _ = b.solve_step()
+    assert st2[1] == 5 and np.all(b.flags()[1] == np.array([1, 0, 1, 1]))
+    b.close(); c.close(); c2.close()
