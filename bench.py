@@ -149,7 +149,7 @@ def traj_linf_vs_oracle(cache_cls, batch_cls, prob, npts):
             "ref": "oracle (IPM on the exact build_model rows + RK4 npts=10); parity with the Julia reference itself is unpinned"}
 
 
-def k1_by_npts(cache, batch, torch, K, B, default_npts):
+def k1_by_npts(cache, batch, torch, K, B, default_npts, sweep=(1, 2, 4, 10), with_f32=True):
     """K1 alone on the batch's current trajectories for rk4 npts in (1, 2, 4, 10): the HBM fraction of the discretisation
     kernel depends on how much FP64 work a segment carries (SURVEY.md 8d), so the bench states it per npts.  Device
     pointers through the C ABI (scvx_linearize_f64), HIP events on the stream the kernel runs on; outside the timed region."""
@@ -162,7 +162,7 @@ def k1_by_npts(cache, batch, torch, K, B, default_npts):
     ts = torch.cuda.Stream()            # torch's events only see kernels on a torch stream: run K1 on one for this leg
     cache.set_stream(ts.cuda_stream)
     torch.cuda.synchronize()
-    for npts in (1, 2, 4, 10):
+    for npts in sweep:
         cache.set_npts(npts)
 
         def call():
@@ -185,7 +185,7 @@ def k1_by_npts(cache, batch, torch, K, B, default_npts):
     ef = torch.empty((B, K, 14), dtype=torch.float32, device="cuda")
     df = torch.empty((B, K, 21, 14), dtype=torch.float32, device="cuda")
     out32 = {}
-    for npts in (1, 2, 4, 10):
+    for npts in (sweep if with_f32 else ()):
         cache.set_npts(npts)
 
         def call32():
@@ -334,7 +334,11 @@ def main():
 
     if rank == 0:
         st, its, merit, pobj = batch.solver_stats()
-        k1_ms = prof["linearize"] / max(nprof, 1)
+        k1_step_ms = prof["linearize"] / max(nprof, 1)   # in the step: launches skip the trajectories whose step was rejected
+        # `roofline` is priced on FULL launches (every trajectory linearised): K1 alone, 5 back-to-back launches at the
+        # default npts on the batch's trajectories, HIP events on the stream it runs on
+        k1_full, _ = k1_by_npts(cache, batch, torch, K, B, args.npts, sweep=(args.npts,), with_f32=False)
+        k1_ms = k1_full[str(args.npts)]["ms"]
         k4_ms = prof["socp"] / max(nprof, 1)
         alg = k1_alg_bytes(K) * B
         achieved = alg / (k1_ms * 1e-3) if k1_ms > 0 else 0.0
@@ -370,9 +374,10 @@ def main():
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
-                "alg_bytes_per_launch": alg, "avg_launch_ms": k1_ms,
+                "alg_bytes_per_launch": alg, "avg_launch_ms": k1_ms, "avg_ms_in_step": k1_step_ms,
                 "fp64_frac": (k1_flops / (k1_ms * 1e-3) / FP64_VECTOR_PEAK) if k1_ms > 0 else None,
-                "note": "K1 at rk4_npts=%d is FP64-FMA-bound, not HBM-bound (SURVEY 8d): fp64_frac = sparse flop count "
+                "note": "avg_launch_ms = full launches (all trajectories); inside a step K1 skips trajectories whose step was rejected "
+                        "(avg_ms_in_step).  K1 at rk4_npts=%d is FP64-FMA-bound, not HBM-bound (SURVEY 8d): fp64_frac = sparse flop count "
                         "(12 kflop per segment per substep) / 78.6 TFLOP/s vector peak; traffic from PMC in profiles/" % args.npts,
             },
             "kernel_ms_per_step": {k: v / max(nprof, 1) for k, v in prof.items()},
