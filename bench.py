@@ -391,8 +391,8 @@ def main():
                 "traffic_source": k4t["source"] if k4t else None,
                 "bandwidth_used_frac_hi": (k4t["hi"] / (k4_ms * 1e-3) / HBM_PEAK) if k4t else None,
                 "note": "frac is ALGORITHMIC bytes (137 KB per trajectory per solve, SURVEY 8d) over time: the interior-point "
-                        "iterations stream a 640 KB per-trajectory state ~7 times each, ~20 iterations per solve, so the "
-                        "measured traffic is ~600x the algorithmic bytes and the kernel runs at the HBM streaming rate",
+                        "iterations stream a 614 KB per-trajectory state ~6 times each, ~20 iterations per solve, so the "
+                        "measured traffic is 300-500x the algorithmic bytes and the kernel runs at the HBM streaming rate",
             },
             "solver_stats_last_step": {"ipm_iters_mean": float(np.mean(its)), "ipm_iters_max": int(np.max(its)),
                                        "optimal_frac": float(np.mean(st == 0)), "almost_optimal_frac": float(np.mean(st == 4)),
