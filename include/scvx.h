@@ -93,7 +93,10 @@ typedef struct scvx_solver_opts {
                        /* when the optimum just found lies strictly inside the new radius -- the radius row is then inactive  */
                        /* and that optimum is provably the new subproblem's optimum too.  The SCvx iterates are unchanged;   */
                        /* on the sample problems ~6 of the 14 solves of a solve_problem are such repeats.                    */
-    int32_t reserved;
+    int32_t warm_start;        /* 1 (default): the solve that follows a REJECTED step (same about / dynam, radius halved,  */
+                       /* rocketland.jl:299-301) starts from the iterate the previous solve passed at merit 1e-4, as long  */
+                       /* as the new radius stays inactive at it -- 5 interior-point iterations instead of 19; every       */
+                       /* solve still runs to `tol`.  0: every solve starts cold, like the reference's.                     */
 } scvx_solver_opts;
 
 typedef struct scvx_ctx scvx_ctx;     /* owns device, stream, problem constants, aero tables */

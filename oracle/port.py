@@ -11,6 +11,7 @@ _dp = C.POINTER(C.c_double)
 
 class Consts(C.Structure):
     _fields_ = [("K", C.c_int), ("max_iter", C.c_int), ("refine", C.c_int), ("pad", C.c_int),
+                ("warm", C.c_int), ("pad2", C.c_int),
                 ("tol", C.c_double), ("accept", C.c_double),
                 ("itan", C.c_double), ("sqcm", C.c_double), ("icos", C.c_double), ("Tmax", C.c_double),
                 ("Tmin", C.c_double), ("omMax", C.c_double), ("mdry", C.c_double), ("wNu", C.c_double),
@@ -37,7 +38,7 @@ def _p(a):
 
 
 def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, max_iter=60, refine=6, nthreads=0, accept=1e-6,
-         f32=False):
+         f32=False, work=None, warm=None):
     """Batched: xbar [B][K+1][14], ubar [B][K+1][3], endpoint [B][K][14], deriv [B][K][21][14], rk [B].
     Returns dict(dx, du, ds, nu, status, iters, merit, pobj)."""
     xbar = np.ascontiguousarray(xbar, float)
@@ -54,7 +55,12 @@ def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, 
     sol = np.zeros((B, (K + 1) * 17 + 1))
     nu = np.zeros((B, K, 14))
     info = np.zeros((B, 4))
-    (port_lib().scvx_port_socp_f32 if f32 else port_lib().scvx_port_socp)(C.byref(c), C.c_int(B), _p(xbar), _p(ubar), _p(endpoint), _p(deriv), _p(rk), _p(ic),
+    if work is not None:   # persistent per-trajectory workspace + warm flags (the device's warm start after a rejected step)
+        wf = np.ascontiguousarray(warm if warm is not None else np.zeros(B), np.int32)
+        port_lib().scvx_port_socp_ws(C.byref(c), C.c_int(B), _p(xbar), _p(ubar), _p(endpoint), _p(deriv), _p(rk), _p(ic), _p(sol), _p(nu),
+                                     _p(info), C.c_int(nthreads), _p(work), wf.ctypes.data_as(C.POINTER(C.c_int32)))
+    else:
+      (port_lib().scvx_port_socp_f32 if f32 else port_lib().scvx_port_socp)(C.byref(c), C.c_int(B), _p(xbar), _p(ubar), _p(endpoint), _p(deriv), _p(rk), _p(ic),
                               _p(sol), _p(nu), _p(info), C.c_int(nthreads))
     nx = 14 * (K + 1)
     return dict(dx=sol[:, :nx].reshape(B, K + 1, 14), du=sol[:, nx:nx + 3 * (K + 1)].reshape(B, K + 1, 3),
@@ -63,7 +69,7 @@ def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, 
 
 
 def scvx_steps(p: DescentProblem, ic, steps, nsub=10, nthreads=0, tol=1e-8, accept=1e-6, max_iter=60, refine=6, f32=False,
-               on_step=None):
+               on_step=None, warm_start=False):
     """`steps` Rocketland.solve_step calls (rocketland.jl:226-321) on B dispersed trajectories, all on the host: the conic
     solve by the CPU twin of the device solver (scvx_port.cpp), discretisation and propagation by the C oracle
     (scvx_oracle.c), accept / reject and radius update in numpy.  Starts from create_initial (straight-line guess).
@@ -84,9 +90,13 @@ def scvx_steps(p: DescentProblem, ic, steps, nsub=10, nthreads=0, tol=1e-8, acce
     e, d = od.linearize(par, x, u, sig, dt, nsub)
     rk = np.full(B, 100.0); cost = np.full(B, np.inf)
     out = dict(merit=[], status=[], iters=[], rejected=[])
+    work = None; was_rej = np.zeros(B, np.int32)
+    if warm_start:
+        port_lib().scvx_port_work_doubles.restype = C.c_size_t
+        work = np.zeros((B, port_lib().scvx_port_work_doubles(C.c_int(K))))
     for s in range(steps):
         r = socp(p, x, u, e, d.astype(np.float32).astype(np.float64) if f32 else d, rk, ic, tol=tol, max_iter=max_iter,
-                 refine=refine, nthreads=nthreads, accept=accept, f32=f32)
+                 refine=refine, nthreads=nthreads, accept=accept, f32=f32, work=work, warm=was_rej)
         xr = x + r["dx"]; ur = u + r["du"]; ns = sig + r["ds"]
         xn = od.propagate(par, xr, ur, ns, dt, nsub)
         jK = -xr[:, K, 0] + p.wNu * np.sqrt(((xr[:, 1:] - xn) ** 2).sum((1, 2)))      # rocketland.jl:289
@@ -101,6 +111,7 @@ def scvx_steps(p: DescentProblem, ic, steps, nsub=10, nthreads=0, tol=1e-8, acce
         rk = np.where(ok, nrk, rk)
         x[acc] = xr[acc]; u[acc] = ur[acc]; sig[acc] = ns[acc]; cost[acc] = jK[acc]
         e, d = od.linearize(par, x, u, sig, dt, nsub)                                   # :318
+        was_rej = rej.astype(np.int32)
         out["merit"].append(r["merit"]); out["status"].append(r["status"]); out["iters"].append(r["iters"])
         out["rejected"].append(rej)
         if on_step is not None:

@@ -122,7 +122,7 @@ size_t scvx_port_work_doubles(int K) {
 template <class Stor>
 static int port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
                      const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
-                     int nthreads) {
+                     int nthreads, Stor* work_all = nullptr, const int* warm = nullptr) {
     const int K = C->K;
     scvx::ipm::Layout L;
     L.init(K, C->vmax > 0.0);
@@ -130,14 +130,16 @@ static int port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, cons
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel
     {
-        std::vector<Stor> work(nw), D((size_t)K * 294);
+        std::vector<Stor> work(work_all ? 0 : nw), D((size_t)K * 294);
         HostEx ex;
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < B; b++) {
             for (size_t i = 0; i < D.size(); i++) D[i] = (Stor)deriv[(size_t)b * K * 294 + i];
             scvx::ipm::Solver<HostEx, Stor> S(ex, *C);
+            Stor* wk = work_all ? work_all + (size_t)b * nw : work.data();   // persistent per-trajectory slab, as on the device
             scvx::ipm::Result r = S.solve(xbar + (size_t)b * (K + 1) * 14, ubar + (size_t)b * (K + 1) * 3,
-                                          endpoint + (size_t)b * K * 14, D.data(), rk[b], ic + (size_t)b * 6, work.data());
+                                          endpoint + (size_t)b * K * 14, D.data(), rk[b], ic + (size_t)b * 6, wk,
+                                          warm && warm[b]);
             double* so = sol + (size_t)b * ((K + 1) * 17 + 1);
             for (int i = 0; i < L.nx + L.nu_; i++) so[i] = S.V[i];
             so[L.nx + L.nu_] = S.V[L.iS];
@@ -154,6 +156,13 @@ int scvx_port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, const 
                    const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
                    int nthreads) {
     return port_socp<double>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads);
+}
+// persistent workspace [B][scvx_port_work_doubles(K)] + per-trajectory warm flags: the device's warm start of the solve that
+// follows a rejected step
+int scvx_port_socp_ws(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
+                      const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
+                      int nthreads, double* work, const int* warm) {
+    return port_socp<double>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads, work, warm);
 }
 // f32 storage: the linearisation and the whole solver workspace are float, arithmetic stays double
 int scvx_port_socp_f32(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,

@@ -325,9 +325,11 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t wo
     Ex ex;
     ipm::Solver<Ex> S(ex, C);
     // kernel arguments are HBM pointers: hand them to the solver typed as such (see ipm::gptr)
+    // warm start: the last solve in this slab was for the same about / dynam (its step was rejected) and is still valid
+    const bool warm = C.warm && step_status[b] == SCVX_ST_REJECTED && ttr[b] < 1e300;
     const ipm::Result r = S.solve((ipm::cgptr)(x + (size_t)b * (K + 1) * 14), (ipm::cgptr)(u + (size_t)b * (K + 1) * 3),
                                   (ipm::cgptr)(endpoint + (size_t)b * K * 14), (ipm::cgptr)(deriv + (size_t)b * K * 294), rk[b],
-                                  (ipm::cgptr)(ic + (size_t)b * 6), (ipm::gptr)(work + (size_t)b * work_stride));
+                                  (ipm::cgptr)(ic + (size_t)b * 6), (ipm::gptr)(work + (size_t)b * work_stride), warm);
     const int nxu = S.L.nx + S.L.nu_;
     const int nl = ex.nlanes();
     double* so = sol + (size_t)b * (nxu + 1);
@@ -655,6 +657,7 @@ int scvx_solver_default_opts(scvx_solver_opts* o) {
     o->tol = 1e-8;
     o->accept_tol = 1e-6;
     o->reuse_inactive_tr = 0;
+    o->warm_start = 1;
     return SCVX_OK;
 }
 
@@ -678,6 +681,8 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     C.K = K; C.max_iter = b->opts.max_iter; C.refine = b->opts.refine; C.pad = 0; C.tol = b->opts.tol;
     C.accept = b->opts.accept_tol;
     C.pad = b->opts.reuse_inactive_tr;
+    C.warm = b->opts.warm_start;
+    C.pad2 = 0;
     C.itan = 1.0 / std::tan(p.gammaGs * d2r);                       // rocketland.jl:63
     C.sqcm = std::sqrt((1.0 - std::cos(p.thetaMax * d2r)) / 2.0);   // :64
     C.icos = 1.0 / std::cos(p.deltaMax * d2r);                      // :65
@@ -749,6 +754,7 @@ int scvx_batch_set_solver(scvx_batch* b, const scvx_solver_opts* o) {
     b->C.tol = o->tol;
     b->C.accept = o->accept_tol;
     b->C.pad = o->reuse_inactive_tr ? 1 : 0;
+    b->C.warm = o->warm_start ? 1 : 0;
     return SCVX_OK;
 }
 

@@ -667,3 +667,41 @@ def test_infeasible_boundary_value_gets_its_own_status():
     st2, _, _ = b.solve_step()
     assert st2[1] == 5 and np.all(b.flags()[1] == np.array([1, 0, 1, 1]))
     b.close(); c.close(); c2.close()
+
+
+def test_warm_start_after_rejected_steps_changes_nothing_but_the_iteration_count():
+    """scvx_solver_opts.warm_start (default on): the solve that follows a rejected step starts from the previous solve's
+    iterate at merit 1e-4 while the halved radius stays inactive there.  A complete solve_problem with and without it:
+    same accept / reject sequence and radius schedule, every solve still at merit < 1e-8, trajectories equal to solver
+    accuracy, and the warm-started solves take a third of the iterations."""
+    from oracle import model
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    po = model.base_prob_scaled()
+    B = 16
+    ic = model.disperse_ics(po, B, 20261004)
+    c = IntegratorCache(sp.base_prob_scaled, npts=10)
+    w = ScvxBatch(c, B).init(ic)                      # default: warm_start = 1
+    k = ScvxBatch(c, B, warm_start=False).init(ic)
+    its_w, its_k, after_reject = [], [], []
+    prev = np.ones(B, np.int32)
+    for n in range(po.imax - 1):
+        sw, nuw, _ = w.solve_step()
+        sk, nuk, _ = k.solve_step()
+        assert np.array_equal(sw, sk), n
+        assert np.array_equal(w.scalars()[0], k.scalars()[0])
+        assert np.allclose(nuw, nuk, rtol=0, atol=1e-7)
+        stw, iw, mw, _ = w.solver_stats()
+        _, ik, mk, _ = k.solver_stats()
+        assert np.all((stw == 0) | (stw == 4)) and mw.max() < 1e-7 and mk.max() < 1e-7
+        its_w.append(iw); its_k.append(ik); after_reject.append(prev == 2)
+        prev = sw
+    xw, uw, sgw = w.trajectory()
+    xk, uk, sgk = k.trajectory()
+    assert np.abs(xw - xk).max() < 1e-6 and np.abs(uw - uk).max() < 1e-6 and np.abs(sgw - sgk).max() < 1e-6
+    its_w, its_k, ar = np.array(its_w), np.array(its_k), np.array(after_reject)
+    assert np.array_equal(its_w[~ar], its_k[~ar])               # a solve after an accepted step starts cold either way
+    assert its_w.sum() < 0.85 * its_k.sum()                      # -23 % iterations over the sample problem's 14 steps
+    assert (its_w[ar] < 0.5 * its_k[ar]).mean() > 0.6            # most solves after a rejection: under half the iterations
+    w.close(); k.close(); c.close()
