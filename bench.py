@@ -105,11 +105,11 @@ def cpu_baseline(npts, seed, steps, reps=5):
 
     def timed(B, threads):
         ic = model.disperse_ics(po, B, seed)
-        port.scvx_steps(po, ic[:min(B, threads)], 1, nsub=npts, nthreads=threads)   # warm the libraries
+        port.scvx_steps(po, ic[:min(B, threads)], 1, nsub=npts, nthreads=threads, warm_start=True)   # warm the libraries
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
-            o = port.scvx_steps(po, ic, steps, nsub=npts, nthreads=threads)
+            o = port.scvx_steps(po, ic, steps, nsub=npts, nthreads=threads, warm_start=True)   # same solver options as the device
             ts.append(time.perf_counter() - t0)
         its = float(np.mean(np.concatenate(o["iters"])))
         return B * steps / float(np.median(ts)), float(np.median(ts)), its
@@ -121,7 +121,7 @@ def cpu_baseline(npts, seed, steps, reps=5):
             "ipm_iters_mean": its,
             "sample": f"{8 * cores} dispersed trajectories x {steps} solve_steps from create_initial (same seed / law / step mix as "
                       f"the device run), OpenMP over trajectories, median of {reps} reps of {tall:.1f} s; same algorithm as the "
-                      f"device path (scvx_ipm_core.hpp + RK4 npts={npts}); the Julia reference itself cannot run here"}
+                      f"device path (scvx_ipm_core.hpp incl. its warm start after rejected steps + RK4 npts={npts}); the Julia reference itself cannot run here"}
 
 
 def traj_linf_vs_oracle(cache_cls, batch_cls, prob, npts):
