@@ -1730,7 +1730,9 @@ struct Solver {
         cur_gate = INFINITY;
         // ... and only while the new radius leaves the kept iterate well inside it (Jtr_w < 0.8 rk): then the radius row stays
         // inactive and the old central path is (nearly) the new one -- 7 iterations instead of 19.  Once the radius starts to
-        // bind the kept iterate is far from the new path and a warm start costs MORE than a cold one (33 vs 21 measured).
+        // bind the kept iterate is far from the new path and a warm start costs MORE than a cold one (33 vs 21 measured);
+        // pulling the kept primal point inside the new radius (a convex combination with the reference point) and keeping
+        // the duals breaks down within two iterations on 80 % of such solves: tried, not kept.
         const bool warmed = warm && wh[0] == 1.0 && Vw[L.iTTR] < 0.8 * rk;
         if (warmed) {
             // same subproblem, new radius: restart from the kept iterate; its radius slack is recomputed (and kept interior)
