@@ -269,7 +269,12 @@ def main():
     batch.init(shard.ic)  # inputs resident in HBM from here on
     gather_how = None
     if dist is not None:
-        why = mc.bootstrap_comm(cache, dist, rank, world) if backend == "nccl" else "gloo dry-run"
+        if backend != "nccl":
+            why = "gloo dry-run"
+        elif os.environ.get("SCVX_BENCH_NATIVE_COMM", "1") == "0":
+            why = "disabled by SCVX_BENCH_NATIVE_COMM=0"
+        else:
+            why = mc.bootstrap_comm(cache, dist, rank, world)
         gather_how = "scvx_allgather_trajectories (library RCCL communicator)" if why is None else f"torch.distributed ({why})"
         native = why is None
 
@@ -390,6 +395,7 @@ def main():
                 "alg_bytes_per_launch": SOCP_ALG_BYTES * B,
                 "achieved": SOCP_ALG_BYTES * B / (k4_ms * 1e-3) / 1e9,
                 "frac": SOCP_ALG_BYTES * B / (k4_ms * 1e-3) / HBM_PEAK,
+                "traffic": k4t["hi"] if k4t else None,
                 "traffic_lo": k4t["lo"] if k4t else None, "traffic_hi": k4t["hi"] if k4t else None,
                 "traffic_source": k4t["source"] if k4t else None,
                 "bandwidth_used_frac_hi": (k4t["hi"] / (k4_ms * 1e-3) / HBM_PEAK) if k4t else None,
