@@ -96,6 +96,31 @@ SIGNATURES = {
 _LIB = None
 
 
+def _preload_torch_hip_runtime():
+    """One process, one HIP / HSA runtime.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 under the
+    same sonames as /opt/rocm's; whichever copy is loaded first serves both torch and libscvx_hip.so.  If this library came
+    first (the system copy), a later `import torch` finds "No HIP GPUs": its extensions were built against the bundled
+    copy.  So when torch is installed its copies are loaded here, before libscvx_hip.so, without importing torch."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 class ScvxError(RuntimeError):
     pass
 
@@ -116,6 +141,7 @@ def lib() -> C.CDLL:
         raise ScvxError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             "Build it with `python -m successiveconvexification_amd.build` or __graft_entry__.build().")
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the library lacks an ABI symbol

@@ -37,9 +37,15 @@ namespace scvx {
 // address space, and every LDS access becomes a flat_load/flat_store that also waits on the global loads and
 // stores in flight (vmcnt) — which serialises the tile arithmetic behind the HBM traffic it is meant to overlap.
 __shared__ __attribute__((aligned(16))) double g_socp_lds[1552];
+// tiles of the two-wavefront factorisation pipeline (multi-wavefront kernels only: a kernel that never references the
+// symbol does not get the allocation)
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 3 * 196 + 294 + 308 + 42 + 2 * 42 + 196 + 8];
+#ifndef SCVX_K4_PIPELINE
+#define SCVX_K4_PIPELINE 1
+#endif
 
 struct WaveEx {
-    __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
+    __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63); }   // lane in the wavefront (BlockEx runs tile work on any of its wavefronts)
     __device__ __forceinline__ int nlanes() const { return 64; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
     // LDS-only ordering inside the single wavefront of the block: a release/acquire pair restricted to the local
@@ -71,6 +77,7 @@ struct WaveEx {
     }
 
     static constexpr int kPrefetchRegs = 5;  // ceil(294 / 64): next D tile held in registers while segment k is processed
+    static constexpr bool kPipelineFactor = false;
 
     // C(14x14) = (acc ? C : 0) + alpha * A(14 x Kd) B(Kd x 14) on the FP64 matrix pipe: ceil(Kd/4) x
     // v_mfma_f64_16x16x4_f64, tiles in LDS with arbitrary element strides (so transposes are free).
@@ -257,6 +264,17 @@ template <int NW>
 struct BlockEx {
     WaveEx w0;
     static constexpr int kPrefetchRegs = (294 + 64 * NW - 1) / (64 * NW);
+    // the factorisation loop as a producer / consumer pair of wavefronts (Solver::factor_pipelined)
+    static constexpr bool kPipelineFactor = SCVX_K4_PIPELINE != 0;
+    __device__ __forceinline__ int wave() const { return (int)(threadIdx.x >> 6); }
+    __device__ __forceinline__ int wlane() const { return (int)(threadIdx.x & 63); }
+    __device__ __forceinline__ double* pipe_scratch() { return g_socp_pipe_lds; }
+    __device__ __forceinline__ void w_sync_lds() { w0.sync_lds(); }
+    __device__ __forceinline__ void w_tile_gemm(double* Cm, int sci, int scj, const double* A, int sai, int sak, const double* B,
+                                                int sbk, int sbj, int Kd, double alpha, bool acc) {
+        w0.tile_gemm(Cm, sci, scj, A, sai, sak, B, sbk, sbj, Kd, alpha, acc);
+    }
+    __device__ __forceinline__ bool w_chol_inv14(const double* M, double* Li) { return w0.chol_inv14(M, Li); }
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int nlanes() const { return 64 * NW; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
@@ -569,7 +587,7 @@ int split_views(scvx_batch* b, const double* rec, double* x, double* u, double* 
 int socp_waves(int B) {
     if (const char* v = std::getenv("SCVX_K4_WAVES")) {
         const int w = std::atoi(v);
-        return w >= 4 ? 4 : (w >= 2 ? 2 : 1);
+        return w >= 4 ? 4 : (w >= 2 ? 2 : 1);   // 8 and 16 wavefronts per trajectory were measured: no faster than 4 at B = 1..64 (barrier cost)
     }
     return B <= SOCP_WAVES4_MAX_B ? 4 : (B <= SOCP_WAVES2_MAX_B ? 2 : 1);
 }

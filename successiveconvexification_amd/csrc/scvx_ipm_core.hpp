@@ -1178,6 +1178,123 @@ struct Solver {
         SCVX_T1(1);
     }
 
+    // ---- the K-step factorisation loop as a two-wavefront pipeline (multi-wavefront executors only) ----
+    // The sequential loop (build_kkt) spends ~16 k cycles per segment in one wavefront: half of it assembles the Schur
+    // blocks Sd_k, So_k from the linearisation and the node inverses -- work that does not depend on the Cholesky chain
+    // -- and half is the chain itself (pivot update, Cholesky + inverse, coupling tile).  With more than one wavefront per
+    // trajectory the two halves run side by side: wavefront 1 PRODUCES (Sd_k, So_k) into a two-slot LDS ring, wavefront 0
+    // CONSUMES them one segment behind; one workgroup barrier per segment.  Same arithmetic, same results.
+    //   producer k:  TBp_k;  Sd_k = Hxi_{k+1} + hnui I + [TA|TBm|TBp]_k D_k';  TA_{k+1}, TBm_{k+1};  So_k = -TA_{k+1} + TBm_{k+1} Bp_k'
+    //   consumer k:  M = Sd_k - Wb_{k-1} Wb_{k-1}';  L^-1 = chol_inv(M);  store L^-1;  Nf_k = -L^-1 Wb_{k-1};  Wb_k = So_k L^-T
+    template <class E2 = Ex>
+    SCVX_HD_NI bool factor_pipelined() {
+        const int K = L.K;
+        const cgptr D_ = D; const cgptr hx_ = hx; const cgptr hu_ = hu;
+        const gptr Linv_ = Linv; const gptr Nf_ = Nf;
+        const double hnui_ = hnui;
+        double* sc = ex.pipe_scratch();
+        double* Sd = sc;                 // 2 x 196
+        double* So = Sd + 392;           // 2 x 196
+        double* M = So + 392;            // consumer: pivot tile / Nf product
+        double* Wp = M + 196;            // consumer: Wb[k-1]
+        double* Li = Wp + 196;           // consumer: Linv[k]
+        double* Dt = Li + 196;           // producer: D_k tile
+        double* T = Dt + 294;            // producer: [TA | TBm | TBp], row stride 22
+        double* Bp = T + 308;            // producer: Bp_k kept across the tile swap
+        double* Hh = Bp + 42;            // producer: node inverses k | k+1
+        double* Hd = Hh + 2 * NODE_SZ;   // producer: dense Hxi_{k+1}
+        constexpr int TS = 22;
+        const int w = ex.wave(), l = ex.wlane();
+        bool ok = true;
+        auto node_elem = [&](int node, int e) -> double {
+            return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[9 * node + (e - HX_SZ)];
+        };
+        if (w == 1) {   // producer prologue: D_0, node 0 -> TA_0, TBm_0
+            for (int e = l; e < 294; e += 64) Dt[e] = D_[e];
+            for (int e = l; e < NODE_SZ; e += 64) Hh[NODE_SZ + e] = node_elem(0, e);
+            ex.w_sync_lds();
+            for (int e = l; e < 196; e += 64) Hd[e] = hxi_entry(Hh + NODE_SZ, e / 14, e % 14);
+            ex.w_sync_lds();
+            ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
+            for (int q = l; q < 42; q += 64) {
+                const int i = q / 3, c = q - 3 * i;
+                const double* h = Hh + NODE_SZ + HX_SZ;
+                T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
+            }
+            ex.w_sync_lds();
+        }
+        for (int t = 0; t <= K; t++) {
+            if (w == 1 && t < K) {
+                const int k = t;
+                double* Sdk = Sd + 196 * (k & 1); double* Sok = So + 196 * (k & 1);
+                // next tile into registers while this segment is assembled
+                double pre[5];
+                cgptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
+                SCVX_UNROLL
+                for (int q = 0; q < 5; q++) { const int e = l + 64 * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
+                for (int e = l; e < NODE_SZ; e += 64) { Hh[e] = Hh[NODE_SZ + e]; }
+                ex.w_sync_lds();
+                for (int e = l; e < NODE_SZ; e += 64) Hh[NODE_SZ + e] = node_elem(k + 1, e);
+                ex.w_sync_lds();
+                for (int e = l; e < 196 + 42; e += 64) {
+                    if (e < 196) {
+                        const int i = e / 14, j = e - 14 * i;
+                        const double h = hxi_entry(Hh + NODE_SZ, i, j);
+                        Hd[e] = h;
+                        Sdk[e] = h + (i == j ? hnui_ : 0.0);
+                    } else {
+                        const int q = e - 196, i = q / 3, c = q - 3 * i;
+                        const double* h = Hh + NODE_SZ + HX_SZ;
+                        T[TS * i + 17 + c] = Dt[14 * 17 + i] * h[c] + Dt[14 * 18 + i] * h[3 + c] + Dt[14 * 19 + i] * h[6 + c];
+                    }
+                }
+                ex.w_sync_lds();
+                ex.w_tile_gemm(Sdk, 14, 1, T, TS, 1, Dt, 14, 1, 20, 1.0, true);
+                if (k + 1 < K) {
+                    for (int q = l; q < 42; q += 64) Bp[q] = Dt[14 * 17 + q];
+                    ex.w_sync_lds();
+                    SCVX_UNROLL
+                    for (int q = 0; q < 5; q++) { const int e = l + 64 * q; if (e < 294) Dt[e] = pre[q]; }
+                    ex.w_sync_lds();
+                    ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
+                    for (int q = l; q < 42; q += 64) {
+                        const int i = q / 3, c = q - 3 * i;
+                        const double* h = Hh + NODE_SZ + HX_SZ;
+                        T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
+                    }
+                    ex.w_sync_lds();
+                    for (int e = l; e < 196; e += 64) {
+                        const int i = e / 14, j = e - 14 * i;
+                        Sok[e] = -T[TS * i + j] + T[TS * i + 14] * Bp[j] + T[TS * i + 15] * Bp[14 + j] + T[TS * i + 16] * Bp[28 + j];
+                    }
+                }
+                ex.w_sync_lds();
+            } else if (w == 0 && t >= 1) {
+                const int k = t - 1;
+                const double* Sdk = Sd + 196 * (k & 1); const double* Sok = So + 196 * (k & 1);
+                for (int e = l; e < 196; e += 64) M[e] = Sdk[e];
+                ex.w_sync_lds();
+                if (k > 0) { ex.w_tile_gemm(M, 14, 1, Wp, 14, 1, Wp, 1, 14, 14, -1.0, true); ex.w_sync_lds(); }
+                ok = ex.w_chol_inv14(M, Li) && ok;
+                ex.w_sync_lds();
+                for (int e = l; e < LINV_SZ; e += 64) {
+                    const int p = e / 15, q = e - 15 * p;
+                    const int i = q <= p ? p : 13 - p, j = q <= p ? q : q - (p + 1);
+                    Linv_[(size_t)k * LINV_SZ + e] = Li[14 * i + j];
+                }
+                if (k > 0) {
+                    ex.w_tile_gemm(M, 1, 14, Li, 14, 1, Wp, 14, 1, 14, -1.0, false);
+                    ex.w_sync_lds();
+                    for (int e = l; e < 196; e += 64) Nf_[(size_t)k * 196 + e] = M[e];
+                }
+                if (k + 1 < K) { ex.w_sync_lds(); ex.w_tile_gemm(Wp, 14, 1, Sok, 14, 1, Li, 1, 14, 14, 1.0, false); }
+                ex.w_sync_lds();
+            }
+            ex.sync();   // hand-over: producer's slot k is complete, consumer has finished with slot k - 1
+        }
+        return ex.all(ok);
+    }
+
     // ---- factorisation for the current scaling (Wv, Wbeta) ----
     // with_pred: gx holds the (masked) predictor right-hand side and ry the equality residual; their banded solution
     // [Hb E'; E 0][dw; dy] = [gx; -ry] is produced alongside the three border systems (dw, dy), so the predictor's
@@ -1319,6 +1436,9 @@ struct Solver {
         double* Hd = Hh + 2 * NODE_SZ;           // 196  dense Hxi of the node being multiplied
         constexpr int TS = 22;          // row stride of T (22: conflict-free fragment reads; 20 would be 2-way)
         bool ok = true;
+        if constexpr (Ex::kPipelineFactor) {
+            ok = factor_pipelined();   // two wavefronts: Schur-block assembly one segment ahead of the Cholesky chain
+        } else {
         // All 14x14xK products below go through ex.tile_gemm: FP64 MFMA (v_mfma_f64_16x16x4) on the device — one A and
         // one B element per lane per instruction instead of 2 LDS reads per multiply-add — plain loops on the host.
         // prologue: D_0, hx_0/hu_0 -> LDS; TA_0, TBm_0
@@ -1428,6 +1548,7 @@ struct Solver {
             ex.sync_lds();
             SCVX_TE(te_, 14);
         }
+        }   // sequential factorisation
         ex.sync();   // the factors written above are read back (by other lanes) in the border solves
         SCVX_TE(tC_, 6);
         SCVX_TS(tB_);
