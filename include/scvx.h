@@ -7,6 +7,7 @@
  *   Dynamics.linearize_dynamics   dynamics.jl:321-334  ->  scvx_linearize_f64[_host]
  *   Dynamics.predict_state        dynamics.jl:315-317  ->  scvx_propagate_f64[_host]
  *   Rocketland.create_initial     rocketland.jl:34-39  ->  scvx_batch_create + scvx_batch_init
+ *   FirstRound.solve_initial      initial_solve.jl:17-110 -> scvx_threedof_solve, scvx_batch_init_threedof
  *   Rocketland.solve_step         rocketland.jl:226-321->  scvx_solve_step
  *   Rocketland.solve_problem      rocketland.jl:432-443->  scvx_solve
  *   MOI.optimize! (conic solve)   rocketland.jl:271    ->  scvx_socp_solve (batched interior-point, device)
@@ -148,6 +149,33 @@ int scvx_propagate_f32(scvx_ctx *ctx, int B, int K, const float *x_dev, const fl
 int scvx_propagate_f32_host(scvx_ctx *ctx, int B, int K, const float *x, const float *u,
                             const float *sigma, float dt, float *xnext);
 
+/* ---- FirstRound.solve_initial: the 3-DoF lossless-convexification landing SOCP, batched --------
+ * (initial_solve.jl:17-110, inside a block comment at HEAD; BASELINE configs[0]).  Per node k = 0..K: position r,
+ * velocity v, mass ma, thrust T, thrust bound ga, virtual acceleration ar and its bound kaR; one global nkaR >= |kaR|;
+ * minimise -ma_K + 100 nkaR under the trapezoidal point-mass recursions with the fixed mass profile of :24, the
+ * boundary values of :59-65 and the cones of :69-70, :80-88.  The problem's K, alpha, tf_guess, mwet, mdry, g, Tmin,
+ * Tmax, thetaMax, gammaGs are read from the context; rIi, vIi per trajectory.
+ * A device interior-point solve, one wavefront per trajectory (csrc/scvx_threedof_core.hpp). */
+typedef struct scvx_threedof_opts {
+    int32_t max_iter;   /* 60 */
+    int32_t refine;     /* refinement passes per Newton solve on the uncondensed residual: 1 */
+    double tol;         /* primal / dual residual and relative gap: 1e-9 */
+    double delta;       /* static regularisation of the quasi-definite KKT matrix: 1e-9 */
+} scvx_threedof_opts;
+int scvx_threedof_default_opts(scvx_threedof_opts *o);
+/* doubles per trajectory of a solution record: (K+1)*15 + 1 -- per node r(3) v(3) ma T(3) ga kaR ar(3), then nkaR */
+int32_t scvx_threedof_record_doubles(int K);
+/* ic [B][6] host = per-trajectory (rIi, vIi), NULL = the problem's own; opts NULL = defaults.  Outputs (host):
+ * sol [B][record_doubles]; status [B] (0 optimal, 1 iteration cap, 2 stalled, 3 non-finite, 5 infeasible: the primal
+ * residual stopped falling while the gap closed); info [B][5] = iterations, objective, gap, primal and dual residual
+ * (status and info may be NULL). */
+int scvx_threedof_solve(scvx_ctx *ctx, int B, const double *ic, const scvx_threedof_opts *opts, double *sol,
+                        int32_t *status, double *info);
+/* The same on device arrays, enqueued on the context's stream: info_dev [B][6] = status, iterations, objective, gap,
+ * primal and dual residual. */
+int scvx_threedof_solve_dev(scvx_ctx *ctx, int B, const double *ic_dev, const scvx_threedof_opts *opts,
+                            double *sol_dev, double *info_dev);
+
 /* ---- batched SCvx: create_initial / solve_step / solve_problem ------------------------------ */
 int scvx_solver_default_opts(scvx_solver_opts *o);
 int scvx_batch_create(scvx_ctx *ctx, int B, scvx_batch **out);
@@ -157,6 +185,11 @@ int scvx_batch_set_solver(scvx_batch *b, const scvx_solver_opts *o);
  * every trajectory uses the problem's own.  Builds the straight-line guess (initial_solve.jl:113-129),
  * linearises it and sets rk=100, cost=Inf, iter=0 (rocketland.jl:38). */
 int scvx_batch_init(scvx_batch *b, const double *ic);
+/* create_initial from FirstRound.solve_initial instead of the straight line: scvx_batch_init(b, ic), then every
+ * trajectory whose 3-DoF solve is optimal starts from its LinPoints (initial_solve.jl:90-105: state (ma, r, v,
+ * rotation_between(e1, -T), 0), control (|T|, 0, 0), sigma = tf_guess); the others keep the straight line.
+ * status3 [B] (host, may be NULL) = the 3-DoF solver statuses.  scvx_batch_reset returns to this start. */
+int scvx_batch_init_threedof(scvx_batch *b, const double *ic, const scvx_threedof_opts *opts, int32_t *status3);
 /* create_initial again for the same initial conditions, entirely on the device and asynchronous on the stream: the
  * straight-line guess kept from scvx_batch_init is restored, rk=100, cost=Inf, iter=0, flags cleared, and the guess is
  * re-linearised.  (A Monte-Carlo driver that re-runs solve_problem, or a benchmark loop, needs no host round trip.) */

@@ -118,3 +118,30 @@ def scvx_steps(p: DescentProblem, ic, steps, nsub=10, nthreads=0, tol=1e-8, acce
             on_step(s, r, rej)
     out.update(x=x, u=u, sigma=sig, rk=rk, cost=cost)
     return out
+
+
+class Problem3(C.Structure):
+    """scvx::td::Problem3 of scvx_threedof_core.hpp: the DescentProblem fields solve_initial reads."""
+    _fields_ = [("K", C.c_int)] + [(n, C.c_double) for n in
+                                   ("alpha", "tf_guess", "mwet", "mdry", "g", "Tmin", "Tmax", "thetaMax", "gammaGs")]
+
+
+def threedof(p: DescentProblem, ic=None, tol=1e-9, max_iter=60, refine=1, delta=1e-9, nthreads=0):
+    """CPU twin of the device 3-DoF initialiser (K0).  ic [B][6] = (rIi, vIi), None = the problem's own.  Returns
+    (sol, status, info) in the layout of successiveconvexification_amd.first_round.solve_initial_batch: sol = dict of
+    T, r, v, ar [B][3][K+1]; ma, ga, kaR [B][K+1]; nkaR [B]; info [B][5] = iterations, objective, gap, pres, dres."""
+    P = Problem3(p.K, p.alpha, p.tf_guess, p.mwet, p.mdry, p.g, p.Tmin, p.Tmax, p.thetaMax, p.gammaGs)
+    ic = np.concatenate([p.rIi, p.vIi])[None, :] if ic is None else ic
+    ic = np.ascontiguousarray(ic, float)
+    B, K = ic.shape[0], p.K
+    rec = np.zeros((B, (K + 1) * 15 + 1))
+    raw = np.zeros((B, 6))
+    rc = port_lib().scvx_port_threedof(C.byref(P), C.c_int(B), _p(ic), _p(rec), _p(raw), C.c_double(tol), C.c_int(max_iter),
+                                       C.c_int(refine), C.c_double(delta), C.c_int(nthreads))
+    if rc != 0:
+        raise RuntimeError("scvx_port_threedof failed")
+    nodes = rec[:, :-1].reshape(B, K + 1, 15)
+    tr = lambda a: np.ascontiguousarray(np.swapaxes(a, 1, 2))
+    sol = dict(r=tr(nodes[:, :, 0:3]), v=tr(nodes[:, :, 3:6]), ma=nodes[:, :, 6].copy(), T=tr(nodes[:, :, 7:10]),
+               ga=nodes[:, :, 10].copy(), kaR=nodes[:, :, 11].copy(), ar=tr(nodes[:, :, 12:15]), nkaR=rec[:, -1].copy())
+    return sol, raw[:, 0].astype(np.int32), raw[:, 1:].copy()

@@ -13,6 +13,7 @@
 #include <vector>
 #include <omp.h>
 #include "../successiveconvexification_amd/csrc/scvx_ipm_core.hpp"
+#include "../successiveconvexification_amd/csrc/scvx_threedof_core.hpp"
 
 namespace {
 struct HostEx {
@@ -170,5 +171,53 @@ int scvx_port_socp_f32(const scvx::ipm::Consts* C, int B, const double* xbar, co
                        const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
                        int nthreads) {
     return port_socp<float>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads);
+}
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// CPU twin of K0, the 3-DoF initialiser (scvx_threedof_core.hpp with a one-lane executor).  The independent check
+// of its optimum is oracle/threedof.py on oracle/ipm.py.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct HostEx3 {
+    std::vector<double> scratch;
+    explicit HostEx3(int N) : scratch(scvx::td::fast_doubles(N)) {}
+    int lane() const { return 0; }
+    int nlanes() const { return 1; }
+    void sync() {}
+    void sync_lds() {}
+    double sum(double x) { return x; }
+    double min(double x) { return x; }
+    double* fast() { return scratch.data(); }
+};
+}  // namespace
+
+extern "C" {
+// P: {K, alpha, tf_guess, mwet, mdry, g, Tmin, Tmax, thetaMax, gammaGs}; ic [B][6]; out [B][(K+1)*15+1] (per node
+// r v ma T ga kaR ar, then nkaR); info [B][6] = status, iters, pobj, gap, pres, dres
+int scvx_port_threedof(const scvx::td::Problem3* P, int B, const double* ic, double* out, double* info, double tol,
+                       int max_iter, int refine, double delta, int nthreads) {
+    scvx::td::HostTables H;
+    if (const char* e = scvx::td::build_tables(*P, tol, max_iter, refine, delta, H)) {
+        fprintf(stderr, "scvx_port_threedof: %s\n", e);
+        return -1;
+    }
+    scvx::td::Layout L;
+    L.init(P->K);
+    const int no = scvx::td::out_doubles(P->K);
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+    {
+        std::vector<double> work(L.total);
+        HostEx3 ex(P->K);
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < B; b++) {
+            scvx::td::Solver<HostEx3> S(ex, H.t, work.data());
+            const scvx::td::Result r = S.solve(ic + (size_t)b * 6, out + (size_t)b * no);
+            double* o = info + (size_t)b * 6;
+            o[0] = r.status; o[1] = r.iters; o[2] = r.pobj; o[3] = r.gap; o[4] = r.pres; o[5] = r.dres;
+        }
+    }
+    return 0;
 }
 }

@@ -41,6 +41,10 @@ class ScvxSolverOpts(C.Structure):
                 ("reuse_inactive_tr", C.c_int32), ("warm_start", C.c_int32)]
 
 
+class ScvxThreedofOpts(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("refine", C.c_int32), ("tol", C.c_double), ("delta", C.c_double)]
+
+
 _vp = C.c_void_p
 # name -> (restype, argtypes); must list every symbol include/scvx.h declares (tests check this)
 SIGNATURES = {
@@ -68,6 +72,11 @@ SIGNATURES = {
     "scvx_batch_set_solver": (C.c_int, [_vp, C.POINTER(ScvxSolverOpts)]),
     "scvx_batch_init": (C.c_int, [_vp, _dp]),
     "scvx_batch_reset": (C.c_int, [_vp]),
+    "scvx_batch_init_threedof": (C.c_int, [_vp, _dp, C.POINTER(ScvxThreedofOpts), _ip]),
+    "scvx_threedof_default_opts": (C.c_int, [C.POINTER(ScvxThreedofOpts)]),
+    "scvx_threedof_record_doubles": (C.c_int32, [C.c_int]),
+    "scvx_threedof_solve": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(ScvxThreedofOpts), _dp, _ip, _dp]),
+    "scvx_threedof_solve_dev": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(ScvxThreedofOpts), _vp, _vp]),
     "scvx_solve_step": (C.c_int, [_vp, _ip, _dp, _dp]),
     "scvx_solve_step_async": (C.c_int, [_vp]),
     "scvx_solve": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),

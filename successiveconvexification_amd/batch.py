@@ -66,6 +66,21 @@ class ScvxBatch:
         self._chk(self._L.scvx_batch_init(self.handle, _p(ic) if ic is not None else None), "scvx_batch_init")
         return self
 
+    def init_threedof(self, ic=None, **opts):
+        """create_initial from FirstRound.solve_initial (initial_solve.jl:17-110) instead of the straight line: the 3-DoF
+        landing SOCP is solved on the device for every trajectory; those whose solve is optimal start from its LinPoints,
+        the others keep the straight line.  Returns the 3-DoF solver statuses [B] (0 = optimal)."""
+        from .first_round import threedof_opts
+        if ic is not None:
+            ic = np.ascontiguousarray(ic, np.float64)
+            if ic.shape != (self.B, 6):
+                raise ValueError("ic must be [B][6] = (rIi, vIi)")
+        o = threedof_opts(self._L, **opts)
+        st3 = np.zeros(self.B, np.int32)
+        self._chk(self._L.scvx_batch_init_threedof(self.handle, _p(ic) if ic is not None else None, C.byref(o), _pi(st3)),
+                  "scvx_batch_init_threedof")
+        return st3
+
     def reset(self):
         """create_initial again on the device for the same initial conditions (asynchronous)."""
         self._chk(self._L.scvx_batch_reset(self.handle), "scvx_batch_reset")

@@ -135,6 +135,7 @@ void scvx_ctx_destroy(scvx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)scvx_comm_destroy(ctx);
+    scvx::td_cache_free(ctx);
     if (ctx->d_cdrag) (void)hipFree(ctx->d_cdrag);
     if (ctx->d_clift) (void)hipFree(ctx->d_clift);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

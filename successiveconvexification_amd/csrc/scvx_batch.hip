@@ -829,6 +829,38 @@ int scvx_batch_init(scvx_batch* b, const double* ic) {
     return SCVX_OK;
 }
 
+int scvx_batch_init_threedof(scvx_batch* b, const double* ic, const scvx_threedof_opts* opts, int32_t* status3) {
+    int rc = scvx_batch_init(b, ic);
+    if (rc) return rc;
+    scvx_ctx* ctx = b->ctx;
+    const int B = b->B, K = b->K;
+    hipStream_t st = ctx->stream;
+    const size_t no = (size_t)scvx_threedof_record_doubles(K);
+    double *d_sol = nullptr, *d_info = nullptr;
+    hipError_t e = hipMalloc((void**)&d_sol, (size_t)B * no * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_info, (size_t)B * 6 * 8);
+    std::vector<double> hinfo((size_t)B * 6);
+    if (e == hipSuccess) {
+        rc = scvx::threedof_solve_dev(ctx, B, b->ic, opts, d_sol, d_info);
+        if (rc == SCVX_OK) rc = scvx::threedof_to_record(ctx, B, K, d_sol, d_info, b->traj);
+        if (rc == SCVX_OK) {
+            e = hipMemcpyAsync(b->traj0, b->traj, (size_t)B * b->nrec * 8, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(hinfo.data(), d_info, hinfo.size() * 8, hipMemcpyDeviceToHost, st);
+        }
+        if (rc == SCVX_OK && e == hipSuccess) rc = split_views(b, b->traj, b->x, b->u, b->sigma);
+        if (rc == SCVX_OK && e == hipSuccess)
+            e = scvx::launch_linearize(ctx, B, K, b->x, b->u, b->sigma, 1.0 / (K + 1), b->endpoint, b->deriv, st);
+    }
+    const hipError_t es = hipStreamSynchronize(st);
+    if (d_sol) (void)hipFree(d_sol);
+    if (d_info) (void)hipFree(d_info);
+    if (rc) return rc;
+    if (e != hipSuccess || es != hipSuccess)
+        return fail(ctx, SCVX_ERR_HIP, std::string("scvx_batch_init_threedof: ") + hipGetErrorString(e != hipSuccess ? e : es));
+    if (status3) for (int t = 0; t < B; t++) status3[t] = (int32_t)hinfo[(size_t)t * 6];
+    return SCVX_OK;
+}
+
 int scvx_batch_reset(scvx_batch* b) {
     int rc = check_batch(b, true);
     if (rc) return rc;

@@ -5,6 +5,8 @@
 #include "scvx.h"
 #include "scvx_dyn.hpp"
 
+namespace scvx { struct TdCache; }   // device tables + workspace of the 3-DoF initialiser (scvx_threedof.hip)
+
 struct scvx_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -18,6 +20,7 @@ struct scvx_ctx {
     double* d_clift = nullptr;
     void* comm = nullptr;   // ncclComm_t of scvx_comm_create (RCCL, bound at run time: csrc/scvx_comm.hip)
     int comm_rank = 0, comm_world = 0;
+    scvx::TdCache* td = nullptr;
     std::string err;
 };
 
@@ -37,6 +40,14 @@ hipError_t launch_linearize_f32(const scvx_ctx* ctx, int B, int K, const float* 
                                 float dt, float* endpoint, float* deriv, hipStream_t st);
 hipError_t launch_propagate_f32(const scvx_ctx* ctx, int B, int K, const float* x, const float* u, const float* sigma,
                                 float dt, float* xnext, hipStream_t st);
+
+// K0 (scvx_threedof.hip): the batched 3-DoF landing SOCP on device arrays, enqueued on ctx->stream; sol [B][(K+1)*15+1],
+// info [B][6] = status, iters, pobj, gap, pres, dres.  threedof_to_record overwrites the trajectory records [B][(K+1)*17+1]
+// of the trajectories whose solve is optimal with the LinPoints of initial_solve.jl:90-105.
+int threedof_solve_dev(scvx_ctx* ctx, int B, const double* ic_dev, const scvx_threedof_opts* opts, double* sol_dev,
+                       double* info_dev);
+int threedof_to_record(scvx_ctx* ctx, int B, int K, const double* sol_dev, const double* info_dev, double* rec_dev);
+void td_cache_free(scvx_ctx* ctx);
 
 inline int fail(scvx_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;

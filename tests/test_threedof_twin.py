@@ -1,0 +1,61 @@
+"""K0 on the host: the 3-DoF initialiser's solver core (csrc/scvx_threedof_core.hpp compiled by g++, oracle/scvx_port.cpp)
+against the independent oracle oracle/threedof.py (explicit JuMP-style rows of initial_solve.jl:17-88 on the generic IPM of
+oracle/ipm.py).  CPU only; the device kernel is compared with both in tests/test_gpu_threedof.py."""
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+from oracle import model, port, threedof
+
+KEYS = ("T", "r", "v", "ma", "ga", "kaR", "ar", "nkaR")
+
+
+def config0():
+    return replace(model.DescentProblem(), K=30)
+
+
+def flyable(K=30):
+    return replace(model.DescentProblem(), K=K, tf_guess=6.0, rIi=np.array([4.0, 2.0, 0.0]), vIi=np.array([-0.5, -0.5, 0.3]),
+                   mdry=1.0, mwet=2.0, alpha=0.05)
+
+
+def linf(sol, b, o):
+    return max(np.abs(np.asarray(sol[k][b]) - np.asarray(o[k])).max() for k in KEYS)
+
+
+@pytest.mark.parametrize("make", [config0, flyable])
+def test_twin_matches_the_independent_oracle(make):
+    p = make()
+    ref, o, _ = threedof.solve_initial(p)
+    assert ref.status == "optimal"
+    sol, st, info = port.threedof(p)
+    assert st[0] == 0
+    # the same algorithm class on the same central path: the iteration counts agree, the optimum to 1e-7
+    assert int(info[0, 0]) == ref.iters
+    assert abs(info[0, 1] - ref.pobj) <= 1e-9 * max(1.0, abs(ref.pobj))
+    assert linf(sol, 0, o) < 1e-7
+
+
+def test_twin_dispersed_batch_and_other_horizon():
+    p = flyable(K=20)
+    ic = model.disperse_ics(p, 12, 20261004)
+    sol, st, info = port.threedof(p, ic)
+    assert np.all(st == 0) and info[:, 0].max() <= 30
+    for b in (0, 5, 11):
+        ref, o, _ = threedof.solve_initial(replace(p, rIi=ic[b, :3], vIi=ic[b, 3:]))
+        assert ref.status == "optimal"
+        assert abs(info[b, 1] - ref.pobj) <= 1e-8 * max(1.0, abs(ref.pobj))
+        assert linf(sol, b, o) < 5e-5   # the fuel-optimal thrust profile is flat along some directions
+    # lossless convexification: |T_k| = ga_k at the optimum, no virtual acceleration
+    assert np.abs(np.linalg.norm(sol["T"], axis=1) - sol["ga"]).max() < 1e-5 and sol["nkaR"].max() < 1e-6
+
+
+def test_twin_reports_an_infeasible_instance():
+    # the normalised 6-DoF sample problem at tf_guess = 1: the fuel between mwet and mdry cannot pay for Tmin over the
+    # whole horizon, whatever the virtual acceleration does -- the oracle's IPM ends "kkt_singular" with the primal
+    # residual stuck at 1e-4, the twin says so
+    p = model.base_prob_scaled()
+    assert p.alpha * p.Tmin * p.tf_guess > p.mwet - p.mdry
+    sol, st, info = port.threedof(p)
+    assert st[0] == 5 and info[0, 3] > 1e-6
