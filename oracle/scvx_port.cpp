@@ -189,6 +189,8 @@ struct HostEx3 {
     double sum(double x) { return x; }
     double min(double x) { return x; }
     double* fast() { return scratch.data(); }
+    static constexpr int kLanes = 1;
+    static constexpr bool kRegisterSweep = false;
 };
 }  // namespace
 

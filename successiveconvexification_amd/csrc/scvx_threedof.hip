@@ -25,7 +25,7 @@ struct TdCache {
 namespace {
 
 struct WaveEx3 {
-    double* lds;
+    td::lptr lds;
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int nlanes() const { return 64; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
@@ -45,14 +45,72 @@ struct WaveEx3 {
         for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o, 64));
         return x;
     }
-    __device__ __forceinline__ double* fast() { return lds; }
+    __device__ __forceinline__ td::lptr fast() { return lds; }
+    static constexpr int kLanes = 64;
+    static constexpr bool kRegisterSweep = true;
+
+    // value of x in lane `src` (wave-uniform, a constant after unrolling) in every lane: two v_readlane_b32
+    static __device__ __forceinline__ double bcast(double x, int src) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+        return __hiloint2double(hi, lo);
+    }
+
+    // The two triangular sweeps of xs <- (L D L')^-1 xs with the running part of the vector in REGISTERS: lane l holds
+    // x[J + l] (forward; x[J - l] backward) for a chunk of CH columns; step t broadcasts the finished x[J + t] with
+    // v_readlane and every lane within the bandwidth does one FMA -- no LDS round trip inside the chunk (the vector
+    // visits LDS once per chunk).  The L entries of the NEXT chunk are in flight while this one computes.
+    static constexpr int CH = 16;   // CH + BW <= 64
+    template <bool FWD>
+    __device__ __forceinline__ void load_chunk(double (&c)[CH], td::cgptr m, int J, int nb) const {
+        const int l = (int)threadIdx.x;
+        // entry of step t: m[(J +- t) * BS + (l - t)] -- one base address, constant stride
+        td::cgptr base = m + ((long)J * td::BS + l);
+#pragma unroll
+        for (int t = 0; t < CH; t++) {
+            const int j = FWD ? J + t : J - t, d = l - t;
+            const bool in = j >= 0 && j < nb && d >= 1 && d <= td::BW && (FWD ? j + d < nb : j - d >= 0);
+            const double v = base[FWD ? t * (td::BS - 1) : -t * (td::BS + 1)];   // unconditional: L is zero-padded by LPAD
+            c[t] = in ? v : 0.0;
+        }
+    }
+    template <bool FWD>
+    __device__ __forceinline__ void run_chunk(const double (&c)[CH], td::lptr xs, int J, int nb) {
+        const int l = (int)threadIdx.x;
+        const int idx = FWD ? J + l : J - l;
+        const bool in = idx >= 0 && idx < nb;
+        double xw = in ? xs[idx] : 0.0;
+#pragma unroll
+        for (int t = 0; t < CH; t++) xw = fma(-c[t], bcast(xw, t), xw);
+        if (in) xs[idx] = xw;
+        sync_lds();
+    }
+    __device__ __forceinline__ void band_sweeps(td::lptr xs, td::cgptr lb, td::cgptr ut, int nb) {
+        double ca[CH], cb[CH];
+        load_chunk<true>(ca, lb, 0, nb);
+        for (int J = 0; J < nb; J += 2 * CH) {
+            load_chunk<true>(cb, lb, J + CH, nb);
+            run_chunk<true>(ca, xs, J, nb);
+            load_chunk<true>(ca, lb, J + 2 * CH, nb);
+            run_chunk<true>(cb, xs, J + CH, nb);
+        }
+        for (int j = (int)threadIdx.x; j < nb; j += 64) xs[j] *= lb[(size_t)j * td::BS];
+        sync_lds();
+        load_chunk<false>(ca, ut, nb - 1, nb);
+        for (int J = nb - 1; J >= 0; J -= 2 * CH) {
+            load_chunk<false>(cb, ut, J - CH, nb);
+            run_chunk<false>(ca, xs, J, nb);
+            load_chunk<false>(ca, ut, J - 2 * CH, nb);
+            run_chunk<false>(cb, xs, J - CH, nb);
+        }
+    }
 };
 
 // sol [B][(K+1)*15+1]; info [B][6] = status, iters, pobj, gap, pres, dres
-__global__ __launch_bounds__(64) void threedof_kernel(td::Tables T, int B, const double* __restrict__ ic, double* work,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void threedof_kernel(td::Tables T, int B, const double* __restrict__ ic, double* work,
                                                       size_t stride, double* sol, double* info) {
     extern __shared__ double td_lds[];
-    WaveEx3 ex{td_lds};
+    WaveEx3 ex{(td::lptr)td_lds};
     const int no = td::out_doubles(T.N);
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         td::Solver<WaveEx3> S(ex, T, work + (size_t)blockIdx.x * stride);
@@ -62,6 +120,10 @@ __global__ __launch_bounds__(64) void threedof_kernel(td::Tables T, int B, const
             o[0] = r.status; o[1] = r.iters; o[2] = r.pobj; o[3] = r.gap; o[4] = r.pres; o[5] = r.dres;
         }
         __syncthreads();
+#if defined(SCVX_TD_PROF)
+        if (b == 0 && threadIdx.x == 0) for (int i = 0; i < 16; i++) work[i] = S.prof[i];   // diagnostic build: section cycles of trajectory 0
+        __syncthreads();
+#endif
     }
 }
 
@@ -194,6 +256,14 @@ int threedof_to_record(scvx_ctx* ctx, int B, int K, const double* sol_dev, const
 }  // namespace scvx
 
 extern "C" {
+
+#if defined(SCVX_TD_PROF)
+int scvx_debug_td_prof(scvx_ctx* ctx, double* out16) {
+    if (!ctx || !ctx->td || !ctx->td->work) return SCVX_ERR_STATE;
+    (void)hipStreamSynchronize(ctx->stream);
+    return hipMemcpy(out16, ctx->td->work, 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : SCVX_ERR_HIP;
+}
+#endif
 
 int scvx_threedof_default_opts(scvx_threedof_opts* o) {
     if (!o) return SCVX_ERR_ARG;

@@ -32,8 +32,31 @@
 #include <vector>
 #include "scvx_ipm_core.hpp"
 
+#if defined(SCVX_TD_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define TD_TS(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define TD_TE(v, slot) prof[slot] += (double)(__builtin_amdgcn_s_memtime() - v)
+#else
+#define TD_TS(v)
+#define TD_TE(v, slot)
+#endif
+
 namespace scvx {
 namespace td {
+
+// Address spaces (device build): the solver's vectors, L and the tables are HBM (global_load/store, vmcnt only), the
+// factorisation window and the solve vector are LDS (ds_read/write, lgkmcnt only).  A plain `double*` kept in the solver
+// object loses its address space as soon as a routine is not inlined and every access becomes a FLAT one, which counts
+// against both counters -- each LDS step of the factorisation then also waits for the L stores in flight.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TD_LOCAL __attribute__((address_space(3)))
+#else
+#define TD_LOCAL
+#endif
+typedef SCVX_GLOBAL double* gptr;
+typedef const SCVX_GLOBAL double* cgptr;
+typedef const SCVX_GLOBAL int* cgiptr;
+typedef TD_LOCAL double* lptr;
+typedef TD_LOCAL int* liptr;
 
 constexpr int BW = 19;        // half bandwidth of the node-ordered KKT matrix
 constexpr int BS = BW + 1;    // entries stored per band column (diagonal + BW below)
@@ -42,7 +65,10 @@ constexpr int NP = 22;        // band positions per node: NV variables + 7 multi
 constexpr int NR = 15;        // cone rows per node: 4 linear, SOC3 (glideslope), SOC4 (thrust), SOC4 (virtual acceleration)
 constexpr int AW = 8;         // ELL width of the symmetric equality part [0 A'; A 0]
 constexpr int TW = 4;         // ELL width of E'
-constexpr int NSLOT = BS + 1; // LDS window of the factorisation: BS live columns + the one being fetched
+constexpr int ST = 32;       // columns staged ahead of the factorisation window (fetched a block early, in registers)
+constexpr int LPAD = 1024;   // zero padding (doubles) before and after L and the constant band: the sweeps and the window fetch
+                             // load unconditionally a little outside [0, nb) and mask, instead of branching around each load
+constexpr int NSLOT = BS + ST; // LDS window of the factorisation: the BS live columns + the ST that become live during a block
 
 // status codes of one solve (the K4 solver's, scvx.h)
 enum { TD_OPTIMAL = 0, TD_ITER_CAP = 1, TD_STALLED = 2, TD_NONFINITE = 3, TD_INFEASIBLE = 5 };
@@ -85,7 +111,7 @@ SCVX_HD void cone_of(int N, int c, int& off, int& dim) {
 // per-trajectory workspace (doubles)
 struct Layout {
     int N, nb, m, ncone;
-    size_t u, s, z, lam, wv, wb, ru, rz, du, dz, ds, bu, bz, t1, t2, t3, tu, tu2, hd, lb, y, total;
+    size_t u, s, z, lam, wv, wb, ru, rz, du, dz, ds, bu, bz, t1, t2, t3, tu, tu2, hd, lb, ut, y, total;
     SCVX_HD void init(int N_) {
         N = N_; nb = band_size(N); m = cone_rows(N); ncone = cone_count(N);
         size_t o = 0;
@@ -94,7 +120,8 @@ struct Layout {
         u = take(nu); s = take(mm); z = take(mm); lam = take(mm); wv = take(mm); wb = take((size_t)ncone);
         ru = take(nu); rz = take(mm); du = take(nu); dz = take(mm); ds = take(mm); bu = take(nu); bz = take(mm);
         t1 = take(mm); t2 = take(mm); t3 = take(mm); tu = take(nu); tu2 = take(nu);
-        hd = take((size_t)(N + 1) * NV * NV); lb = take((size_t)nb * BS); y = take(nu);
+        hd = take((size_t)(N + 1) * NV * NV + 8);   // + a zero entry the window fetch reads for positions outside a node block
+        lb = take((size_t)nb * BS + 2 * LPAD) + LPAD; ut = take((size_t)nb * BS + 2 * LPAD) + LPAD; y = take(nu);
         total = o;
     }
 };
@@ -112,12 +139,12 @@ struct Result {
 // ------------------------------------------------------------------------------------------------------------------
 // small-cone arithmetic on memory-resident rows (dim 1 = linear); formulas of oracle/ipm.py::Cone
 // ------------------------------------------------------------------------------------------------------------------
-SCVX_HD double jdot(const double* a, const double* b, int q) {
+SCVX_HD double jdot(cgptr a, cgptr b, int q) {
     double t = a[0] * b[0];
     for (int k = 1; k < q; k++) t -= a[k] * b[k];
     return t;
 }
-SCVX_HD void cone_nt(const double* s, const double* z, int q, double* v, double& beta, double* lam) {
+SCVX_HD void cone_nt(cgptr s, cgptr z, int q, gptr v, double& beta, gptr lam) {
     if (q == 1) { v[0] = sqrt(s[0] / z[0]); beta = 1.0; lam[0] = sqrt(s[0] * z[0]); return; }
     double s1 = 0, z1 = 0, sz = 0;
     for (int k = 1; k < q; k++) { s1 += s[k] * s[k]; z1 += z[k] * z[k]; sz += s[k] * z[k]; }
@@ -138,7 +165,7 @@ SCVX_HD void cone_nt(const double* s, const double* z, int q, double* v, double&
     for (int k = 1; k < q; k++) lam[k] = beta * (2.0 * vz * v[k] + z[k]);
 }
 // y = W x or W^-1 x (y may alias x)
-SCVX_HD void cone_W(const double* v, double beta, int q, const double* x, double* y, bool inverse) {
+SCVX_HD void cone_W(cgptr v, double beta, int q, cgptr x, gptr y, bool inverse) {
     if (q == 1) { y[0] = inverse ? x[0] / v[0] : x[0] * v[0]; return; }
     double vx = v[0] * x[0];
     if (!inverse) { for (int k = 1; k < q; k++) vx += v[k] * x[k]; }
@@ -149,7 +176,7 @@ SCVX_HD void cone_W(const double* v, double beta, int q, const double* x, double
     y[0] = y0;
 }
 // o = a o b (Jordan product); o may alias a or b
-SCVX_HD void cone_prod(const double* a, const double* b, int q, double* o) {
+SCVX_HD void cone_prod(cgptr a, cgptr b, int q, gptr o) {
     if (q == 1) { o[0] = a[0] * b[0]; return; }
     double dot = 0;
     for (int k = 0; k < q; k++) dot += a[k] * b[k];
@@ -158,7 +185,7 @@ SCVX_HD void cone_prod(const double* a, const double* b, int q, double* o) {
     o[0] = dot;
 }
 // o = lam \ d; o may alias d
-SCVX_HD void cone_div(const double* lam, const double* d, int q, double* o) {
+SCVX_HD void cone_div(cgptr lam, cgptr d, int q, gptr o) {
     if (q == 1) { o[0] = d[0] / lam[0]; return; }
     double l1d1 = 0, l1l1 = 0;
     for (int k = 1; k < q; k++) { l1d1 += lam[k] * d[k]; l1l1 += lam[k] * lam[k]; }
@@ -169,12 +196,12 @@ SCVX_HD void cone_div(const double* lam, const double* d, int q, double* o) {
     o[0] = x0;
 }
 // largest alpha with lam + alpha d in the cone
-SCVX_HD double cone_maxstep(const double* lam, const double* d, int q) {
+SCVX_HD double cone_maxstep(cgptr lam, cgptr d, int q) {
     if (q == 1) return d[0] < 0.0 ? -lam[0] / d[0] : INFINITY;
     return ipm::soc_maxstep_parts(lam[0], d[0], jdot(lam, lam, q), jdot(lam, d, q), jdot(d, d, q));
 }
 // smallest t with x + t e in the cone
-SCVX_HD double cone_shift(const double* x, int q) {
+SCVX_HD double cone_shift(cgptr x, int q) {
     if (q == 1) return -x[0];
     double n1 = 0;
     for (int k = 1; k < q; k++) n1 += x[k] * x[k];
@@ -189,25 +216,32 @@ struct Solver {
     Ex& ex;
     const Tables& T;
     Layout L;
-    double* w;        // this trajectory's workspace
-    double* win;      // fast scratch: factorisation window, then the solve vector
-    double* xs;
-    double* dorig;    // |diagonal| of each window column as assembled: the scale of its pivot floor
-    int* ptab;        // (a << 8 | b) of the trailing-update entries, 1 <= b <= a <= BW
-    const double* icv;   // initial position and velocity: the b entries of band rows 0..5
+    gptr w;           // this trajectory's workspace
+    lptr win;         // fast scratch: factorisation window, then the solve vector
+    lptr xs;
+    lptr dorig;       // |diagonal| of each window column as assembled: the scale of its pivot floor
+    liptr ptab;       // (a << 8 | b) of the trailing-update entries, 1 <= b <= a <= BW
+    cgptr icv;           // initial position and velocity: the b entries of band rows 0..5
     double beta_big, w0_big, qY;
+    struct { cgiptr a_col, e_v0, e_v1, t_row; cgptr a_val, kc, e_c0, e_c1, e_h, t_coef, q; } tt;   // T's tables, typed
+#if defined(SCVX_TD_PROF)
+    double prof[16] = {0};   // section cycles (diagnostic builds): tools/prof_threedof.py
+#endif
 
-    SCVX_HD Solver(Ex& e, const Tables& t, double* work) : ex(e), T(t), w(work) {
+    SCVX_HD Solver(Ex& e, const Tables& t, double* work) : ex(e), T(t), w((gptr)work) {
         L.init(T.N);
+        tt.a_col = (cgiptr)T.a_col; tt.e_v0 = (cgiptr)T.e_v0; tt.e_v1 = (cgiptr)T.e_v1; tt.t_row = (cgiptr)T.t_row;
+        tt.a_val = (cgptr)T.a_val; tt.kc = (cgptr)T.kc; tt.e_c0 = (cgptr)T.e_c0; tt.e_c1 = (cgptr)T.e_c1; tt.e_h = (cgptr)T.e_h;
+        tt.t_coef = (cgptr)T.t_coef; tt.q = (cgptr)T.q;
         win = ex.fast();
         xs = win + (size_t)NSLOT * BS;
         dorig = xs + (((size_t)T.nb + 7) & ~(size_t)7);
-        ptab = (int*)(dorig + NSLOT + 1);
+        ptab = (liptr)(dorig + NSLOT + 1);
         for (int a = 1 + ex.lane(); a <= BW; a += ex.nlanes())
             for (int b = 1; b <= a; b++) ptab[a * (a - 1) / 2 + b - 1] = (a << 8) | b;
         ex.sync_lds();
     }
-    SCVX_HD double bq(int pos) const { return pos < 6 ? icv[pos] : T.q[pos]; }
+    SCVX_HD double bq(int pos) const { return pos < 6 ? icv[pos] : tt.q[pos]; }
 
     template <class F> SCVX_HD void each(int n, F&& f) { for (int i = ex.lane(); i < n; i += ex.nlanes()) f(i); }
     template <class F> SCVX_HD double sum(int n, F&& f) {
@@ -224,66 +258,69 @@ struct Solver {
     }
 
     // o = [0 A'; A 0] v over the band positions (position nb, nkaR, has no equality entry)
-    SCVX_HD void A_apply(const double* v, double* o) {
+    SCVX_HD void A_apply(cgptr v, gptr o) {
         each(T.nb, [&](int p) {
             double a = 0;
             for (int k = 0; k < AW; k++) {
-                const int c = T.a_col[p * AW + k];
-                if (c >= 0) a += T.a_val[p * AW + k] * v[c];
+                const int c = tt.a_col[p * AW + k];
+                if (c >= 0) a += tt.a_val[p * AW + k] * v[c];
             }
             o[p] = a;
         });
         if (ex.lane() == 0) o[T.nb] = 0.0;
     }
     // o = E x (+ h)
-    SCVX_HD void E_apply(const double* v, double* o, bool with_h) {
+    SCVX_HD void E_apply(cgptr v, gptr o, bool with_h) {
         each(T.m, [&](int r) {
-            double a = T.e_c0[r] * v[T.e_v0[r]];
-            const int v1 = T.e_v1[r];
-            if (v1 >= 0) a += T.e_c1[r] * v[v1];
-            o[r] = a + (with_h ? T.e_h[r] : 0.0);
+            double a = tt.e_c0[r] * v[tt.e_v0[r]];
+            const int v1 = tt.e_v1[r];
+            if (v1 >= 0) a += tt.e_c1[r] * v[v1];
+            o[r] = a + (with_h ? tt.e_h[r] : 0.0);
         });
     }
     // (E' zz)[p]
-    SCVX_HD double Et_at(const double* zz, int p) const {
+    SCVX_HD double Et_at(cgptr zz, int p) const {
         double a = 0;
         for (int k = 0; k < TW; k++) {
-            const int r = T.t_row[p * TW + k];
-            if (r >= 0) a += T.t_coef[p * TW + k] * zz[r];
+            const int r = tt.t_row[p * TW + k];
+            if (r >= 0) a += tt.t_coef[p * TW + k] * zz[r];
         }
         return a;
     }
     // o = W in or W^-1 in over all cones
-    SCVX_HD void W_all(const double* in, double* o, bool inverse) {
-        const double* wv = w + L.wv;
-        const double* wb = w + L.wb;
+    SCVX_HD void W_all(cgptr in, gptr o, bool inverse) {
+        cgptr wv = w + L.wv;
+        cgptr wb = w + L.wb;
         each_cone([&](int c, int off, int q) { cone_W(wv + off, wb[c], q, in + off, o + off, inverse); });
     }
 
     // ---- NT scaling from (s, z); lam = W z; the per-node blocks of H = E' W^-2 E; border data of the long cone ----
-    SCVX_HD void scale(bool identity) {
-        double* wv = w + L.wv;
-        double* wb = w + L.wb;
+    SCVX_HD_NI void scale(bool identity) {
+        TD_TS(t0_);
+        gptr wv = w + L.wv;
+        gptr wb = w + L.wb;
         if (identity) {
             each(T.m, [&](int r) { wv[r] = 0.0; });
             ex.sync();
             each_cone([&](int c, int off, int) { wv[off] = 1.0; wb[c] = 1.0; });
         } else {
-            const double* s = w + L.s;
-            const double* z = w + L.z;
-            double* lam = w + L.lam;
+            cgptr s = w + L.s;
+            cgptr z = w + L.z;
+            gptr lam = w + L.lam;
             each_cone([&](int c, int off, int q) { cone_nt(s + off, z + off, q, wv + off, wb[c], lam + off); });
         }
         ex.sync();
+        TD_TE(t0_, 0);
+        TD_TS(t1_);
         const int bo = NR * (T.N + 1);
         beta_big = wb[T.ncone - 1];
         const double v0 = wv[bo];
         w0_big = 2.0 * v0 * v0 - 1.0;
         const double ib2 = 1.0 / (beta_big * beta_big);
-        double* hd = w + L.hd;
+        gptr hd = w + L.hd;
         // one lane per node: its 7 cones in turn (they share entries)
         each(T.N + 1, [&](int i) {
-            double* H = hd + (size_t)i * NV * NV;
+            gptr H = hd + (size_t)i * NV * NV;
             for (int k = 0; k < NV * NV; k++) H[k] = 0.0;
             for (int cc = 0; cc < 7; cc++) {
                 int off, q;
@@ -303,14 +340,14 @@ struct Solver {
                         // entries of rows a and b
                         const int ra = off + a, rb = off + b;
                         for (int ea = 0; ea < 2; ea++) {
-                            const int va = ea == 0 ? T.e_v0[ra] : T.e_v1[ra];
+                            const int va = ea == 0 ? tt.e_v0[ra] : tt.e_v1[ra];
                             if (va < 0) continue;
-                            const double ca = ea == 0 ? T.e_c0[ra] : T.e_c1[ra];
+                            const double ca = ea == 0 ? tt.e_c0[ra] : tt.e_c1[ra];
                             const int la = (va - 7) % NP;
                             for (int eb = 0; eb < 2; eb++) {
-                                const int vb = eb == 0 ? T.e_v0[rb] : T.e_v1[rb];
+                                const int vb = eb == 0 ? tt.e_v0[rb] : tt.e_v1[rb];
                                 if (vb < 0) continue;
-                                const double cb = eb == 0 ? T.e_c0[rb] : T.e_c1[rb];
+                                const double cb = eb == 0 ? tt.e_c0[rb] : tt.e_c1[rb];
                                 const int lb_ = (vb - 7) % NP;
                                 const double val = ca * w2 * cb;
                                 H[la * NV + lb_] += val;
@@ -323,49 +360,90 @@ struct Solver {
             H[11 * NV + 11] += ib2;   // the -J part of the long cone on kaR_i
         });
         ex.sync();
+        TD_TE(t1_, 1);
     }
 
     // ---- banded LDL' of [H + delta I, A'; A, -delta I] without the border; L and 1/d to HBM ----
-    SCVX_HD double kcol(int c, int d) const {   // entry (c + d, c)
-        if (c >= T.nb || c + d >= T.nb) return 0.0;
-        double v = T.kc[(size_t)c * BS + d];
-        if (is_var(T.N, c)) {
-            const int pt = c - 7, i = pt / NP, l = pt - NP * i;
-            if (l + d < NV) v += (w + L.hd)[(size_t)i * NV * NV + (l + d) * NV + l];
-        }
-        return v;
+    // entry (c + d, c) of the band matrix without the border: constant part + the node block of H.  Branch-free: kc is
+    // zero-padded past nb, positions outside a node block read the zero entry behind the H blocks.
+    static SCVX_HD double kcol(cgptr __restrict__ kc, cgptr __restrict__ hd, int N, int c, int d) {
+        const int pt = c - 7, i = pt / NP, l = pt - NP * i;
+        const bool blk = pt >= 0 && i <= N && l + d < NV;   // l + d < NV implies l < NV: a variable column
+        const int hz = (N + 1) * NV * NV;
+        return kc[(size_t)c * BS + d] + hd[blk ? i * NV * NV + (l + d) * NV + l : hz];
     }
-    SCVX_HD bool factor() {
-        double* lb = w + L.lb;
+    // L by columns (lb[j][d] = L[j+d][j], lb[j][0] = 1/d_j) for the forward sweep and by rows (ut[r][d] = L[r][r-d]) for
+    // the backward one, so both stream contiguous memory.  The window holds columns [j0, j0 + NSLOT) during the block of
+    // ST steps starting at j0; the ST columns that enter afterwards are fetched into registers at the start of the
+    // block, so no step waits for HBM.
+    SCVX_HD_NI bool factor() {
+        gptr __restrict__ lb = w + L.lb;
+        gptr __restrict__ ut = w + L.ut;
+        cgptr __restrict__ kc = tt.kc;
+        cgptr __restrict__ hd = w + L.hd;
+        lptr wn = win;
+        lptr dor = dorig;
+        const int N = T.N, nb = T.nb;
+        const int spare = (int)(dorig + NSLOT - win);   // dorig has NSLOT + 1 entries
         const int lane = ex.lane(), nl = ex.nlanes();
-        for (int c = 0; c < BS; c++)
-            for (int d = lane; d < BS; d += nl) {
-                const double v = kcol(c, d);
-                win[(c % NSLOT) * BS + d] = v;
-                if (d == 0) dorig[c % NSLOT] = fabs(v);
-            }
+        constexpr int PER = (ST * BS + Ex::kLanes - 1) / Ex::kLanes;
+        constexpr int PP = (NPAIR + Ex::kLanes - 1) / Ex::kLanes;
+        for (int e = lane; e < NSLOT * BS; e += nl) {
+            const int c = e / BS, d = e - c * BS;
+            const double v = kcol(kc, hd, N, c, d);
+            wn[e] = v;
+            if (d == 0) dor[c] = fabs(v);
+        }
+        int pab[PP];
+        for (int q = 0; q < PP; q++) { const int p = lane + q * nl; pab[q] = p < NPAIR ? ptab[p] : 0; }
         ex.sync_lds();
         bool ok = true;
-        for (int j = 0; j < T.nb; j++) {
-            const double* col = win + (j % NSLOT) * BS;
-            double dj = col[0];
-            const bool var = is_var(T.N, j);
-            // dynamic regularisation: the pivot keeps the sign quasi-definiteness gives it, and does not fall below the
-            // rounding level of the entry it started from (an active cone's block is rank one to working precision in
-            // the last iterations); the refinement passes absorb the perturbation
-            const double fl = 1e-15 * dorig[j % NSLOT] + 1e-13;
-            if (var ? !(dj > fl) : !(dj < -fl)) { if (!(dj == dj)) ok = false; dj = var ? fl : -fl; }
-            const double idj = 1.0 / dj;
-            for (int p = lane; p < NPAIR; p += nl) {
-                const int ab = ptab[p], a = ab >> 8, b = ab & 255;
-                win[((j + b) % NSLOT) * BS + (a - b)] -= col[a] * col[b] * idj;
+        double stage[PER];
+        for (int j0 = 0; j0 < nb; j0 += ST) {
+            const int cbase = j0 + NSLOT;
+            SCVX_UNROLL
+            for (int q = 0; q < PER; q++) {
+                const int e = lane + q * nl;
+                stage[q] = e < ST * BS ? kcol(kc, hd, N, cbase + e / BS, e % BS) : 0.0;
             }
-            const int cn = j + BS;   // the column entering the window
-            for (int d = lane; d < BS; d += nl) {
-                lb[(size_t)j * BS + d] = d == 0 ? idj : col[d] * idj;
-                const double v = kcol(cn, d);
-                win[(cn % NSLOT) * BS + d] = v;
-                if (d == 0) dorig[cn % NSLOT] = fabs(v);
+            const int jend = j0 + ST < nb ? j0 + ST : nb;
+            for (int j = j0; j < jend; j++) {
+                const TD_LOCAL double* col = wn + (j % NSLOT) * BS;
+                double dj = col[0];
+                const bool var = is_var(N, j);
+                // dynamic regularisation: the pivot keeps the sign quasi-definiteness gives it, and does not fall below
+                // the rounding level of the entry it started from (an active cone's block is rank one to working
+                // precision in the last iterations); the refinement passes absorb the perturbation
+                const double fl = 1e-15 * dor[j % NSLOT] + 1e-13;
+                if (var ? !(dj > fl) : !(dj < -fl)) { if (!(dj == dj)) ok = false; dj = var ? fl : -fl; }
+                const double idj = 1.0 / dj;
+                // all reads of the trailing update, then all writes: one LDS round trip per step (a lane without a
+                // q-th entry updates the spare double behind the pivot scales)
+                double tv[PP];
+                int ti[PP];
+                SCVX_UNROLL
+                for (int q = 0; q < PP; q++) {
+                    const int ab = pab[q], a = ab >> 8, b = ab & 255;
+                    ti[q] = ab ? ((j + b) % NSLOT) * BS + (a - b) : spare;
+                    tv[q] = wn[ti[q]] - col[a] * col[b] * idj;
+                }
+                SCVX_UNROLL
+                for (int q = 0; q < PP; q++) wn[ti[q]] = tv[q];
+                for (int d = lane; d < BS; d += nl) {
+                    const double lv = col[d] * idj;
+                    lb[(size_t)j * BS + d] = d == 0 ? idj : lv;
+                    if (d >= 1 && j + d < nb) ut[(size_t)(j + d) * BS + d] = lv;
+                }
+                ex.sync_lds();
+            }
+            SCVX_UNROLL
+            for (int q = 0; q < PER; q++) {
+                const int e = lane + q * nl;
+                if (e < ST * BS) {
+                    const int c = cbase + e / BS, d = e % BS;
+                    wn[(c % NSLOT) * BS + d] = stage[q];
+                    if (d == 0) dor[c % NSLOT] = fabs(stage[q]);
+                }
             }
             ex.sync_lds();
         }
@@ -373,28 +451,37 @@ struct Solver {
         return ok;
     }
     // xs <- K_band^-1 xs
-    SCVX_HD void band_solve() {
-        const double* lb = w + L.lb;
-        const int lane = ex.lane(), nl = ex.nlanes(), nb = T.nb;
-        for (int j = 0; j < nb; j++) {
-            const double xj = xs[j];
-            for (int d = 1 + lane; d <= BW; d += nl)
-                if (j + d < nb) xs[j + d] -= lb[(size_t)j * BS + d] * xj;
+    SCVX_HD_NI void band_solve() {
+        cgptr lb = w + L.lb;
+        cgptr ut = w + L.ut;
+        const int nb = T.nb;
+        if constexpr (Ex::kRegisterSweep) {
+            ex.band_sweeps(xs, lb, ut, nb);
+        } else {
+            const int lane = ex.lane(), nl = ex.nlanes();
+            for (int j = 0; j < nb; j++) {
+                const double xj = xs[j];
+                for (int d = 1 + lane; d <= BW; d += nl)
+                    if (j + d < nb) xs[j + d] -= lb[(size_t)j * BS + d] * xj;
+                ex.sync_lds();
+            }
+            for (int j = lane; j < nb; j += nl) xs[j] *= lb[(size_t)j * BS];
             ex.sync_lds();
-        }
-        for (int j = lane; j < nb; j += nl) xs[j] *= lb[(size_t)j * BS];
-        ex.sync_lds();
-        for (int j = nb - 1; j > 0; j--) {
-            const double xj = xs[j];
-            for (int d = 1 + lane; d <= BW; d += nl)
-                if (j - d >= 0) xs[j - d] -= lb[(size_t)(j - d) * BS + d] * xj;
-            ex.sync_lds();
+            for (int j = nb - 1; j > 0; j--) {
+                const double xj = xs[j];
+                for (int d = 1 + lane; d <= BW; d += nl)
+                    if (j - d >= 0) xs[j - d] -= ut[(size_t)j * BS + d] * xj;
+                ex.sync_lds();
+            }
         }
     }
-    SCVX_HD bool factor_all() {
+    SCVX_HD_NI bool factor_all() {
+        TD_TS(t2_);
         const bool ok = factor();
+        TD_TE(t2_, 2);
+        TD_TS(t3_);
         // border: Y = K_band^-1 wh_b (wh_b = the long cone's wh tail at the kaR positions), qY = wh_b' Y
-        const double* wv = w + L.wv;
+        cgptr wv = w + L.wv;
         const int bo = NR * (T.N + 1);
         const double v0 = wv[bo];
         each(T.nb, [&](int p) { xs[p] = 0.0; });
@@ -402,19 +489,21 @@ struct Solver {
         each(T.N + 1, [&](int i) { xs[pos_z(i, 11)] = -2.0 * v0 * wv[bo + 1 + i]; });
         ex.sync_lds();
         band_solve();
-        double* y = w + L.y;
+        gptr y = w + L.y;
         each(T.nb, [&](int p) { y[p] = xs[p]; });
         qY = sum(T.N + 1, [&](int i) { return -2.0 * v0 * wv[bo + 1 + i] * xs[pos_z(i, 11)]; });
         ex.sync();
+        TD_TE(t3_, 3);
         return ok;
     }
 
     // ---- one condensed solve: [H A'; A 0][du] = [bu - E' W^-2 bz ; bu_eq],  dz = -W^-2 (E du + bz) ----
-    SCVX_HD void condensed(const double* bu, const double* bz, double* du, double* dz) {
-        double* t1 = w + L.t1;
-        const double* wv = w + L.wv;
+    SCVX_HD_NI void condensed(cgptr bu, cgptr bz, gptr du, gptr dz) {
+        gptr t1 = w + L.t1;
+        cgptr wv = w + L.wv;
         const int bo = NR * (T.N + 1);
         const double v0 = wv[bo];
+        TD_TS(t4_);
         W_all(bz, t1, true);
         ex.sync();
         W_all(t1, t1, true);
@@ -422,7 +511,11 @@ struct Solver {
         each(T.nb, [&](int p) { xs[p] = bu[p] - Et_at(t1, p); });
         const double rnu = bu[T.nb] - Et_at(t1, T.nb);
         ex.sync_lds();
+        TD_TE(t4_, 4);
+        TD_TS(t5_);
         band_solve();
+        TD_TE(t5_, 5);
+        TD_TS(t6_);
         const double wk = sum(T.N + 1, [&](int i) { return -2.0 * v0 * wv[bo + 1 + i] * xs[pos_z(i, 11)]; });
         // [-beta^-2 + delta, w0; w0, -(beta^2/2 + qY)] [nu; t] = [rnu; -wk]
         const double b2 = beta_big * beta_big;
@@ -430,7 +523,7 @@ struct Solver {
         const double det = m00 * m11 - m01 * m01;
         const double nu = (rnu * m11 + m01 * wk) / det;
         const double tt = (-m00 * wk - m01 * rnu) / det;
-        const double* y = w + L.y;
+        cgptr y = w + L.y;
         each(T.nb, [&](int p) { du[p] = xs[p] - y[p] * tt; });
         if (ex.lane() == 0) du[T.nb] = nu;
         ex.sync();
@@ -442,16 +535,18 @@ struct Solver {
         ex.sync();
         W_all(dz, dz, true);
         ex.sync();
+        TD_TE(t6_, 6);
     }
     // Newton solve with T.refine passes on the uncondensed residual; bu, bz are overwritten with the last residual
-    SCVX_HD void kkt_solve(double* bu, double* bz, double* du, double* dz) {
+    SCVX_HD_NI void kkt_solve(gptr bu, gptr bz, gptr du, gptr dz) {
         condensed(bu, bz, du, dz);
-        double* r1 = w + L.tu;
-        double* r3 = w + L.t2;
-        double* ddu = w + L.tu2;
-        double* ddz = w + L.t3;
+        gptr r1 = w + L.tu;
+        gptr r3 = w + L.t2;
+        gptr ddu = w + L.tu2;
+        gptr ddz = w + L.t3;
         for (int pass = 0; pass < T.refine; pass++) {
             // r1 = bu - ([0 A'; A 0] du - E' dz),  r3 = bz + E du + W^2 dz
+            TD_TS(t7_);
             A_apply(du, r1);
             W_all(dz, r3, false);
             ex.sync();
@@ -459,12 +554,13 @@ struct Solver {
             ex.sync();
             each(T.nb + 1, [&](int p) { r1[p] = bu[p] - r1[p] + Et_at(dz, p); });
             each(T.m, [&](int r) {
-                double a = T.e_c0[r] * du[T.e_v0[r]];
-                const int v1 = T.e_v1[r];
-                if (v1 >= 0) a += T.e_c1[r] * du[v1];
+                double a = tt.e_c0[r] * du[tt.e_v0[r]];
+                const int v1 = tt.e_v1[r];
+                if (v1 >= 0) a += tt.e_c1[r] * du[v1];
                 r3[r] = bz[r] + a + r3[r];
             });
             ex.sync();
+            TD_TE(t7_, 7);
             condensed(r1, r3, ddu, ddz);
             each(T.nb + 1, [&](int p) { du[p] += ddu[p]; });
             each(T.m, [&](int r) { dz[r] += ddz[r]; });
@@ -473,7 +569,7 @@ struct Solver {
     }
 
     // shift x into the interior of the cone if it is not (CVXOPT initialisation)
-    SCVX_HD void shift_in(double* x) {
+    SCVX_HD_NI void shift_in(gptr x) {
         double t = -INFINITY, n2 = 0;
         for (int c = ex.lane(); c < T.ncone; c += ex.nlanes()) {
             int off, q;
@@ -491,8 +587,8 @@ struct Solver {
         ex.sync();
     }
     // min over cones of the largest step keeping lam + alpha d inside
-    SCVX_HD double max_step(const double* d) {
-        const double* lam = w + L.lam;
+    SCVX_HD_NI double max_step(cgptr d) {
+        cgptr lam = w + L.lam;
         double a = INFINITY;
         for (int c = ex.lane(); c < T.ncone; c += ex.nlanes()) {
             int off, q;
@@ -503,23 +599,33 @@ struct Solver {
         return ex.min(a);
     }
 
-    SCVX_HD Result solve(const double* ic, double* out) {
+    SCVX_HD Result solve(const double* ic_, double* out_) {
+        cgptr ic = (cgptr)ic_;
+        gptr out = (gptr)out_;
         icv = ic;
-        double *u = w + L.u, *s = w + L.s, *z = w + L.z, *lam = w + L.lam;
-        double *ru = w + L.ru, *rz = w + L.rz, *du = w + L.du, *dz = w + L.dz, *ds = w + L.ds;
-        double *bu = w + L.bu, *bz = w + L.bz, *t1 = w + L.t1, *t2 = w + L.t2, *t3 = w + L.t3;
+        gptr u = w + L.u, s = w + L.s, z = w + L.z, lam = w + L.lam;
+        gptr ru = w + L.ru, rz = w + L.rz, du = w + L.du, dz = w + L.dz, ds = w + L.ds;
+        gptr bu = w + L.bu, bz = w + L.bz, t1 = w + L.t1, t2 = w + L.t2, t3 = w + L.t3;
         const int nb = T.nb, m = T.m, N = T.N;
+        TD_TS(tt_);
         Result R;
         R.status = TD_ITER_CAP; R.iters = 0; R.pobj = 0; R.gap = INFINITY; R.pres = INFINITY; R.dres = INFINITY;
         double b2 = T.b2_rest;
         for (int i = 0; i < 6; i++) b2 += icv[i] * icv[i];
         const double nrm_b = sqrt(b2) > 1.0 ? sqrt(b2) : 1.0;
 
+        // the zero entry behind the H blocks and the padding around L (read, masked, by the window fetch and the sweeps)
+        each(8, [&](int k) { (w + L.hd)[(size_t)(N + 1) * NV * NV + k] = 0.0; });
+        each(LPAD, [&](int k) {
+            (w + L.lb)[-1 - k] = 0.0; (w + L.lb)[(size_t)nb * BS + k] = 0.0;
+            (w + L.ut)[-1 - k] = 0.0; (w + L.ut)[(size_t)nb * BS + k] = 0.0;
+        });
+        ex.sync();
         // ---- initial point: W = I,  [0 A' G'; A 0 0; G 0 -I][x; y; z] = [-c; b; h],  s = -z, shifted into the cone ----
         scale(true);
         bool ok = factor_all();
-        each(nb + 1, [&](int p) { bu[p] = (p == nb || is_var(N, p)) ? -T.q[p] : bq(p); });
-        each(m, [&](int r) { bz[r] = T.e_h[r]; });
+        each(nb + 1, [&](int p) { bu[p] = (p == nb || is_var(N, p)) ? -tt.q[p] : bq(p); });
+        each(m, [&](int r) { bz[r] = tt.e_h[r]; });
         ex.sync();
         kkt_solve(bu, bz, u, z);
         each(m, [&](int r) { s[r] = -z[r]; });
@@ -532,6 +638,7 @@ struct Solver {
         int flat = 0;
         for (int it = 1; it <= T.max_iter; it++) {
             R.iters = it;
+            TD_TS(t8_);
             // residuals: ru = [c + A'y - E'z at variables; A x - b at equalities], rz = s - e(x)
             A_apply(u, ru);
             E_apply(u, rz, true);
@@ -539,7 +646,7 @@ struct Solver {
             double pobj = 0, dobj = 0, nx = 0, ny = 0;
             for (int p = ex.lane(); p <= nb; p += ex.nlanes()) {
                 const bool var = p == nb || is_var(N, p);
-                const double qp = var ? T.q[p] : bq(p);
+                const double qp = var ? tt.q[p] : bq(p);
                 if (var) {
                     const double r = qp + ru[p] - Et_at(z, p);
                     ru[p] = r; nx += r * r; pobj += qp * u[p];
@@ -551,13 +658,14 @@ struct Solver {
             double gap = 0, nz = 0;
             for (int r = ex.lane(); r < m; r += ex.nlanes()) {
                 const double rr = s[r] - rz[r];
-                rz[r] = rr; nz += rr * rr; gap += s[r] * z[r]; dobj -= T.e_h[r] * z[r];
+                rz[r] = rr; nz += rr * rr; gap += s[r] * z[r]; dobj -= tt.e_h[r] * z[r];
             }
             pobj = ex.sum(pobj); dobj = ex.sum(dobj); nx = ex.sum(nx); ny = ex.sum(ny); nz = ex.sum(nz); gap = ex.sum(gap);
             ex.sync();
             const double pres = fmax(sqrt(ny) / nrm_b, sqrt(nz) / T.nrm_h), dres = sqrt(nx) / T.nrm_c;
             const double relgap = gap / fmax(1.0, fmax(fabs(pobj), fabs(dobj)));
             R.pobj = pobj; R.gap = gap; R.pres = pres; R.dres = dres;
+            TD_TE(t8_, 8);
             SCVX_DBG("td %3d pobj %+.10e dobj %+.10e gap %.2e pres %.2e dres %.2e\n", it, pobj, dobj, gap, pres, dres);
             if (!(pres == pres) || !(dres == dres) || !(gap == gap) || !ok) { R.status = TD_NONFINITE; break; }
             if (pres < T.tol && dres < T.tol && (gap < T.tol || relgap < T.tol)) { R.status = TD_OPTIMAL; break; }
@@ -577,6 +685,7 @@ struct Solver {
             each(m, [&](int r) { bz[r] = -rz[r] + s[r]; });
             ex.sync();
             kkt_solve(bu, bz, du, dz);
+            TD_TS(t9_);
             E_apply(du, ds, false);
             ex.sync();
             each(m, [&](int r) { ds[r] = -rz[r] + ds[r]; });
@@ -600,7 +709,9 @@ struct Solver {
             each(nb + 1, [&](int p) { bu[p] = -ru[p]; });
             each(m, [&](int r) { bz[r] = -rz[r] - t1[r]; });
             ex.sync();
+            TD_TE(t9_, 9);
             kkt_solve(bu, bz, du, dz);
+            TD_TS(t10_);
             E_apply(du, ds, false);
             ex.sync();
             each(m, [&](int r) { ds[r] = -rz[r] + ds[r]; });
@@ -613,11 +724,13 @@ struct Solver {
             each(nb + 1, [&](int p) { u[p] += alpha * du[p]; });
             each(m, [&](int r) { z[r] += alpha * dz[r]; s[r] += alpha * ds[r]; });
             ex.sync();
+            TD_TE(t10_, 10);
         }
         // the variables, node by node, then nkaR
         each((N + 1) * NV, [&](int k) { out[k] = u[pos_z(k / NV, k % NV)]; });
         if (ex.lane() == 0) out[(N + 1) * NV] = u[nb];
         ex.sync();
+        TD_TE(tt_, 15);
         (void)t3;
         return R;
     }
@@ -647,7 +760,7 @@ inline const char* build_tables(const Problem3& P, double tol, int max_iter, int
     std::vector<double> mu(N + 1);
     for (int k = 0; k <= N; k++) mu[k] = ((double)(N - k) / N) * P.mwet + ((double)k / N) * P.mdry;   // :24
     H.a_col.assign((size_t)nb * AW, -1); H.a_val.assign((size_t)nb * AW, 0.0);
-    H.kc.assign((size_t)nb * BS, 0.0);
+    H.kc.assign((size_t)nb * BS + 2 * LPAD, 0.0);   // zero past nb: the window fetch runs NSLOT + ST columns ahead
     H.q.assign((size_t)nb + 1, 0.0);
     const char* err = nullptr;
     auto put = [&](int row, int col, double v) {   // A[row, col] = v, both triangles
