@@ -19,6 +19,7 @@ struct TdCache {
     td::Tables t{};           // device pointers
     void* blob = nullptr;     // one device allocation behind them
     double* work = nullptr;   // [grid][stride]
+    double* prof = nullptr;   // diagnostic builds (SCVX_TD_PROF): section cycles of trajectory 0
     size_t work_doubles = 0;
 };
 
@@ -108,7 +109,7 @@ struct WaveEx3 {
 
 // sol [B][(K+1)*15+1]; info [B][6] = status, iters, pobj, gap, pres, dres
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void threedof_kernel(td::Tables T, int B, const double* __restrict__ ic, double* work,
-                                                      size_t stride, double* sol, double* info) {
+                                                      size_t stride, double* sol, double* info, double* prof_out) {
     extern __shared__ double td_lds[];
     WaveEx3 ex{(td::lptr)td_lds};
     const int no = td::out_doubles(T.N);
@@ -121,8 +122,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         __syncthreads();
 #if defined(SCVX_TD_PROF)
-        if (b == 0 && threadIdx.x == 0) for (int i = 0; i < 16; i++) work[i] = S.prof[i];   // diagnostic build: section cycles of trajectory 0
-        __syncthreads();
+        if (b == 0 && threadIdx.x == 0) for (int i = 0; i < 16; i++) prof_out[i] = S.prof[i];
 #endif
     }
 }
@@ -167,6 +167,7 @@ void td_cache_free(scvx_ctx* ctx) {
     if (!ctx || !ctx->td) return;
     if (ctx->td->blob) (void)hipFree(ctx->td->blob);
     if (ctx->td->work) (void)hipFree(ctx->td->work);
+    if (ctx->td->prof) (void)hipFree(ctx->td->prof);
     delete ctx->td;
     ctx->td = nullptr;
 }
@@ -239,8 +240,11 @@ int threedof_solve_dev(scvx_ctx* ctx, int B, const double* ic_dev, const scvx_th
         c->work_doubles = need;
     }
     const size_t lds = td::fast_doubles(c->P.K) * 8;
+#if defined(SCVX_TD_PROF)
+    if (!c->prof) SCVX_HIP(ctx, hipMalloc((void**)&c->prof, 16 * 8));
+#endif
     hipLaunchKernelGGL(threedof_kernel, dim3(grid), dim3(64), lds, ctx->stream, c->t, B, ic_dev, c->work, L.total, sol_dev,
-                       info_dev);
+                       info_dev, c->prof);
     SCVX_HIP(ctx, hipGetLastError());
     return SCVX_OK;
 }
@@ -259,9 +263,9 @@ extern "C" {
 
 #if defined(SCVX_TD_PROF)
 int scvx_debug_td_prof(scvx_ctx* ctx, double* out16) {
-    if (!ctx || !ctx->td || !ctx->td->work) return SCVX_ERR_STATE;
+    if (!ctx || !ctx->td || !ctx->td->prof) return SCVX_ERR_STATE;
     (void)hipStreamSynchronize(ctx->stream);
-    return hipMemcpy(out16, ctx->td->work, 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : SCVX_ERR_HIP;
+    return hipMemcpy(out16, ctx->td->prof, 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : SCVX_ERR_HIP;
 }
 #endif
 
