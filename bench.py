@@ -94,6 +94,28 @@ def host_cores():
     return n
 
 
+def k0_threedof(B, seed):
+    """NOT the headline: the 3-DoF lossless-convexification initialiser (FirstRound.solve_initial, initial_solve.jl:17-110;
+    BASELINE configs[0] problem class at K = 30) for B dispersed initial conditions through scvx_threedof_solve (host arrays in
+    and out), wall clock of the second call."""
+    from successiveconvexification_amd import first_round
+    from successiveconvexification_amd.defns import DescentProblem
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    from successiveconvexification_amd.montecarlo import disperse_ics
+    p = DescentProblem()
+    p.K, p.tf_guess, p.mdry, p.mwet, p.alpha = 30, 6.0, 1.0, 2.0, 0.05
+    p.rIi, p.vIi = np.array([4.0, 2.0, 0.0]), np.array([-0.5, -0.5, 0.3])
+    c = IntegratorCache(p)
+    ic = disperse_ics(p, 0, B, seed)
+    first_round.solve_initial_batch(c, ic)
+    t0 = time.perf_counter()
+    sol, st, info = first_round.solve_initial_batch(c, ic)
+    t = time.perf_counter() - t0
+    c.close()
+    return {"workload": "3-DoF landing SOCP, K=30, flyable instance, 10% dispersed (rIi, vIi), tol 1e-9", "B": int(B), "ms": 1e3 * t,
+            "solves_per_s": B / t, "ipm_iters_mean": float(info[:, 0].mean()), "optimal_frac": float(np.mean(st == 0))}
+
+
 def cpu_baseline(npts, seed, steps, reps=5):
     """The CPU twin (oracle/scvx_port.cpp = the device solver core compiled for the host, + oracle/scvx_oracle.c,
     OpenMP over trajectories) on a bounded sample of the SAME workload: `steps` solve_steps from create_initial (one
@@ -442,6 +464,8 @@ def main():
                                                   "rejected step the conic solve is skipped when the optimum just found lies strictly "
                                                   "inside the halved radius (it is then the new optimum too); every solve_step still runs "
                                                   "its propagation, trust-region test and re-linearisation")
+        if world == 1 and not args.no_traj_check and not args.aero:
+            line["k0_threedof_init"] = k0_threedof(B, args.seed)
         if not args.no_cpu_baseline and world == 1 and not args.aero:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.npts, args.seed, period)
         print(json.dumps(line), flush=True)

@@ -5,6 +5,7 @@
 # It keeps RocketlandDefns' types and replaces
 #   Dynamics.IntegratorCache (dynamics.jl:258), Dynamics.linearize_dynamics (:321), Dynamics.predict_state (:315),
 #   Rocketland.create_initial (rocketland.jl:34), solve_step (:226), solve_problem (:432)
+#   FirstRound.solve_initial (initial_solve.jl:17-110): the 3-DoF initialiser, batched on the device
 # with calls through include/scvx.h.  The exact ccall sequence, argument types and array layouts used below for the
 # reference's recipe (rocketland.jl:26-32, the aero problem) are replayed from C by tests/abi_harness.c on the GPU
 # and compared bit for bit with the Python host layer, which binds the identical C signatures.
@@ -150,6 +151,48 @@ function create_batch(problem::DescentProblem, cache::Cache; ics::Union{Nothing,
     return b
 end
 create_initial(problem::DescentProblem, cache::Cache) = iteration(create_batch(problem, cache))
+
+# FirstRound.solve_initial (initial_solve.jl:17-110): the 3-DoF lossless-convexification landing SOCP, on the device.
+struct ThreedofOpts
+    max_iter::Int32; refine::Int32; tol::Cdouble; delta::Cdouble
+end
+function threedof_opts(; kw...)
+    o = Ref(ThreedofOpts(0, 0, 0.0, 0.0))
+    ccall((:scvx_threedof_default_opts, LIB), Cint, (Ref{ThreedofOpts},), o)
+    d = Dict(kw)
+    return ThreedofOpts(get(d, :max_iter, o[].max_iter), get(d, :refine, o[].refine), get(d, :tol, o[].tol), get(d, :delta, o[].delta))
+end
+# ics: 6 x B = (rIi; vIi) per trajectory.  Returns (sol, status, info): sol is 15 x (K+1) x B in the variable order
+# r(3) v(3) ma T(3) ga kaR ar(3) per node plus nkaR (length B); status 0 = optimal, 5 = infeasible; info 5 x B.
+function solve_initial_batch(cache::Cache, ics::Matrix{Float64}; kw...)
+    B = size(ics, 2); K = Int(cache.problem.K)
+    n = ccall((:scvx_threedof_record_doubles, LIB), Int32, (Cint,), K)
+    rec = Matrix{Float64}(undef, n, B); st = Vector{Int32}(undef, B); info = Matrix{Float64}(undef, 5, B)
+    o = Ref(threedof_opts(; kw...))
+    check(cache.ctx, ccall((:scvx_threedof_solve, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ref{ThreedofOpts}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}),
+                           cache.ctx, B, ics, o, rec, st, info), "scvx_threedof_solve")
+    return reshape(rec[1:end-1, :], 15, K + 1, B), rec[end, :], st, info
+end
+# create_initial from solve_initial instead of the straight line (initial_solve.jl:90-107): trajectories whose 3-DoF solve is
+# not optimal keep the straight-line guess; returns (batch, 3-DoF statuses)
+function create_batch_threedof(problem::DescentProblem, cache::Cache; ics::Union{Nothing,Matrix{Float64}}=nothing, kw...)
+    B = ics === nothing ? 1 : size(ics, 2)
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    check(cache.ctx, ccall((:scvx_batch_create, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), cache.ctx, B, ref), "scvx_batch_create")
+    b = Batch(ref[], cache, B)
+    st3 = Vector{Int32}(undef, B)
+    o = Ref(threedof_opts(; kw...))
+    check(cache.ctx, ccall((:scvx_batch_init_threedof, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ref{ThreedofOpts}, Ptr{Int32}),
+                           b.h, ics === nothing ? C_NULL : ics, o, st3), "scvx_batch_init_threedof")
+    return b, st3
+end
+# solve_initial(prob) -> (initial_points, linearisation), as the reference's commented-out function returns them
+function solve_initial(problem::DescentProblem, cache::Cache; kw...)
+    b, st3 = create_batch_threedof(problem, cache; kw...)
+    st3[1] == 0 || error("3-DoF initial solve not optimal (status $(st3[1]))")
+    it = iteration(b)
+    return it.about, it.dynam
+end
 
 const STATUS_NAME = Dict(3 => "SLOW_PROGRESS", 4 => "NUMERICAL_ERROR", 5 => "INFEASIBLE")
 

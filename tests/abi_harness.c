@@ -103,6 +103,20 @@ int main(int argc, char **argv) {
         fwrite(out, 8, 14, fo);
         free(rec); free(e); free(d);
     }
+    /* FirstRound.solve_initial(prob): the 3-DoF SOCP through scvx_threedof_solve, options struct by pointer */
+    {
+        scvx_threedof_opts o;
+        CHECK(ctx, scvx_threedof_default_opts(&o));
+        o.max_iter = 45;
+        const int n = scvx_threedof_record_doubles(K);
+        double *sol = malloc((size_t)n * 8), info[5];
+        int32_t st3;
+        CHECK(ctx, scvx_threedof_solve(ctx, 1, NULL, &o, sol, &st3, info));
+        fwrite(sol, 8, (size_t)n, fo);
+        double o2[6] = {(double)st3, info[0], info[1], info[2], info[3], info[4]};
+        fwrite(o2, 8, 6, fo);
+        free(sol);
+    }
     fclose(fo);
     scvx_batch_destroy(b);
     scvx_ctx_destroy(ctx);

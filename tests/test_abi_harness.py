@@ -72,7 +72,8 @@ def test_harness_replays_the_julia_call_sequence_bit_for_bit(tmp_path, aero_tabl
     out = np.fromfile(fout)
     nrec = (K + 1) * 17 + 1
     per_iter = nrec + K * 14 + K * 294 + 3
-    assert out.size == per_iter * (nstep + 1) + 3 * nstep + K * 14 + K * 294 + 14
+    n3 = (K + 1) * 15 + 1
+    assert out.size == per_iter * (nstep + 1) + 3 * nstep + K * 14 + K * 294 + 14 + n3 + 6
 
     b = ScvxBatch(cache, 1).init(None)
 
@@ -99,5 +100,15 @@ def test_harness_replays_the_julia_call_sequence_bit_for_bit(tmp_path, aero_tabl
     assert np.array_equal(out[pos:pos + K * 294], d2.ravel()); pos += K * 294
     xs = np.zeros((1, 2, 14)); xs[0, 0] = x[0, 3]
     xp = propagate_batch(cache, xs, u[:, 3:5], s, 1.0 / (K + 1))
-    assert np.array_equal(out[pos:pos + 14], xp[0, 0])
+    assert np.array_equal(out[pos:pos + 14], xp[0, 0]); pos += 14
+    # FirstRound.solve_initial through scvx_threedof_solve (whatever its status on this problem: the same bits)
+    from successiveconvexification_amd import first_round
+    L = cache._L
+    o = first_round.threedof_opts(L, max_iter=45)
+    rec = np.zeros(n3); st3 = np.zeros(1, np.int32); info = np.zeros(5)
+    dp = C.POINTER(C.c_double)
+    assert L.scvx_threedof_solve(cache.handle, 1, None, C.byref(o), rec.ctypes.data_as(dp), st3.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 info.ctypes.data_as(dp)) == 0
+    assert np.array_equal(out[pos:pos + n3], rec, equal_nan=True); pos += n3
+    assert np.array_equal(out[pos:pos + 6], np.concatenate([[float(st3[0])], info]), equal_nan=True)
     b.close(); cache.close()
