@@ -161,6 +161,11 @@ typedef struct scvx_threedof_opts {
     int32_t refine;     /* refinement passes per Newton solve on the uncondensed residual: 1 */
     double tol;         /* primal / dual residual and relative gap: 1e-9 */
     double delta;       /* static regularisation of the quasi-definite KKT matrix: 1e-9 */
+    int32_t attitude;   /* scvx_batch_init_threedof only.  0 (default) = the reference's rotation_between(e1, -T_k)
+                         * (initial_solve.jl:98); 1 = rotation_between(e1, +T_k): the body axis the engine pushes along
+                         * points along the 3-DoF thrust, which is what the 6-DoF model (control (|T|,0,0) in body axes)
+                         * means -- the reference's sign makes the start fly backwards (tools/init_compare.py) */
+    int32_t reserved;
 } scvx_threedof_opts;
 int scvx_threedof_default_opts(scvx_threedof_opts *o);
 /* doubles per trajectory of a solution record: (K+1)*15 + 1 -- per node r(3) v(3) ma T(3) ga kaR ar(3), then nkaR */

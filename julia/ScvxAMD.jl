@@ -154,13 +154,14 @@ create_initial(problem::DescentProblem, cache::Cache) = iteration(create_batch(p
 
 # FirstRound.solve_initial (initial_solve.jl:17-110): the 3-DoF lossless-convexification landing SOCP, on the device.
 struct ThreedofOpts
-    max_iter::Int32; refine::Int32; tol::Cdouble; delta::Cdouble
+    max_iter::Int32; refine::Int32; tol::Cdouble; delta::Cdouble; attitude::Int32; reserved::Int32
 end
 function threedof_opts(; kw...)
-    o = Ref(ThreedofOpts(0, 0, 0.0, 0.0))
+    o = Ref(ThreedofOpts(0, 0, 0.0, 0.0, 0, 0))
     ccall((:scvx_threedof_default_opts, LIB), Cint, (Ref{ThreedofOpts},), o)
     d = Dict(kw)
-    return ThreedofOpts(get(d, :max_iter, o[].max_iter), get(d, :refine, o[].refine), get(d, :tol, o[].tol), get(d, :delta, o[].delta))
+    return ThreedofOpts(get(d, :max_iter, o[].max_iter), get(d, :refine, o[].refine), get(d, :tol, o[].tol), get(d, :delta, o[].delta),
+                        get(d, :align_thrust, false) ? 1 : 0, 0)   # align_thrust: rotation_between(e1, +T) instead of the reference's -T
 end
 # ics: 6 x B = (rIi; vIi) per trajectory.  Returns (sol, status, info): sol is 15 x (K+1) x B in the variable order
 # r(3) v(3) ma T(3) ga kaR ar(3) per node plus nkaR (length B); status 0 = optimal, 5 = infeasible; info 5 x B.

@@ -42,7 +42,8 @@ class ScvxSolverOpts(C.Structure):
 
 
 class ScvxThreedofOpts(C.Structure):
-    _fields_ = [("max_iter", C.c_int32), ("refine", C.c_int32), ("tol", C.c_double), ("delta", C.c_double)]
+    _fields_ = [("max_iter", C.c_int32), ("refine", C.c_int32), ("tol", C.c_double), ("delta", C.c_double),
+                ("attitude", C.c_int32), ("reserved", C.c_int32)]
 
 
 _vp = C.c_void_p

@@ -842,7 +842,7 @@ int scvx_batch_init_threedof(scvx_batch* b, const double* ic, const scvx_threedo
     std::vector<double> hinfo((size_t)B * 6);
     if (e == hipSuccess) {
         rc = scvx::threedof_solve_dev(ctx, B, b->ic, opts, d_sol, d_info);
-        if (rc == SCVX_OK) rc = scvx::threedof_to_record(ctx, B, K, d_sol, d_info, b->traj);
+        if (rc == SCVX_OK) rc = scvx::threedof_to_record(ctx, B, K, d_sol, d_info, b->traj, opts ? opts->attitude : 0);
         if (rc == SCVX_OK) {
             e = hipMemcpyAsync(b->traj0, b->traj, (size_t)B * b->nrec * 8, hipMemcpyDeviceToDevice, st);
             if (e == hipSuccess) e = hipMemcpyAsync(hinfo.data(), d_info, hinfo.size() * 8, hipMemcpyDeviceToHost, st);

@@ -46,7 +46,7 @@ hipError_t launch_propagate_f32(const scvx_ctx* ctx, int B, int K, const float* 
 // of the trajectories whose solve is optimal with the LinPoints of initial_solve.jl:90-105.
 int threedof_solve_dev(scvx_ctx* ctx, int B, const double* ic_dev, const scvx_threedof_opts* opts, double* sol_dev,
                        double* info_dev);
-int threedof_to_record(scvx_ctx* ctx, int B, int K, const double* sol_dev, const double* info_dev, double* rec_dev);
+int threedof_to_record(scvx_ctx* ctx, int B, int K, const double* sol_dev, const double* info_dev, double* rec_dev, int attitude);
 void td_cache_free(scvx_ctx* ctx);
 
 inline int fail(scvx_ctx* ctx, int code, const std::string& msg) {

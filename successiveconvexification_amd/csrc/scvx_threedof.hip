@@ -140,7 +140,7 @@ __device__ void rotation_between_e1_dev(const double* b, double* q) {
 // initial_solve.jl:90-105: LinPoints from the 3-DoF optimum -- state (ma, r, v, rotation_between(e1, -T), 0), control
 // (|T|, 0, 0) -- written over the trajectory record of every trajectory whose 3-DoF solve is optimal
 __global__ void threedof_to_record_kernel(int B, int K, const double* __restrict__ sol, const double* __restrict__ info,
-                                          double sigma, double* __restrict__ rec) {
+                                          double sigma, double tsign, double* __restrict__ rec) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * (K + 1)) return;
     const int b = i / (K + 1), k = i - b * (K + 1);
@@ -151,7 +151,7 @@ __global__ void threedof_to_record_kernel(int B, int K, const double* __restrict
     double* u = rec + (size_t)b * nrec + (size_t)(K + 1) * 14 + 3 * k;
     x[0] = z[6];
     for (int j = 0; j < 3; j++) { x[1 + j] = z[j]; x[4 + j] = z[3 + j]; x[11 + j] = 0.0; }
-    const double nT[3] = {-z[7], -z[8], -z[9]};
+    const double nT[3] = {tsign * z[7], tsign * z[8], tsign * z[9]};
     rotation_between_e1_dev(nT, x + 7);
     u[0] = sqrt(z[7] * z[7] + z[8] * z[8] + z[9] * z[9]); u[1] = 0.0; u[2] = 0.0;
     if (k == 0) rec[(size_t)b * nrec + nrec - 1] = sigma;
@@ -179,8 +179,8 @@ static int td_setup(scvx_ctx* ctx, const scvx_threedof_opts& o) {
     P.K = p.K; P.alpha = p.alpha; P.tf_guess = p.tf_guess; P.mwet = p.mwet; P.mdry = p.mdry; P.g = p.g;
     P.Tmin = p.Tmin; P.Tmax = p.Tmax; P.thetaMax = p.thetaMax; P.gammaGs = p.gammaGs;
     if (same_setup(ctx->td, P, o)) return SCVX_OK;
-    if (!(o.tol > 0.0) || o.max_iter < 1 || o.refine < 0 || !(o.delta > 0.0))
-        return fail(ctx, SCVX_ERR_ARG, "threedof options: tol > 0, max_iter >= 1, refine >= 0, delta > 0 required");
+    if (!(o.tol > 0.0) || o.max_iter < 1 || o.refine < 0 || !(o.delta > 0.0) || o.attitude < 0 || o.attitude > 1)
+        return fail(ctx, SCVX_ERR_ARG, "threedof options: tol > 0, max_iter >= 1, refine >= 0, delta > 0, attitude 0 or 1 required");
     td::HostTables H;
     if (const char* e = td::build_tables(P, o.tol, o.max_iter, o.refine, o.delta, H)) return fail(ctx, SCVX_ERR_ARG, e);
     if (td::fast_doubles(P.K) * 8 > 64 * 1024) return fail(ctx, SCVX_ERR_ARG, "K too large for the 3-DoF solver's LDS window");
@@ -249,10 +249,10 @@ int threedof_solve_dev(scvx_ctx* ctx, int B, const double* ic_dev, const scvx_th
     return SCVX_OK;
 }
 
-int threedof_to_record(scvx_ctx* ctx, int B, int K, const double* sol_dev, const double* info_dev, double* rec_dev) {
+int threedof_to_record(scvx_ctx* ctx, int B, int K, const double* sol_dev, const double* info_dev, double* rec_dev, int attitude) {
     const int n = B * (K + 1);
     hipLaunchKernelGGL(threedof_to_record_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, B, K, sol_dev, info_dev,
-                       ctx->prob.tf_guess, rec_dev);
+                       ctx->prob.tf_guess, attitude == 1 ? 1.0 : -1.0, rec_dev);
     SCVX_HIP(ctx, hipGetLastError());
     return SCVX_OK;
 }
@@ -275,6 +275,8 @@ int scvx_threedof_default_opts(scvx_threedof_opts* o) {
     o->refine = 1;
     o->tol = 1e-9;
     o->delta = 1e-9;
+    o->attitude = 0;
+    o->reserved = 0;
     return SCVX_OK;
 }
 

@@ -46,7 +46,7 @@ def linear_initial(problem: DescentProblem, cache):
 THREEDOF_STATUS = {0: "optimal", 1: "iteration cap", 2: "stalled", 3: "non-finite", 5: "infeasible"}
 
 
-def threedof_opts(L, tol=None, max_iter=None, refine=None, delta=None):
+def threedof_opts(L, tol=None, max_iter=None, refine=None, delta=None, align_thrust=None):
     from . import _lib
     o = _lib.ScvxThreedofOpts()
     L.scvx_threedof_default_opts(C.byref(o))
@@ -58,6 +58,8 @@ def threedof_opts(L, tol=None, max_iter=None, refine=None, delta=None):
         o.refine = refine
     if delta is not None:
         o.delta = delta
+    if align_thrust is not None:   # attitude of the 6-DoF start: False = the reference's rotation_between(e1, -T), True = +T
+        o.attitude = 1 if align_thrust else 0
     return o
 
 

@@ -43,6 +43,13 @@ def _flyable(K=30):
                    mdry=1.0, mwet=2.0, alpha=0.05)
 
 
+def _T_of(tnorm, q):
+    """the thrust vector behind a reference-convention start: q = rotation_between(e1, -T), |T| = tnorm"""
+    w, x, y, z = q
+    e1_rot = np.array([1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)])   # R(q) e1 = -T / |T|
+    return -tnorm * e1_rot
+
+
 def _linf(sol, b, o):
     return max(np.abs(np.asarray(sol[k][b]) - np.asarray(o[k])).max() for k in KEYS)
 
@@ -82,6 +89,22 @@ def test_device_dispersed_batch_other_horizon():
         assert ref.status == "optimal"
         assert abs(info[b, 1] - ref.pobj) <= 1e-8 * max(1.0, abs(ref.pobj))
         assert _linf(sol, b, o) < 5e-5   # the fuel-optimal thrust profile is flat along some directions
+
+
+def test_device_long_horizon_K100():
+    """K = 100: the long cone has 102 rows (more than a wavefront: lanes own several), the band 2,230 positions."""
+    from oracle import model, port, threedof
+    from successiveconvexification_amd import first_round
+    po = _flyable(K=100)
+    ic = model.disperse_ics(po, 6, 3)
+    c = _cache(po)
+    sol, st, info = first_round.solve_initial_batch(c, ic)
+    assert np.all(st == 0), (st, info)
+    tw, tst, tinfo = port.threedof(po, ic)
+    assert np.all(tst == 0) and np.abs(info[:, 1] - tinfo[:, 1]).max() < 1e-9
+    ref, o, _ = threedof.solve_initial(replace(po, rIi=ic[2, :3], vIi=ic[2, 3:]))
+    assert ref.status == "optimal" and abs(info[2, 1] - ref.pobj) <= 1e-8 * max(1.0, abs(ref.pobj))
+    assert _linf(sol, 2, o) < 5e-5
 
 
 def test_device_monte_carlo_batch_properties():
@@ -166,6 +189,15 @@ def test_batch_init_from_threedof_and_first_steps():
     b.reset()
     x0, u0, s0 = b.trajectory()
     assert np.array_equal(x0, x) and np.array_equal(u0, u)
+    # attitude option: the body axis along +T instead of the reference's -T; everything else identical
+    b2 = ScvxBatch(c, B)
+    assert np.all(b2.init_threedof(ic, align_thrust=True) == 0)
+    x2, u2, _ = b2.trajectory()
+    assert np.array_equal(x2[:, :, :7], x[:, :, :7]) and np.array_equal(u2, u)
+    for k in (0, po.K // 2, po.K):
+        q = first_round.rotation_between([1, 0, 0], _T_of(u[0, k, 0], x[0, k, 7:11]))
+        assert min(np.abs(x2[0, k, 7:11] - q).max(), np.abs(x2[0, k, 7:11] + q).max()) < 1e-12
+    b2.close()
     # an infeasible 3-DoF problem keeps the straight-line guess
     pi = model.base_prob_scaled()
     ci = _cache(pi)
