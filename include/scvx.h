@@ -171,8 +171,9 @@ int scvx_threedof_default_opts(scvx_threedof_opts *o);
 /* doubles per trajectory of a solution record: (K+1)*15 + 1 -- per node r(3) v(3) ma T(3) ga kaR ar(3), then nkaR */
 int32_t scvx_threedof_record_doubles(int K);
 /* ic [B][6] host = per-trajectory (rIi, vIi), NULL = the problem's own; opts NULL = defaults.  Outputs (host):
- * sol [B][record_doubles]; status [B] (0 optimal, 1 iteration cap, 2 stalled, 3 non-finite, 5 infeasible: the primal
- * residual stopped falling while the gap closed); info [B][5] = iterations, objective, gap, primal and dual residual
+ * sol [B][record_doubles]; status [B] (0 optimal: residuals and relative gap below tol -- or, when the KKT system breaks
+ * down at the numerical floor, below 10 tol / 100 tol, the band the oracle's solver reports as optimal too; 1 iteration
+ * cap, 2 stalled, 3 non-finite, 5 infeasible: the primal residual stopped falling while the gap closed); info [B][5] = iterations, objective, gap, primal and dual residual
  * (status and info may be NULL). */
 int scvx_threedof_solve(scvx_ctx *ctx, int B, const double *ic, const scvx_threedof_opts *opts, double *sol,
                         int32_t *status, double *info);

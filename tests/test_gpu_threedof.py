@@ -91,6 +91,19 @@ def test_device_dispersed_batch_other_horizon():
         assert _linf(sol, b, o) < 5e-5   # the fuel-optimal thrust profile is flat along some directions
 
 
+@pytest.mark.parametrize("K", [1, 3])
+def test_device_tiny_horizons(K):
+    from oracle import port
+    from successiveconvexification_amd import first_round
+    po = _flyable(K=K)
+    c = _cache(po)
+    sol, st, info = first_round.solve_initial_batch(c)
+    tw, tst, tinfo = port.threedof(po)
+    assert st[0] == 0 and tst[0] == 0 and abs(info[0, 1] - tinfo[0, 1]) < 1e-8
+    # K = 3 ends on the numerical floor (gap 2e-8) on both sides, an iteration apart: the flat thrust directions differ by 5e-5
+    assert _linf(sol, 0, {k: tw[k][0] for k in KEYS}) < 2e-4
+
+
 def test_device_long_horizon_K100():
     """K = 100: the long cone has 102 rows (more than a wavefront: lanes own several), the band 2,230 positions."""
     from oracle import model, port, threedof

@@ -51,6 +51,17 @@ def test_twin_dispersed_batch_and_other_horizon():
     assert np.abs(np.linalg.norm(sol["T"], axis=1) - sol["ga"]).max() < 1e-5 and sol["nkaR"].max() < 1e-6
 
 
+@pytest.mark.parametrize("K", [1, 2, 3, 7])
+def test_twin_tiny_horizons(K):
+    # fewer band positions than the factorisation window has slots; K = 3 ends on the numerical floor (gap 2e-8, accepted
+    # as a certified near-optimum like the oracle's solver does)
+    p = flyable(K=K)
+    ref, o, _ = threedof.solve_initial(p)
+    sol, st, info = port.threedof(p)
+    assert ref.status == "optimal" and st[0] == 0
+    assert abs(info[0, 1] - ref.pobj) <= 1e-7 * max(1.0, abs(ref.pobj)) and linf(sol, 0, o) < 1e-4
+
+
 def test_twin_reports_an_infeasible_instance():
     # the normalised 6-DoF sample problem at tf_guess = 1: the fuel between mwet and mdry cannot pay for Tmin over the
     # whole horizon, whatever the virtual acceleration does -- the oracle's IPM ends "kkt_singular" with the primal
