@@ -125,7 +125,9 @@ int scvx_ctx_create(const scvx_problem* p, int device, scvx_ctx** out) {
         return SCVX_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->num_cus = 0;
     if (const char* v = std::getenv("SCVX_K1_VARIANT")) ctx->k1_variant = std::atoi(v) ? 1 : 0;
+    if (const char* v = std::getenv("SCVX_K1_PERSIST")) ctx->k1_persist = std::atoi(v) ? 1 : 0;
     if (const char* v = std::getenv("SCVX_K1_SG")) ctx->k1_sg = std::atoi(v) ? 1 : 0;
     *out = ctx;
     return SCVX_OK;

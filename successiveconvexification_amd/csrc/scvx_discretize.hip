@@ -190,8 +190,19 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, sizeof(R) == 4 ? 2 : 1) void 
 #ifndef SCVX_PC_PROD
 #define SCVX_PC_PROD 0
 #endif
+#ifndef SCVX_PC_BLOCKS_PER_CU
+#define SCVX_PC_BLOCKS_PER_CU 1
+#endif
+constexpr int PC_BLOCKS_PER_CU = SCVX_PC_BLOCKS_PER_CU;
 constexpr int PC_WAVES = SCVX_PC_WAVES;
 constexpr int PC_PROD = SCVX_PC_PROD;
+// workgroup barrier that orders LDS traffic only: global loads and stores stay in flight across it (__syncthreads() also
+// drains vmcnt)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 constexpr int PC_GROUP = 4;              // stages published per barrier (one RK4 substep)
 // SG (stage-granular, the default): one barrier per RK stage and the producer one STAGE ahead (2-slot ring) instead of
 // one barrier per substep and the producer one substep ahead: the pipeline fills after one stage instead of four (at
@@ -338,6 +349,193 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
     }
 }
 
+// The same producer/consumer pipeline (stage-granular) as a PERSISTENT block, used from 3 substeps up.
+template <bool AERO, typename R>
+__global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
+    DynP<R> p, long nseg, int K, const R* __restrict__ x, const R* __restrict__ u,
+    const R* __restrict__ sigma, R dt, int nsub, R* __restrict__ endpoint,
+    R* __restrict__ deriv, const int* __restrict__ skip) {
+    constexpr int LPS = K1Map<AERO>::LPS, SPW = K1Map<AERO>::SPW;
+    typedef typename Vec2<R>::type VEC2;
+    constexpr bool SG = true;
+    constexpr int NC = PC_WAVES - 1;
+    constexpr int NS = NC * SPW;               // segments per group
+    constexpr int NR = StageRec<AERO>::N;
+    constexpr int RING = SG ? 2 : 2 * PC_GROUP;   // stage records in flight: the producer runs one stage / one substep ahead
+    constexpr int RING_D = RING * NR * NS, TILE_D = NC * SPW * 294;
+    // PERSISTENT block: it walks the groups of NS segments blockIdx.x, blockIdx.x + gridDim.x, ...  The output tiles of a
+    // group leave through 16-byte global stores that nothing waits for: every barrier in here orders LDS only
+    // (lds_barrier), so the 2.4 KB per segment of group g drain to HBM while group g + 1 integrates -- with one block per
+    // CU and a block per group, the store phase (0.3 ms of a launch at B = 8192, the whole intercept of the time-vs-npts
+    // line) ran after the arithmetic instead of under it.  Ring and tiles are separate LDS regions for that reason.
+    constexpr bool SHARE = false;
+    // (the one-group-per-block kernel above keeps ring and tiles in one 66 KB slab, so a CU's LDS holds a second block whose
+    // wavefronts start as the first block's retire: the better shape when a group is latency-bound, npts <= 2 -- measured)
+    __shared__ __attribute__((aligned(16))) R lds[SHARE ? (RING_D > TILE_D ? RING_D : TILE_D) : RING_D + TILE_D];
+    R* const tiles = SHARE ? lds : lds + RING_D;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const R h = dt / R(nsub);
+    const R inv_n = R(1.0) / R(nsub);
+    const long ngrp = (nseg + NS - 1) / NS;
+    // next group of this block that has something to recompute (uniform for the block)
+    auto advance = [&](long g) {
+        while (g < ngrp && block_unchanged(skip, g * NS, NS, nseg, K)) g += gridDim.x;
+        return g;
+    };
+    long grp = advance(blockIdx.x);
+    // vmcnt counts loads and stores in one in-order queue: a global load issued after a group's stores could only be
+    // waited for together with them.  So each role fetches the inputs of its NEXT group before it issues the stores of
+    // the current one, and nothing waits on vmcnt between a group's stores and the end of the next group's arithmetic.
+
+    if (wave == PC_PROD) {
+        // ---------------- producer: lane = segment ----------------
+        const bool live = lane < NS;
+        const int l = live ? lane : 0;
+        R nx[14], nu6[6], nsig = R(0.0);
+        auto fetch = [&](long g) {
+            long seg = g * NS + l;
+            if (seg >= nseg) seg = nseg - 1;
+            const long b = seg / K;
+            const int k = (int)(seg - b * K);
+            const R* xk = x + ((size_t)b * (K + 1) + k) * 14;
+            const R* uk = u + ((size_t)b * (K + 1) + k) * 3;
+#pragma unroll
+            for (int i = 0; i < 14; i++) nx[i] = xk[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) nu6[i] = uk[i];
+            nsig = sigma[b];
+        };
+        if (grp < ngrp) fetch(grp);
+        while (grp < ngrp) {
+            const long nxt = advance(grp + gridDim.x);
+            const long seg = grp * NS + l;
+            const bool valid = live && seg < nseg;
+            const R sig = nsig;
+            R xs[14], xa[14], xt[14];
+#pragma unroll
+            for (int i = 0; i < 14; i++) { xs[i] = nx[i]; xa[i] = xs[i]; xt[i] = xs[i]; }
+            const R uk0 = nu6[0], uk1 = nu6[1], uk2 = nu6[2], up0 = nu6[3], up1 = nu6[4], up2 = nu6[5];
+            for (int s = 0; s <= nsub; s++) {
+                if (s < nsub) {
+#pragma unroll
+                    for (int stg = 0; stg < 4; stg++) {
+                        const R lkp = (R(s) + (stg == 0 ? R(0.0) : (stg == 3 ? R(1.0) : R(0.5)))) * inv_n;
+                        const R lkm = R(1.0) - lkp;
+                        R uu[3] = {fma(uk0, lkm, up0 * lkp), fma(uk1, lkm, up1 * lkp), fma(uk2, lkm, up2 * lkp)};
+                        Stage<AERO, R> st;
+                        stage_eval<AERO>(p, xt, uu, st);
+                        if (live) stage_publish<AERO>(p, st, xt, uu, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + l, NS);
+                        const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
+                        const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
+#pragma unroll
+                        for (int i = 0; i < 14; i++) {
+                            const R dx = sig * st.g[i];
+                            xa[i] = fma(wacc, dx, xa[i]);
+                            xt[i] = (stg < 3) ? fma(wnext, dx, xs[i]) : xa[i];
+                        }
+                        if (SG) lds_barrier();   // stage 4 s + stg is published
+                    }
+#pragma unroll
+                    for (int i = 0; i < 14; i++) xs[i] = xa[i];
+                }
+                if (!SG || s == nsub) lds_barrier();
+            }
+            if (nxt < ngrp) fetch(nxt);
+            if (valid) {
+                R* ep = endpoint + (size_t)seg * 14;
+#pragma unroll
+                for (int i = 0; i < 14; i++) ep[i] = xs[i];
+            }
+            lds_barrier();  // matches the consumers' tile barrier
+            if (SHARE) lds_barrier();   // the tiles have been read out of the shared slab
+            grp = nxt;
+        }
+        return;
+    }
+
+    // ---------------- consumers: lane = (segment, column) ----------------
+    const int cw = wave < PC_PROD ? wave : wave - 1;
+    const int sl = lane / LPS;
+    const int slot = lane - sl * LPS;
+    const int col = AERO ? slot : exo_slot_to_col(slot);
+    const bool lane_live = sl < SPW;
+    const int ls = cw * SPW + (lane_live ? sl : 0);   // local segment index in the group
+    const bool is_uk = (col >= 14) && (col < 17);
+    const bool is_up = (col >= 17) && (col < 20);
+    const int comp = is_uk ? col - 14 : (is_up ? col - 17 : -1);
+    const R gsel = (col == 20) ? R(1.0) : R(0.0);
+    const R e0 = (comp == 0) ? R(1.0) : R(0.0), e1 = (comp == 1) ? R(1.0) : R(0.0), e2 = (comp == 2) ? R(1.0) : R(0.0);
+    auto sigma_of = [&](long g) {
+        long seg = g * NS + ls;
+        if (seg >= nseg) seg = nseg - 1;
+        return sigma[seg / K];
+    };
+    R nsig = grp < ngrp ? sigma_of(grp) : R(0.0);
+    while (grp < ngrp) {
+        const long nxt = advance(grp + gridDim.x);
+        const long seg_base = grp * NS;
+        const R sig = nsig;
+        R c[14], ca[14], ct[14];
+#pragma unroll
+        for (int i = 0; i < 14; i++) { c[i] = (col == i) ? R(1.0) : R(0.0); ca[i] = c[i]; ct[i] = c[i]; }
+        lds_barrier();  // records of substep 0 are ready
+        for (int s = 0; s < nsub; s++) {
+#pragma unroll
+            for (int stg = 0; stg < 4; stg++) {
+                const R lkp = (R(s) + (stg == 0 ? R(0.0) : (stg == 3 ? R(1.0) : R(0.5)))) * inv_n;
+                const R lkm = R(1.0) - lkp;
+                const R wk = is_uk ? lkm : (is_up ? lkp : R(0.0));
+                const R wc[3] = {e0 * wk, e1 * wk, e2 * wk};
+                R dc[14];
+                column_deriv_rec<AERO>(p, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + ls, NS, ct, wc, gsel, sig, dc);
+                const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
+                const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
+#pragma unroll
+                for (int i = 0; i < 14; i++) {
+                    ca[i] = fma(wacc, dc[i], ca[i]);
+                    ct[i] = (stg < 3) ? fma(wnext, dc[i], c[i]) : ca[i];
+                }
+                if (SG) lds_barrier();   // this slot is free again / the next stage is published
+            }
+#pragma unroll
+            for (int i = 0; i < 14; i++) c[i] = ca[i];
+            if (!SG) lds_barrier();
+        }
+        if (nxt < ngrp) nsig = sigma_of(nxt);
+        // ---- epilogue: columns into this wavefront's LDS tile -> coalesced 16-byte stores ----
+        R* t = tiles + cw * SPW * 294;
+        if (lane_live) {
+#pragma unroll
+            for (int i = 0; i < 14; i++) t[sl * 294 + col * 14 + i] = c[i];
+            if (!AERO && slot < 6) {
+                const int j = slot < 3 ? slot : slot - 3;
+                R* cc = t + sl * 294 + (slot < 3 ? 1 + j : 4 + j) * 14;
+#pragma unroll
+                for (int i = 0; i < 14; i++) cc[i] = R(0.0);
+                if (slot < 3) cc[1 + j] = R(1.0);
+                else { cc[1 + j] = sig * dt; cc[4 + j] = R(1.0); }
+            }
+        }
+        lds_barrier();
+        const long seg0 = seg_base + (long)cw * SPW;
+        if (seg0 < nseg) {
+            const long rem = nseg - seg0;
+            const int nvalid = rem < SPW ? (int)rem : SPW;
+            const int n2 = nvalid * 147;
+            VEC2* out = reinterpret_cast<VEC2*>(deriv + (size_t)seg0 * 294);
+            const VEC2* src = reinterpret_cast<const VEC2*>(t);
+#pragma unroll
+            for (int r = 0; r < (SPW * 147 + 63) / 64; r++) {
+                const int e = lane + 64 * r;
+                if (e < n2) out[e] = src[e];
+            }
+        }
+        if (SHARE) lds_barrier();
+        grp = nxt;
+    }
+}
+
 template <bool AERO, typename R>
 __global__ __launch_bounds__(256) void propagate_kernel(DynP<R> p, long nseg, int K, const R* __restrict__ x,
                                                         const R* __restrict__ u,
@@ -413,13 +611,21 @@ hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, con
     if (nseg == 0) return hipSuccess;
     if (ctx->k1_variant == 0) return launch_linearize_simple<R>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st, skip);
     const int ns = (PC_WAVES - 1) * (ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW);
-    const unsigned grid = (unsigned)((nseg + ns - 1) / ns);
     // stage-granular pipeline by default (faster at every npts measured: 0.70 -> 0.60 ms at npts 1, 3.05 -> 2.96 ms
     // at npts 10, B = 8192, fp64); SCVX_K1_SG=0 selects the substep-granular form
     const bool sg = ctx->k1_sg != 0;
+    const long ngrp = (nseg + ns - 1) / ns;
+    const long cap = (long)(ctx->num_cus > 0 ? ctx->num_cus : 256) * PC_BLOCKS_PER_CU;   // persistent blocks, one per CU (LDS and VGPRs allow no more)
+    // persistent kernel from 3 substeps up (measured, B = 8192 fp64: npts 10 3.21 -> 2.95 ms; npts 1: 0.59 -> 0.67, npts 2:
+    // 0.87 -> 0.90 -- a group is latency-bound there, pipeline fill + epilogue); SCVX_K1_PERSIST = 0 / 1 forces
+    const bool persist = sg && (ctx->k1_persist < 0 ? ctx->nsub >= 3 : ctx->k1_persist != 0);
+    const unsigned grid = (unsigned)(!persist || ngrp < cap ? ngrp : cap);
     const dim3 g(grid), blk(64 * PC_WAVES);
     const DynP<R> dp(ctx->dyn);
-    if (ctx->dyn.aero) {
+    if (persist) {
+        if (ctx->dyn.aero) hipLaunchKernelGGL((linearize_pcp_kernel<true, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+        else hipLaunchKernelGGL((linearize_pcp_kernel<false, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+    } else if (ctx->dyn.aero) {
         if (sg) hipLaunchKernelGGL((linearize_pc_kernel<true, true, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
         else hipLaunchKernelGGL((linearize_pc_kernel<true, false, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
     } else {

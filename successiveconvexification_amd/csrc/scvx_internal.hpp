@@ -14,6 +14,8 @@ struct scvx_ctx {
     scvx_problem prob{};
     scvx::DynParams dyn{};
     int nsub = 10;
+    int k1_persist = -1; // persistent blocks in K1's producer/consumer kernel: -1 auto (by npts), 0 / 1 forced (SCVX_K1_PERSIST)
+    int num_cus = 0;     // compute units of the device (persistent-block launch shapes)
     int k1_variant = 1;  // 0: one-lane-per-column kernel, 1: producer/consumer kernel (SCVX_K1_VARIANT overrides)
     int k1_sg = 1;       // producer/consumer pipeline per RK stage (1, default) or per substep (0); SCVX_K1_SG overrides
     double* d_cdrag = nullptr;

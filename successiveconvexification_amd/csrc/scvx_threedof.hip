@@ -225,9 +225,7 @@ int threedof_solve_dev(scvx_ctx* ctx, int B, const double* ic_dev, const scvx_th
     int rc = td_setup(ctx, o);
     if (rc) return rc;
     TdCache* c = ctx->td;
-    hipDeviceProp_t prop;
-    SCVX_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    const int cap = prop.multiProcessorCount * 8;
+    const int cap = (ctx->num_cus > 0 ? ctx->num_cus : 256) * 8;   // 2 wavefronts per SIMD
     const int grid = B < cap ? B : cap;
     td::Layout L;
     L.init(c->P.K);
