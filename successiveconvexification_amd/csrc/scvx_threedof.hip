@@ -158,7 +158,9 @@ __global__ void threedof_to_record_kernel(int B, int K, const double* __restrict
 }
 
 bool same_setup(const TdCache* c, const td::Problem3& P, const scvx_threedof_opts& o) {
-    return c && c->blob && std::memcmp(&c->P, &P, sizeof P) == 0 && std::memcmp(&c->o, &o, sizeof o) == 0;
+    // the tables depend on the problem and on the solver options, not on the attitude convention of the 6-DoF start
+    return c && c->blob && std::memcmp(&c->P, &P, sizeof P) == 0 && c->o.max_iter == o.max_iter && c->o.refine == o.refine &&
+           c->o.tol == o.tol && c->o.delta == o.delta;
 }
 
 }  // namespace

@@ -222,6 +222,32 @@ def test_batch_init_from_threedof_and_first_steps():
     assert np.abs(xi[0] - xo).max() < 1e-14 and np.abs(ui[1] - uo).max() < 1e-14
 
 
+def test_device_pointer_entry_point():
+    """scvx_threedof_solve_dev on device arrays (another framework's tensors), enqueued on the context's stream."""
+    import ctypes as C
+    import torch
+    from oracle import model
+    from successiveconvexification_amd import first_round
+    po = _flyable(K=30)
+    B = 5
+    ic = model.disperse_ics(po, B, 5)
+    c = _cache(po)
+    ref, st, info = first_round.solve_initial_batch(c, ic)
+    L = c._L
+    n = L.scvx_threedof_record_doubles(po.K)
+    d_ic = torch.tensor(ic, dtype=torch.float64, device="cuda")
+    d_sol = torch.zeros((B, n), dtype=torch.float64, device="cuda")
+    d_info = torch.zeros((B, 6), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    assert L.scvx_threedof_solve_dev(c.handle, B, C.c_void_p(d_ic.data_ptr()), None, C.c_void_p(d_sol.data_ptr()),
+                                     C.c_void_p(d_info.data_ptr())) == 0
+    c.synchronize()
+    raw = d_sol.cpu().numpy()
+    inf = d_info.cpu().numpy()
+    assert np.array_equal(inf[:, 0], st.astype(float)) and np.array_equal(inf[:, 1:], info)
+    assert np.array_equal(raw[:, -1], ref["nkaR"]) and np.array_equal(raw[:, :-1].reshape(B, po.K + 1, 15)[:, :, 6], ref["ma"])
+
+
 def test_first_round_solve_initial_mirror():
     from successiveconvexification_amd import first_round
     po = _flyable(K=30)
