@@ -540,6 +540,7 @@ struct scvx_batch {
     int *active = nullptr;   // 0 once a trajectory has failed (solver / non-finite): never stepped again
     int *live = nullptr;     // active and not yet converged: the trajectories scvx_solve still steps
     int device = 0;          // cached: scvx_batch_destroy must not touch a context that may already be gone
+    int nlive_hint = -1;     // trajectories scvx_solve still steps (host view, a few steps old); -1 = all: picks the conic solver's executor
     bool initialised = false;
     bool profiling = false;
     std::vector<hipEvent_t> events;  // pool, 7 per profiled step, reused across scvx_batch_get_profile calls
@@ -599,7 +600,9 @@ void launch_socp_block(scvx_batch* b, const int* mask) {
 }
 
 int enqueue_socp(scvx_batch* b, const int* mask) {
-    const int w = socp_waves(b->B);
+    // scvx_solve's tail: once few trajectories are still live the solve is latency-bound again, and the executors with
+    // several wavefronts per trajectory (dead blocks return at once) finish a step in half the time
+    const int w = socp_waves(b->nlive_hint >= 0 && b->nlive_hint < b->B ? (b->nlive_hint > 0 ? b->nlive_hint : 1) : b->B);
     if (w == 4) launch_socp_block<4>(b, mask);
     else if (w == 2) launch_socp_block<2>(b, mask);
     else
@@ -914,18 +917,21 @@ int scvx_solve(scvx_batch* b, int32_t* status, int32_t* iters, double* nu_norm, 
     hipLaunchKernelGGL(scvx::copy_flags_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, ctx->stream, B, b->active, b->live);
     SCVX_HIP(ctx, hipGetLastError());
     std::vector<int> lv(B);
-    constexpr int CHECK_EVERY = 4;
+    constexpr int CHECK_EVERY = 2;
+    b->nlive_hint = -1;
     for (int it = 1; it < ctx->prob.imax; it++) {
         rc = enqueue_step(b, b->live);
-        if (rc) return rc;
+        if (rc) { b->nlive_hint = -1; return rc; }
         if (it % CHECK_EVERY == 0 && it + 1 < ctx->prob.imax) {
             SCVX_HIP(ctx, hipMemcpyAsync(lv.data(), b->live, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
             SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            bool any = false;
-            for (int t = 0; t < B && !any; t++) any = lv[t] != 0;
-            if (!any) break;
+            int nlive = 0;
+            for (int t = 0; t < B; t++) nlive += lv[t] != 0;
+            if (nlive == 0) break;
+            b->nlive_hint = nlive;
         }
     }
+    b->nlive_hint = -1;
     if (iters) {
         SCVX_HIP(ctx, hipMemcpyAsync(iters, b->iter, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
