@@ -104,6 +104,39 @@ def test_both_socp_executors_agree(monkeypatch):
         assert np.abs(a[i] - bq[i]).max() < 2e-6
 
 
+def test_solve_problem_tail_executor_matches_single_wavefront(monkeypatch):
+    """scvx_solve picks the conic solver's executor from the live count (2 wavefronts per trajectory once <= 512 are
+    still stepped, 4 once <= 256): same trajectories, statuses and step counts as the one-wavefront form forced for the
+    whole run, on a flyable problem whose trajectories converge after different numbers of steps."""
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.defns import DescentProblem
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    from successiveconvexification_amd.montecarlo import disperse_ics
+    p = DescentProblem()
+    p.K, p.tf_guess, p.mdry, p.mwet, p.alpha, p.imax = 20, 6.0, 1.0, 2.0, 0.05, 12
+    p.rIi, p.vIi = np.array([4.0, 2.0, 0.0]), np.array([-0.5, -0.5, 0.3])
+    B = 560
+    ic = disperse_ics(p, 0, B, 99, frac=0.3)
+    res = {}
+    for waves in (None, "1"):
+        if waves is None:
+            monkeypatch.delenv("SCVX_K4_WAVES", raising=False)
+        else:
+            monkeypatch.setenv("SCVX_K4_WAVES", waves)
+        c = IntegratorCache(p, npts=4)
+        b = ScvxBatch(c, B).init(ic)
+        st, it, nu, dj = b.solve()
+        x, u, s = b.trajectory()
+        res[waves] = (st, it, x, u, s)
+        b.close(); c.close()
+    a, r = res[None], res["1"]
+    assert len(np.unique(a[1])) > 1, "the instance should finish trajectories at different steps"
+    same = (a[0] == r[0]) & (a[1] == r[1])
+    assert same.mean() > 0.99     # a trajectory sitting on a convergence threshold may take one step more on one side
+    assert np.abs(a[2][same] - r[2][same]).max() < 1e-5 and np.abs(a[3][same] - r[3][same]).max() < 1e-5
+    assert np.abs(a[4][same] - r[4][same]).max() < 1e-5
+
+
 def test_solve_step_matches_oracle_scvx_two_iterations():
     """Two full solve_step calls against oracle.scvx (IPM + exact discretisation) on one trajectory."""
     from oracle import model, scvx as oscvx
