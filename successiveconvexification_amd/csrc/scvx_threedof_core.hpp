@@ -313,6 +313,19 @@ struct Solver {
     SCVX_HD double bq(int pos) const { return pos < 6 ? icv[pos] : tt.q[pos]; }
 
     template <class F> SCVX_HD void each(int n, F&& f) { for (int i = ex.lane(); i < n; i += ex.nlanes()) f(i); }
+    // rows i = lane, lane + nlanes, ... in blocks of U per lane: all loads of a block (ld, any value type) before its stores
+    // (st).  A plain loop serialises the rows -- the store of row i needs its loads back before row i + 1 may issue its own,
+    // and a row is a chain of two or three dependent loads (index, then value) -- so a pass took U times a memory latency.
+    template <int U, class LD, class ST_> SCVX_HD void each2(int n, LD&& ld, ST_&& st) {
+        const int nl = ex.nlanes();
+        for (int i0 = ex.lane(); i0 < n; i0 += U * nl) {
+            decltype(ld(0)) t[U];
+            SCVX_UNROLL
+            for (int k = 0; k < U; k++) { const int i = i0 + k * nl; t[k] = ld(i < n ? i : n - 1); }
+            SCVX_UNROLL
+            for (int k = 0; k < U; k++) { const int i = i0 + k * nl; if (i < n) st(i, t[k]); }
+        }
+    }
     template <class F> SCVX_HD double sum(int n, F&& f) {
         double a = 0;
         for (int i = ex.lane(); i < n; i += ex.nlanes()) a += f(i);
@@ -577,7 +590,7 @@ struct Solver {
             cone_W(rg, wv + off, wb[c], t1 + off, t1 + off, true);
         });
         ex.sync();
-        each(T.nb, [&](int p) { xs[p] = bu[p] - Et_at(t1, p); });
+        each2<4>(T.nb, [&](int p) { return bu[p] - Et_at(t1, p); }, [&](int p, double v) { xs[p] = v; });
         const double rnu = bu[T.nb] - Et_at(t1, T.nb);
         ex.sync_lds();
         TD_TE(t4_, 4);
@@ -593,7 +606,7 @@ struct Solver {
         const double nu = (rnu * m11 + m01 * wk) / det;
         const double tt = (-m00 * wk - m01 * rnu) / det;
         cgptr y = w + L.y;
-        each(T.nb, [&](int p) { du[p] = xs[p] - y[p] * tt; });
+        each2<4>(T.nb, [&](int p) { return xs[p] - y[p] * tt; }, [&](int p, double v) { du[p] = v; });
         if (ex.lane() == 0) du[T.nb] = nu;
         ex.sync();
         // dz = -W^-2 (E du + bz), cone by cone
@@ -615,7 +628,7 @@ struct Solver {
         for (int pass = 0; pass < passes; pass++) {
             // r1 = bu - ([0 A'; A 0] du - E' dz),  r3 = bz + E du + W^2 dz
             TD_TS(t7_);
-            each(T.nb + 1, [&](int p) { r1[p] = bu[p] - A_row(du, p) + Et_at(dz, p); });
+            each2<4>(T.nb + 1, [&](int p) { return bu[p] - A_row(du, p) + Et_at(dz, p); }, [&](int p, double v) { r1[p] = v; });
             {
                 cgptr wv = w + L.wv;
                 cgptr wb = w + L.wb;
@@ -629,8 +642,8 @@ struct Solver {
             ex.sync();
             TD_TE(t7_, 7);
             condensed(r1, r3, ddu, ddz);
-            each(T.nb + 1, [&](int p) { du[p] += ddu[p]; });
-            each(T.m, [&](int r) { dz[r] += ddz[r]; });
+            each2<4>(T.nb + 1, [&](int p) { return du[p] + ddu[p]; }, [&](int p, double v) { du[p] = v; });
+            each2<4>(T.m, [&](int r) { return dz[r] + ddz[r]; }, [&](int r, double v) { dz[r] = v; });
             ex.sync();
         }
     }
@@ -716,22 +729,31 @@ struct Solver {
             TD_TS(t8_);
             // residuals: ru = [c + A'y - E'z at variables; A x - b at equalities], rz = s - e(x)
             double pobj = 0, dobj = 0, nx = 0, ny = 0;
-            for (int p = ex.lane(); p <= nb; p += ex.nlanes()) {
+            struct Two { double r, o, w; };
+            each2<4>(nb + 1, [&](int p) {
                 const bool var = p == nb || is_var(N, p);
                 const double qp = var ? tt.q[p] : bq(p);
-                if (var) {
-                    const double r = qp + A_row(u, p) - Et_at(z, p);
-                    ru[p] = r; nx += r * r; pobj += qp * u[p];
-                } else {
-                    const double r = A_row(u, p) - qp;
-                    ru[p] = r; ny += r * r; dobj -= qp * u[p];
-                }
-            }
+                const double a = A_row(u, p);
+                Two t;
+                t.r = var ? qp + a - Et_at(z, p) : a - qp;
+                t.o = qp * u[p];
+                t.w = 0.0;
+                return t;
+            }, [&](int p, Two t) {
+                ru[p] = t.r;
+                if (p == nb || is_var(N, p)) { nx += t.r * t.r; pobj += t.o; }
+                else { ny += t.r * t.r; dobj -= t.o; }
+            });
             double gap = 0, nz = 0;
-            for (int r = ex.lane(); r < m; r += ex.nlanes()) {
-                const double rr = s[r] - (E_row(u, r) + tt.e_h[r]);
-                rz[r] = rr; nz += rr * rr; gap += s[r] * z[r]; dobj -= tt.e_h[r] * z[r];
-            }
+            each2<4>(m, [&](int r) {
+                Two t;
+                t.w = s[r];
+                t.r = t.w - (E_row(u, r) + tt.e_h[r]);
+                t.o = z[r];
+                return t;
+            }, [&](int r, Two t) {
+                rz[r] = t.r; nz += t.r * t.r; gap += t.w * t.o; dobj -= tt.e_h[r] * t.o;
+            });
             pobj = ex.sum(pobj); dobj = ex.sum(dobj); nx = ex.sum(nx); ny = ex.sum(ny); nz = ex.sum(nz); gap = ex.sum(gap);
             ex.sync();
             const double pres = fmax(sqrt(ny) / nrm_b, sqrt(nz) / T.nrm_h), dres = sqrt(nx) / T.nrm_c;
@@ -754,8 +776,8 @@ struct Solver {
             const double mu = gap / degree;
 
             // predictor: ds_rhs = -lam o lam, so W (lam \ ds_rhs) = -W lam = -s:  bz = -rz + s
-            each(nb + 1, [&](int p) { bu[p] = -ru[p]; });
-            each(m, [&](int r) { bz[r] = -rz[r] + s[r]; });
+            each2<4>(nb + 1, [&](int p) { return -ru[p]; }, [&](int p, double v) { bu[p] = v; });
+            each2<4>(m, [&](int r) { return -rz[r] + s[r]; }, [&](int r, double v) { bz[r] = v; });
             ex.sync();
             kkt_solve(bu, bz, du, dz, TD_PRED_REFINE);
             TD_TS(t9_);
@@ -773,7 +795,7 @@ struct Solver {
                 cone_W(rg, wv_ + off, wb_[c], t1 + off, t1 + off, false);
                 rg.rows(0, [&](int k) { return -rz[off + k] - t1[off + k]; }, [&](int k, double t) { bz[off + k] = t; });
             });
-            each(nb + 1, [&](int p) { bu[p] = -ru[p]; });
+            each2<4>(nb + 1, [&](int p) { return -ru[p]; }, [&](int p, double v) { bu[p] = v; });
             ex.sync();
             TD_TE(t9_, 9);
             kkt_solve(bu, bz, du, dz, fmax(pres, relgap) < TD_REFINE_FROM ? T.refine : 0);
@@ -782,8 +804,9 @@ struct Solver {
             // the numerical floor: an iterate that is a certified near-optimum (the band the oracle's solver, oracle/ipm.py,
             // and Mosek / ECOS at their default tolerances report as OPTIMAL) is accepted when the KKT system breaks down
             if (!(alpha >= 1e-8)) { R.status = near ? TD_OPTIMAL : (alpha == alpha ? TD_STALLED : TD_NONFINITE); break; }
-            each(nb + 1, [&](int p) { u[p] += alpha * du[p]; });
-            each(m, [&](int r) { z[r] += alpha * dz[r]; s[r] += alpha * ds[r]; });
+            each2<4>(nb + 1, [&](int p) { return u[p] + alpha * du[p]; }, [&](int p, double v) { u[p] = v; });
+            each2<4>(m, [&](int r) { return z[r] + alpha * dz[r]; }, [&](int r, double v) { z[r] = v; });
+            each2<4>(m, [&](int r) { return s[r] + alpha * ds[r]; }, [&](int r, double v) { s[r] = v; });
             ex.sync();
             TD_TE(t10_, 10);
         }
