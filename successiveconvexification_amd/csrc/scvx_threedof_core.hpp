@@ -91,6 +91,7 @@ struct Tables {
     int N, nb, m, ncone;      // nodes - 1, band size (nkaR sits at position nb), cone rows, cones
     int max_iter, refine;
     double tol, delta;
+    double itg, cth;          // 1 / tan(gammaGs), cos(thetaMax): the two non-unit coefficients of the cone rows
     double nrm_c, nrm_h, b2_rest, mwet;   // max(1,|c|), max(1,|h|), sum of b^2 without the six initial r, v rows
     const int* a_col;     // [nb][AW]      symmetric equality part, -1 = empty
     const double* a_val;  // [nb][AW]
@@ -251,8 +252,8 @@ SCVX_HD void cone_div(R rg, cgptr lam, cgptr d, gptr o) {
     if (rg.q == 1) { o[0] = d[0] / lam[0]; return; }
     const double l0 = rg.head(lam), d0 = rg.head(d);
     const double l1d1 = rg.sum1([&](int k) { return lam[k] * d[k]; }), l1l1 = rg.sum1([&](int k) { return lam[k] * lam[k]; });
-    const double det = l0 * l0 - l1l1;
-    const double x0 = (l0 * d0 - l1d1) / det;
+    const double n1 = sqrt(l1l1);
+    const double x0 = (l0 * d0 - l1d1) / (fmax(l0 - n1, 2.3e-16 * l0) * (l0 + n1));   // lam on the boundary to rounding: kept inside
     const double il0 = 1.0 / l0;
     rg.rows(1, [&](int k) { return (d[k] - x0 * lam[k]) * il0; }, [&](int k, double t) { o[k] = t; });
     if (rg.owns_head()) o[0] = x0;
@@ -275,6 +276,146 @@ SCVX_HD double cone_shift(R rg, cgptr x, double& n2) {
     const double n1 = rg.sum1([&](int k) { return x[k] * x[k]; });
     n2 = x0 * x0 + n1;
     return sqrt(n1) - x0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The 15 cone rows of ONE NODE in registers -- [4 linear | SOC3 rows 4..6 | SOC4 rows 7..10 | SOC4 rows 11..14] -- with
+// every index a compile-time constant: a pass loads a node's rows in one round trip, does the whole fused sequence
+// (E du, W^-1 W^-1, Jordan products ...) in registers and stores once.  (Walking the node's cones one after the other
+// through memory costs a dependent load round per cone and per step of the sequence.)
+// ------------------------------------------------------------------------------------------------------------------
+struct NodeScal { double v[NR]; double b[3]; };   // NT scaling of a node: v rows (d for the linear rows), beta of the 3 cones
+
+SCVX_HD void nd_load(cgptr p, double (&x)[NR]) { SCVX_UNROLL for (int r = 0; r < NR; r++) x[r] = p[r]; }
+SCVX_HD void nd_store(gptr p, const double (&x)[NR]) { SCVX_UNROLL for (int r = 0; r < NR; r++) p[r] = x[r]; }
+// rows of E for one node from its 15 variables d (r v ma T ga kaR ar): the row table of build_tables, hard-wired
+// (build_tables checks that the two agree)
+SCVX_HD void nd_E(const double (&d)[NV], double itg, double cth, double (&e)[NR]) {
+    e[0] = d[6]; e[1] = d[10]; e[2] = -d[10]; e[3] = d[7] - cth * d[10];
+    e[4] = d[0] * itg; e[5] = d[1]; e[6] = d[2];
+    e[7] = d[10]; e[8] = d[7]; e[9] = d[8]; e[10] = d[9];
+    e[11] = d[11]; e[12] = d[12]; e[13] = d[13]; e[14] = d[14];
+}
+template <int O, int Q>
+SCVX_HD void rg_W(const double (&v)[NR], double beta, const double (&x)[NR], double (&y)[NR], bool inverse) {
+    const double sg = inverse ? -1.0 : 1.0;
+    double t = 0;
+    SCVX_UNROLL
+    for (int k = 1; k < Q; k++) t += v[O + k] * x[O + k];
+    const double x0 = x[O];
+    const double vx = v[O] * x0 + sg * t;
+    const double sc = inverse ? 1.0 / beta : beta;
+    const double tw = 2.0 * sg * vx;
+    SCVX_UNROLL
+    for (int k = 1; k < Q; k++) y[O + k] = (tw * v[O + k] + x[O + k]) * sc;
+    y[O] = (2.0 * vx * v[O] - x0) * sc;
+}
+SCVX_HD void nd_W(const NodeScal& S, const double (&x)[NR], double (&y)[NR], bool inverse) {   // y may be x
+    SCVX_UNROLL
+    for (int r = 0; r < 4; r++) y[r] = inverse ? x[r] / S.v[r] : x[r] * S.v[r];
+    rg_W<4, 3>(S.v, S.b[0], x, y, inverse);
+    rg_W<7, 4>(S.v, S.b[1], x, y, inverse);
+    rg_W<11, 4>(S.v, S.b[2], x, y, inverse);
+}
+template <int O, int Q>
+SCVX_HD void rg_nt(const double (&s)[NR], const double (&z)[NR], double (&v)[NR], double& beta, double (&lam)[NR]) {
+    double s1 = 0, z1 = 0, sz = 0;
+    SCVX_UNROLL
+    for (int k = 1; k < Q; k++) { s1 += s[O + k] * s[O + k]; z1 += z[O + k] * z[O + k]; sz += s[O + k] * z[O + k]; }
+    const double s0 = s[O], z0 = z[O];
+    const double ns = sqrt(s1), nz = sqrt(z1);
+    const double sj = sqrt(fmax(s0 - ns, 2.3e-16 * s0) * (s0 + ns)), zj = sqrt(fmax(z0 - nz, 2.3e-16 * z0) * (z0 + nz));
+    const double isj = 1.0 / sj, izj = 1.0 / zj;
+    const double gam = sqrt(0.5 * (1.0 + (s0 * z0 + sz) * isj * izj));
+    const double ig = 0.5 / gam;
+    const double wb0 = (s0 * isj + z0 * izj) * ig;
+    const double den = 1.0 / sqrt(2.0 * (wb0 + 1.0));
+    const double v0 = (wb0 + 1.0) * den;
+    const double c1 = ig * den;
+    beta = sqrt(sj * izj);
+    const double vz = v0 * z0 + c1 * (sz * isj - z1 * izj);
+    SCVX_UNROLL
+    for (int k = 1; k < Q; k++) {
+        const double t = (s[O + k] * isj - z[O + k] * izj) * c1;
+        v[O + k] = t;
+        lam[O + k] = beta * (2.0 * vz * t + z[O + k]);
+    }
+    v[O] = v0;
+    lam[O] = beta * (2.0 * vz * v0 - z0);
+}
+SCVX_HD void nd_nt(const double (&s)[NR], const double (&z)[NR], NodeScal& S, double (&lam)[NR]) {
+    SCVX_UNROLL
+    for (int r = 0; r < 4; r++) { S.v[r] = sqrt(s[r] / z[r]); lam[r] = sqrt(s[r] * z[r]); }
+    rg_nt<4, 3>(s, z, S.v, S.b[0], lam);
+    rg_nt<7, 4>(s, z, S.v, S.b[1], lam);
+    rg_nt<11, 4>(s, z, S.v, S.b[2], lam);
+}
+template <int O, int Q>
+SCVX_HD void rg_prod(const double (&a)[NR], const double (&b)[NR], double (&o)[NR]) {   // o may be a or b
+    double dot = 0;
+    SCVX_UNROLL
+    for (int k = 0; k < Q; k++) dot += a[O + k] * b[O + k];
+    const double a0 = a[O], b0 = b[O];
+    SCVX_UNROLL
+    for (int k = 1; k < Q; k++) o[O + k] = a0 * b[O + k] + b0 * a[O + k];
+    o[O] = dot;
+}
+SCVX_HD void nd_prod(const double (&a)[NR], const double (&b)[NR], double (&o)[NR]) {
+    SCVX_UNROLL
+    for (int r = 0; r < 4; r++) o[r] = a[r] * b[r];
+    rg_prod<4, 3>(a, b, o); rg_prod<7, 4>(a, b, o); rg_prod<11, 4>(a, b, o);
+}
+template <int O, int Q>
+SCVX_HD void rg_div(const double (&lam)[NR], const double (&d)[NR], double (&o)[NR]) {   // o may be d
+    double l1d1 = 0, l1l1 = 0;
+    SCVX_UNROLL
+    for (int k = 1; k < Q; k++) { l1d1 += lam[O + k] * d[O + k]; l1l1 += lam[O + k] * lam[O + k]; }
+    const double l0 = lam[O];
+    const double n1 = sqrt(l1l1);
+    const double x0 = (l0 * d[O] - l1d1) / (fmax(l0 - n1, 2.3e-16 * l0) * (l0 + n1));   // lam on the boundary to rounding: kept inside
+    const double il0 = 1.0 / l0;
+    SCVX_UNROLL
+    for (int k = 1; k < Q; k++) o[O + k] = (d[O + k] - x0 * lam[O + k]) * il0;
+    o[O] = x0;
+}
+SCVX_HD void nd_div(const double (&lam)[NR], const double (&d)[NR], double (&o)[NR]) {
+    SCVX_UNROLL
+    for (int r = 0; r < 4; r++) o[r] = d[r] / lam[r];
+    rg_div<4, 3>(lam, d, o); rg_div<7, 4>(lam, d, o); rg_div<11, 4>(lam, d, o);
+}
+template <int O, int Q>
+SCVX_HD double rg_maxstep(const double (&lam)[NR], const double (&d)[NR]) {
+    double ll = lam[O] * lam[O], ld = lam[O] * d[O], dd = d[O] * d[O];
+    SCVX_UNROLL
+    for (int k = 1; k < Q; k++) { ll -= lam[O + k] * lam[O + k]; ld -= lam[O + k] * d[O + k]; dd -= d[O + k] * d[O + k]; }
+    return ipm::soc_maxstep_parts(lam[O], d[O], ll, ld, dd);
+}
+SCVX_HD double nd_maxstep(const double (&lam)[NR], const double (&d)[NR]) {
+    double a = INFINITY;
+    SCVX_UNROLL
+    for (int r = 0; r < 4; r++) { const double ar = d[r] < 0.0 ? -lam[r] / d[r] : INFINITY; a = ar < a ? ar : a; }
+    const double a1 = rg_maxstep<4, 3>(lam, d), a2 = rg_maxstep<7, 4>(lam, d), a3 = rg_maxstep<11, 4>(lam, d);
+    a = a1 < a ? a1 : a; a = a2 < a ? a2 : a; a = a3 < a ? a3 : a;
+    return a;
+}
+template <int O, int Q>
+SCVX_HD double rg_shift(const double (&x)[NR]) {
+    double n1 = 0;
+    SCVX_UNROLL
+    for (int k = 1; k < Q; k++) n1 += x[O + k] * x[O + k];
+    return sqrt(n1) - x[O];
+}
+// smallest t with x + t e in the node's cones; n2 = |x|^2
+SCVX_HD double nd_shift(const double (&x)[NR], double& n2) {
+    double t = -INFINITY;
+    n2 = 0;
+    SCVX_UNROLL
+    for (int r = 0; r < NR; r++) n2 += x[r] * x[r];
+    SCVX_UNROLL
+    for (int r = 0; r < 4; r++) t = -x[r] > t ? -x[r] : t;
+    const double t1 = rg_shift<4, 3>(x), t2 = rg_shift<7, 4>(x), t3 = rg_shift<11, 4>(x);
+    t = t1 > t ? t1 : t; t = t2 > t ? t2 : t; t = t3 > t ? t3 : t;
+    return t;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -342,6 +483,26 @@ struct Solver {
         f(nsmall, NR * (T.N + 1), Coop<Ex>{ex, T.N + 2});
     }
 
+    // node-level pieces of a cone pass: f(i) for the nodes (one lane each, rows in registers), g(c, off, rg) for the long cone
+    template <int ID, class F, class G> SCVX_HD void cone_pass(F&& f, G&& g) {
+#if defined(TD_GENERIC_MASK)
+        if ((TD_GENERIC_MASK >> ID) & 1) { all_cones(g); return; }   // diagnostic: the memory-walking form of pass ID
+#endif
+        for (int i = ex.lane(); i <= T.N; i += ex.nlanes()) f(i);
+        g(T.ncone - 1, NR * (T.N + 1), Coop<Ex>{ex, T.N + 2});
+    }
+    SCVX_HD void scal_load(int i, NodeScal& S) const {
+        cgptr wv = w + L.wv + NR * i;
+        cgptr wb = w + L.wb + 7 * i + 4;
+        SCVX_UNROLL
+        for (int r = 0; r < NR; r++) S.v[r] = wv[r];
+        S.b[0] = wb[0]; S.b[1] = wb[1]; S.b[2] = wb[2];
+    }
+    SCVX_HD void vars_load(cgptr v, int i, double (&d)[NV]) const {
+        cgptr pv = v + pos_z(i, 0);
+        SCVX_UNROLL
+        for (int l = 0; l < NV; l++) d[l] = pv[l];
+    }
     // (E v)[r] and ([0 A'; A 0] v)[p]
     SCVX_HD double E_row(cgptr v, int r) const {
         double a = tt.e_c0[r] * v[tt.e_v0[r]];
@@ -382,7 +543,15 @@ struct Solver {
             cgptr s = w + L.s;
             cgptr z = w + L.z;
             gptr lam = w + L.lam;
-            all_cones([&](int c, int off, auto rg) {
+            cone_pass<0>([&](int i) {
+                double sr[NR], zr[NR], lr[NR];
+                NodeScal S;
+                nd_load(s + NR * i, sr); nd_load(z + NR * i, zr);
+                nd_nt(sr, zr, S, lr);
+                nd_store(wv + NR * i, S.v); nd_store(lam + NR * i, lr);
+                gptr b7 = wb + 7 * i;
+                b7[0] = 1.0; b7[1] = 1.0; b7[2] = 1.0; b7[3] = 1.0; b7[4] = S.b[0]; b7[5] = S.b[1]; b7[6] = S.b[2];
+            }, [&](int c, int off, auto rg) {
                 double beta;
                 cone_nt(rg, s + off, z + off, wv + off, beta, lam + off);
                 if (rg.owns_head()) wb[c] = beta;
@@ -585,7 +754,13 @@ struct Solver {
         TD_TS(t4_);
         cgptr wb = w + L.wb;
         // t1 = W^-2 bz: both applications by the cone's own lane, no pass boundary in between
-        all_cones([&](int c, int off, auto rg) {
+        cone_pass<1>([&](int i) {
+            NodeScal S;
+            double x[NR];
+            scal_load(i, S); nd_load(bz + NR * i, x);
+            nd_W(S, x, x, true); nd_W(S, x, x, true);
+            nd_store(t1 + NR * i, x);
+        }, [&](int c, int off, auto rg) {
             cone_W(rg, wv + off, wb[c], bz + off, t1 + off, true);
             cone_W(rg, wv + off, wb[c], t1 + off, t1 + off, true);
         });
@@ -610,7 +785,16 @@ struct Solver {
         if (ex.lane() == 0) du[T.nb] = nu;
         ex.sync();
         // dz = -W^-2 (E du + bz), cone by cone
-        all_cones([&](int c, int off, auto rg) {
+        cone_pass<2>([&](int i) {
+            NodeScal S;
+            double d[NV], e[NR], x[NR];
+            scal_load(i, S); vars_load(du, i, d); nd_load(bz + NR * i, x);
+            nd_E(d, T.itg, T.cth, e);
+            SCVX_UNROLL
+            for (int r = 0; r < NR; r++) x[r] = -(e[r] + x[r]);
+            nd_W(S, x, x, true); nd_W(S, x, x, true);
+            nd_store(dz + NR * i, x);
+        }, [&](int c, int off, auto rg) {
             rg.rows(0, [&](int k) { return -(E_row(du, off + k) + bz[off + k]); }, [&](int k, double t) { dz[off + k] = t; });
             cone_W(rg, wv + off, wb[c], dz + off, dz + off, true);
             cone_W(rg, wv + off, wb[c], dz + off, dz + off, true);
@@ -632,7 +816,16 @@ struct Solver {
             {
                 cgptr wv = w + L.wv;
                 cgptr wb = w + L.wb;
-                all_cones([&](int c, int off, auto rg) {
+                cone_pass<3>([&](int i) {
+                    NodeScal S;
+                    double d[NV], e[NR], x[NR], b[NR];
+                    scal_load(i, S); vars_load(du, i, d); nd_load(dz + NR * i, x); nd_load(bz + NR * i, b);
+                    nd_E(d, T.itg, T.cth, e);
+                    nd_W(S, x, x, false); nd_W(S, x, x, false);
+                    SCVX_UNROLL
+                    for (int r = 0; r < NR; r++) x[r] = b[r] + e[r] + x[r];
+                    nd_store(r3 + NR * i, x);
+                }, [&](int c, int off, auto rg) {
                     cone_W(rg, wv + off, wb[c], dz + off, r3 + off, false);
                     cone_W(rg, wv + off, wb[c], r3 + off, r3 + off, false);
                     rg.rows(0, [&](int k) { return bz[off + k] + E_row(du, off + k) + r3[off + k]; },
@@ -651,7 +844,12 @@ struct Solver {
     // shift x into the interior of the cone if it is not (CVXOPT initialisation)
     SCVX_HD_NI void shift_in(gptr x) {
         double t = -INFINITY, n2 = 0;
-        all_cones([&](int, int off, auto rg) {
+        cone_pass<4>([&](int i) {
+            double xr[NR], c2;
+            nd_load(x + NR * i, xr);
+            const double tc = nd_shift(xr, c2);
+            t = tc > t ? tc : t; n2 += c2;
+        }, [&](int, int off, auto rg) {
             double c2;
             const double tc = cone_shift(rg, x + off, c2);
             if (rg.owns_head()) { t = tc > t ? tc : t; n2 += c2; }
@@ -673,26 +871,73 @@ struct Solver {
         cgptr rz = w + L.rz;
         gptr ds = w + L.ds, t1 = w + L.t1, t2 = w + L.t2;
         double a = INFINITY;
-        all_cones([&](int c, int off, auto rg) {
+        cone_pass<5>([&](int i) {
+            NodeScal S;
+            double d[NV], e[NR], x[NR], y[NR], lr[NR];
+            scal_load(i, S); vars_load(du, i, d); nd_load(rz + NR * i, x); nd_load(dz + NR * i, y); nd_load(lam + NR * i, lr);
+            nd_E(d, T.itg, T.cth, e);
+            SCVX_UNROLL
+            for (int r = 0; r < NR; r++) x[r] = -x[r] + e[r];
+            nd_store(ds + NR * i, x);
+            nd_W(S, x, x, true); nd_W(S, y, y, false);
+            nd_store(t1 + NR * i, x); nd_store(t2 + NR * i, y);
+            const double a1 = nd_maxstep(lr, x), a2 = nd_maxstep(lr, y);
+            const double am = a1 < a2 ? a1 : a2;
+            a = am < a ? am : a;
+            if (!(am == am)) a = -1.0;   // non-finite: a comparison would drop it
+        }, [&](int c, int off, auto rg) {
             rg.rows(0, [&](int k) { return -rz[off + k] + E_row(du, off + k); }, [&](int k, double t) { ds[off + k] = t; });
             cone_W(rg, wv + off, wb[c], ds + off, t1 + off, true);
             cone_W(rg, wv + off, wb[c], dz + off, t2 + off, false);
             const double a1 = cone_maxstep(rg, lam + off, t1 + off), a2 = cone_maxstep(rg, lam + off, t2 + off);
             const double am = a1 < a2 ? a1 : a2;
             a = am < a ? am : a;
+            if (!(am == am)) a = -1.0;   // non-finite: a comparison would drop it
         });
         a = ex.min(a);
         ex.sync();
-        return a;
+        return a >= 0.0 ? a : 0.0;   // a non-finite direction takes no step: the caller stops
+    }
+
+    // (kept out of solve(), like every pass that holds a node's rows in registers: inlined into the kernel body next to the
+    // other passes, hipcc 7.2 produced a kernel that returned NaN after the first iteration -- either pass alone was fine)
+    // combined direction's right-hand side: ds_rhs = -lam o lam - (W^-1 ds_a) o (W dz_a) + sigma mu e;  bz = -rz - W (lam \ ds_rhs)
+    SCVX_HD_NI void corr_rhs(double sm) {
+        cgptr wv_ = w + L.wv;
+        cgptr wb_ = w + L.wb;
+        cgptr lam = w + L.lam;
+        cgptr rz = w + L.rz;
+        gptr t1 = w + L.t1, t2 = w + L.t2, bz = w + L.bz;
+        cone_pass<6>([&](int i) {
+            NodeScal S;
+            double x[NR], y[NR], lr[NR], rr[NR];
+            scal_load(i, S); nd_load(t1 + NR * i, x); nd_load(t2 + NR * i, y); nd_load(lam + NR * i, lr); nd_load(rz + NR * i, rr);
+            nd_prod(x, y, x);
+            nd_prod(lr, lr, y);
+            SCVX_UNROLL
+            for (int r = 0; r < NR; r++) x[r] = -y[r] - x[r] + ((r < 4 || r == 4 || r == 7 || r == 11) ? sm : 0.0);
+            nd_div(lr, x, x);
+            nd_W(S, x, x, false);
+            SCVX_UNROLL
+            for (int r = 0; r < NR; r++) x[r] = -rr[r] - x[r];
+            nd_store(bz + NR * i, x);
+        }, [&](int c, int off, auto rg) {
+            cone_prod(rg, t1 + off, t2 + off, t1 + off);
+            cone_prod(rg, lam + off, lam + off, t2 + off);
+            rg.rows(0, [&](int k) { return -t2[off + k] - t1[off + k] + (k == 0 ? sm : 0.0); }, [&](int k, double t) { t1[off + k] = t; });
+            cone_div(rg, lam + off, t1 + off, t1 + off);
+            cone_W(rg, wv_ + off, wb_[c], t1 + off, t1 + off, false);
+            rg.rows(0, [&](int k) { return -rz[off + k] - t1[off + k]; }, [&](int k, double t) { bz[off + k] = t; });
+        });
     }
 
     SCVX_HD Result solve(const double* ic_, double* out_) {
         cgptr ic = (cgptr)ic_;
         gptr out = (gptr)out_;
         icv = ic;
-        gptr u = w + L.u, s = w + L.s, z = w + L.z, lam = w + L.lam;
+        gptr u = w + L.u, s = w + L.s, z = w + L.z;
         gptr ru = w + L.ru, rz = w + L.rz, du = w + L.du, dz = w + L.dz, ds = w + L.ds;
-        gptr bu = w + L.bu, bz = w + L.bz, t1 = w + L.t1, t2 = w + L.t2, t3 = w + L.t3;
+        gptr bu = w + L.bu, bz = w + L.bz;
         const int nb = T.nb, m = T.m, N = T.N;
         TD_TS(tt_);
         Result R;
@@ -784,17 +1029,7 @@ struct Solver {
             double alpha = fmin(1.0, step_pass(du, dz));
             const double sigma = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
             // combined: ds_rhs = -lam o lam - (W^-1 ds_a) o (W dz_a) + sigma mu e;  bz = -rz - W (lam \ ds_rhs)
-            cgptr wv_ = w + L.wv;
-            cgptr wb_ = w + L.wb;
-            const double sm = sigma * mu;
-            all_cones([&](int c, int off, auto rg) {
-                cone_prod(rg, t1 + off, t2 + off, t1 + off);
-                cone_prod(rg, lam + off, lam + off, t2 + off);
-                rg.rows(0, [&](int k) { return -t2[off + k] - t1[off + k] + (k == 0 ? sm : 0.0); }, [&](int k, double t) { t1[off + k] = t; });
-                cone_div(rg, lam + off, t1 + off, t1 + off);
-                cone_W(rg, wv_ + off, wb_[c], t1 + off, t1 + off, false);
-                rg.rows(0, [&](int k) { return -rz[off + k] - t1[off + k]; }, [&](int k, double t) { bz[off + k] = t; });
-            });
+            corr_rhs(sigma * mu);
             each2<4>(nb + 1, [&](int p) { return -ru[p]; }, [&](int p, double v) { bu[p] = v; });
             ex.sync();
             TD_TE(t9_, 9);
@@ -815,7 +1050,6 @@ struct Solver {
         if (ex.lane() == 0) out[(N + 1) * NV] = u[nb];
         ex.sync();
         TD_TE(tt_, 15);
-        (void)t3;
         return R;
     }
 };
@@ -936,6 +1170,22 @@ inline const char* build_tables(const Problem3& P, double tol, int max_iter, int
     t.nrm_h = std::sqrt(h2) > 1.0 ? std::sqrt(h2) : 1.0;
     t.b2_rest = bb;
     t.mwet = P.mwet;
+    t.itg = 1.0 / tggs; t.cth = cth;
+    // the hard-wired node rows of nd_E must be the row table
+    for (int i = 0; i <= N; i++) {
+        double d[NV], e[NR];
+        for (int probe = 0; probe < NV; probe++) {
+            for (int l = 0; l < NV; l++) d[l] = l == probe ? 1.0 : 0.0;
+            nd_E(d, t.itg, t.cth, e);
+            for (int r = 0; r < NR; r++) {
+                const int row = NR * i + r;
+                double ref = 0;
+                if (H.e_v0[row] == pos_z(i, probe)) ref += H.e_c0[row];
+                if (H.e_v1[row] == pos_z(i, probe)) ref += H.e_c1[row];
+                if (ref != e[r]) return "node row map out of step with the row table";
+            }
+        }
+    }
     t.a_col = H.a_col.data(); t.a_val = H.a_val.data(); t.kc = H.kc.data();
     t.e_v0 = H.e_v0.data(); t.e_v1 = H.e_v1.data(); t.e_c0 = H.e_c0.data(); t.e_c1 = H.e_c1.data(); t.e_h = H.e_h.data();
     t.t_row = H.t_row.data(); t.t_coef = H.t_coef.data(); t.q = H.q.data();
