@@ -173,7 +173,7 @@ int32_t scvx_threedof_record_doubles(int K);
 /* ic [B][6] host = per-trajectory (rIi, vIi), NULL = the problem's own; opts NULL = defaults.  Outputs (host):
  * sol [B][record_doubles]; status [B] (0 optimal: residuals and relative gap below tol -- or, when the KKT system breaks
  * down at the numerical floor, below 10 tol / 100 tol, the band the oracle's solver reports as optimal too; 1 iteration
- * cap, 2 stalled, 3 non-finite, 5 infeasible: the primal residual stopped falling while the gap closed); info [B][5] = iterations, objective, gap, primal and dual residual
+ * cap, 2 stalled, 3 non-finite, 4 almost optimal: breakdown with residuals and relative gap below 1e-6, 5 infeasible: the primal residual stopped falling while the gap closed); info [B][5] = iterations, objective, gap, primal and dual residual
  * (status and info may be NULL). */
 int scvx_threedof_solve(scvx_ctx *ctx, int B, const double *ic, const scvx_threedof_opts *opts, double *sol,
                         int32_t *status, double *info);

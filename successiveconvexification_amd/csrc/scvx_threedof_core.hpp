@@ -85,7 +85,7 @@ constexpr int LPAD = 1024;   // zero padding (doubles) before and after L and th
 constexpr int NSLOT = BS + ST; // LDS window of the factorisation: the BS live columns + the ST that become live during a block
 
 // status codes of one solve (the K4 solver's, scvx.h)
-enum { TD_OPTIMAL = 0, TD_ITER_CAP = 1, TD_STALLED = 2, TD_NONFINITE = 3, TD_INFEASIBLE = 5 };
+enum { TD_OPTIMAL = 0, TD_ITER_CAP = 1, TD_STALLED = 2, TD_NONFINITE = 3, TD_ALMOST = 4, TD_INFEASIBLE = 5 };
 
 struct Tables {
     int N, nb, m, ncone;      // nodes - 1, band size (nkaR sits at position nb), cone rows, cones
@@ -418,6 +418,44 @@ SCVX_HD double nd_shift(const double (&x)[NR], double& n2) {
     return t;
 }
 
+// W^-2 entry (a, b) of the cone at rows O..O+Q-1:  beta^-2 (2 wh wh' - J),  wh = (2 v0^2 - 1, -2 v0 v_tail)
+template <int O>
+SCVX_HD double rg_w2(const double (&v)[NR], double b2, int a, int b) {
+    const double v0 = v[O];
+    const double wa = a == 0 ? 2.0 * v0 * v0 - 1.0 : -2.0 * v0 * v[O + a];
+    const double wb = b == 0 ? 2.0 * v0 * v0 - 1.0 : -2.0 * v0 * v[O + b];
+    return b2 * (2.0 * wa * wb - (a == b ? (a == 0 ? 1.0 : -1.0) : 0.0));
+}
+// The structural non-zeros (lower triangle) of a node's block of H = E' W^-2 E, straight from the scaling in registers:
+// r (3x3, glideslope cone), ma, (T, ga) (thrust cone + the three linear rows on ga and T1), (kaR, ar).  The long cone's
+// -J part on kaR is added once its beta is known.  The rest of the 15 x 15 block is zero and is never written.
+SCVX_HD void nd_H(const NodeScal& S, double itg, double cth, gptr H) {
+    const double c3[3] = {itg, 1.0, 1.0};
+    const double b20 = 1.0 / (S.b[0] * S.b[0]), b21 = 1.0 / (S.b[1] * S.b[1]), b22 = 1.0 / (S.b[2] * S.b[2]);
+    SCVX_UNROLL
+    for (int a = 0; a < 3; a++)
+        SCVX_UNROLL
+        for (int b = 0; b <= a; b++) H[a * NV + b] = c3[a] * c3[b] * rg_w2<4>(S.v, b20, a, b);
+    H[6 * NV + 6] = 1.0 / (S.v[0] * S.v[0]);
+    const double w1 = 1.0 / (S.v[1] * S.v[1]), w2 = 1.0 / (S.v[2] * S.v[2]), w3 = 1.0 / (S.v[3] * S.v[3]);
+    // thrust cone rows 7..10 <-> variables (ga = 10, T = 7, 8, 9)
+    SCVX_UNROLL
+    for (int a = 0; a < 4; a++)
+        SCVX_UNROLL
+        for (int b = 0; b <= a; b++) {
+            const int va = a == 0 ? 10 : 6 + a, vb = b == 0 ? 10 : 6 + b;
+            double val = rg_w2<7>(S.v, b21, a, b);
+            if (a == 0 && b == 0) val += w1 + w2 + cth * cth * w3;   // Tmin <= ga, ga <= Tmax, ga cos(thetaMax) <= T1
+            if (a == 1 && b == 0) val += -cth * w3;
+            if (a == 1 && b == 1) val += w3;
+            H[(va > vb ? va : vb) * NV + (va > vb ? vb : va)] = val;
+        }
+    SCVX_UNROLL
+    for (int a = 0; a < 4; a++)
+        SCVX_UNROLL
+        for (int b = 0; b <= a; b++) H[(11 + a) * NV + 11 + b] = rg_w2<11>(S.v, b22, a, b);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // the solver: Ex provides lane(), nlanes(), sync(), sync_lds(), sum(), min(), fast() (scratch of fast_doubles(N))
 // ------------------------------------------------------------------------------------------------------------------
@@ -433,6 +471,7 @@ struct Solver {
     liptr ptab;       // (a << 8 | b) of the trailing-update entries, 1 <= b <= a <= BW
     cgptr icv;           // initial position and velocity: the b entries of band rows 0..5
     double beta_big, w0_big, qY;
+    double xreg = 0.0;   // extra static regularisation of the current factorisation (0 unless a factorisation had to be retried)
     struct { cgiptr a_col, e_v0, e_v1, t_row; cgptr a_val, kc, e_c0, e_c1, e_h, t_coef, q; } tt;   // T's tables, typed
 #if defined(SCVX_TD_PROF)
     double prof[16] = {0};   // section cycles (diagnostic builds): tools/prof_threedof.py
@@ -535,10 +574,18 @@ struct Solver {
         TD_TS(t0_);
         gptr wv = w + L.wv;
         gptr wb = w + L.wb;
+        gptr hd = w + L.hd;
         if (identity) {
             each(T.m, [&](int r) { wv[r] = 0.0; });
             ex.sync();
             all_cones([&](int c, int off, auto rg) { if (rg.owns_head()) { wv[off] = 1.0; wb[c] = 1.0; } });
+            each(T.N + 1, [&](int i) {
+                NodeScal S;
+                SCVX_UNROLL
+                for (int r = 0; r < NR; r++) S.v[r] = (r < 5 || r == 7 || r == 11) ? 1.0 : 0.0;
+                S.b[0] = 1.0; S.b[1] = 1.0; S.b[2] = 1.0;
+                nd_H(S, T.itg, T.cth, hd + (size_t)i * NV * NV);
+            });
         } else {
             cgptr s = w + L.s;
             cgptr z = w + L.z;
@@ -551,6 +598,7 @@ struct Solver {
                 nd_store(wv + NR * i, S.v); nd_store(lam + NR * i, lr);
                 gptr b7 = wb + 7 * i;
                 b7[0] = 1.0; b7[1] = 1.0; b7[2] = 1.0; b7[3] = 1.0; b7[4] = S.b[0]; b7[5] = S.b[1]; b7[6] = S.b[2];
+                nd_H(S, T.itg, T.cth, hd + (size_t)i * NV * NV);
             }, [&](int c, int off, auto rg) {
                 double beta;
                 cone_nt(rg, s + off, z + off, wv + off, beta, lam + off);
@@ -565,48 +613,7 @@ struct Solver {
         const double v0 = wv[bo];
         w0_big = 2.0 * v0 * v0 - 1.0;
         const double ib2 = 1.0 / (beta_big * beta_big);
-        gptr hd = w + L.hd;
-        // one lane per node: its 7 cones in turn (they share entries)
-        each(T.N + 1, [&](int i) {
-            gptr H = hd + (size_t)i * NV * NV;
-            for (int k = 0; k < NV * NV; k++) H[k] = 0.0;
-            for (int cc = 0; cc < 7; cc++) {
-                int off, q;
-                cone_of(T.N, 7 * i + cc, off, q);
-                const double b2 = 1.0 / (wb[7 * i + cc] * wb[7 * i + cc]);
-                const double vh = wv[off];
-                for (int a = 0; a < q; a++) {
-                    for (int b = 0; b <= a; b++) {
-                        double w2;
-                        if (q == 1) w2 = 1.0 / (vh * vh);
-                        else {
-                            // W^-2 = beta^-2 (2 wh wh' - J), wh = (2 v0^2 - 1, -2 v0 v_tail)
-                            const double wa = a == 0 ? 2.0 * vh * vh - 1.0 : -2.0 * vh * wv[off + a];
-                            const double wbb = b == 0 ? 2.0 * vh * vh - 1.0 : -2.0 * vh * wv[off + b];
-                            w2 = b2 * (2.0 * wa * wbb - (a == b ? (a == 0 ? 1.0 : -1.0) : 0.0));
-                        }
-                        // entries of rows a and b
-                        const int ra = off + a, rb = off + b;
-                        for (int ea = 0; ea < 2; ea++) {
-                            const int va = ea == 0 ? tt.e_v0[ra] : tt.e_v1[ra];
-                            if (va < 0) continue;
-                            const double ca = ea == 0 ? tt.e_c0[ra] : tt.e_c1[ra];
-                            const int la = (va - 7) % NP;
-                            for (int eb = 0; eb < 2; eb++) {
-                                const int vb = eb == 0 ? tt.e_v0[rb] : tt.e_v1[rb];
-                                if (vb < 0) continue;
-                                const double cb = eb == 0 ? tt.e_c0[rb] : tt.e_c1[rb];
-                                const int lb_ = (vb - 7) % NP;
-                                const double val = ca * w2 * cb;
-                                H[la * NV + lb_] += val;
-                                if (a != b) H[lb_ * NV + la] += val;
-                            }
-                        }
-                    }
-                }
-            }
-            H[11 * NV + 11] += ib2;   // the -J part of the long cone on kaR_i
-        });
+        each(T.N + 1, [&](int i) { hd[(size_t)i * NV * NV + 11 * NV + 11] += ib2; });   // the -J part of the long cone on kaR_i (same lane as nd_H)
         ex.sync();
         TD_TE(t1_, 1);
     }
@@ -614,11 +621,13 @@ struct Solver {
     // ---- banded LDL' of [H + delta I, A'; A, -delta I] without the border; L and 1/d to HBM ----
     // entry (c + d, c) of the band matrix without the border: constant part + the node block of H.  Branch-free: kc is
     // zero-padded past nb, positions outside a node block read the zero entry behind the H blocks.
-    static SCVX_HD double kcol(cgptr __restrict__ kc, cgptr __restrict__ hd, int N, int c, int d) {
+    static SCVX_HD double kcol(cgptr __restrict__ kc, cgptr __restrict__ hd, int N, int c, int d, double xreg) {
         const int pt = c - 7, i = pt / NP, l = pt - NP * i;
         const bool blk = pt >= 0 && i <= N && l + d < NV;   // l + d < NV implies l < NV: a variable column
         const int hz = (N + 1) * NV * NV;
-        return kc[(size_t)c * BS + d] + hd[blk ? i * NV * NV + (l + d) * NV + l : hz];
+        // xreg: extra regularisation of a retried factorisation, +xreg on variable pivots, -xreg on equality pivots
+        const bool var = pt >= 0 && i <= N && l < NV;
+        return kc[(size_t)c * BS + d] + hd[blk ? i * NV * NV + (l + d) * NV + l : hz] + (d == 0 ? (var ? xreg : -xreg) : 0.0);
     }
     // L by columns (lb[j][d] = L[j+d][j], lb[j][0] = 1/d_j) for the forward sweep and by rows (ut[r][d] = L[r][r-d]) for
     // the backward one, so both stream contiguous memory.  The window holds columns [j0, j0 + NSLOT) during the block of
@@ -632,13 +641,14 @@ struct Solver {
         lptr wn = win;
         lptr dor = dorig;
         const int N = T.N, nb = T.nb;
+        const double xr = xreg;
         const int spare = (int)(dorig + NSLOT - win);   // dorig has NSLOT + 1 entries
         const int lane = ex.lane(), nl = ex.nlanes();
         constexpr int PER = (ST * BS + Ex::kLanes - 1) / Ex::kLanes;
         constexpr int PP = (NPAIR + Ex::kLanes - 1) / Ex::kLanes;
         for (int e = lane; e < NSLOT * BS; e += nl) {
             const int c = e / BS, d = e - c * BS;
-            const double v = kcol(kc, hd, N, c, d);
+            const double v = kcol(kc, hd, N, c, d, xr);
             wn[e] = v;
             if (d == 0) dor[c] = fabs(v);
         }
@@ -652,7 +662,7 @@ struct Solver {
             SCVX_UNROLL
             for (int q = 0; q < PER; q++) {
                 const int e = lane + q * nl;
-                stage[q] = e < ST * BS ? kcol(kc, hd, N, cbase + e / BS, e % BS) : 0.0;
+                stage[q] = e < ST * BS ? kcol(kc, hd, N, cbase + e / BS, e % BS, xr) : 0.0;
             }
             const int jend = j0 + ST < nb ? j0 + ST : nb;
             for (int j = j0; j < jend; j++) {
@@ -663,7 +673,8 @@ struct Solver {
                 // the rounding level of the entry it started from (an active cone's block is rank one to working
                 // precision in the last iterations); the refinement passes absorb the perturbation
                 const double fl = 1e-15 * dor[j % NSLOT] + 1e-13;
-                if (var ? !(dj > fl) : !(dj < -fl)) { if (!(dj == dj)) ok = false; dj = var ? fl : -fl; }
+                if (!(fabs(dj) < 1e300)) ok = false;   // NaN or overflow: the caller retries with more regularisation
+                if (var ? !(dj > fl) : !(dj < -fl)) dj = var ? fl : -fl;
                 const double idj = 1.0 / dj;
                 // all reads of the trailing update, then all writes: one LDS round trip per step (a lane without a
                 // q-th entry updates the spare double behind the pivot scales)
@@ -947,7 +958,7 @@ struct Solver {
         const double nrm_b = sqrt(b2) > 1.0 ? sqrt(b2) : 1.0;
 
         // the zero entry behind the H blocks and the padding around L (read, masked, by the window fetch and the sweeps)
-        each(8, [&](int k) { (w + L.hd)[(size_t)(N + 1) * NV * NV + k] = 0.0; });
+        each((N + 1) * NV * NV + 8, [&](int k) { (w + L.hd)[k] = 0.0; });   // the H blocks' structural zeros, and the zero entry behind them
         each(LPAD, [&](int k) {
             (w + L.lb)[-1 - k] = 0.0; (w + L.lb)[(size_t)nb * BS + k] = 0.0;
             (w + L.ut)[-1 - k] = 0.0; (w + L.ut)[(size_t)nb * BS + k] = 0.0;
@@ -968,7 +979,7 @@ struct Solver {
         const int degree = T.ncone;
         double best_pres = INFINITY;
         int flat = 0;
-        bool near = false;
+        bool near = false, almost = false;
         for (int it = 1; it <= T.max_iter; it++) {
             R.iters = it;
             TD_TS(t8_);
@@ -1008,6 +1019,7 @@ struct Solver {
             SCVX_DBG("td %3d pobj %+.10e dobj %+.10e gap %.2e pres %.2e dres %.2e\n", it, pobj, dobj, gap, pres, dres);
             if (!(pres == pres) || !(dres == dres) || !(gap == gap) || !ok) { R.status = TD_NONFINITE; break; }
             near = pres < 10.0 * T.tol && dres < 10.0 * T.tol && relgap < 100.0 * T.tol;
+            almost = fmax(pres, fmax(dres, relgap)) < 1e-6;   // a breakdown here is reported as ALMOST optimal (K4's status 4), not as a failure
             if (pres < T.tol && dres < T.tol && (gap < T.tol || relgap < T.tol)) { R.status = TD_OPTIMAL; break; }
             // primal infeasibility shows as a primal residual that stops falling while complementarity and the dual
             // residual converge (the multipliers run off along a Farkas ray, dobj grows without bound)
@@ -1017,7 +1029,15 @@ struct Solver {
 
             scale(false);
             ok = factor_all();
-            if (!ok) { R.status = near ? TD_OPTIMAL : TD_NONFINITE; break; }
+            // a non-finite pivot (the matrix lost quasi-definiteness to rounding): retry with 1e-7, 1e-5 on the diagonal --
+            // the refinement passes work against the unregularised system, so the direction stays a Newton direction
+            for (int retry = 0; !ok && retry < 2; retry++) {
+                xreg = retry == 0 ? 1e-7 : 1e-5;
+                ok = factor_all();
+            }
+            const bool retried = xreg != 0.0;
+            xreg = 0.0;
+            if (!ok) { R.status = near ? TD_OPTIMAL : (almost ? TD_ALMOST : TD_NONFINITE); break; }
             const double mu = gap / degree;
 
             // predictor: ds_rhs = -lam o lam, so W (lam \ ds_rhs) = -W lam = -s:  bz = -rz + s
@@ -1033,12 +1053,12 @@ struct Solver {
             each2<4>(nb + 1, [&](int p) { return -ru[p]; }, [&](int p, double v) { bu[p] = v; });
             ex.sync();
             TD_TE(t9_, 9);
-            kkt_solve(bu, bz, du, dz, fmax(pres, relgap) < TD_REFINE_FROM ? T.refine : 0);
+            kkt_solve(bu, bz, du, dz, (retried || fmax(pres, relgap) < TD_REFINE_FROM) ? (T.refine > 1 ? T.refine : 1) + (retried ? 1 : 0) : 0);
             TD_TS(t10_);
             alpha = fmin(1.0, 0.99 * step_pass(du, dz));
             // the numerical floor: an iterate that is a certified near-optimum (the band the oracle's solver, oracle/ipm.py,
             // and Mosek / ECOS at their default tolerances report as OPTIMAL) is accepted when the KKT system breaks down
-            if (!(alpha >= 1e-8)) { R.status = near ? TD_OPTIMAL : (alpha == alpha ? TD_STALLED : TD_NONFINITE); break; }
+            if (!(alpha >= 1e-8)) { R.status = near ? TD_OPTIMAL : (almost ? TD_ALMOST : (alpha == alpha ? TD_STALLED : TD_NONFINITE)); break; }
             each2<4>(nb + 1, [&](int p) { return u[p] + alpha * du[p]; }, [&](int p, double v) { u[p] = v; });
             each2<4>(m, [&](int r) { return z[r] + alpha * dz[r]; }, [&](int r, double v) { z[r] = v; });
             each2<4>(m, [&](int r) { return s[r] + alpha * ds[r]; }, [&](int r, double v) { s[r] = v; });

@@ -43,7 +43,7 @@ def linear_initial(problem: DescentProblem, cache):
     return pts, dynamics.linearize_dynamics(pts, problem.tf_guess, 1 / (problem.K + 1), cache)
 
 
-THREEDOF_STATUS = {0: "optimal", 1: "iteration cap", 2: "stalled", 3: "non-finite", 5: "infeasible"}
+THREEDOF_STATUS = {0: "optimal", 1: "iteration cap", 2: "stalled", 3: "non-finite", 4: "almost optimal", 5: "infeasible"}
 
 
 def threedof_opts(L, tol=None, max_iter=None, refine=None, delta=None, align_thrust=None):
