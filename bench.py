@@ -400,7 +400,7 @@ def main():
                 "all_gather": gather_how,
             },
             "roofline": {
-                "kernel": "scvx::linearize_pc_kernel (K1, the discretisation kernel SURVEY 8d names)", "bound": "hbm",
+                "kernel": "scvx::linearize_pcp_kernel (K1, the discretisation kernel SURVEY 8d names; linearize_pc_kernel at npts <= 2)", "bound": "hbm",
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
