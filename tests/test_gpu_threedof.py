@@ -222,6 +222,31 @@ def test_batch_init_from_threedof_and_first_steps():
     assert np.abs(xi[0] - xo).max() < 1e-14 and np.abs(ui[1] - uo).max() < 1e-14
 
 
+def test_device_random_instances_match_twin():
+    """Random problem classes (tools/k0_fuzz.py draws 60 of them): statuses, iteration counts and objectives of device and twin."""
+    from oracle import model, port
+    from successiveconvexification_amd import first_round
+    rng = np.random.default_rng(3)
+    for n in range(8):
+        po = replace(model.DescentProblem(), K=int(rng.choice([8, 20, 30, 45])), tf_guess=float(rng.uniform(2.0, 10.0)), mdry=1.0,
+                     mwet=float(rng.uniform(1.2, 3.0)), alpha=float(rng.uniform(0.01, 0.2)), Tmax=float(rng.uniform(2.0, 8.0)),
+                     Tmin=float(rng.uniform(0.1, 0.8)), thetaMax=float(rng.choice([30.0, 60.0, 90.0])),
+                     gammaGs=float(rng.choice([10.0, 20.0, 35.0])),
+                     rIi=np.array([rng.uniform(2, 6), rng.uniform(-3, 3), rng.uniform(-1, 1)]),
+                     vIi=np.array([rng.uniform(-1.5, 0.2), rng.uniform(-1, 1), rng.uniform(-0.5, 0.5)]))
+        ic = model.disperse_ics(po, 16, 200 + n)
+        c = _cache(po)
+        sol, st, info = first_round.solve_initial_batch(c, ic)
+        tw, tst, tinfo = port.threedof(po, ic)
+        assert np.array_equal(st, tst), (n, st, tst)
+        ok = st == 0
+        assert np.all(np.isin(st, (0, 5)))
+        if ok.any():
+            assert np.abs(info[ok, 0] - tinfo[ok, 0]).max() <= 1
+            assert (np.abs(info[ok, 1] - tinfo[ok, 1]) / np.maximum(1.0, np.abs(tinfo[ok, 1]))).max() < 1e-8
+        c.close()
+
+
 def test_device_pointer_entry_point():
     """scvx_threedof_solve_dev on device arrays (another framework's tensors), enqueued on the context's stream."""
     import ctypes as C

@@ -72,3 +72,30 @@ def test_twin_reports_an_infeasible_instance():
     assert p.alpha * p.Tmin * p.tf_guess > p.mwet - p.mdry
     sol, st, info = port.threedof(p)
     assert st[0] == 5 and info[0, 3] > 1e-6
+
+
+def _random_problem(rng):
+    K = int(rng.choice([8, 20, 30]))
+    return replace(model.DescentProblem(), K=K, tf_guess=float(rng.uniform(2.0, 10.0)), mdry=1.0, mwet=float(rng.uniform(1.2, 3.0)),
+                   alpha=float(rng.uniform(0.01, 0.2)), Tmax=float(rng.uniform(2.0, 8.0)), Tmin=float(rng.uniform(0.1, 0.8)),
+                   thetaMax=float(rng.choice([30.0, 60.0, 90.0])), gammaGs=float(rng.choice([10.0, 20.0, 35.0])),
+                   rIi=np.array([rng.uniform(2, 6), rng.uniform(-3, 3), rng.uniform(-1, 1)]),
+                   vIi=np.array([rng.uniform(-1.5, 0.2), rng.uniform(-1, 1), rng.uniform(-0.5, 0.5)]))
+
+
+def test_twin_random_instances_against_the_independent_oracle():
+    """Random horizons, masses, thrust limits and cone angles: wherever the oracle's solver ends optimal the twin does, with the
+    same objective; an instance the twin calls infeasible is one the oracle cannot solve either."""
+    rng = np.random.default_rng(7)
+    n_opt = 0
+    for _ in range(10):
+        p = _random_problem(rng)
+        ref, o, _ = threedof.solve_initial(p)
+        sol, st, info = port.threedof(p)
+        if st[0] == 5:
+            assert ref.status != "optimal"
+            continue
+        assert ref.status == "optimal" and st[0] == 0, (ref.status, st, info)
+        assert abs(info[0, 1] - ref.pobj) <= 1e-7 * max(1.0, abs(ref.pobj))
+        n_opt += 1
+    assert n_opt >= 5
