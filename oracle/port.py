@@ -93,7 +93,7 @@ def scvx_steps(p: DescentProblem, ic, steps, nsub=10, nthreads=0, tol=1e-8, acce
     work = None; was_rej = np.zeros(B, np.int32)
     if warm_start:
         port_lib().scvx_port_work_doubles.restype = C.c_size_t
-        work = np.zeros((B, port_lib().scvx_port_work_doubles(C.c_int(K))))
+        work = np.zeros((B, port_lib().scvx_port_work_doubles(C.c_int(K), C.c_int(1 if getattr(p, "enforce_dp", False) else 0))))
     for s in range(steps):
         r = socp(p, x, u, e, d.astype(np.float32).astype(np.float64) if f32 else d, rk, ic, tol=tol, max_iter=max_iter,
                  refine=refine, nthreads=nthreads, accept=accept, f32=f32, work=work, warm=was_rej)

@@ -110,9 +110,10 @@ extern "C" {
 
 void scvx_port_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
-size_t scvx_port_work_doubles(int K) {
+// with_dp: the problem enforces the dynamic-pressure cone (one more cone group in the layout)
+size_t scvx_port_work_doubles(int K, int with_dp) {
     scvx::ipm::Layout L;
-    L.init(K);
+    L.init(K, with_dp != 0);
     return L.work_doubles();
 }
 
