@@ -203,6 +203,14 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+#if defined(SCVX_K1_PROF)
+// diagnostic build: per-wavefront cycles spent waiting at the stage barriers of the persistent kernel (block 0), read back by
+// scvx_debug_k1_prof: [wave][0] = cycles in barriers, [wave][1] = cycles in the kernel
+__device__ double g_k1prof[2 * 16];
+#define K1_BAR() do { const unsigned long long tb_ = __builtin_amdgcn_s_memtime(); lds_barrier(); k1wait_ += (double)(__builtin_amdgcn_s_memtime() - tb_); } while (0)
+#else
+#define K1_BAR() lds_barrier()
+#endif
 constexpr int PC_GROUP = 4;              // stages published per barrier (one RK4 substep)
 // SG (stage-granular, the default): one barrier per RK stage and the producer one STAGE ahead (2-slot ring) instead of
 // one barrier per substep and the producer one substep ahead: the pipeline fills after one stage instead of four (at
@@ -375,6 +383,10 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
     R* const tiles = SHARE ? lds : lds + RING_D;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+#if defined(SCVX_K1_PROF)
+    double k1wait_ = 0.0;
+    const unsigned long long k1t0_ = __builtin_amdgcn_s_memtime();
+#endif
     const R h = dt / R(nsub);
     const R inv_n = R(1.0) / R(nsub);
     const long ngrp = (nseg + NS - 1) / NS;
@@ -434,12 +446,12 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
                             xa[i] = fma(wacc, dx, xa[i]);
                             xt[i] = (stg < 3) ? fma(wnext, dx, xs[i]) : xa[i];
                         }
-                        if (SG) lds_barrier();   // stage 4 s + stg is published
+                        if (SG) K1_BAR();   // stage 4 s + stg is published
                     }
 #pragma unroll
                     for (int i = 0; i < 14; i++) xs[i] = xa[i];
                 }
-                if (!SG || s == nsub) lds_barrier();
+                if (!SG || s == nsub) K1_BAR();
             }
             if (nxt < ngrp) fetch(nxt);
             if (valid) {
@@ -447,10 +459,13 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
 #pragma unroll
                 for (int i = 0; i < 14; i++) ep[i] = xs[i];
             }
-            lds_barrier();  // matches the consumers' tile barrier
-            if (SHARE) lds_barrier();   // the tiles have been read out of the shared slab
+            K1_BAR();  // matches the consumers' tile barrier
+            if (SHARE) K1_BAR();   // the tiles have been read out of the shared slab
             grp = nxt;
         }
+#if defined(SCVX_K1_PROF)
+        if (blockIdx.x == 0 && lane == 0) { g_k1prof[2 * wave] = k1wait_; g_k1prof[2 * wave + 1] = (double)(__builtin_amdgcn_s_memtime() - k1t0_); }
+#endif
         return;
     }
 
@@ -479,7 +494,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
         R c[14], ca[14], ct[14];
 #pragma unroll
         for (int i = 0; i < 14; i++) { c[i] = (col == i) ? R(1.0) : R(0.0); ca[i] = c[i]; ct[i] = c[i]; }
-        lds_barrier();  // records of substep 0 are ready
+        K1_BAR();  // records of substep 0 are ready
         for (int s = 0; s < nsub; s++) {
 #pragma unroll
             for (int stg = 0; stg < 4; stg++) {
@@ -496,11 +511,11 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
                     ca[i] = fma(wacc, dc[i], ca[i]);
                     ct[i] = (stg < 3) ? fma(wnext, dc[i], c[i]) : ca[i];
                 }
-                if (SG) lds_barrier();   // this slot is free again / the next stage is published
+                if (SG) K1_BAR();   // this slot is free again / the next stage is published
             }
 #pragma unroll
             for (int i = 0; i < 14; i++) c[i] = ca[i];
-            if (!SG) lds_barrier();
+            if (!SG) K1_BAR();
         }
         if (nxt < ngrp) nsig = sigma_of(nxt);
         // ---- epilogue: columns into this wavefront's LDS tile -> coalesced 16-byte stores ----
@@ -517,7 +532,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
                 else { cc[1 + j] = sig * dt; cc[4 + j] = R(1.0); }
             }
         }
-        lds_barrier();
+        K1_BAR();
         const long seg0 = seg_base + (long)cw * SPW;
         if (seg0 < nseg) {
             const long rem = nseg - seg0;
@@ -531,9 +546,12 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
                 if (e < n2) out[e] = src[e];
             }
         }
-        if (SHARE) lds_barrier();
+        if (SHARE) K1_BAR();
         grp = nxt;
     }
+#if defined(SCVX_K1_PROF)
+    if (blockIdx.x == 0 && lane == 0) { g_k1prof[2 * wave] = k1wait_; g_k1prof[2 * wave + 1] = (double)(__builtin_amdgcn_s_memtime() - k1t0_); }
+#endif
 }
 
 template <bool AERO, typename R>
@@ -674,5 +692,12 @@ hipError_t launch_propagate_f32(const scvx_ctx* ctx, int B, int K, const float* 
                                 float dt, float* xnext, hipStream_t st) {
     return launch_propagate_t<float>(ctx, B, K, x, u, sigma, dt, xnext, st);
 }
+
+#if defined(SCVX_K1_PROF)
+extern "C" int scvx_debug_k1_prof(double* out32) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_k1prof), sizeof(double) * 32) == hipSuccess ? 0 : -2;
+}
+#endif
 
 }  // namespace scvx
