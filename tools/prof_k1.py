@@ -1,4 +1,6 @@
-"""Barrier-wait shares of the persistent K1 kernel, per wavefront of block 0 (diagnostic build variants/libscvx_hip_k1prof.so:
+"""Build first:  mkdir -p variants && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSCVX_K1_PROF -I include \
+    -I successiveconvexification_amd/csrc -o variants/libscvx_hip_k1prof.so successiveconvexification_amd/csrc/*.hip
+Barrier-wait shares of the persistent K1 kernel, per wavefront of block 0 (diagnostic build variants/libscvx_hip_k1prof.so:
 -DSCVX_K1_PROF).  Wave 0 is the producer, 1..7 the consumers.    python tools/prof_k1.py [npts]"""
 import ctypes as C
 import os

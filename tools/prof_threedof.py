@@ -1,4 +1,6 @@
-"""In-kernel section shares of the 3-DoF initialiser (K0) for trajectory 0, from a diagnostic build
+"""Build first:  mkdir -p variants && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSCVX_TD_PROF -I include \
+    -I successiveconvexification_amd/csrc -o variants/libscvx_hip_tdprof.so successiveconvexification_amd/csrc/*.hip
+In-kernel section shares of the 3-DoF initialiser (K0) for trajectory 0, from a diagnostic build
 (variants/libscvx_hip_tdprof.so: -DSCVX_TD_PROF, s_memtime around the sections of scvx_threedof_core.hpp).
     python tools/prof_threedof.py [B]"""
 import ctypes as C
