@@ -34,7 +34,7 @@ def _oracle_problem(aero_tables=None):
     return model.base_prob_scaled(model.AeroData(d, l, t))
 
 
-@pytest.mark.parametrize("B,K,npts", [(1, 50, 10), (7, 50, 4), (64, 30, 1), (3, 1, 2), (5, 100, 10)])
+@pytest.mark.parametrize("B,K,npts", [(1, 50, 10), (7, 50, 4), (64, 30, 1), (3, 1, 2), (5, 100, 10), (1, 13, 3), (1, 15, 3)])
 def test_linearize_matches_oracle_exo(B, K, npts):
     from oracle import dynamics as od
     from successiveconvexification_amd.dynamics import linearize_batch, propagate_batch
