@@ -387,8 +387,13 @@ __global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_kernel(ipm::Consts C, in
 }
 
 // NW wavefronts per trajectory (batches that cannot fill the chip with one wavefront each)
+// Compiled for 2 wavefronts per SIMD like socp_kernel (248 VGPRs, no spills; unconstrained the compiler takes 274 = one
+// per SIMD, and a batch of more than 1,024 / NW trajectories runs in two rounds: B = 1,024 with NW = 2 took 14.5 ms, now 9.9).
+#ifndef SCVX_K4_BLOCK_OCC
+#define SCVX_K4_BLOCK_OCC 2
+#endif
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void socp_block_kernel(ipm::Consts C, int B, size_t work_stride,
+__global__ __launch_bounds__(64 * NW, SCVX_K4_BLOCK_OCC) void socp_block_kernel(ipm::Consts C, int B, size_t work_stride,
                                                   const double* __restrict__ x, const double* __restrict__ u,
                                                   const double* __restrict__ endpoint, const double* __restrict__ deriv,
                                                   const double* __restrict__ rk, const double* __restrict__ ic,
@@ -549,8 +554,6 @@ struct scvx_batch {
 
 namespace {
 
-constexpr int SOCP_WAVES4_MAX_B = 256;    // 4 wavefronts per trajectory up to here
-constexpr int SOCP_WAVES2_MAX_B = 512;    // 2 up to here, then one
 
 void rotation_between_e1(const double* b, double* q) {
     // Rotations.rotation_between([1,0,0], b) as [w,x,y,z] (initial_solve.jl:121-122)
@@ -581,16 +584,20 @@ int split_views(scvx_batch* b, const double* rec, double* x, double* u, double* 
     return SCVX_OK;
 }
 
-// Wavefronts per trajectory of the conic solve.  One wavefront per trajectory is the throughput form (3 per SIMD,
-// 3,072 in flight): below that many trajectories the chip is not full and a solve is latency-bound, so several
-// wavefronts share one trajectory (the sweeps and E / E' products spread over their lanes; the 14x14 tile arithmetic
-// stays on the first).  Thresholds from the measured B-sweep (profiles/r02_bsweep.md); SCVX_K4_WAVES = 1 / 2 / 4 forces.
-int socp_waves(int B) {
+// Wavefronts per trajectory of the conic solve.  One wavefront per trajectory is the throughput form; every form is
+// compiled for 2 wavefronts per SIMD (<= 256 VGPRs, nothing spills), i.e. 8 per CU are resident.  While ALL trajectories
+// of the batch are resident at once a solve is latency-bound and more wavefronts per trajectory shorten it (the sweeps
+// and E / E' products spread over their lanes; the 14x14 tile arithmetic stays on the first, the factorisation pipelines
+// over two), so: 4 wavefronts while B <= 2 per CU (512 on 256 CUs), 2 while B <= 4 per CU (1,024), else 1 -- one more
+// trajectory than that starts a second round of blocks (measured: B = 1,024 -> 1,152 with 2 wavefronts 9.9 -> 12.8 ms).
+// B-sweep: profiles/r02_bsweep_occ2.md; SCVX_K4_WAVES = 1 / 2 / 4 forces.
+int socp_waves(int B, int num_cus) {
     if (const char* v = std::getenv("SCVX_K4_WAVES")) {
         const int w = std::atoi(v);
         return w >= 4 ? 4 : (w >= 2 ? 2 : 1);   // 8 and 16 wavefronts per trajectory were measured: no faster than 4 at B = 1..64 (barrier cost)
     }
-    return B <= SOCP_WAVES4_MAX_B ? 4 : (B <= SOCP_WAVES2_MAX_B ? 2 : 1);
+    const int cus = num_cus > 0 ? num_cus : 256;
+    return B <= 2 * cus ? 4 : (B <= 4 * cus ? 2 : 1);
 }
 
 template <int NW>
@@ -602,7 +609,7 @@ void launch_socp_block(scvx_batch* b, const int* mask) {
 int enqueue_socp(scvx_batch* b, const int* mask) {
     // scvx_solve's tail: once few trajectories are still live the solve is latency-bound again, and the executors with
     // several wavefronts per trajectory (dead blocks return at once) finish a step in half the time
-    const int w = socp_waves(b->nlive_hint >= 0 && b->nlive_hint < b->B ? (b->nlive_hint > 0 ? b->nlive_hint : 1) : b->B);
+    const int w = socp_waves(b->nlive_hint >= 0 && b->nlive_hint < b->B ? (b->nlive_hint > 0 ? b->nlive_hint : 1) : b->B, b->ctx->num_cus);
     if (w == 4) launch_socp_block<4>(b, mask);
     else if (w == 2) launch_socp_block<2>(b, mask);
     else

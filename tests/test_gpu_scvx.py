@@ -105,9 +105,11 @@ def test_both_socp_executors_agree(monkeypatch):
 
 
 def test_solve_problem_tail_executor_matches_single_wavefront(monkeypatch):
-    """scvx_solve picks the conic solver's executor from the live count (2 wavefronts per trajectory once <= 512 are
-    still stepped, 4 once <= 256): same trajectories, statuses and step counts as the one-wavefront form forced for the
-    whole run, on a flyable problem whose trajectories converge after different numbers of steps."""
+    """scvx_solve picks the conic solver's executor from the live count (one wavefront per trajectory above 4 per CU,
+    2 once <= 1,024 are still stepped on 256 CUs, 4 once <= 512): same trajectories and statuses as the one-wavefront form
+    forced for the whole run, on a flyable problem whose trajectories converge after different numbers of steps.  The step
+    at which a trajectory passes the convergence test may differ by one: at the optimum dJ is rounding noise (1e-11), so
+    "accepted" against "rejected" there is decided by the summation order of the executor."""
     from successiveconvexification_amd.batch import ScvxBatch
     from successiveconvexification_amd.defns import DescentProblem
     from successiveconvexification_amd.dynamics import IntegratorCache
@@ -115,7 +117,7 @@ def test_solve_problem_tail_executor_matches_single_wavefront(monkeypatch):
     p = DescentProblem()
     p.K, p.tf_guess, p.mdry, p.mwet, p.alpha, p.imax = 20, 6.0, 1.0, 2.0, 0.05, 12
     p.rIi, p.vIi = np.array([4.0, 2.0, 0.0]), np.array([-0.5, -0.5, 0.3])
-    B = 560
+    B = 1100
     ic = disperse_ics(p, 0, B, 99, frac=0.3)
     res = {}
     for waves in (None, "1"):
@@ -131,10 +133,12 @@ def test_solve_problem_tail_executor_matches_single_wavefront(monkeypatch):
         b.close(); c.close()
     a, r = res[None], res["1"]
     assert len(np.unique(a[1])) > 1, "the instance should finish trajectories at different steps"
-    same = (a[0] == r[0]) & (a[1] == r[1])
-    assert same.mean() > 0.99     # a trajectory sitting on a convergence threshold may take one step more on one side
-    assert np.abs(a[2][same] - r[2][same]).max() < 1e-5 and np.abs(a[3][same] - r[3][same]).max() < 1e-5
-    assert np.abs(a[4][same] - r[4][same]).max() < 1e-5
+    same_status = a[0] == r[0]
+    assert same_status.mean() > 0.99
+    assert (np.abs(a[1] - r[1])[same_status] <= 1).mean() > 0.99
+    assert ((a[1] == r[1]) & same_status).mean() > 0.9
+    assert np.abs(a[2][same_status] - r[2][same_status]).max() < 1e-5 and np.abs(a[3][same_status] - r[3][same_status]).max() < 1e-5
+    assert np.abs(a[4][same_status] - r[4][same_status]).max() < 1e-5
 
 
 def test_solve_step_matches_oracle_scvx_two_iterations():
