@@ -328,6 +328,7 @@ def main():
     prof, nprof = batch.profile()
     batch.set_profiling(False)
     st_f, act_f, _ = batch.flags()
+    rec64 = batch.trajectory_record() if world == 1 and not args.no_traj_check else None   # for the f32_linearization leg
     done = B * args.steps  # every trajectory is stepped by every solve_step (failed ones are reported below, not hidden)
 
     # final trajectories: the only exchange step of the path -- one all-gather over RCCL
@@ -440,8 +441,11 @@ def main():
             # skipped).  Reported beside `value`, never instead of it.
             batch.close()
 
-            def variant(**kw):
-                b2 = ScvxBatch(cache, B, **kw).init(shard.ic)
+            def variant(lin32=False, **kw):
+                b2 = ScvxBatch(cache, B, **kw)
+                if lin32:
+                    b2.set_linearization_f32(True)
+                b2.init(shard.ic)
                 cnt = [0]
 
                 def run2(n):
@@ -456,8 +460,19 @@ def main():
                 run2(args.steps)
                 cache.synchronize()
                 t2 = time.perf_counter() - t2
+                out = {"value": B * args.steps / t2, "unit": "traj-iter/s", "ms_per_step": 1e3 * t2 / args.steps}
+                if lin32:   # how far the mixed-precision iterates are from the fp64 run's after the same steps
+                    s2, i2, m2, _ = b2.solver_stats()
+                    out["optimal_frac"] = float(np.mean(s2 == 0))
+                    out["merit_max"] = float(np.max(m2))
+                    out["traj_linf_vs_f64_run"] = float(np.abs(b2.trajectory_record() - rec64).max()) if rec64 is not None else None
                 b2.close()
-                return {"value": B * args.steps / t2, "unit": "traj-iter/s", "ms_per_step": 1e3 * t2 / args.steps}
+                return out
+            line["f32_linearization"] = dict(variant(lin32=True), dtype="f64 arithmetic, f32 derivative tiles",
+                                             note="NOT the headline: scvx_batch_set_linearization_f32 -- K1 integrates in double and "
+                                             "stores dynam[k].derivative as float, the conic solve widens on load and keeps its "
+                                             "workspace, norms and pivots in double (BASELINE configs[3-4] 'fp32', SURVEY H7); "
+                                             "same loop, same seed as `value`")
             line["cold_start_only"] = dict(variant(warm_start=False), note="warm_start = 0: every conic solve starts from the "
                                            "CVXOPT-style cold point, also the re-solve after a rejected step")
             line["with_reuse_inactive_tr"] = dict(variant(reuse_inactive_tr=True), note="opt-in shortcut, off in the headline: after a "

@@ -222,6 +222,12 @@ int scvx_batch_set_trajectory(scvx_batch *b, const double *traj);
 /* device pointer to the same layout (zero-copy views; scvx_allgather_trajectories gathers it); valid until destroy */
 int scvx_batch_trajectory_dev(scvx_batch *b, double **traj_dev, int64_t *n_doubles);
 int scvx_batch_get_linearization(scvx_batch *b, double *endpoint, double *deriv);
+/* Mixed precision (BASELINE configs[3-4] "fp32"; SURVEY 8b `_f64/_f32`, H7): keep the derivative tiles `dynam[k].derivative`
+ * (LinRes, master.jl:91-93) in float.  The discretisation still integrates in double and rounds each entry once, at the
+ * store; the conic solve widens on load and keeps its arithmetic, workspace, norms and pivots in double; the endpoint stays
+ * double.  Halves the bytes of the one input every pass of the solve re-reads.  on = 1 / 0; an initialised batch is
+ * re-linearised at once.  scvx_batch_get_linearization then returns the float values, widened. */
+int scvx_batch_set_linearization_f32(scvx_batch *b, int on);
 int scvx_batch_get_scalars(scvx_batch *b, double *rk, double *cost, int32_t *iter);
 int scvx_batch_set_scalars(scvx_batch *b, const double *rk, const double *cost, const int32_t *iter);
 /* per-trajectory flags, the rest of a checkpoint (trajectory + scalars + flags restore a batch after

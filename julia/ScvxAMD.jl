@@ -126,6 +126,10 @@ struct Iteration
     cost::Float64
 end
 
+# mixed precision: derivative tiles kept in float (K1 integrates in double, the conic solve stays double)
+linearization_f32!(b::Batch, on::Bool=true) =
+    (check(b.cache.ctx, ccall((:scvx_batch_set_linearization_f32, LIB), Cint, (Ptr{Cvoid}, Cint), b.h, on ? 1 : 0), "scvx_batch_set_linearization_f32"); b)
+
 # snapshot of trajectory t (1-based) of a batch as the reference's ProblemIteration
 function iteration(b::Batch, t::Int=1)
     K = b.cache.problem.K; nrec = (K + 1) * 17 + 1

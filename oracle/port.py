@@ -38,7 +38,7 @@ def _p(a):
 
 
 def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, max_iter=60, refine=6, nthreads=0, accept=1e-6,
-         f32=False, work=None, warm=None):
+         f32=False, work=None, warm=None, lin32=False):
     """Batched: xbar [B][K+1][14], ubar [B][K+1][3], endpoint [B][K][14], deriv [B][K][21][14], rk [B].
     Returns dict(dx, du, ds, nu, status, iters, merit, pobj)."""
     xbar = np.ascontiguousarray(xbar, float)
@@ -60,7 +60,7 @@ def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, 
         port_lib().scvx_port_socp_ws(C.byref(c), C.c_int(B), _p(xbar), _p(ubar), _p(endpoint), _p(deriv), _p(rk), _p(ic), _p(sol), _p(nu),
                                      _p(info), C.c_int(nthreads), _p(work), wf.ctypes.data_as(C.POINTER(C.c_int32)))
     else:
-      (port_lib().scvx_port_socp_f32 if f32 else port_lib().scvx_port_socp)(C.byref(c), C.c_int(B), _p(xbar), _p(ubar), _p(endpoint), _p(deriv), _p(rk), _p(ic),
+      (port_lib().scvx_port_socp_f32 if f32 else (port_lib().scvx_port_socp_lin32 if lin32 else port_lib().scvx_port_socp))(C.byref(c), C.c_int(B), _p(xbar), _p(ubar), _p(endpoint), _p(deriv), _p(rk), _p(ic),
                               _p(sol), _p(nu), _p(info), C.c_int(nthreads))
     nx = 14 * (K + 1)
     return dict(dx=sol[:, :nx].reshape(B, K + 1, 14), du=sol[:, nx:nx + 3 * (K + 1)].reshape(B, K + 1, 3),

@@ -122,7 +122,7 @@ size_t scvx_port_work_doubles(int K, int with_dp) {
 // Solve B subproblems.  Layouts as include/scvx.h: xbar [B][K+1][14], ubar [B][K+1][3], endpoint [B][K][14],
 // deriv [B][K][21][14], rk [B], ic [B][6].  Outputs: sol [B][(K+1)*17+1] = dx, du, dsigma ; nu [B][K][14];
 // info [B][4] = status, iters, merit, pobj.  Stor = storage type of the linearisation and of the solver workspace.
-template <class Stor>
+template <class Stor, class DStor = Stor>
 static int port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
                      const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
                      int nthreads, Stor* work_all = nullptr, const int* warm = nullptr) {
@@ -133,12 +133,13 @@ static int port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, cons
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel
     {
-        std::vector<Stor> work(work_all ? 0 : nw), D((size_t)K * 294);
+        std::vector<Stor> work(work_all ? 0 : nw);
+        std::vector<DStor> D((size_t)K * 294);
         HostEx ex;
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < B; b++) {
-            for (size_t i = 0; i < D.size(); i++) D[i] = (Stor)deriv[(size_t)b * K * 294 + i];
-            scvx::ipm::Solver<HostEx, Stor> S(ex, *C);
+            for (size_t i = 0; i < D.size(); i++) D[i] = (DStor)deriv[(size_t)b * K * 294 + i];
+            scvx::ipm::Solver<HostEx, Stor, DStor> S(ex, *C);
             Stor* wk = work_all ? work_all + (size_t)b * nw : work.data();   // persistent per-trajectory slab, as on the device
             scvx::ipm::Result r = S.solve(xbar + (size_t)b * (K + 1) * 14, ubar + (size_t)b * (K + 1) * 3,
                                           endpoint + (size_t)b * K * 14, D.data(), rk[b], ic + (size_t)b * 6, wk,
@@ -166,6 +167,12 @@ int scvx_port_socp_ws(const scvx::ipm::Consts* C, int B, const double* xbar, con
                       const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
                       int nthreads, double* work, const int* warm) {
     return port_socp<double>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads, work, warm);
+}
+// f32 linearisation (scvx_batch_set_linearization_f32): D rounded to float, workspace and arithmetic double
+int scvx_port_socp_lin32(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
+                         const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
+                         int nthreads) {
+    return port_socp<double, float>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads);
 }
 // f32 storage: the linearisation and the whole solver workspace are float, arithmetic stays double
 int scvx_port_socp_f32(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,

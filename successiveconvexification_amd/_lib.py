@@ -85,6 +85,7 @@ SIGNATURES = {
     "scvx_batch_set_trajectory": (C.c_int, [_vp, _dp]),
     "scvx_batch_trajectory_dev": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int64)]),
     "scvx_batch_get_linearization": (C.c_int, [_vp, _dp, _dp]),
+    "scvx_batch_set_linearization_f32": (C.c_int, [_vp, C.c_int]),
     "scvx_batch_get_scalars": (C.c_int, [_vp, _dp, _dp, _ip]),
     "scvx_batch_set_scalars": (C.c_int, [_vp, _dp, _dp, _ip]),
     "scvx_batch_get_flags": (C.c_int, [_vp, _ip, _ip, _ip]),

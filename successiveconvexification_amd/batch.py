@@ -149,6 +149,12 @@ class ScvxBatch:
         self._chk(self._L.scvx_batch_get_linearization(self.handle, _p(e), _p(d)), "scvx_batch_get_linearization")
         return e, d
 
+    def set_linearization_f32(self, on=True):
+        """Keep the derivative tiles in float (double arithmetic in K1, rounded at the store; the conic solve widens on load
+        and stays double): the mixed-precision form of BASELINE configs[3-4].  Re-linearises an initialised batch."""
+        self._chk(self._L.scvx_batch_set_linearization_f32(self.handle, 1 if on else 0), "scvx_batch_set_linearization_f32")
+        return self
+
     def scalars(self):
         rk = np.zeros(self.B)
         cost = np.zeros(self.B)

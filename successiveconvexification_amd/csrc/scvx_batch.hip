@@ -323,9 +323,10 @@ struct BlockEx {
 };
 
 // info[b] = {status, iters, merit, pobj}
-template <class Ex>
+// DS: element type of the linearisation the discretisation kernel wrote (double; float behind scvx_batch_set_linearization_f32)
+template <class Ex, class DS = double>
 __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t work_stride, const double* x, const double* u,
-                                          const double* endpoint, const double* deriv, const double* rk, const double* ic,
+                                          const double* endpoint, const DS* deriv, const double* rk, const double* ic,
                                           const int* active, double* work, double* sol, double* nu, double* info,
                                           const int* step_status, double* ttr) {
     const int b = blockIdx.x;
@@ -341,12 +342,12 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t wo
     }
     const int K = C.K;
     Ex ex;
-    ipm::Solver<Ex> S(ex, C);
+    ipm::Solver<Ex, double, DS> S(ex, C);
     // kernel arguments are HBM pointers: hand them to the solver typed as such (see ipm::gptr)
     // warm start: the last solve in this slab was for the same about / dynam (its step was rejected) and is still valid
     const bool warm = C.warm && step_status[b] == SCVX_ST_REJECTED && ttr[b] < 1e300;
     const ipm::Result r = S.solve((ipm::cgptr)(x + (size_t)b * (K + 1) * 14), (ipm::cgptr)(u + (size_t)b * (K + 1) * 3),
-                                  (ipm::cgptr)(endpoint + (size_t)b * K * 14), (ipm::cgptr)(deriv + (size_t)b * K * 294), rk[b],
+                                  (ipm::cgptr)(endpoint + (size_t)b * K * 14), (typename ipm::gp<DS>::cptr)(deriv + (size_t)b * K * 294), rk[b],
                                   (ipm::cgptr)(ic + (size_t)b * 6), (ipm::gptr)(work + (size_t)b * work_stride), warm);
     const int nxu = S.L.nx + S.L.nu_;
     const int nl = ex.nlanes();
@@ -385,6 +386,17 @@ __global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_kernel(ipm::Consts C, in
                                                   double* __restrict__ ttr) {
     socp_body<WaveEx>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr);
 }
+// the same solve on float derivative tiles (scvx_batch_set_linearization_f32)
+__global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_lin32_kernel(ipm::Consts C, int B, size_t work_stride,
+                                                  const double* __restrict__ x, const double* __restrict__ u,
+                                                  const double* __restrict__ endpoint, const float* __restrict__ deriv,
+                                                  const double* __restrict__ rk, const double* __restrict__ ic,
+                                                  const int* __restrict__ active, double* __restrict__ work,
+                                                  double* __restrict__ sol, double* __restrict__ nu,
+                                                  double* __restrict__ info, const int* __restrict__ step_status,
+                                                  double* __restrict__ ttr) {
+    socp_body<WaveEx, float>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr);
+}
 
 // NW wavefronts per trajectory (batches that cannot fill the chip with one wavefront each)
 // Compiled for 2 wavefronts per SIMD like socp_kernel (248 VGPRs, no spills; unconstrained the compiler takes 274 = one
@@ -392,16 +404,16 @@ __global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_kernel(ipm::Consts C, in
 #ifndef SCVX_K4_BLOCK_OCC
 #define SCVX_K4_BLOCK_OCC 2
 #endif
-template <int NW>
+template <int NW, class DS = double>
 __global__ __launch_bounds__(64 * NW, SCVX_K4_BLOCK_OCC) void socp_block_kernel(ipm::Consts C, int B, size_t work_stride,
                                                   const double* __restrict__ x, const double* __restrict__ u,
-                                                  const double* __restrict__ endpoint, const double* __restrict__ deriv,
+                                                  const double* __restrict__ endpoint, const DS* __restrict__ deriv,
                                                   const double* __restrict__ rk, const double* __restrict__ ic,
                                                   const int* __restrict__ active, double* __restrict__ work,
                                                   double* __restrict__ sol, double* __restrict__ nu,
                                                   double* __restrict__ info, const int* __restrict__ step_status,
                                                   double* __restrict__ ttr) {
-    socp_body<BlockEx<NW>>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr);
+    socp_body<BlockEx<NW>, DS>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr);
 }
 
 // cand = about + step (x, u in one contiguous [B][(K+1)*17+1] trajectory record, sigma last)
@@ -539,6 +551,7 @@ struct scvx_batch {
     double *x = nullptr, *u = nullptr, *sigma = nullptr;          // split views of traj (kernels' input layout)
     double *cx = nullptr, *cu = nullptr, *csigma = nullptr;       // split views of cand
     double *endpoint = nullptr, *deriv = nullptr, *xprop = nullptr, *nu = nullptr;
+    float* deriv_f = nullptr;   // the derivative tiles in float (scvx_batch_set_linearization_f32): then `deriv` is not allocated
     double *rk = nullptr, *cost = nullptr, *ic = nullptr, *info = nullptr, *out = nullptr, *work = nullptr;
     double *ttr = nullptr;   // trust-region norm bound at the last optimum (reuse_inactive_tr)
     int *iter = nullptr, *status = nullptr;
@@ -602,8 +615,20 @@ int socp_waves(int B, int num_cus) {
 
 template <int NW>
 void launch_socp_block(scvx_batch* b, const int* mask) {
-    hipLaunchKernelGGL(scvx::socp_block_kernel<NW>, dim3(b->B), dim3(64 * NW), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x,
-                       b->u, b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr);
+    if (b->deriv_f)
+        hipLaunchKernelGGL((scvx::socp_block_kernel<NW, float>), dim3(b->B), dim3(64 * NW), 0, b->ctx->stream, b->C, b->B, b->work_stride,
+                           b->x, b->u, b->endpoint, b->deriv_f, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr);
+    else
+        hipLaunchKernelGGL((scvx::socp_block_kernel<NW, double>), dim3(b->B), dim3(64 * NW), 0, b->ctx->stream, b->C, b->B, b->work_stride,
+                           b->x, b->u, b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr);
+}
+
+// K1 for the batch's iterate, into the derivative buffer of the batch's mode
+hipError_t relinearize(scvx_batch* b, const int* skip) {
+    const double dt = 1.0 / (b->K + 1);
+    if (b->deriv_f)
+        return scvx::launch_linearize_store_f32(b->ctx, b->B, b->K, b->x, b->u, b->sigma, dt, b->endpoint, b->deriv_f, b->ctx->stream, skip);
+    return scvx::launch_linearize(b->ctx, b->B, b->K, b->x, b->u, b->sigma, dt, b->endpoint, b->deriv, b->ctx->stream, skip);
 }
 
 int enqueue_socp(scvx_batch* b, const int* mask) {
@@ -612,6 +637,9 @@ int enqueue_socp(scvx_batch* b, const int* mask) {
     const int w = socp_waves(b->nlive_hint >= 0 && b->nlive_hint < b->B ? (b->nlive_hint > 0 ? b->nlive_hint : 1) : b->B, b->ctx->num_cus);
     if (w == 4) launch_socp_block<4>(b, mask);
     else if (w == 2) launch_socp_block<2>(b, mask);
+    else if (b->deriv_f)
+        hipLaunchKernelGGL(scvx::socp_lin32_kernel, dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
+                           b->endpoint, b->deriv_f, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr);
     else
         hipLaunchKernelGGL(scvx::socp_kernel, dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
                            b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr);
@@ -659,7 +687,7 @@ int enqueue_step(scvx_batch* b, const int* mask) {
     if (rc) return rc;
     if ((rc = mark(b))) return rc;
     // rocketland.jl:318; a rejected step returns before it (:301, about / dynam kept): those trajectories are skipped
-    SCVX_HIP(ctx, scvx::launch_linearize(ctx, b->B, b->K, b->x, b->u, b->sigma, dt, b->endpoint, b->deriv, st, b->status));
+    SCVX_HIP(ctx, relinearize(b, b->status));
     if ((rc = mark(b))) return rc;
     return SCVX_OK;
 }
@@ -766,7 +794,7 @@ void scvx_batch_destroy(scvx_batch* b) {
     (void)hipSetDevice(b->device);
     for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
     void* ptrs[] = {b->traj0, b->traj, b->cand, b->sol, b->x, b->u, b->sigma, b->cx, b->cu, b->csigma, b->endpoint, b->deriv, b->xprop,
-                    b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active, b->live, b->ttr};
+                    b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active, b->live, b->ttr, b->deriv_f};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete b;
@@ -833,7 +861,7 @@ int scvx_batch_init(scvx_batch* b, const double* ic) {
     SCVX_HIP(ctx, hipMemsetAsync(b->ttr, 0x7f, (size_t)B * 8, st));   // a huge finite value: nothing to reuse yet
     rc = split_views(b, b->traj, b->x, b->u, b->sigma);
     if (rc) return rc;
-    SCVX_HIP(ctx, scvx::launch_linearize(ctx, B, K, b->x, b->u, b->sigma, 1.0 / (K + 1), b->endpoint, b->deriv, st));
+    SCVX_HIP(ctx, relinearize(b, nullptr));
     SCVX_HIP(ctx, hipStreamSynchronize(st));  // host staging buffers go out of scope
     b->initialised = true;
     return SCVX_OK;
@@ -859,7 +887,7 @@ int scvx_batch_init_threedof(scvx_batch* b, const double* ic, const scvx_threedo
         }
         if (rc == SCVX_OK && e == hipSuccess) rc = split_views(b, b->traj, b->x, b->u, b->sigma);
         if (rc == SCVX_OK && e == hipSuccess)
-            e = scvx::launch_linearize(ctx, B, K, b->x, b->u, b->sigma, 1.0 / (K + 1), b->endpoint, b->deriv, st);
+            e = relinearize(b, nullptr);
     }
     const hipError_t es = hipStreamSynchronize(st);
     if (d_sol) (void)hipFree(d_sol);
@@ -882,7 +910,7 @@ int scvx_batch_reset(scvx_batch* b) {
     SCVX_HIP(ctx, hipGetLastError());
     rc = split_views(b, b->traj, b->x, b->u, b->sigma);
     if (rc) return rc;
-    SCVX_HIP(ctx, scvx::launch_linearize(ctx, b->B, b->K, b->x, b->u, b->sigma, 1.0 / (b->K + 1), b->endpoint, b->deriv, st));
+    SCVX_HIP(ctx, relinearize(b, nullptr));
     return SCVX_OK;
 }
 
@@ -963,8 +991,7 @@ int scvx_batch_set_trajectory(scvx_batch* b, const double* traj) {
     SCVX_HIP(ctx, hipMemsetAsync(b->ttr, 0x7f, (size_t)b->B * 8, ctx->stream));   // a new iterate: no optimum to reuse
     rc = split_views(b, b->traj, b->x, b->u, b->sigma);
     if (rc) return rc;
-    SCVX_HIP(ctx, scvx::launch_linearize(ctx, b->B, b->K, b->x, b->u, b->sigma, 1.0 / (b->K + 1), b->endpoint, b->deriv,
-                                        ctx->stream));
+    SCVX_HIP(ctx, relinearize(b, nullptr));
     SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SCVX_OK;
 }
@@ -981,8 +1008,45 @@ int scvx_batch_get_linearization(scvx_batch* b, double* endpoint, double* deriv)
     if (rc) return rc;
     scvx_ctx* ctx = b->ctx;
     if (endpoint) SCVX_HIP(ctx, hipMemcpyAsync(endpoint, b->endpoint, (size_t)b->B * b->K * 14 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (deriv) SCVX_HIP(ctx, hipMemcpyAsync(deriv, b->deriv, (size_t)b->B * b->K * 294 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t nd = (size_t)b->B * b->K * 294;
+    if (deriv && b->deriv_f) {   // float tiles: widened on the host (the values the conic solve reads)
+        std::vector<float> tmp(nd);
+        SCVX_HIP(ctx, hipMemcpyAsync(tmp.data(), b->deriv_f, nd * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < nd; i++) deriv[i] = (double)tmp[i];
+    } else if (deriv) {
+        SCVX_HIP(ctx, hipMemcpyAsync(deriv, b->deriv, nd * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
     SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCVX_OK;
+}
+
+// Keep the derivative tiles [B][K][21][14] in float: the discretisation still integrates in double and rounds each entry
+// once, at the store; the conic solve widens on load and does all of its arithmetic, its workspace and its pivots in double.
+// Halves the bytes of the one input the solve re-reads in every pass (E, E', the factorisation).  The endpoint stays double.
+// Switching re-linearises an initialised batch at once, so the buffer the next solve reads is always current.
+int scvx_batch_set_linearization_f32(scvx_batch* b, int on) {
+    if (!b || !b->ctx) return SCVX_ERR_ARG;
+    scvx_ctx* ctx = b->ctx;
+    int rc = SCVX_OK;
+    SCVX_HIP(ctx, hipSetDevice(ctx->device));
+    if ((on != 0) == (b->deriv_f != nullptr)) return SCVX_OK;
+    SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t nd = (size_t)b->B * b->K * 294;
+    if (on) {
+        if ((rc = dmalloc(ctx, &b->deriv_f, nd))) return rc;
+        (void)hipFree(b->deriv);
+        b->deriv = nullptr;
+    } else {
+        if ((rc = dmalloc(ctx, &b->deriv, nd))) return rc;
+        (void)hipFree(b->deriv_f);
+        b->deriv_f = nullptr;
+    }
+    if (b->initialised) {
+        SCVX_HIP(ctx, relinearize(b, nullptr));
+        SCVX_HIP(ctx, hipMemsetAsync(b->ttr, 0x7f, (size_t)b->B * 8, ctx->stream));   // the data changed: no optimum to reuse, no warm start
+        SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return SCVX_OK;
 }
 

@@ -16,6 +16,7 @@
 // structural non-zeros straight to its column (scvx_dyn.hpp).  The finished 3 x 14 x 21 tile is
 // transposed through LDS so that the wavefront writes its 7,056 contiguous output bytes with
 // 16-byte-per-lane coalesced stores in the reference's column-major LinRes layout.
+#include <type_traits>
 #include "scvx_internal.hpp"
 
 namespace scvx {
@@ -215,13 +216,16 @@ constexpr int PC_GROUP = 4;              // stages published per barrier (one RK
 // SG (stage-granular, the default): one barrier per RK stage and the producer one STAGE ahead (2-slot ring) instead of
 // one barrier per substep and the producer one substep ahead: the pipeline fills after one stage instead of four (at
 // npts = 1 the substep-granular form does not overlap at all), which outweighs the 4x barrier count at every npts.
-template <bool AERO, bool SG, typename R>
+// O = element type of the derivative tiles in HBM: R, or float under double arithmetic (scvx_batch_set_linearization_f32:
+// the conic solve reads them as float; rounded once, at the store)
+template <bool AERO, bool SG, typename R, typename O = R>
 __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
     DynP<R> p, long nseg, int K, const R* __restrict__ x, const R* __restrict__ u,
     const R* __restrict__ sigma, R dt, int nsub, R* __restrict__ endpoint,
-    R* __restrict__ deriv, const int* __restrict__ skip) {
+    O* __restrict__ deriv, const int* __restrict__ skip) {
     constexpr int LPS = K1Map<AERO>::LPS, SPW = K1Map<AERO>::SPW;
     typedef typename Vec2<R>::type VEC2;
+    typedef typename Vec2<O>::type OVEC2;
     constexpr int NC = PC_WAVES - 1;
     if (block_unchanged(skip, (long)blockIdx.x * (NC * SPW), NC * SPW, nseg, K)) return;
     constexpr int NS = NC * SPW;               // segments per block
@@ -347,24 +351,25 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
         const long rem = nseg - seg0;
         const int nvalid = rem < SPW ? (int)rem : SPW;
         const int n2 = nvalid * 147;
-        VEC2* out = reinterpret_cast<VEC2*>(deriv + (size_t)seg0 * 294);
+        OVEC2* out = reinterpret_cast<OVEC2*>(deriv + (size_t)seg0 * 294);
         const VEC2* src = reinterpret_cast<const VEC2*>(t);
 #pragma unroll
         for (int r = 0; r < (SPW * 147 + 63) / 64; r++) {
             const int e = lane + 64 * r;
-            if (e < n2) out[e] = src[e];
+            if (e < n2) { const VEC2 v = src[e]; OVEC2 o; o.x = O(v.x); o.y = O(v.y); out[e] = o; }
         }
     }
 }
 
 // The same producer/consumer pipeline (stage-granular) as a PERSISTENT block, used from 3 substeps up.
-template <bool AERO, typename R>
+template <bool AERO, typename R, typename O = R>
 __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
     DynP<R> p, long nseg, int K, const R* __restrict__ x, const R* __restrict__ u,
     const R* __restrict__ sigma, R dt, int nsub, R* __restrict__ endpoint,
-    R* __restrict__ deriv, const int* __restrict__ skip) {
+    O* __restrict__ deriv, const int* __restrict__ skip) {
     constexpr int LPS = K1Map<AERO>::LPS, SPW = K1Map<AERO>::SPW;
     typedef typename Vec2<R>::type VEC2;
+    typedef typename Vec2<O>::type OVEC2;
     constexpr bool SG = true;
     constexpr int NC = PC_WAVES - 1;
     constexpr int NS = NC * SPW;               // segments per group
@@ -538,12 +543,12 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
             const long rem = nseg - seg0;
             const int nvalid = rem < SPW ? (int)rem : SPW;
             const int n2 = nvalid * 147;
-            VEC2* out = reinterpret_cast<VEC2*>(deriv + (size_t)seg0 * 294);
+            OVEC2* out = reinterpret_cast<OVEC2*>(deriv + (size_t)seg0 * 294);
             const VEC2* src = reinterpret_cast<const VEC2*>(t);
 #pragma unroll
             for (int r = 0; r < (SPW * 147 + 63) / 64; r++) {
                 const int e = lane + 64 * r;
-                if (e < n2) out[e] = src[e];
+                if (e < n2) { const VEC2 v = src[e]; OVEC2 o; o.x = O(v.x); o.y = O(v.y); out[e] = o; }
             }
         }
         if (SHARE) K1_BAR();
@@ -622,12 +627,13 @@ hipError_t launch_linearize_simple(const scvx_ctx* ctx, int B, int K, const R* x
     return hipGetLastError();
 }
 
-template <typename R>
+template <typename R, typename O = R>
 hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, const R* u, const R* sigma, R dt, R* endpoint,
-                              R* deriv, hipStream_t st, const int* skip = nullptr) {
+                              O* deriv, hipStream_t st, const int* skip = nullptr) {
     const long nseg = (long)B * K;
     if (nseg == 0) return hipSuccess;
-    if (ctx->k1_variant == 0) return launch_linearize_simple<R>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st, skip);
+    if constexpr (std::is_same<R, O>::value)
+        if (ctx->k1_variant == 0) return launch_linearize_simple<R>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st, skip);
     const int ns = (PC_WAVES - 1) * (ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW);
     // stage-granular pipeline by default (faster at every npts measured: 0.70 -> 0.60 ms at npts 1, 3.05 -> 2.96 ms
     // at npts 10, B = 8192, fp64); SCVX_K1_SG=0 selects the substep-granular form
@@ -641,14 +647,14 @@ hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, con
     const dim3 g(grid), blk(64 * PC_WAVES);
     const DynP<R> dp(ctx->dyn);
     if (persist) {
-        if (ctx->dyn.aero) hipLaunchKernelGGL((linearize_pcp_kernel<true, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
-        else hipLaunchKernelGGL((linearize_pcp_kernel<false, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+        if (ctx->dyn.aero) hipLaunchKernelGGL((linearize_pcp_kernel<true, R, O>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+        else hipLaunchKernelGGL((linearize_pcp_kernel<false, R, O>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
     } else if (ctx->dyn.aero) {
-        if (sg) hipLaunchKernelGGL((linearize_pc_kernel<true, true, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
-        else hipLaunchKernelGGL((linearize_pc_kernel<true, false, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+        if (sg) hipLaunchKernelGGL((linearize_pc_kernel<true, true, R, O>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+        else hipLaunchKernelGGL((linearize_pc_kernel<true, false, R, O>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
     } else {
-        if (sg) hipLaunchKernelGGL((linearize_pc_kernel<false, true, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
-        else hipLaunchKernelGGL((linearize_pc_kernel<false, false, R>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+        if (sg) hipLaunchKernelGGL((linearize_pc_kernel<false, true, R, O>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+        else hipLaunchKernelGGL((linearize_pc_kernel<false, false, R, O>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
     }
     return hipGetLastError();
 }
@@ -656,6 +662,12 @@ hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, con
 hipError_t launch_linearize(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
                             double dt, double* endpoint, double* deriv, hipStream_t st, const int* skip) {
     return launch_linearize_t<double>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st, skip);
+}
+
+// double arithmetic, float derivative tiles (scvx_batch_set_linearization_f32): the endpoint stays double
+hipError_t launch_linearize_store_f32(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
+                                      double dt, double* endpoint, float* deriv, hipStream_t st, const int* skip) {
+    return launch_linearize_t<double, float>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st, skip);
 }
 
 // fp32 form of K1 (scvx_linearize_f32): the same kernels instantiated in float arithmetic -- half the bytes, twice the

@@ -33,6 +33,9 @@ struct NcclId { char internal[SCVX_COMM_ID_BYTES]; };   // layout of ncclUniqueI
 // K1: endpoint[B*K][14], deriv[B*K][21][14] from x[B][K+1][14], u[B][K+1][3], sigma[B].
 hipError_t launch_linearize(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
                             double dt, double* endpoint, double* deriv, hipStream_t st, const int* skip = nullptr);
+// K1 in double arithmetic with the derivative tiles stored as float (scvx_batch_set_linearization_f32)
+hipError_t launch_linearize_store_f32(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
+                                      double dt, double* endpoint, float* deriv, hipStream_t st, const int* skip = nullptr);
 // K2: xnext[B*K][14].
 hipError_t launch_propagate(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
                             double dt, double* xnext, hipStream_t st);

@@ -304,17 +304,20 @@ struct Result {
     double merit, pobj;
 };
 
-template <class Ex, class Stor = double>
+template <class Ex, class Stor = double, class DStor = Stor>
 struct Solver {
-    typedef typename gp<Stor>::ptr gptr;     // workspace and linearisation (storage type)
+    typedef typename gp<Stor>::ptr gptr;     // workspace (storage type)
     typedef typename gp<Stor>::cptr cgptr;
+    typedef typename gp<DStor>::ptr dptr;
+    typedef typename gp<DStor>::cptr dcptr;   // the linearisation D as the discretisation kernel wrote it (double, or float
+                                              // behind scvx_batch_set_linearization_f32: every load widens, arithmetic stays double)
     typedef typename gp<double>::cptr cdptr;  // the SCvx iterate: always double
     Ex& ex;
     const Consts& C;
     Layout L;
     // inputs
     cdptr xbar, ubar, endpoint;
-    cgptr D;
+    dcptr D;
     double rk;
     // workspace
     gptr dk, V, rx, gx, dw, r1, cw, Vbest, tmpv;
@@ -322,7 +325,8 @@ struct Solver {
     gptr S, Z, lam, Wv, Wibz, tmpc, Wirz, sd;
     gptr Wbeta;
     gptr hx, hu;
-    gptr Linv, Nf, tchain, At;
+    gptr Linv, Nf, tchain;
+    dptr At;   // A_k' copies, in the element type of D (a float D uses half of the slot)
     gptr ys, ytr, ynu;   // the three border multipliers  S y = Sg, E Hb^-1 Ptr, hnui Pnu
     gptr ptl, rtr;       // ptl = Hb^-1 Ptr (local, zero on nu),  rtr = E ptl
     gptr tmpl, tmpl2;
@@ -356,7 +360,7 @@ struct Solver {
         Wibz = w; w += nc; tmpc = w; w += nc; Wirz = w; w += nc; sd = w; w += nc;
         Wbeta = w; w += L.ncones;
         hx = w; w += (size_t)(K + 1) * HX_SZ; hu = w; w += (size_t)(K + 1) * 9;
-        Linv = w; w += (size_t)K * LINV_SZ; Nf = w; w += (size_t)K * 196; At = w; w += (size_t)K * 196;
+        Linv = w; w += (size_t)K * LINV_SZ; Nf = w; w += (size_t)K * 196; At = (dptr)w; w += (size_t)K * 196;
         tchain = w; w += ny;
         ys = w; w += ny; ytr = w; w += ny; ynu = w; w += ny; rtr = w; w += ny; ptl = w; w += nloc;
         tmpl = w; w += nloc; tmpl2 = w; w += nloc;
@@ -426,7 +430,7 @@ struct Solver {
         double n2 = 0;
         for (int r = ex.lane(); r < 14 * K; r += ex.nlanes()) {
             const int k = r / 14, i = r - 14 * k;
-            cgptr Dk = D + (size_t)k * 294 + i;
+            dcptr Dk = D + (size_t)k * 294 + i;
             cgptr dx = v + 14 * k;
             cgptr du = v + L.nx + 3 * k;
             const double ad = add ? add[r] : 0.0;   // issued with the batch of loads below, not after it
@@ -457,7 +461,7 @@ struct Solver {
             const double b0 = mode ? base[t] - (corr ? pc * Pt[t] : 0.0) : 0.0;   // loaded with the batch below
             double a = 0;
             if (k < K) {
-                cgptr col = At + (size_t)k * 196 + j;   // A_k' row-major: lanes j read consecutive doubles
+                dcptr col = At + (size_t)k * 196 + j;   // A_k' row-major: lanes j read consecutive doubles
                 cgptr yk = yy + 14 * k;
                 for (int i = 0; i < 14; i++) a += col[14 * i] * yk[i];
             }
@@ -470,12 +474,12 @@ struct Solver {
             const double b0 = mode ? base[L.nx + t] - (corr ? pc * Pt[L.nx + t] : 0.0) : 0.0;
             double a = 0;
             if (k < K) {
-                cgptr col = D + (size_t)k * 294 + 14 * (14 + c);
+                dcptr col = D + (size_t)k * 294 + 14 * (14 + c);
                 cgptr yk = yy + 14 * k;
                 for (int i = 0; i < 14; i++) a += col[i] * yk[i];
             }
             if (k > 0) {
-                cgptr col = D + (size_t)(k - 1) * 294 + 14 * (17 + c);
+                dcptr col = D + (size_t)(k - 1) * 294 + 14 * (17 + c);
                 cgptr yk = yy + 14 * (k - 1);
                 for (int i = 0; i < 14; i++) a += col[i] * yk[i];
             }
@@ -484,7 +488,7 @@ struct Solver {
         }
         double sg = 0;
         {
-            const cgptr D_ = D; cgptr bn = mode ? base + L.nx + L.nu_ : yy; const gptr gn = g + L.nx + L.nu_;
+            const dcptr D_ = D; cgptr bn = mode ? base + L.nx + L.nu_ : yy; const gptr gn = g + L.nx + L.nu_;
             if (corr)
                 stream(0, 14 * K, [&](int r) { const int k = r / 14, i = r - 14 * k; return D4{yy[r], bn[r], D_[(size_t)k * 294 + 14 * 20 + i], Pn[r]}; },
                        [&](int r, const D4& w) { gn[r] = (w.b - pn * w.d) - w.a; sg += w.c * w.a; });
@@ -1164,7 +1168,7 @@ struct Solver {
         const int K = L.K;
         for (int r = ex.lane(); r < 14 * K; r += ex.nlanes()) {
             const int k = r / 14, i = r - 14 * k;
-            cgptr Dk = D + (size_t)k * 294 + i;
+            dcptr Dk = D + (size_t)k * 294 + i;
             const double ad = add1[r];
             double a = 0, b = 0;
             for (int j = 0; j < 14; j++) { const double d = Dk[14 * j]; a += d * v0[14 * k + j]; b += d * v1[14 * k + j]; }
@@ -1189,7 +1193,7 @@ struct Solver {
     template <class E2 = Ex>
     SCVX_HD_NI bool factor_pipelined() {
         const int K = L.K;
-        const cgptr D_ = D; const cgptr hx_ = hx; const cgptr hu_ = hu;
+        const dcptr D_ = D; const cgptr hx_ = hx; const cgptr hu_ = hu;
         const gptr Linv_ = Linv; const gptr Nf_ = Nf;
         const double hnui_ = hnui;
         double* sc = ex.pipe_scratch();
@@ -1229,7 +1233,7 @@ struct Solver {
                 double* Sdk = Sd + 196 * (k & 1); double* Sok = So + 196 * (k & 1);
                 // next tile into registers while this segment is assembled
                 double pre[5];
-                cgptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
+                dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
                 SCVX_UNROLL
                 for (int q = 0; q < 5; q++) { const int e = l + 64 * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
                 for (int e = l; e < NODE_SZ; e += 64) { Hh[e] = Hh[NODE_SZ + e]; }
@@ -1419,7 +1423,7 @@ struct Solver {
         // The D_{k+1} tile is fetched (coalesced, into registers on the device) while segment k is processed.
         // members hoisted into locals: the Solver object sits in scratch memory on the device and would be
         // re-read after every barrier
-        const cgptr D_ = D;
+        const dcptr D_ = D;
         const cgptr hx_ = hx;
         const cgptr hu_ = hu;
         const gptr Linv_ = Linv;
@@ -1468,7 +1472,7 @@ struct Solver {
             double hn2 = 0.0;
             if (NPRE > 0 && ex.lane() < NODE_SZ) hn2 = node_elem(k + 2 <= K ? k + 2 : K, ex.lane());
             double pre[NPRE > 0 ? NPRE : 1];
-            cgptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
+            dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
             if (NPRE > 0) {
                 SCVX_UNROLL
                 for (int q = 0; q < NPRE; q++) { const int e = ex.lane() + ex.nlanes() * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
@@ -1631,7 +1635,7 @@ struct Solver {
         //   <Ptr, dl> = <ptl, g> - <rtr, dy>,   <Pnu, dl_nu> = hnui (<Pnu, g_nu> - <Pnu, dy>)
         double a = 0, bt = 0, bn = 0, gn = 0;
         {
-            const cgptr D_ = D; cgptr rt = rtr; cgptr wn = Wv + L.o_nu + 1; cgptr gnu = g + L.nx + L.nu_;
+            const dcptr D_ = D; cgptr rt = rtr; cgptr wn = Wv + L.o_nu + 1; cgptr gnu = g + L.nx + L.nu_;
             stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D5{D_[(size_t)k * 294 + 14 * 20 + i], dyv[r], rt[r], wn[r], gnu[r]}; },
                    [&](int, const D5& v) { a += v.a * v.b; bt += v.c * v.b; bn += v.d * v.b; gn += v.d * v.e; });
         }
@@ -1804,7 +1808,7 @@ struct Solver {
     // ---- the solve.  ic: (rIi, vIi) of this trajectory.  Outputs in V (dx, du, nu, s, ...). ----
     // warm: the previous solve in this workspace was for the same (xbar, ubar, endpoint, D) -- the step it belonged to was
     // rejected -- so its saved iterate may be used as the starting point
-    SCVX_HD Result solve(cdptr xbar_, cdptr ubar_, cdptr endpoint_, cgptr D_,
+    SCVX_HD Result solve(cdptr xbar_, cdptr ubar_, cdptr endpoint_, dcptr D_,
                          double rk_, cdptr ic, gptr work, bool warm = false) {
         xbar = xbar_; ubar = ubar_; endpoint = endpoint_; D = D_; rk = rk_;
         SCVX_TS(tTot_);
@@ -1813,7 +1817,7 @@ struct Solver {
         // constants of this subproblem
         for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) dk[r] = endpoint[r] - xbar[14 + r];
         {   // A_k' once per subproblem: element (i, j) of A_k sits at 14 j + i in D (column-major), at 14 i + j here
-            const cgptr D_ = D; const gptr At_ = At;
+            const dcptr D_ = D; const dptr At_ = At;
             stream(0, 196 * K, [&](int e) { const int k = e / 196, r = e - 196 * k, i = r / 14, j = r - 14 * i; return D_[(size_t)k * 294 + 14 * j + i]; },
                    [&](int e, double v) { At_[e] = v; });
         }

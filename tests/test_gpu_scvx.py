@@ -141,6 +141,42 @@ def test_solve_problem_tail_executor_matches_single_wavefront(monkeypatch):
     assert np.abs(a[4][same_status] - r[4][same_status]).max() < 1e-5
 
 
+def test_f32_linearisation_mode_against_the_fp64_path():
+    """scvx_batch_set_linearization_f32: K1 integrates in double and stores the derivative tiles as float, the conic
+    solve reads them as float and stays double.  (i) the stored tiles are the fp64 tiles rounded once (bit for bit), the
+    endpoint is untouched; (ii) one solve_step differs from the fp64 path by the rounding only (1e-6); (iii) so does a
+    whole solve_problem on dispersed trajectories; (iv) switching an initialised batch re-linearises it."""
+    from oracle import model
+    po = model.base_prob_scaled()
+    B = 8
+    ic = model.disperse_ics(po, B, 20261004)
+    c, b64 = _setup(B, ic)
+    from successiveconvexification_amd.batch import ScvxBatch
+    b32 = ScvxBatch(c, B).set_linearization_f32(True).init(ic)
+    e64, d64 = b64.linearization()
+    e32, d32 = b32.linearization()
+    assert np.array_equal(e32, e64)
+    assert np.array_equal(d32, d64.astype(np.float32).astype(np.float64))
+    st64, nu64, dj64 = b64.solve_step()
+    st32, nu32, dj32 = b32.solve_step()
+    assert np.array_equal(st32, st64)
+    for a, r in zip(b32.trajectory(), b64.trajectory()):
+        assert np.abs(a - r).max() < 1e-6
+    (s64, it64, m64, _), (s32, it32, m32, _) = b64.solver_stats(), b32.solver_stats()
+    assert np.all(s32 == 0) and np.all(m32 < 1e-8) and np.abs(it32 - it64).max() <= 1
+    r64 = b64.solve()
+    r32 = b32.solve()
+    assert np.array_equal(r32[0], r64[0]) and np.array_equal(r32[1], r64[1])      # statuses, step counts
+    for a, r in zip(b32.trajectory(), b64.trajectory()):
+        assert np.abs(a - r).max() < 1e-4
+    # (iv) back to double on a live batch: the tiles are the fp64 ones again
+    x32 = b32.trajectory()
+    b32.set_linearization_f32(False)
+    b64.set_trajectory(*x32)
+    assert np.array_equal(b32.linearization()[1], b64.linearization()[1])
+    b32.close(); b64.close(); c.close()
+
+
 def test_solve_step_matches_oracle_scvx_two_iterations():
     """Two full solve_step calls against oracle.scvx (IPM + exact discretisation) on one trajectory."""
     from oracle import model, scvx as oscvx

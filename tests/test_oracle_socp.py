@@ -135,3 +135,27 @@ def test_dynamic_pressure_cone_twin_matches_independent_oracle():
     it0 = oscvx.create_initial(p0, 10)
     tw0 = port.socp(p0, it0.x[None], it0.u[None], it0.endpoint[None], it0.deriv[None], 100.0)
     assert np.linalg.norm((it0.x + tw0["dx"][0])[:p.K, 4:7], axis=1).max() > vm + 1e-3
+
+
+def test_f32_linearisation_twin_converges_and_solves_the_rounded_problem():
+    """scvx_batch_set_linearization_f32: the conic solve reads the linearisation D in float (workspace and arithmetic stay
+    double).  It converges to the same tolerance, its optimum is the double solver's optimum for the ROUNDED D (same
+    numbers, widened), and it differs from the optimum for the unrounded D by the size of the perturbation only."""
+    from oracle import dynamics as od
+    p = model.base_prob_scaled()
+    B = 4
+    ic = model.disperse_ics(p, B, 20261004)
+    x = np.zeros((B, p.K + 1, 14))
+    u = np.zeros((B, p.K + 1, 3))
+    for b in range(B):
+        x[b], u[b] = model.linear_points(p, ic[b, :3], ic[b, 3:])
+    e, d = od.linearize(od.Params(p), x, u, np.full(B, p.tf_guess), 1 / (p.K + 1), 4)
+    r64 = port.socp(p, x, u, e, d, 100.0, ic)
+    r32 = port.socp(p, x, u, e, d, 100.0, ic, lin32=True)
+    rr = port.socp(p, x, u, e, d.astype(np.float32).astype(np.float64), 100.0, ic)
+    assert np.all(r32["status"] == 0) and np.all(r32["merit"] < 1e-8)
+    assert np.array_equal(r32["iters"], rr["iters"])
+    for key in ("dx", "du", "ds", "nu"):
+        assert np.array_equal(r32[key], rr[key])          # same arithmetic on the same (widened) numbers
+        assert np.abs(r32[key] - r64[key]).max() < 1e-4   # float rounding of D: 6e-8 relative
+    assert np.abs(r32["pobj"] / r64["pobj"] - 1.0).max() < 1e-7
