@@ -24,7 +24,27 @@ def load_aerodata(liftdrag: str, finforce=None) -> AtmosphericData:
     def tab(name):
         return np.ascontiguousarray(data[name].reshape(n_mach, n_aoa))
 
+    if finforce is not None:
+        load_fin_table(finforce)   # aerodynamics.jl:23-26: the reference reads fin.csv here and uses it nowhere; neither does this
     return AtmosphericData(tab("drag"), tab("lift"), tab("torque"), 1.0, 1.0)
+
+
+def load_fin_table(finforce: str):
+    """aero/fin.csv (columns lift,drag,mach,aoa: 60 Mach numbers x 901 fin deflections, aero/AeroTable.jl:94-112) as
+    (mach [60], aoa [901], lift [60][901], drag [60][901]).  The reference loads the file and drops it
+    (aerodynamics.jl:23-26; the fin-force model is commented out, dynamics.jl:60-69) -- it is parsed here so that a
+    malformed file fails where the reference's CSV.read would."""
+    data = np.genfromtxt(finforce, delimiter=",", names=True)
+    for col in ("lift", "drag", "mach", "aoa"):
+        if col not in data.dtype.names:
+            raise ValueError(f"{finforce}: no column '{col}'")
+    mach = np.unique(data["mach"])
+    aoa = np.unique(data["aoa"])
+    if data.shape[0] != mach.size * aoa.size:
+        raise ValueError(f"{finforce}: {data.shape[0]} rows are not a {mach.size} x {aoa.size} (mach x aoa) grid")
+    order = np.lexsort((data["aoa"], data["mach"]))
+    shape = (mach.size, aoa.size)
+    return mach, aoa, data["lift"][order].reshape(shape), data["drag"][order].reshape(shape)
 
 
 def rescale_aerodata(data, Ul: float, Ut: float, Um: float):

@@ -172,3 +172,29 @@ def test_plot_solution_data_matches_the_reference_formulas(tmp_path):
     assert tab.shape == (7, 9) and np.array_equal(tab[:, 4], d["thr"])
     z = np.load(R.dump_solution(ip, str(tmp_path / "sol.npz")))
     assert np.array_equal(z["dp"], d["dp"]) and float(z["sigma"]) == 1.25
+
+
+def test_aero_csv_loader_and_fin_table(tmp_path, aero_tables):
+    """Aerodynamics.load_aerodata (aerodynamics.jl:11-28) on the CSV layout of aero/lift_drag.csv -- written here from the
+    golden tables -- and the fin table the reference reads and drops (aerodynamics.jl:23-26)."""
+    from successiveconvexification_amd import aerodynamics as ae
+    d, l, t = aero_tables                     # [61 mach][181 aoa]
+    n_mach, n_aoa = d.shape
+    aoa = np.tile(np.arange(n_aoa), n_mach)   # cos(AoA) index fastest, Mach slowest: reshape(col, 181, 61) in the reference
+    mach = np.repeat(np.arange(n_mach) * 0.025, n_aoa)
+    csv = tmp_path / "lift_drag.csv"
+    np.savetxt(csv, np.column_stack([aoa, mach, d.ravel(), l.ravel(), t.ravel()]), delimiter=",",
+               header="aoa,mach,drag,lift,torque", comments="")
+    fin = tmp_path / "fin.csv"
+    fm, fa = np.array([0.01, 0.035, 0.06]), np.array([0.0, 0.1, 0.2, 0.3])
+    rows = [(m * a, -m * a * a, m, a) for m in fm for a in fa]
+    np.savetxt(fin, np.array(rows), delimiter=",", header="lift,drag,mach,aoa", comments="")
+    a = ae.load_aerodata(str(csv), str(fin))
+    assert np.array_equal(a.drag_itrp, d) and np.array_equal(a.lift_itrp, l) and np.array_equal(a.trq_itrp, t)
+    m2, a2, lift, drag = ae.load_fin_table(str(fin))
+    assert np.allclose(m2, fm) and np.allclose(a2, fa) and lift.shape == (3, 4)
+    assert np.allclose(lift, fm[:, None] * fa[None, :]) and np.allclose(drag, -fm[:, None] * fa[None, :] ** 2)
+    bad = tmp_path / "bad.csv"
+    np.savetxt(bad, np.array(rows[:-1]), delimiter=",", header="lift,drag,mach,aoa", comments="")
+    with pytest.raises(ValueError):
+        ae.load_aerodata(str(csv), str(bad))
