@@ -314,6 +314,35 @@ def test_aero_B256_dispersed_matches_oracle_on_a_sample(aero_tables):
     b.close(); c.close()
 
 
+def test_f32_linearisation_mode_on_the_aero_model_and_small_batches(aero_tables):
+    """The mixed-precision mode through the aero instantiation of K1 and the 2- / 4-wavefront executors of the conic solve
+    (B = 600 / 40): one solve_step against the fp64 path, rounding-sized differences only."""
+    from oracle import model
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.defns import AtmosphericData
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    d, l, t = aero_tables
+    pp = sp.base_prob_aero_scaled(AtmosphericData(d, l, t))
+    po = model.base_prob_scaled(model.AeroData(d, l, t))
+    c = IntegratorCache(pp, npts=4)
+    for B in (40, 600):
+        ic = model.disperse_ics(po, B, 20261003)
+        b64 = ScvxBatch(c, B).init(ic)
+        b32 = ScvxBatch(c, B).set_linearization_f32(True).init(ic)
+        d64, d32 = b64.linearization()[1], b32.linearization()[1]
+        assert np.array_equal(d32, d64.astype(np.float32).astype(np.float64))
+        st64 = b64.solve_step()[0]
+        st32 = b32.solve_step()[0]
+        assert np.array_equal(st32, st64)
+        for a, r in zip(b32.trajectory(), b64.trajectory()):
+            assert np.abs(a - r).max() < 2e-6
+        s32 = b32.solver_stats()
+        assert np.all((s32[0] == 0) | (s32[0] == 4)) and s32[2].max() < 1e-7
+        b32.close(); b64.close()
+    c.close()
+
+
 def test_tight_tolerance_agrees_with_independent_oracle_to_5e6():
     """Both solvers at 1e-10: the device minimiser and the independent oracle's agree to 5e-6 (the flatness of the
     optimum limits the default-tolerance comparison to 2e-5, not the solver)."""
