@@ -39,7 +39,7 @@ namespace scvx {
 __shared__ __attribute__((aligned(16))) double g_socp_lds[1552];
 // tiles of the two-wavefront factorisation pipeline (multi-wavefront kernels only: a kernel that never references the
 // symbol does not get the allocation)
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 3 * 196 + 294 + 308 + 42 + 2 * 42 + 196 + 8];
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 196 + 8];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
 #ifndef SCVX_K4_PIPELINE
 #define SCVX_K4_PIPELINE 1
 #endif
@@ -366,6 +366,9 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t wo
         if (b == 0) for (int i = 0; i < 32; i++) work[i] = S.prof[i];  // diagnostic build: section cycles of trajectory 0
 #endif
     }
+#if defined(SCVX_IPM_PROF)
+    if (b == 0 && threadIdx.x == 64) for (int i = 0; i < 32; i++) work[32 + i] = S.prof[i];  // ... and of its second wavefront
+#endif
 }
 
 // one wavefront per trajectory (large batches: the chip is filled by trajectories)
@@ -1091,7 +1094,7 @@ int scvx_batch_get_solver_stats(scvx_batch* b, int32_t* status, int32_t* iters, 
 #if defined(SCVX_IPM_PROF)
 int scvx_debug_ipm_prof(scvx_batch* b, double* out32) {
     (void)hipStreamSynchronize(b->ctx->stream);
-    return hipMemcpy(out32, b->work, 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+    return hipMemcpy(out32, b->work, 64 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;   // out32: 64 doubles (wavefront 0, wavefront 1)
 }
 #endif
 

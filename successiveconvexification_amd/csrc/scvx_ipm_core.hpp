@@ -1197,12 +1197,12 @@ struct Solver {
         const gptr Linv_ = Linv; const gptr Nf_ = Nf;
         const double hnui_ = hnui;
         double* sc = ex.pipe_scratch();
-        double* Sd = sc;                 // 2 x 196
+        double* Sd = sc;                 // 2 x 196: ring; the chain factorises slot k in place (pivot tile)
         double* So = Sd + 392;           // 2 x 196
-        double* M = So + 392;            // consumer: pivot tile / Nf product
-        double* Wp = M + 196;            // consumer: Wb[k-1]
-        double* Li = Wp + 196;           // consumer: Linv[k]
-        double* Dt = Li + 196;           // producer: D_k tile
+        double* Wp = So + 392;           // 3 x 196: Wb ring (chain writes k, reads k-1; the post stage reads k-2)
+        double* Li = Wp + 588;           // 2 x 196: Linv ring (chain writes k; the post stage reads k-1)
+        double* Mq = Li + 392;           // post stage: Nf product
+        double* Dt = Mq + 196;           // producer: D_k tile
         double* T = Dt + 294;            // producer: [TA | TBm | TBp], row stride 22
         double* Bp = T + 308;            // producer: Bp_k kept across the tile swap
         double* Hh = Bp + 42;            // producer: node inverses k | k+1
@@ -1227,9 +1227,11 @@ struct Solver {
             }
             ex.w_sync_lds();
         }
-        for (int t = 0; t <= K; t++) {
+        const int PW = ex.nlanes() > 128 ? 2 : 1;   // wavefront of the post stage: an idle one if the block has more than two
+        for (int t = 0; t <= K + 1; t++) {
             if (w == 1 && t < K) {
                 const int k = t;
+                SCVX_TS(tp0_);
                 double* Sdk = Sd + 196 * (k & 1); double* Sok = So + 196 * (k & 1);
                 // next tile into registers while this segment is assembled
                 double pre[5];
@@ -1253,7 +1255,11 @@ struct Solver {
                     }
                 }
                 ex.w_sync_lds();
+                SCVX_TE(tp0_, 24);
+                SCVX_TS(tp1_);
                 ex.w_tile_gemm(Sdk, 14, 1, T, TS, 1, Dt, 14, 1, 20, 1.0, true);
+                SCVX_TE(tp1_, 25);
+                SCVX_TS(tp2_);
                 if (k + 1 < K) {
                     for (int q = l; q < 42; q += 64) Bp[q] = Dt[14 * 17 + q];
                     ex.w_sync_lds();
@@ -1273,28 +1279,46 @@ struct Solver {
                     }
                 }
                 ex.w_sync_lds();
-            } else if (w == 0 && t >= 1) {
+                SCVX_TE(tp2_, 26);
+            }
+            if (w == 0 && t >= 1 && t <= K) {
+                // ---- chain: pivot tile in place on the ring slot, Cholesky + inverse, coupling tile ----
                 const int k = t - 1;
-                const double* Sdk = Sd + 196 * (k & 1); const double* Sok = So + 196 * (k & 1);
-                for (int e = l; e < 196; e += 64) M[e] = Sdk[e];
+                SCVX_TS(tc0_);
+                double* M = Sd + 196 * (k & 1); const double* Sok = So + 196 * (k & 1);
+                double* Lik = Li + 196 * (k & 1);
+                const double* Wpm = Wp + 196 * ((k + 2) % 3);   // Wb[k-1]
+                if (k > 0) { ex.w_tile_gemm(M, 14, 1, Wpm, 14, 1, Wpm, 1, 14, 14, -1.0, true); ex.w_sync_lds(); }
+                SCVX_TE(tc0_, 24);
+                SCVX_TS(tc1_);
+                ok = ex.w_chol_inv14(M, Lik) && ok;
                 ex.w_sync_lds();
-                if (k > 0) { ex.w_tile_gemm(M, 14, 1, Wp, 14, 1, Wp, 1, 14, 14, -1.0, true); ex.w_sync_lds(); }
-                ok = ex.w_chol_inv14(M, Li) && ok;
-                ex.w_sync_lds();
+                SCVX_TE(tc1_, 25);
+                SCVX_TS(tc3_);
+                if (k + 1 < K) { ex.w_tile_gemm(Wp + 196 * (k % 3), 14, 1, Sok, 14, 1, Lik, 1, 14, 14, 1.0, false); ex.w_sync_lds(); }
+                SCVX_TE(tc3_, 27);
+            }
+            if (w == PW && t >= 2) {
+                // ---- post stage, one step behind the chain: L^-1 (packed) and Nf_j = -L_j^-1 Wb_{j-1} to HBM ----
+                const int j = t - 2;
+                SCVX_TS(tc2_);
+                const double* Lij = Li + 196 * (j & 1);
                 for (int e = l; e < LINV_SZ; e += 64) {
                     const int p = e / 15, q = e - 15 * p;
-                    const int i = q <= p ? p : 13 - p, j = q <= p ? q : q - (p + 1);
-                    Linv_[(size_t)k * LINV_SZ + e] = Li[14 * i + j];
+                    const int i = q <= p ? p : 13 - p, jj = q <= p ? q : q - (p + 1);
+                    Linv_[(size_t)j * LINV_SZ + e] = Lij[14 * i + jj];
                 }
-                if (k > 0) {
-                    ex.w_tile_gemm(M, 1, 14, Li, 14, 1, Wp, 14, 1, 14, -1.0, false);
+                if (j > 0) {
+                    ex.w_tile_gemm(Mq, 1, 14, Lij, 14, 1, Wp + 196 * ((j + 2) % 3), 14, 1, 14, -1.0, false);
                     ex.w_sync_lds();
-                    for (int e = l; e < 196; e += 64) Nf_[(size_t)k * 196 + e] = M[e];
+                    for (int e = l; e < 196; e += 64) Nf_[(size_t)j * 196 + e] = Mq[e];
+                    ex.w_sync_lds();
                 }
-                if (k + 1 < K) { ex.w_sync_lds(); ex.w_tile_gemm(Wp, 14, 1, Sok, 14, 1, Li, 1, 14, 14, 1.0, false); }
-                ex.w_sync_lds();
+                SCVX_TE(tc2_, 26);
             }
+            SCVX_TS(tb_);
             ex.sync();   // hand-over: producer's slot k is complete, consumer has finished with slot k - 1
+            SCVX_TE(tb_, 28);
         }
         return ex.all(ok);
     }

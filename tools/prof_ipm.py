@@ -10,7 +10,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 c = IntegratorCache(sp.base_prob_scaled)
 b = ScvxBatch(c, B).init(bench.disperse_ics(sp.base_prob_scaled, 0, B, 20261004))
 b.socp_solve()
-out = np.zeros(32)
+out = np.zeros(64)
 _lib.lib().scvx_debug_ipm_prof.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 _lib.lib().scvx_debug_ipm_prof(b.handle, out.ctypes.data_as(C.POINTER(C.c_double)))
 st, its, merit, pobj = b.solver_stats()
@@ -18,3 +18,9 @@ names = {2:"  k: stage+TBp",5:"  k: pivot tile",12:"  k: chol_inv14",13:"  k: Li
 tot = out[15]
 print("ipm iters traj0:", its[0], " total Mcycles(100MHz ticks?) %.1f" % (tot/1e6))
 for k,v in names.items(): print("%-14s %10.0f  %5.1f%%" % (v, out[k], 100*out[k]/tot))
+
+if out[32:].any():
+    print("two-wavefront factorisation pipeline (cycles per segment-step of one factorisation; wavefront 0 = chain, 1 = assembly):")
+    nf = max(int(its[0]) + 1, 1) * (50 + 1)
+    for k, (a, b) in {24: ("copy + pivot update", "stage node + TBp"), 25: ("chol_inv14", "Sd gemm"), 26: ("Linv store, Nf", "TA, TBm, So of k+1"), 27: ("Wb gemm", "-"), 28: ("barrier wait", "barrier wait")}.items():
+        print("  slot %d  w0 %-22s %8.0f   w1 %-22s %8.0f" % (k, a, out[k] / nf, b, out[32 + k] / nf))
