@@ -43,6 +43,13 @@ __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 588 + 3
 #ifndef SCVX_K4_PIPELINE
 #define SCVX_K4_PIPELINE 1
 #endif
+// second tile set of the TWO-ENDED factorisation (four-wavefront blocks only: wavefronts 2 / 3 eliminate the bottom half of
+// the chain upwards while 0 / 1 eliminate the top half downwards); a separate symbol so that the two-wavefront kernel, which
+// never references it, keeps its LDS footprint (4 blocks per CU)
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds2[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 2 * 196 + 8];
+#ifndef SCVX_K4_TWISTED
+#define SCVX_K4_TWISTED 1
+#endif
 
 struct WaveEx {
     __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63); }   // lane in the wavefront (BlockEx runs tile work on any of its wavefronts)
@@ -77,6 +84,7 @@ struct WaveEx {
     }
 
     static constexpr int kPrefetchRegs = 5;  // ceil(294 / 64): next D tile held in registers while segment k is processed
+    static constexpr bool kTwisted = false;
     static constexpr bool kPipelineFactor = false;
 
     // C(14x14) = (acc ? C : 0) + alpha * A(14 x Kd) B(Kd x 14) on the FP64 matrix pipe: ceil(Kd/4) x
@@ -178,6 +186,13 @@ struct WaveEx {
     template <int NR>
     __device__ __forceinline__ void chain_n(int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
                                                bool reverse) {
+        chain_range_n<NR>(K, z, N, o, reverse, reverse ? K - 1 : 0, K, true);
+    }
+    // The same recurrence over ns nodes starting at node k0 (the first one without a coupling term), for the two-ended
+    // solve of BlockEx<4>: K is only the number of tiles (the reverse form reads the tile of node k + 1).
+    template <int NR>
+    __device__ __forceinline__ void chain_range_n(int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
+                                                     bool reverse, int k0, int ns, bool store_first) {
         static_assert(NR >= 1 && NR <= 4, "right-hand sides ride in k-slots 16..19");
         constexpr int R = SCVX_CHAIN_R;
         const int l = lane(), n = l & 15, g = l >> 4;
@@ -205,7 +220,6 @@ struct WaveEx {
         const double bsel = (g == n) ? 1.0 : 0.0;
         const bool oin = n < NR;
         const bool oin3 = oin && g < 2;   // register 3 holds row g + 12
-        const int k0 = reverse ? K - 1 : 0;
         const int dk = reverse ? -1 : 1;
         double st[R][5];
         auto issue = [&](int s, double (&f)[5]) {
@@ -217,13 +231,13 @@ struct WaveEx {
         };
 #pragma unroll
         for (int q = 0; q < R; q++)
-            if (q < K) issue(q, st[q]);
+            if (q < ns) issue(q, st[q]);
         v4f64 d = {0.0, 0.0, 0.0, 0.0};
-        for (int s0 = 0; s0 < K; s0 += R) {
+        for (int s0 = 0; s0 < ns; s0 += R) {
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 const int s = s0 + q;
-                if (s < K) {
+                if (s < ns) {
                     // the first node has no coupling term (its tile is never written: mask, don't multiply)
                     const double m0 = s > 0 ? 1.0 : 0.0;
                     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
@@ -235,14 +249,15 @@ struct WaveEx {
                     }
                     d = acc;
                     // operands of step s + R go into the registers this step has just consumed
-                    if (s + R < K) issue(s + R, st[q]);
+                    if (s + R < ns) issue(s + R, st[q]);
                     const int k = k0 + dk * s;
-                    if (oin) {
+                    const bool st_ = store_first || s > 0;
+                    if (oin && st_) {
                         op[14 * k + g] = d[0];
                         op[14 * k + g + 4] = d[1];
                         op[14 * k + g + 8] = d[2];
                     }
-                    if (oin3) op[14 * k + g + 12] = d[3];
+                    if (oin3 && st_) op[14 * k + g + 12] = d[3];
                 }
             }
         }
@@ -266,6 +281,15 @@ struct BlockEx {
     static constexpr int kPrefetchRegs = (294 + 64 * NW - 1) / (64 * NW);
     // the factorisation loop as a producer / consumer pair of wavefronts (Solver::factor_pipelined)
     static constexpr bool kPipelineFactor = SCVX_K4_PIPELINE != 0;
+    // two-ended (twisted) factorisation and solve: the chain is eliminated from both ends towards the middle block by two
+    // producer / consumer pairs, and the solve's recurrences run on wavefronts 0 and 2 side by side (Solver::factor_twisted)
+    static constexpr bool kTwisted = NW == 4 && SCVX_K4_PIPELINE != 0 && SCVX_K4_TWISTED != 0;
+    __device__ __forceinline__ double* pipe_scratch2() { return g_socp_pipe_lds2; }
+    template <int NR>
+    __device__ __forceinline__ void chain_range_n(int wv, int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
+                                                     bool reverse, int k0, int ns, bool store_first) {
+        if (wave() == wv) w0.template chain_range_n<NR>(K, z, N, o, reverse, k0, ns, store_first);
+    }
     __device__ __forceinline__ int wave() const { return (int)(threadIdx.x >> 6); }
     __device__ __forceinline__ int wlane() const { return (int)(threadIdx.x & 63); }
     __device__ __forceinline__ double* pipe_scratch() { return g_socp_pipe_lds; }

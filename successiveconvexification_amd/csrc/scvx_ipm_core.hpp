@@ -1072,11 +1072,50 @@ struct Solver {
     // serves both sweeps and no second coupling matrix is formed, stored or read.)
     // The Linv products are chain-free (all k in parallel); only the 14x14 matrix-vector recurrences are sequential
     // and run inside the executor (ex.chain: FP64 matrix pipe on the device, no barriers).
+    // The two recurrences of a solve: on entry t holds z = L^-1 r, on exit t holds w (x is scratch: the forward result).
+    // TWO-ENDED form (Ex::kTwisted, Solver::factor_twisted): nodes 0..m-1 are eliminated downwards, K-1..m+1 upwards, the
+    // middle node m last.  Tile slot j couples nodes j-1 and j: for j <= m it is N_j = -L_j^-1 Wb_{j-1} in the standard
+    // (transposed) layout; for j > m it holds N'_{j-1} = -L_{j-1}^-1 Wb'_j untransposed -- so the executor's `reverse`
+    // recurrence IS the bottom half's forward substitution and its forward recurrence the bottom half's back substitution,
+    // and the two halves run side by side on wavefronts 0 and 2.
+    SCVX_HD bool twisted() const { return Ex::kTwisted && L.K >= 8; }
+    template <int N>
+    SCVX_HD void solve_chains(const gptr (&t)[N], const gptr (&x)[N]) {
+        const int K = L.K;
+        const cgptr Nf = this->Nf;
+        cgptr tz[N], xz[N];
+        for (int q = 0; q < N; q++) { tz[q] = t[q]; xz[q] = x[q]; }
+        if constexpr (Ex::kTwisted) {
+            if (twisted()) {
+                const int m = K / 2;
+                ex.template chain_range_n<N>(0, K, tz, Nf, x, false, 0, m, true);
+                ex.template chain_range_n<N>(2, K, tz, Nf, x, true, K - 1, K - 1 - m, true);
+                ex.sync();
+                for (int e = ex.lane(); e < 14 * N; e += ex.nlanes()) {   // the middle node: both neighbours feed it
+                    const int q = e / 14, i = e - 14 * q;
+                    cgptr Na = Nf + (size_t)m * 196 + i;            // N_m(i, j) at 14 j + i
+                    cgptr Nb = Nf + (size_t)(m + 1) * 196 + 14 * i;   // N'_m(i, j) at 14 i + j
+                    cgptr xa = x[q] + 14 * (m - 1); cgptr xb = x[q] + 14 * (m + 1);
+                    double a = t[q][14 * m + i];
+                    for (int j = 0; j < 14; j++) a += Na[14 * j] * xa[j] + Nb[j] * xb[j];
+                    x[q][14 * m + i] = a;
+                }
+                ex.sync();
+                ex.template chain_range_n<N>(0, K, xz, Nf, t, true, m, m + 1, true);
+                ex.template chain_range_n<N>(2, K, xz, Nf, t, false, m, K - m, false);
+                ex.sync();
+                return;
+            }
+        }
+        ex.template chain_n<N>(K, tz, Nf, x, false);
+        ex.sync();
+        ex.template chain_n<N>(K, xz, Nf, t, true);
+        ex.sync();
+    }
     SCVX_HD_NI void S_solve(cgptr r, gptr x) {
         SCVX_T0();
         const int K = L.K;
         const cgptr Linv = this->Linv;
-        const cgptr Nf = this->Nf;
         const gptr tchain = this->tchain;
         for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
             const int k = t / 14, i = t - 14 * k;
@@ -1092,13 +1131,12 @@ struct Solver {
         ex.sync();
         SCVX_TE(t0_, 16);
         SCVX_TS(tc1_);
-        ex.chain(K, tchain, Nf, x, false);       // t -> x
-        ex.sync();
+        {
+            const gptr ts[1] = {tchain};
+            const gptr xs[1] = {x};
+            solve_chains<1>(ts, xs);              // t -> x -> w in tchain
+        }
         SCVX_TE(tc1_, 17);
-        SCVX_TS(tc2_);
-        ex.chain(K, x, Nf, tchain, true);        // w -> tchain
-        ex.sync();
-        SCVX_TE(tc2_, 19);
         SCVX_TS(tp2_);
         for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
             const int k = t / 14, i = t - 14 * k;
@@ -1122,7 +1160,6 @@ struct Solver {
     SCVX_HD_NI void S_solveN(const cgptr (&r)[N], const gptr (&x)[N], const gptr (&t)[N]) {
         const int K = L.K;
         const cgptr Linv = this->Linv;
-        const cgptr Nf = this->Nf;
         for (int e = ex.lane(); e < 14 * K; e += ex.nlanes()) {
             const int k = e / 14, i = e - 14 * k;
             cgptr Li = Linv + (size_t)k * LINV_SZ + linv_row(i);
@@ -1136,18 +1173,7 @@ struct Solver {
             for (int q = 0; q < N; q++) t[q][e] = a[q];
         }
         ex.sync();
-        {
-            cgptr tz[N];
-            for (int q = 0; q < N; q++) tz[q] = t[q];
-            ex.template chain_n<N>(K, tz, Nf, x, false);
-        }
-        ex.sync();
-        {
-            cgptr xz[N];
-            for (int q = 0; q < N; q++) xz[q] = x[q];
-            ex.template chain_n<N>(K, xz, Nf, t, true);
-        }
-        ex.sync();
+        solve_chains<N>(t, x);
         for (int e = ex.lane(); e < 14 * K; e += ex.nlanes()) {
             const int k = e / 14, i = e - 14 * k;
             cgptr Lk = Linv + (size_t)k * LINV_SZ;
@@ -1323,6 +1349,223 @@ struct Solver {
         return ex.all(ok);
     }
 
+    // TWO-ENDED (twisted) form of the pipelined factorisation, four wavefronts per trajectory: wavefronts 1 / 0 assemble and
+    // eliminate nodes 0 .. m-1 downwards exactly as factor_pipelined does, wavefronts 3 / 2 assemble and eliminate nodes
+    // K-1 .. m+1 UPWARDS at the same time, and the middle node m receives both corrections at the end:
+    //     bottom node k:   M'_k = Sd_k - Wb'_{k+1} Wb'_{k+1}',  L_k = chol(M'_k),  Wb'_k = So_{k-1}' L_k^-T   (couples k to k-1)
+    //     middle:          M_m  = Sd_m - Wb_{m-1} Wb_{m-1}' - Wb'_{m+1} Wb'_{m+1}'
+    // The chain is half as long; what the solve does with the factor is in solve_chains.  Tile slot j > m holds
+    // N'_{j-1} = -L_{j-1}^-1 Wb'_j UNtransposed, slot j <= m the usual N_j = -L_j^-1 Wb_{j-1} transposed.
+    template <class E2 = Ex>
+    SCVX_HD_NI bool factor_twisted() {
+        const int K = L.K, m = K / 2, nb = K - 1 - m;   // nb nodes in the bottom half
+        const dcptr D_ = D; const cgptr hx_ = hx; const cgptr hu_ = hu;
+        const gptr Linv_ = Linv; const gptr Nf_ = Nf;
+        const double hnui_ = hnui;
+        const int w = ex.wave(), l = ex.wlane();
+        const bool bot = w >= 2;
+        double* sc = bot ? ex.pipe_scratch2() : ex.pipe_scratch();
+        double* Sd = sc;                 // 2 x 196 ring, factorised in place
+        double* So = Sd + 392;           // 2 x 196 ring
+        double* Wp = So + 392;           // 3 x 196: Wb ring
+        double* Li = Wp + 588;           // 2 x 196: Linv ring
+        double* Mq = Li + 392;           // N tile product
+        double* Dt = Mq + 196;           // producer: D_k tile
+        double* T = Dt + 294;            // producer: [TA | TBm | TBp], row stride 22
+        double* Bp = T + 308;            // producer: Bp of the neighbouring tile
+        double* Hh = Bp + 42;            // producer: node inverses (two slots)
+        double* Hd = Hh + 2 * NODE_SZ;   // producer: dense Hxi (bottom: two of them, by step parity)
+        constexpr int TS = 22;
+        bool ok = true;
+        auto node_elem = [&](int node, int e) -> double {
+            return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[9 * node + (e - HX_SZ)];
+        };
+        auto store_linv = [&](int k, const double* Lik) {
+            for (int e = l; e < LINV_SZ; e += 64) {
+                const int p = e / 15, q = e - 15 * p;
+                const int i = q <= p ? p : 13 - p, jj = q <= p ? q : q - (p + 1);
+                Linv_[(size_t)k * LINV_SZ + e] = Lik[14 * i + jj];
+            }
+        };
+        // ---- prologues ----
+        if (w == 1) {   // top producer: D_0, node 0 -> TA_0, TBm_0 (as factor_pipelined)
+            for (int e = l; e < 294; e += 64) Dt[e] = D_[e];
+            for (int e = l; e < NODE_SZ; e += 64) Hh[NODE_SZ + e] = node_elem(0, e);
+            ex.w_sync_lds();
+            for (int e = l; e < 196; e += 64) Hd[e] = hxi_entry(Hh + NODE_SZ, e / 14, e % 14);
+            ex.w_sync_lds();
+            ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
+            for (int q = l; q < 42; q += 64) {
+                const int i = q / 3, c = q - 3 * i;
+                const double* h = Hh + NODE_SZ + HX_SZ;
+                T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
+            }
+            ex.w_sync_lds();
+        }
+        if (w == 3) {   // bottom producer: tile K-1, nodes K-1 (slot 0) and K (slot 1), Bp of tile K-2, dense Hxi_K
+            dcptr Dk = D_ + (size_t)(K - 1) * 294;
+            for (int e = l; e < 294; e += 64) Dt[e] = Dk[e];
+            for (int e = l; e < NODE_SZ; e += 64) { Hh[e] = node_elem(K - 1, e); Hh[NODE_SZ + e] = node_elem(K, e); }
+            for (int q = l; q < 42; q += 64) Bp[q] = D_[(size_t)(K - 2) * 294 + 14 * 17 + q];
+            ex.w_sync_lds();
+            for (int e = l; e < 196; e += 64) Hd[196 + e] = hxi_entry(Hh + NODE_SZ, e / 14, e % 14);   // parity 1 = "step -1"
+            ex.w_sync_lds();
+        }
+        const int nsteps = (m > nb ? m : nb) + 1;
+        for (int t = 0; t < nsteps; t++) {
+            if (w == 1 && t <= m) {
+                // ---- top producer, node k = t: Sd_k; So_k for k < m ----
+                const int k = t;
+                double* Sdk = Sd + 196 * (k & 1); double* Sok = So + 196 * (k & 1);
+                double pre[5];
+                dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
+                SCVX_UNROLL
+                for (int q = 0; q < 5; q++) { const int e = l + 64 * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
+                for (int e = l; e < NODE_SZ; e += 64) { Hh[e] = Hh[NODE_SZ + e]; }
+                ex.w_sync_lds();
+                for (int e = l; e < NODE_SZ; e += 64) Hh[NODE_SZ + e] = node_elem(k + 1, e);
+                ex.w_sync_lds();
+                for (int e = l; e < 196 + 42; e += 64) {
+                    if (e < 196) {
+                        const int i = e / 14, j = e - 14 * i;
+                        const double h = hxi_entry(Hh + NODE_SZ, i, j);
+                        Hd[e] = h;
+                        Sdk[e] = h + (i == j ? hnui_ : 0.0);
+                    } else {
+                        const int q = e - 196, i = q / 3, c = q - 3 * i;
+                        const double* h = Hh + NODE_SZ + HX_SZ;
+                        T[TS * i + 17 + c] = Dt[14 * 17 + i] * h[c] + Dt[14 * 18 + i] * h[3 + c] + Dt[14 * 19 + i] * h[6 + c];
+                    }
+                }
+                ex.w_sync_lds();
+                ex.w_tile_gemm(Sdk, 14, 1, T, TS, 1, Dt, 14, 1, 20, 1.0, true);
+                if (k < m) {
+                    for (int q = l; q < 42; q += 64) Bp[q] = Dt[14 * 17 + q];
+                    ex.w_sync_lds();
+                    SCVX_UNROLL
+                    for (int q = 0; q < 5; q++) { const int e = l + 64 * q; if (e < 294) Dt[e] = pre[q]; }
+                    ex.w_sync_lds();
+                    ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
+                    for (int q = l; q < 42; q += 64) {
+                        const int i = q / 3, c = q - 3 * i;
+                        const double* h = Hh + NODE_SZ + HX_SZ;
+                        T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
+                    }
+                    ex.w_sync_lds();
+                    for (int e = l; e < 196; e += 64) {
+                        const int i = e / 14, j = e - 14 * i;
+                        Sok[e] = -T[TS * i + j] + T[TS * i + 14] * Bp[j] + T[TS * i + 15] * Bp[14 + j] + T[TS * i + 16] * Bp[28 + j];
+                    }
+                }
+                ex.w_sync_lds();
+            }
+            if (w == 0 && t >= 1 && t <= m) {
+                // ---- top chain, node k = t - 1 < m ----
+                const int k = t - 1;
+                double* M = Sd + 196 * (k & 1); const double* Sok = So + 196 * (k & 1);
+                double* Lik = Li + 196 * (k & 1);
+                const double* Wpm = Wp + 196 * ((k + 2) % 3);   // Wb[k-1]
+                if (k > 0) { ex.w_tile_gemm(M, 14, 1, Wpm, 14, 1, Wpm, 1, 14, 14, -1.0, true); ex.w_sync_lds(); }
+                ok = ex.w_chol_inv14(M, Lik) && ok;
+                ex.w_sync_lds();
+                ex.w_tile_gemm(Wp + 196 * (k % 3), 14, 1, Sok, 14, 1, Lik, 1, 14, 14, 1.0, false);   // Wb_k = So_k L_k^-T (k < m: always needed)
+                store_linv(k, Lik);
+                if (k > 0) {
+                    ex.w_tile_gemm(Mq, 1, 14, Lik, 14, 1, Wpm, 14, 1, 14, -1.0, false);
+                    ex.w_sync_lds();
+                    for (int e = l; e < 196; e += 64) Nf_[(size_t)k * 196 + e] = Mq[e];
+                }
+                ex.w_sync_lds();
+            }
+            if (w == 3 && t < nb) {
+                // ---- bottom producer, node k = K-1-t: Sd_k and So_{k-1} ----
+                const int u = t, k = K - 1 - u;
+                double* Sdk = Sd + 196 * (u & 1); double* Sok = So + 196 * (u & 1);
+                double* Hd0 = Hd + 196 * (u & 1);            // dense Hxi_k
+                const double* Hd1 = Hd + 196 * ((u + 1) & 1);   // dense Hxi_{k+1}: the previous step's Hd0
+                // the next step's inputs into registers: tile k-1, node k-1, Bp of tile k-2 (indices clamped at the end of the half)
+                const int kn = k - 1 > m ? k - 1 : k, kb2 = kn - 1;
+                double pre[5];
+                dcptr Dn = D_ + (size_t)kn * 294;
+                SCVX_UNROLL
+                for (int q = 0; q < 5; q++) { const int e = l + 64 * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
+                const double hn = l < NODE_SZ ? node_elem(kn, l) : 0.0;
+                const double bpn = l < 42 ? (double)D_[(size_t)kb2 * 294 + 14 * 17 + l] : 0.0;
+                for (int e = l; e < 196; e += 64) {
+                    const int i = e / 14, j = e - 14 * i;
+                    Hd0[e] = hxi_entry(Hh, i, j);
+                    Sdk[e] = Hd1[e] + (i == j ? hnui_ : 0.0);
+                }
+                ex.w_sync_lds();
+                ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd0, 14, 1, 14, 1.0, false);     // TA_k = A_k Hxi_k
+                for (int q = l; q < 84; q += 64) {
+                    const bool pls = q >= 42;
+                    const int qq = pls ? q - 42 : q, i = qq / 3, c = qq - 3 * i;
+                    const double* h = Hh + (pls ? NODE_SZ : 0) + HX_SZ;            // Hui_k for TBm_k, Hui_{k+1} for TBp_k
+                    const int c0 = pls ? 17 : 14;
+                    T[TS * i + c0 + c] = Dt[14 * c0 + i] * h[c] + Dt[14 * (c0 + 1) + i] * h[3 + c] + Dt[14 * (c0 + 2) + i] * h[6 + c];
+                }
+                ex.w_sync_lds();
+                ex.w_tile_gemm(Sdk, 14, 1, T, TS, 1, Dt, 14, 1, 20, 1.0, true);
+                for (int e = l; e < 196; e += 64) {
+                    const int i = e / 14, j = e - 14 * i;
+                    Sok[e] = -T[TS * i + j] + T[TS * i + 14] * Bp[j] + T[TS * i + 15] * Bp[14 + j] + T[TS * i + 16] * Bp[28 + j];   // So_{k-1}
+                }
+                ex.w_sync_lds();
+                // rotate: node k becomes "k+1" of the next step, the prefetched tile / node / Bp move in
+                if (l < NODE_SZ) { Hh[NODE_SZ + l] = Hh[l]; }
+                ex.w_sync_lds();
+                if (l < NODE_SZ) Hh[l] = hn;
+                if (l < 42) Bp[l] = bpn;
+                SCVX_UNROLL
+                for (int q = 0; q < 5; q++) { const int e = l + 64 * q; if (e < 294) Dt[e] = pre[q]; }
+                ex.w_sync_lds();
+            }
+            if (w == 2 && t >= 1 && t <= nb) {
+                // ---- bottom chain, step v = t - 1, node k = K-1-v > m ----
+                const int v = t - 1, k = K - 1 - v;
+                double* M = Sd + 196 * (v & 1); const double* Sok = So + 196 * (v & 1);   // So_{k-1}
+                double* Lik = Li + 196 * (v & 1);
+                const double* Wpm = Wp + 196 * ((v + 2) % 3);   // Wb'_{k+1}
+                if (v > 0) { ex.w_tile_gemm(M, 14, 1, Wpm, 14, 1, Wpm, 1, 14, 14, -1.0, true); ex.w_sync_lds(); }
+                ok = ex.w_chol_inv14(M, Lik) && ok;
+                ex.w_sync_lds();
+                ex.w_tile_gemm(Wp + 196 * (v % 3), 14, 1, Sok, 1, 14, Lik, 1, 14, 14, 1.0, false);   // Wb'_k = So_{k-1}' L_k^-T
+                store_linv(k, Lik);
+                if (v > 0) {   // N'_k = -L_k^-1 Wb'_{k+1}, untransposed, into slot k + 1
+                    ex.w_tile_gemm(Mq, 14, 1, Lik, 14, 1, Wpm, 14, 1, 14, -1.0, false);
+                    ex.w_sync_lds();
+                    for (int e = l; e < 196; e += 64) Nf_[(size_t)(k + 1) * 196 + e] = Mq[e];
+                }
+                ex.w_sync_lds();
+            }
+            ex.sync();
+        }
+        // ---- the middle node: both corrections, its two coupling tiles ----
+        if (w == 0) {
+            double* sc2 = ex.pipe_scratch2();
+            const double* WbB = sc2 + 784 + 196 * ((nb - 1) % 3);    // Wb'_{m+1}: the bottom chain's last coupling tile
+            const double* WbT = Wp + 196 * ((m - 1) % 3);            // Wb_{m-1}
+            double* M = Sd + 196 * (m & 1);
+            double* Lik = Li + 196 * (m & 1);
+            ex.w_tile_gemm(M, 14, 1, WbT, 14, 1, WbT, 1, 14, 14, -1.0, true);
+            ex.w_sync_lds();
+            ex.w_tile_gemm(M, 14, 1, WbB, 14, 1, WbB, 1, 14, 14, -1.0, true);
+            ex.w_sync_lds();
+            ok = ex.w_chol_inv14(M, Lik) && ok;
+            ex.w_sync_lds();
+            store_linv(m, Lik);
+            ex.w_tile_gemm(Mq, 1, 14, Lik, 14, 1, WbT, 14, 1, 14, -1.0, false);     // N_m, transposed, slot m
+            ex.w_sync_lds();
+            for (int e = l; e < 196; e += 64) Nf_[(size_t)m * 196 + e] = Mq[e];
+            ex.w_sync_lds();
+            ex.w_tile_gemm(Mq, 14, 1, Lik, 14, 1, WbB, 14, 1, 14, -1.0, false);     // N'_m, untransposed, slot m + 1
+            ex.w_sync_lds();
+            for (int e = l; e < 196; e += 64) Nf_[(size_t)(m + 1) * 196 + e] = Mq[e];
+        }
+        return ex.all(ok);
+    }
+
     // ---- factorisation for the current scaling (Wv, Wbeta) ----
     // with_pred: gx holds the (masked) predictor right-hand side and ry the equality residual; their banded solution
     // [Hb E'; E 0][dw; dy] = [gx; -ry] is produced alongside the three border systems (dw, dy), so the predictor's
@@ -1465,6 +1708,9 @@ struct Solver {
         constexpr int TS = 22;          // row stride of T (22: conflict-free fragment reads; 20 would be 2-way)
         bool ok = true;
         if constexpr (Ex::kPipelineFactor) {
+            if constexpr (Ex::kTwisted) {
+                ok = twisted() ? factor_twisted() : factor_pipelined();
+            } else
             ok = factor_pipelined();   // two wavefronts: Schur-block assembly one segment ahead of the Cholesky chain
         } else {
         // All 14x14xK products below go through ex.tile_gemm: FP64 MFMA (v_mfma_f64_16x16x4) on the device — one A and
