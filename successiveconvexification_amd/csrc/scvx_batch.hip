@@ -39,14 +39,14 @@ namespace scvx {
 __shared__ __attribute__((aligned(16))) double g_socp_lds[1552];
 // tiles of the two-wavefront factorisation pipeline (multi-wavefront kernels only: a kernel that never references the
 // symbol does not get the allocation)
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 196 + 8];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 3 * 196 + 8];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
 #ifndef SCVX_K4_PIPELINE
 #define SCVX_K4_PIPELINE 1
 #endif
 // second tile set of the TWO-ENDED factorisation (four-wavefront blocks only: wavefronts 2 / 3 eliminate the bottom half of
 // the chain upwards while 0 / 1 eliminate the top half downwards); a separate symbol so that the two-wavefront kernel, which
 // never references it, keeps its LDS footprint (4 blocks per CU)
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds2[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 2 * 196 + 8];
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds2[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 3 * 196 + 8];
 #ifndef SCVX_K4_TWISTED
 #define SCVX_K4_TWISTED 1
 #endif

@@ -1375,6 +1375,7 @@ struct Solver {
         double* Bp = T + 308;            // producer: Bp of the neighbouring tile
         double* Hh = Bp + 42;            // producer: node inverses (two slots)
         double* Hd = Hh + 2 * NODE_SZ;   // producer: dense Hxi (bottom: two of them, by step parity)
+        double* Mp = Hd + 392;           // producer: N tile of the node the chain finished one step ago
         constexpr int TS = 22;
         bool ok = true;
         auto node_elem = [&](int node, int e) -> double {
@@ -1386,6 +1387,21 @@ struct Solver {
                 const int i = q <= p ? p : 13 - p, jj = q <= p ? q : q - (p + 1);
                 Linv_[(size_t)k * LINV_SZ + e] = Lik[14 * i + jj];
             }
+        };
+        // the coupling tiles are formed one step behind the chain, by the assembly wavefront of the half (which has the slack):
+        // top node j: N_j = -L_j^-1 Wb_{j-1}, transposed, slot j;  bottom step v (node k): N'_k = -L_k^-1 Wb'_{k+1}, slot k + 1
+        auto post_top = [&](int j) {
+            ex.w_tile_gemm(Mp, 1, 14, Li + 196 * (j & 1), 14, 1, Wp + 196 * ((j + 2) % 3), 14, 1, 14, -1.0, false);
+            ex.w_sync_lds();
+            for (int e = l; e < 196; e += 64) Nf_[(size_t)j * 196 + e] = Mp[e];
+            ex.w_sync_lds();
+        };
+        auto post_bot = [&](int v) {
+            const int k = K - 1 - v;
+            ex.w_tile_gemm(Mp, 14, 1, Li + 196 * (v & 1), 14, 1, Wp + 196 * ((v + 2) % 3), 14, 1, 14, -1.0, false);
+            ex.w_sync_lds();
+            for (int e = l; e < 196; e += 64) Nf_[(size_t)(k + 1) * 196 + e] = Mp[e];
+            ex.w_sync_lds();
         };
         // ---- prologues ----
         if (w == 1) {   // top producer: D_0, node 0 -> TA_0, TBm_0 (as factor_pipelined)
@@ -1470,13 +1486,9 @@ struct Solver {
                 ex.w_sync_lds();
                 ex.w_tile_gemm(Wp + 196 * (k % 3), 14, 1, Sok, 14, 1, Lik, 1, 14, 14, 1.0, false);   // Wb_k = So_k L_k^-T (k < m: always needed)
                 store_linv(k, Lik);
-                if (k > 0) {
-                    ex.w_tile_gemm(Mq, 1, 14, Lik, 14, 1, Wpm, 14, 1, 14, -1.0, false);
-                    ex.w_sync_lds();
-                    for (int e = l; e < 196; e += 64) Nf_[(size_t)k * 196 + e] = Mq[e];
-                }
                 ex.w_sync_lds();
             }
+            if (w == 1 && t >= 3 && t - 2 <= m - 2) post_top(t - 2);
             if (w == 3 && t < nb) {
                 // ---- bottom producer, node k = K-1-t: Sd_k and So_{k-1} ----
                 const int u = t, k = K - 1 - u;
@@ -1532,15 +1544,14 @@ struct Solver {
                 ex.w_sync_lds();
                 ex.w_tile_gemm(Wp + 196 * (v % 3), 14, 1, Sok, 1, 14, Lik, 1, 14, 14, 1.0, false);   // Wb'_k = So_{k-1}' L_k^-T
                 store_linv(k, Lik);
-                if (v > 0) {   // N'_k = -L_k^-1 Wb'_{k+1}, untransposed, into slot k + 1
-                    ex.w_tile_gemm(Mq, 14, 1, Lik, 14, 1, Wpm, 14, 1, 14, -1.0, false);
-                    ex.w_sync_lds();
-                    for (int e = l; e < 196; e += 64) Nf_[(size_t)(k + 1) * 196 + e] = Mq[e];
-                }
                 ex.w_sync_lds();
             }
+            if (w == 3 && t >= 3 && t - 2 <= nb - 1) post_bot(t - 2);
             ex.sync();
         }
+        // the coupling tiles of the last node of each half, beside the middle node's factorisation
+        if (w == 1 && m - 1 >= 1) post_top(m - 1);
+        if (w == 3 && nb - 1 >= 1 && nb - 1 > nsteps - 3) post_bot(nb - 1);
         // ---- the middle node: both corrections, its two coupling tiles ----
         if (w == 0) {
             double* sc2 = ex.pipe_scratch2();
