@@ -1254,6 +1254,7 @@ struct Solver {
             ex.w_sync_lds();
         }
         const int PW = ex.nlanes() > 128 ? 2 : 1;   // wavefront of the post stage: an idle one if the block has more than two
+        double hnext = (w == 1 && l < NODE_SZ) ? node_elem(1, l) : 0.0;   // the assembly wavefront keeps the next node's inverses one step ahead
         for (int t = 0; t <= K + 1; t++) {
             if (w == 1 && t < K) {
                 const int k = t;
@@ -1266,7 +1267,8 @@ struct Solver {
                 for (int q = 0; q < 5; q++) { const int e = l + 64 * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
                 for (int e = l; e < NODE_SZ; e += 64) { Hh[e] = Hh[NODE_SZ + e]; }
                 ex.w_sync_lds();
-                for (int e = l; e < NODE_SZ; e += 64) Hh[NODE_SZ + e] = node_elem(k + 1, e);
+                if (l < NODE_SZ) Hh[NODE_SZ + l] = hnext;                          // node k + 1, requested a step ago
+                hnext = l < NODE_SZ ? node_elem(k + 2 <= K ? k + 2 : K, l) : 0.0;   // node k + 2 for the next step
                 ex.w_sync_lds();
                 for (int e = l; e < 196 + 42; e += 64) {
                     if (e < 196) {
@@ -1428,6 +1430,7 @@ struct Solver {
             ex.w_sync_lds();
         }
         const int nsteps = (m > nb ? m : nb) + 1;
+        double hnext = (w == 1 && l < NODE_SZ) ? node_elem(1, l) : 0.0;   // top assembly: the next node's inverses one step ahead
         for (int t = 0; t < nsteps; t++) {
             if (w == 1 && t <= m) {
                 // ---- top producer, node k = t: Sd_k; So_k for k < m ----
@@ -1439,7 +1442,8 @@ struct Solver {
                 for (int q = 0; q < 5; q++) { const int e = l + 64 * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
                 for (int e = l; e < NODE_SZ; e += 64) { Hh[e] = Hh[NODE_SZ + e]; }
                 ex.w_sync_lds();
-                for (int e = l; e < NODE_SZ; e += 64) Hh[NODE_SZ + e] = node_elem(k + 1, e);
+                if (l < NODE_SZ) Hh[NODE_SZ + l] = hnext;                          // node k + 1, requested a step ago
+                hnext = l < NODE_SZ ? node_elem(k + 2 <= K ? k + 2 : K, l) : 0.0;   // node k + 2 for the next step
                 ex.w_sync_lds();
                 for (int e = l; e < 196 + 42; e += 64) {
                     if (e < 196) {
