@@ -391,7 +391,8 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t wo
 #endif
     }
 #if defined(SCVX_IPM_PROF)
-    if (b == 0 && threadIdx.x == 64) for (int i = 0; i < 32; i++) work[32 + i] = S.prof[i];  // ... and of its second wavefront
+    if (b == 0 && threadIdx.x > 0 && (threadIdx.x & 63) == 0 && threadIdx.x < 256)
+        for (int i = 0; i < 32; i++) work[32 * (threadIdx.x >> 6) + i] = S.prof[i];  // ... and of its other wavefronts
 #endif
 }
 
@@ -1118,7 +1119,7 @@ int scvx_batch_get_solver_stats(scvx_batch* b, int32_t* status, int32_t* iters, 
 #if defined(SCVX_IPM_PROF)
 int scvx_debug_ipm_prof(scvx_batch* b, double* out32) {
     (void)hipStreamSynchronize(b->ctx->stream);
-    return hipMemcpy(out32, b->work, 64 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;   // out32: 64 doubles (wavefront 0, wavefront 1)
+    return hipMemcpy(out32, b->work, 128 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;   // out32: 128 doubles (wavefronts 0..3)
 }
 #endif
 

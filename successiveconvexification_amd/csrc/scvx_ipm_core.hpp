@@ -1435,6 +1435,7 @@ struct Solver {
             if (w == 1 && t <= m) {
                 // ---- top producer, node k = t: Sd_k; So_k for k < m ----
                 const int k = t;
+                SCVX_TS(ta_);
                 double* Sdk = Sd + 196 * (k & 1); double* Sok = So + 196 * (k & 1);
                 double pre[5];
                 dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
@@ -1478,10 +1479,12 @@ struct Solver {
                     }
                 }
                 ex.w_sync_lds();
+                SCVX_TE(ta_, 24);
             }
             if (w == 0 && t >= 1 && t <= m) {
                 // ---- top chain, node k = t - 1 < m ----
                 const int k = t - 1;
+                SCVX_TS(tb0_);
                 double* M = Sd + 196 * (k & 1); const double* Sok = So + 196 * (k & 1);
                 double* Lik = Li + 196 * (k & 1);
                 const double* Wpm = Wp + 196 * ((k + 2) % 3);   // Wb[k-1]
@@ -1491,11 +1494,13 @@ struct Solver {
                 ex.w_tile_gemm(Wp + 196 * (k % 3), 14, 1, Sok, 14, 1, Lik, 1, 14, 14, 1.0, false);   // Wb_k = So_k L_k^-T (k < m: always needed)
                 store_linv(k, Lik);
                 ex.w_sync_lds();
+                SCVX_TE(tb0_, 24);
             }
-            if (w == 1 && t >= 3 && t - 2 <= m - 2) post_top(t - 2);
+            if (w == 1 && t >= 3 && t - 2 <= m - 2) { SCVX_TS(tp_); post_top(t - 2); SCVX_TE(tp_, 26); }
             if (w == 3 && t < nb) {
                 // ---- bottom producer, node k = K-1-t: Sd_k and So_{k-1} ----
                 const int u = t, k = K - 1 - u;
+                SCVX_TS(tc_);
                 double* Sdk = Sd + 196 * (u & 1); double* Sok = So + 196 * (u & 1);
                 double* Hd0 = Hd + 196 * (u & 1);            // dense Hxi_k
                 const double* Hd1 = Hd + 196 * ((u + 1) & 1);   // dense Hxi_{k+1}: the previous step's Hd0
@@ -1536,10 +1541,12 @@ struct Solver {
                 SCVX_UNROLL
                 for (int q = 0; q < 5; q++) { const int e = l + 64 * q; if (e < 294) Dt[e] = pre[q]; }
                 ex.w_sync_lds();
+                SCVX_TE(tc_, 24);
             }
             if (w == 2 && t >= 1 && t <= nb) {
                 // ---- bottom chain, step v = t - 1, node k = K-1-v > m ----
                 const int v = t - 1, k = K - 1 - v;
+                SCVX_TS(td_);
                 double* M = Sd + 196 * (v & 1); const double* Sok = So + 196 * (v & 1);   // So_{k-1}
                 double* Lik = Li + 196 * (v & 1);
                 const double* Wpm = Wp + 196 * ((v + 2) % 3);   // Wb'_{k+1}
@@ -1549,15 +1556,19 @@ struct Solver {
                 ex.w_tile_gemm(Wp + 196 * (v % 3), 14, 1, Sok, 1, 14, Lik, 1, 14, 14, 1.0, false);   // Wb'_k = So_{k-1}' L_k^-T
                 store_linv(k, Lik);
                 ex.w_sync_lds();
+                SCVX_TE(td_, 24);
             }
-            if (w == 3 && t >= 3 && t - 2 <= nb - 1) post_bot(t - 2);
+            if (w == 3 && t >= 3 && t - 2 <= nb - 1) { SCVX_TS(tq_); post_bot(t - 2); SCVX_TE(tq_, 26); }
+            SCVX_TS(tbar_);
             ex.sync();
+            SCVX_TE(tbar_, 28);
         }
         // the coupling tiles of the last node of each half, beside the middle node's factorisation
         if (w == 1 && m - 1 >= 1) post_top(m - 1);
         if (w == 3 && nb - 1 >= 1 && nb - 1 > nsteps - 3) post_bot(nb - 1);
         // ---- the middle node: both corrections, its two coupling tiles ----
         if (w == 0) {
+            SCVX_TS(tm_);
             double* sc2 = ex.pipe_scratch2();
             const double* WbB = sc2 + 784 + 196 * ((nb - 1) % 3);    // Wb'_{m+1}: the bottom chain's last coupling tile
             const double* WbT = Wp + 196 * ((m - 1) % 3);            // Wb_{m-1}
@@ -1577,6 +1588,7 @@ struct Solver {
             ex.w_tile_gemm(Mq, 14, 1, Lik, 14, 1, WbB, 14, 1, 14, -1.0, false);     // N'_m, untransposed, slot m + 1
             ex.w_sync_lds();
             for (int e = l; e < 196; e += 64) Nf_[(size_t)(m + 1) * 196 + e] = Mq[e];
+            SCVX_TE(tm_, 27);
         }
         return ex.all(ok);
     }

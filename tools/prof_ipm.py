@@ -10,7 +10,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 c = IntegratorCache(sp.base_prob_scaled)
 b = ScvxBatch(c, B).init(bench.disperse_ics(sp.base_prob_scaled, 0, B, 20261004))
 b.socp_solve()
-out = np.zeros(64)
+out = np.zeros(128)
 _lib.lib().scvx_debug_ipm_prof.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 _lib.lib().scvx_debug_ipm_prof(b.handle, out.ctypes.data_as(C.POINTER(C.c_double)))
 st, its, merit, pobj = b.solver_stats()
@@ -20,7 +20,10 @@ print("ipm iters traj0:", its[0], " total Mcycles(100MHz ticks?) %.1f" % (tot/1e
 for k,v in names.items(): print("%-14s %10.0f  %5.1f%%" % (v, out[k], 100*out[k]/tot))
 
 if out[32:].any():
-    print("two-wavefront factorisation pipeline (cycles per segment-step of one factorisation; wavefront 0 = chain, 1 = assembly):")
-    nf = max(int(its[0]) + 1, 1) * (50 + 1)
-    for k, (a, b) in {24: ("copy + pivot update", "stage node + TBp"), 25: ("chol_inv14", "Sd gemm"), 26: ("Linv store, Nf", "TA, TBm, So of k+1"), 27: ("Wb gemm", "-"), 28: ("barrier wait", "barrier wait")}.items():
-        print("  slot %d  w0 %-22s %8.0f   w1 %-22s %8.0f" % (k, a, out[k] / nf, b, out[32 + k] / nf))
+    nf = max(int(its[0]) + 1, 1)
+    print("factorisation pipeline, cycles per factorisation by wavefront (slot 24 = own stage, 26 = coupling tiles, 27 = middle node, 28 = barrier):")
+    for wv in range(4):
+        o = out[32 * wv:32 * wv + 32]
+        if o[24:29].any():
+            print("  wavefront %d: stage %8.0f  tiles %8.0f  middle %8.0f  barrier %8.0f   (per step of 26: %5.0f / %5.0f / - / %5.0f)" % (
+                wv, o[24] / nf, o[26] / nf, o[27] / nf, o[28] / nf, o[24] / nf / 26, o[26] / nf / 26, o[28] / nf / 26))
