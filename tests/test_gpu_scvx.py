@@ -528,6 +528,41 @@ def test_other_horizons_match_twin_and_independent_oracle(K):
     assert np.all(st2 == 1)
 
 
+@pytest.mark.parametrize("K", [4, 8, 9, 31])
+def test_two_ended_factorisation_at_odd_and_small_horizons(K, monkeypatch):
+    """The four-wavefront executor factorises and solves the block chain from both ends (middle node K // 2; below 8 nodes it
+    keeps the one-ended form): odd horizons put one more node in the bottom half and finish its last coupling tile beside
+    the middle node.  Same solves as the one-wavefront executor and as the CPU twin."""
+    from dataclasses import replace
+    from oracle import model, port
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    po = replace(model.base_prob_scaled(), K=K)
+    pp = replace(sp.base_prob_scaled, K=K)
+    B = 3
+    ic = model.disperse_ics(po, B, 20261005)
+    res = {}
+    for waves in ("1", "4"):
+        monkeypatch.setenv("SCVX_K4_WAVES", waves)
+        c = IntegratorCache(pp, npts=4)
+        b = ScvxBatch(c, B).init(ic)
+        xb, ub, sg = b.trajectory()
+        e, d = b.linearization()
+        x, u, s, nu = b.socp_solve()
+        st, its, merit, pobj = b.solver_stats()
+        assert np.all((st == 0) | (st == 4)), (waves, st, merit)
+        res[waves] = (x, u, s, nu, its, pobj, st)
+        b.close(); c.close()
+    a, r = res["4"], res["1"]
+    assert np.array_equal(a[6], r[6]) and np.abs(a[4] - r[4]).max() <= 1
+    assert np.abs(a[5] - r[5]).max() < 1e-8 * np.abs(r[5]).max()
+    for i in range(4):
+        assert np.abs(a[i] - r[i]).max() < 5e-6
+    tw = port.socp(po, xb, ub, e, d, 100.0, ic)
+    assert np.abs(a[0] - (xb + tw["dx"])).max() < 5e-6 and np.abs(a[1] - (ub + tw["du"])).max() < 5e-6
+
+
 def test_flyable_problem_converges():
     """A variant of the sample problem with enough propellant (the reference's own sample never converges: 71 kg):
     every trajectory reaches SCVX_ST_CONVERGED (||nu|| <= nuTol and dJ <= delTol, rocketland.jl:436) with nu driven to
