@@ -633,7 +633,7 @@ int split_views(scvx_batch* b, const double* rec, double* x, double* u, double* 
 // trajectory than that starts a second round of blocks (measured: B = 1,024 -> 1,152 with 2 wavefronts 9.9 -> 12.8 ms).
 // B-sweep: profiles/r02_bsweep_occ2.md; SCVX_K4_WAVES = 1 / 2 / 4 forces.
 int socp_waves(int B, int num_cus) {
-    if (const char* v = std::getenv("SCVX_K4_WAVES")) {
+    if (const char* v = std::getenv("SCVX_K4_WAVES"); v && *v) {   // an empty value means "not set"
         const int w = std::atoi(v);
         return w >= 4 ? 4 : (w >= 2 ? 2 : 1);   // 8 and 16 wavefronts per trajectory were measured: no faster than 4 at B = 1..64 (barrier cost)
     }
