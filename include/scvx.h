@@ -86,9 +86,9 @@ typedef struct scvx_solver_opts {
     double tol;        /* primal / dual residual and relative-gap tolerance (default 1e-8)                     */
     double accept_tol; /* a solve that stops on its numerical floor with tol <= merit < accept_tol is reported */
                        /* as solver status 4 "almost optimal" and still feeds the trust-region test (MOI's     */
-                       /* ALMOST_OPTIMAL band; default 1e-6).  accept_tol = tol reproduces the reference, which */
-                       /* errors on anything but OPTIMAL (rocketland.jl:273-276): such solves become           */
-                       /* SCVX_ST_SOLVER.                                                                       */
+                       /* ALMOST_OPTIMAL band).  DEFAULT = tol (1e-8): the reference errors on anything but     */
+                       /* OPTIMAL (rocketland.jl:273-276), so such solves become SCVX_ST_SOLVER; a wider band   */
+                       /* (e.g. 1e-6) is opt-in.                                                                */
     int32_t reuse_inactive_tr; /* 0 (default): every solve_step solves its subproblem, as the reference does.  1: after a   */
                        /* REJECTED step (same about / dynam, radius halved, rocketland.jl:299-301) the conic solve is skipped  */
                        /* when the optimum just found lies strictly inside the new radius -- the radius row is then inactive  */
@@ -232,7 +232,11 @@ int scvx_batch_get_scalars(scvx_batch *b, double *rk, double *cost, int32_t *ite
 int scvx_batch_set_scalars(scvx_batch *b, const double *rk, const double *cost, const int32_t *iter);
 /* per-trajectory flags, the rest of a checkpoint (trajectory + scalars + flags restore a batch after
  * scvx_batch_init with the same ic): status as above; active = 0 once failed (never stepped again);
- * live = active and not yet converged inside scvx_solve.  Any pointer may be NULL. */
+ * live = active and not yet converged inside scvx_solve.  Any pointer may be NULL.
+ * The conic solver's own warm-start state is NOT part of a checkpoint: scvx_batch_set_scalars / set_flags / set_trajectory
+ * drop it, so the first solve of a restored (or edited) batch starts cold.  After an ACCEPTED step that is what an
+ * uninterrupted run does too (bit-identical continuation); after a REJECTED step the uninterrupted run would have
+ * warm-started, so the continuation agrees to the solver tolerance, not bit for bit. */
 int scvx_batch_get_flags(scvx_batch *b, int32_t *status, int32_t *active, int32_t *live);
 int scvx_batch_set_flags(scvx_batch *b, const int32_t *status, const int32_t *active, const int32_t *live);
 /* last SOCP solve, per trajectory: solver status (0 optimal: merit < tol; 4 almost optimal: numerical floor with
@@ -253,6 +257,9 @@ int scvx_batch_get_profile(scvx_batch *b, double *ms, int64_t *steps);
  * context's stream.  Bootstrap as with NCCL: rank 0 calls scvx_comm_unique_id, the host language ships the
  * SCVX_COMM_ID_BYTES to every rank by whatever channel it has, every rank calls scvx_comm_create. */
 #define SCVX_COMM_ID_BYTES 128
+/* Non-collective: 0 when the RCCL library can be bound in this process (SCVX_RCCL_LIB overrides the soname), else
+ * SCVX_ERR_COMM.  Ranks exchange this BEFORE scvx_comm_create, whose ncclCommInitRank blocks until every rank arrives. */
+int scvx_comm_probe(void);
 int scvx_comm_unique_id(void *id_out /* SCVX_COMM_ID_BYTES */);
 int scvx_comm_create(scvx_ctx *ctx, const void *unique_id, int rank, int world);
 int scvx_comm_destroy(scvx_ctx *ctx);

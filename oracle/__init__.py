@@ -19,7 +19,8 @@ Modules
     socp      the trust-region SOCP exactly as Rocketland.build_model assembles it
     ipm       primal-dual interior-point conic solver (the role Mosek/ECOS play in the reference)
     scvx      solve_step / solve_problem on top of the three
-    port      ctypes front-end of scvx_port.c — C twin of the device algorithm (RK4 + ADMM), the
+    port      ctypes front-end of scvx_port.cpp — C++ twin of the device algorithm (RK4 discretisation +
+              the structure-exploiting interior-point solver, same source as the kernel), the
               ``cpu_baseline`` of bench.py
 """
 import ctypes

@@ -20,7 +20,7 @@ class Consts(C.Structure):
                 ("wBi", C.c_double * 3), ("wBf", C.c_double * 3)]
 
 
-def consts(p: DescentProblem, tol=1e-8, max_iter=60, refine=6, accept=1e-6) -> Consts:
+def consts(p: DescentProblem, tol=1e-8, max_iter=60, refine=6, accept=0.0) -> Consts:
     c = Consts()
     c.K, c.max_iter, c.refine, c.tol, c.accept = p.K, max_iter, refine, tol, max(accept, tol)
     c.itan = 1.0 / np.tan(np.radians(p.gammaGs))       # rocketland.jl:63
@@ -37,7 +37,7 @@ def _p(a):
     return a.ctypes.data_as(_dp)
 
 
-def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, max_iter=60, refine=6, nthreads=0, accept=1e-6,
+def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, max_iter=60, refine=6, nthreads=0, accept=0.0,
          f32=False, work=None, warm=None, lin32=False):
     """Batched: xbar [B][K+1][14], ubar [B][K+1][3], endpoint [B][K][14], deriv [B][K][21][14], rk [B].
     Returns dict(dx, du, ds, nu, status, iters, merit, pobj)."""
@@ -68,7 +68,7 @@ def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, 
                 merit=info[:, 2], pobj=info[:, 3])
 
 
-def scvx_steps(p: DescentProblem, ic, steps, nsub=10, nthreads=0, tol=1e-8, accept=1e-6, max_iter=60, refine=6, f32=False,
+def scvx_steps(p: DescentProblem, ic, steps, nsub=10, nthreads=0, tol=1e-8, accept=0.0, max_iter=60, refine=6, f32=False,
                on_step=None, warm_start=False):
     """`steps` Rocketland.solve_step calls (rocketland.jl:226-321) on B dispersed trajectories, all on the host: the conic
     solve by the CPU twin of the device solver (scvx_port.cpp), discretisation and propagation by the C oracle

@@ -91,6 +91,7 @@ SIGNATURES = {
     "scvx_batch_get_flags": (C.c_int, [_vp, _ip, _ip, _ip]),
     "scvx_batch_set_flags": (C.c_int, [_vp, _ip, _ip, _ip]),
     "scvx_batch_get_solver_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
+    "scvx_comm_probe": (C.c_int, []),
     "scvx_comm_unique_id": (C.c_int, [_vp]),
     "scvx_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "scvx_comm_destroy": (C.c_int, [_vp]),

@@ -41,7 +41,7 @@ class ScvxBatch:
             self._L.scvx_solver_default_opts(C.byref(o))
             if tol is not None:
                 o.tol = tol
-                o.accept_tol = max(o.accept_tol, tol)
+                o.accept_tol = tol   # the default band is empty (accept_tol = tol), whatever tol is
             if max_iter is not None:
                 o.max_iter = max_iter
             if refine is not None:
@@ -216,4 +216,21 @@ class ScvxBatch:
 
 
 # ---- multi-GPU: see montecarlo.py (kept importable from here) -------------------------------------------
-from .montecarlo import gather_records as gather_trajectories, shard_range  # noqa: E402,F401
+from .montecarlo import gather_records, shard_range  # noqa: E402,F401
+
+
+def gather_trajectories(rec, group=None):
+    """All-gather of the per-rank trajectory records [B][n] over the (default) torch.distributed process group into
+    [world][B][n]; without an initialised group: [1][B][n].  Thin wrapper over montecarlo.gather_records."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return rec.unsqueeze(0).clone()
+    if group is None:
+        return gather_records(rec, dist=dist)
+
+    class _G:  # the module's collectives bound to `group`
+        is_initialized = staticmethod(dist.is_initialized)
+        get_world_size = staticmethod(lambda: dist.get_world_size(group))
+        all_gather_into_tensor = staticmethod(lambda o, i: dist.all_gather_into_tensor(o, i, group=group))
+        all_gather = staticmethod(lambda o, i: dist.all_gather(o, i, group=group))
+    return gather_records(rec, dist=_G)

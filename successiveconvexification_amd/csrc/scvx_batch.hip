@@ -477,8 +477,8 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
                                                        const double* __restrict__ info, double* __restrict__ traj,
                                                        double* __restrict__ rk, double* __restrict__ cost,
                                                        int* __restrict__ iter, int* __restrict__ status,
-                                                       const int* __restrict__ mask, int* __restrict__ active,
-                                                       int* __restrict__ live, double* __restrict__ out) {
+                                                       const int* mask /* may be `active` or `live` itself */, int* active,
+                                                       int* live, double* __restrict__ out) {
     const int b = blockIdx.x;
     if (b >= B) return;
     // not stepped by this call (failed earlier, or converged inside scvx_solve): status[b] keeps saying why and
@@ -739,7 +739,7 @@ int scvx_solver_default_opts(scvx_solver_opts* o) {
     o->max_iter = 60;
     o->refine = 6;
     o->tol = 1e-8;
-    o->accept_tol = 1e-6;
+    o->accept_tol = 1e-8;   // = tol: anything but OPTIMAL is an error, as in the reference (rocketland.jl:273-276); widen to opt in to status 4
     o->reuse_inactive_tr = 0;
     o->warm_start = 1;
     return SCVX_OK;
@@ -1096,6 +1096,9 @@ int scvx_batch_set_scalars(scvx_batch* b, const double* rk, const double* cost, 
     if (rk) SCVX_HIP(ctx, hipMemcpyAsync(b->rk, rk, (size_t)b->B * 8, hipMemcpyHostToDevice, ctx->stream));
     if (cost) SCVX_HIP(ctx, hipMemcpyAsync(b->cost, cost, (size_t)b->B * 8, hipMemcpyHostToDevice, ctx->stream));
     if (iter) SCVX_HIP(ctx, hipMemcpyAsync(b->iter, iter, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
+    // an edited / restored batch solves its next subproblem cold: the kept optimum (reuse_inactive_tr) and the warm-start
+    // iterate in the work slab belong to the state before the edit (ttr >= 1e300 disables both)
+    SCVX_HIP(ctx, hipMemsetAsync(b->ttr, 0x7f, (size_t)b->B * 8, ctx->stream));
     SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SCVX_OK;
 }
@@ -1169,6 +1172,7 @@ int scvx_batch_set_flags(scvx_batch* b, const int32_t* status, const int32_t* ac
     if (status) SCVX_HIP(ctx, hipMemcpyAsync(b->status, status, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
     if (active) SCVX_HIP(ctx, hipMemcpyAsync(b->active, active, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
     if (live) SCVX_HIP(ctx, hipMemcpyAsync(b->live, live, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
+    SCVX_HIP(ctx, hipMemsetAsync(b->ttr, 0x7f, (size_t)b->B * 8, ctx->stream));   // see scvx_batch_set_scalars
     SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SCVX_OK;
 }

@@ -6,6 +6,7 @@
 // library -- torch ships its own under the same soname -- gets THAT copy, so there are never two RCCL runtimes in one
 // address space, and libscvx_hip.so loads on a single-GPU box whether or not RCCL is installed.
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include "scvx_internal.hpp"
@@ -31,13 +32,23 @@ Rccl& rccl() {
 bool load_rccl() {
     Rccl& r = rccl();
     if (r.handle) return true;
+    // SCVX_RCCL_LIB names the one library to try (a site with its own build; tests point it at a missing file to see
+    // the failure path), otherwise the usual sonames
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (r.handle) break;
+    const char* forced = std::getenv("SCVX_RCCL_LIB");
+    const char* why = nullptr;
+    if (forced && *forced) {
+        r.handle = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.handle) why = dlerror();
+    } else {
+        for (const char* n : names) {
+            r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+            if (const char* e = dlerror()) why = e;   // dlerror() clears the message: one call per failure
+        }
     }
     if (!r.handle) {
-        r.err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+        r.err = std::string("RCCL not found: ") + (why ? why : "dlopen failed");
         return false;
     }
     r.GetUniqueId = (int (*)(void*))dlsym(r.handle, "ncclGetUniqueId");
@@ -64,6 +75,8 @@ constexpr int kNcclInt32 = 2, kNcclFloat64 = 8;   // ncclDataType_t values of rc
 }  // namespace
 
 extern "C" {
+
+int scvx_comm_probe(void) { return load_rccl() ? SCVX_OK : SCVX_ERR_COMM; }
 
 int scvx_comm_unique_id(void* id_out) {
     if (!id_out) return SCVX_ERR_ARG;

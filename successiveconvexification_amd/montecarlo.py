@@ -54,6 +54,12 @@ def bootstrap_comm(cache, dist, rank, world, lib=None):
     group) broadcasts its 128 bytes.  Returns None on success, else the reason the native communicator is unavailable
     (the caller then falls back to a torch all-gather and says so)."""
     L = lib if lib is not None else cache._L
+    # pre-flight, non-collective: ncclCommInitRank blocks until every rank has arrived, so a rank that cannot even bind
+    # the library must be known to all of them BEFORE anyone enters it
+    flags = [None] * world
+    dist.all_gather_object(flags, int(L.scvx_comm_probe()))
+    if any(f != 0 for f in flags):
+        return "RCCL not loadable on rank(s) %s" % [i for i, f in enumerate(flags) if f != 0]
     buf = (C.c_char * 128)()
     ok = 1
     if rank == 0:

@@ -33,6 +33,10 @@ def _worker(rank, world, port, batch, scaling, q):
     rec[:, 0] = np.arange(shard.lo, shard.hi)
     rec[:, 1:7] = shard.ic
     out = mc.gather_records(torch.tensor(rec), dist)
+    # the old public helper (rec, group=None) still gathers over the default group
+    from successiveconvexification_amd.batch import gather_trajectories
+    assert torch.equal(gather_trajectories(torch.tensor(rec)), out)
+    assert torch.equal(gather_trajectories(torch.tensor(rec), dist.group.WORLD), out)
     t, n = mc.reduce_clock(1.0 + rank, shard.B * 3, dist)
     # the native communicator cannot exist without a GPU: the bootstrap must say so on every rank, not hang
     class _Cache:  # what bootstrap_comm needs of an IntegratorCache
@@ -64,7 +68,7 @@ def test_two_rank_shard_and_gather(scaling, batch):
     from successiveconvexification_amd import montecarlo as mc, sample_problems as sp
     assert np.array_equal(flat[:, 1:7], mc.disperse_ics(sp.base_prob_scaled, 0, total, 20261004))  # same ICs as one big batch
     assert t == 2.0 and n == total * 3           # max over ranks of the clock, sum of the work
-    assert why is not None and ("unique_id" in why or "scvx_comm_create" in why)  # no GPU here: the bootstrap reports it, on every rank
+    assert why is not None and ("unique_id" in why or "scvx_comm_create" in why or "RCCL not loadable" in why)  # no GPU here: the bootstrap reports it, on every rank
 
 
 def test_strong_scaling_needs_divisible_batch():
@@ -75,3 +79,24 @@ def test_strong_scaling_needs_divisible_batch():
     assert (s.lo, s.hi, s.B, s.global_batch) == (3072, 4096, 1024, 8192)   # BASELINE configs[3]: 1024 per GPU at N = 8
     w = mc.Shard(sp.base_prob_scaled, 16, 1, 3, 8, "weak")
     assert (w.lo, w.hi, w.global_batch) == (48, 64, 128)
+
+
+def _rccl_missing_child(q):
+    import ctypes as C
+    os.environ["SCVX_RCCL_LIB"] = "/nonexistent/librccl-not-here.so"
+    from successiveconvexification_amd import _lib
+    L = _lib.lib()
+    buf = (C.c_char * 128)()
+    q.put((L.scvx_comm_probe(), L.scvx_comm_unique_id(buf)))
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """ADVICE r2: dlerror() was called twice (the second call returns NULL -> std::string(nullptr)).  With the library
+    forced to a missing file both entry points must return SCVX_ERR_COMM (-5) and the process must survive."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_missing_child, args=(q,))
+    p.start()
+    probe, uid = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and probe == -5 and uid == -5
