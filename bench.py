@@ -121,7 +121,9 @@ def cpu_baseline(npts, seed, steps, reps=5):
     OpenMP over trajectories) on a bounded sample of the SAME workload: `steps` solve_steps from create_initial (one
     Rocketland.solve_problem when steps = imax-1 = 14, the mix the device is timed on), median of `reps` repetitions,
     once on all host cores of this box's share and once single-threaded."""
+    import oracle
     from oracle import model, port
+    oracle.use_native(True)   # -O3 -march=native builds of the two oracle sources, compiled on this host (oracle/__init__.py)
     po = model.base_prob_scaled()
     cores = int(os.environ.get("SCVX_CPU_THREADS", min(host_cores(), 16)))  # one GPU's share of a pool host is 16 cores
 
@@ -138,7 +140,9 @@ def cpu_baseline(npts, seed, steps, reps=5):
     # ~100 solves/s per core: 8 trajectories per core x 14 steps ~ 1 s per repetition
     vall, tall, its = timed(8 * cores, cores)
     v1, t1, _ = timed(8, 1)
+    oracle.use_native(False)
     return {"value": vall, "unit": "traj-iter/s", "cores": int(cores), "kind": "port",
+            "flags": "gcc/g++ " + oracle.NATIVE_FLAGS + " (built on this host; the parity build of the same sources is -O2 -ffp-contract=off)",
             "single_thread": {"value": v1, "cores": 1, "sample": f"8 trajectories x {steps} solve_steps, median of {reps} reps of {t1:.1f} s"},
             "ipm_iters_mean": its,
             "sample": f"{8 * cores} dispersed trajectories x {steps} solve_steps from create_initial (same seed / law / step mix as "
@@ -320,13 +324,16 @@ def main():
     run(args.warmup, counter)
     barrier()
     batch.set_profiling(True)
+    batch.step_stats(reset=True)
     barrier()
+    first_timed = counter[0]
     t0 = time.perf_counter()
     run(args.steps, counter)
     barrier()
     elapsed = time.perf_counter() - t0
     prof, nprof = batch.profile()
     batch.set_profiling(False)
+    tstats = batch.step_stats(reset=True)   # what the timed region executed (rank 0's shard)
     st_f, act_f, _ = batch.flags()
     rec64 = batch.trajectory_record() if world == 1 and not args.no_traj_check else None   # for the f32_linearization leg
     done = B * args.steps  # every trajectory is stepped by every solve_step (failed ones are reported below, not hidden)
@@ -392,8 +399,8 @@ def main():
                             "%d steps%s" % (args.seed, "base_prob_aero normalised (lift_drag tables)" if args.aero else "base_prob normalised (exo)",
                                             period, " (disabled)" if args.no_reset else ""),
                 "K": K, "batch_per_gpu": B, "global_batch": shard.global_batch, "rk4_npts": args.npts,
-                "solver": "interior-point (NT scaling): optimal = merit < 1e-8; a solve that stops on its numerical floor "
-                          "below 1e-6 is reported as almost-optimal (solver status 4) and counted separately; the solve that "
+                "solver": "interior-point (NT scaling): optimal = merit < 1e-8, anything else freezes the trajectory as the "
+                          "reference's error() does (accept_tol = tol, the default); the solve that "
                           "follows a REJECTED step (same subproblem, radius halved) is warm-started from the previous solve's "
                           "iterate at merit 1e-4 while the radius stays inactive there, and still runs to 1e-8 "
                           "(cold_start_only = the same loop without it)",
@@ -401,7 +408,8 @@ def main():
                 "all_gather": gather_how,
             },
             "roofline": {
-                "kernel": "scvx::linearize_pcp_kernel (K1, the discretisation kernel SURVEY 8d names; linearize_pc_kernel at npts <= 2)", "bound": "hbm",
+                "kernel": "scvx::linearize_pcp_kernel (K1, the discretisation kernel SURVEY 8d names; linearize_pc_kernel at npts <= 2)",
+                "bound": "fp64" if args.npts >= 3 else "hbm",
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
@@ -412,6 +420,19 @@ def main():
                         "(12 kflop per segment per substep) / 78.6 TFLOP/s vector peak; traffic from PMC in profiles/" % args.npts,
             },
             "kernel_ms_per_step": {k: v / max(nprof, 1) for k, v in prof.items()},
+            "timed_region": {
+                "solve_step_indices": [first_timed, first_timed + args.steps - 1],
+                "indices_within_solve_problem": [(first_timed + i) % period for i in range(args.steps)] if not args.no_reset else None,
+                "period": period,
+                "traj_steps": int(tstats["traj_steps"]), "conic_solves": int(tstats["solves"]),
+                "ipm_iters_mean": tstats["ipm_iters"] / max(tstats["solves"], 1.0),
+                "warm_started_frac": tstats["warm_started"] / max(tstats["solves"], 1.0),
+                "skipped_solves_frac": tstats["skipped"] / max(tstats["traj_steps"], 1.0),
+                "rejected_frac": tstats["rejected"] / max(tstats["traj_steps"], 1.0),
+                "failed_steps": int(tstats["failed"]), "converged_steps": int(tstats["converged"]),
+                "note": "totals over the timed solve_steps of rank 0's shard (device-side counters, scvx_batch_get_step_stats): the "
+                        "throughput depends on this mix -- a step whose solves are warm-started (after a rejection) costs ~1/3 of a cold one",
+            },
             "roofline_socp": None if k4_ms <= 0 else {
                 "kernel": "scvx::socp_kernel (K4, the conic solve: 97 % of the step)", "bound": "hbm", "unit": "GB/s",
                 "peak": HBM_PEAK / 1e9, "avg_launch_ms": k4_ms,

@@ -245,6 +245,12 @@ int scvx_batch_set_flags(scvx_batch *b, const int32_t *status, const int32_t *ac
  * interior-point iterations, final merit max(pres, dres, relgap) of the returned iterate, its objective */
 int scvx_batch_get_solver_stats(scvx_batch *b, int32_t *status, int32_t *iters, double *merit, double *pobj);
 
+/* Running totals over every solve_step enqueued since the last call with reset != 0 (what a timed region really executed):
+ * out8 = {trajectory-steps, conic solves run, interior-point iterations summed over them, solves that were warm-started,
+ * solves skipped by reuse_inactive_tr, steps REJECTED, steps that failed (SOLVER / NONFINITE / INFEASIBLE), steps that ended
+ * CONVERGED}.  Synchronises the stream. */
+int scvx_batch_get_step_stats(scvx_batch *b, double *out8, int reset);
+
 /* ---- per-kernel device time of the solve_step chain (HIP events on the context's stream) ------ */
 int scvx_batch_set_profiling(scvx_batch *b, int enable);
 /* ms[5] = {socp (K4), propagate (K2), tr_update (K5), linearize (K1), glue (K3: candidate/unpack)}

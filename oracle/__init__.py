@@ -47,10 +47,49 @@ def build(force: bool = False) -> str:
     return so
 
 
+# ---- the same two sources built for SPEED on the host they run on: bench.py's cpu_baseline -------------------------------
+# The parity build above is -O2 -ffp-contract=off (bit-stable against the device's fused/unfused choices are irrelevant
+# there; it is the checker).  A CPU *baseline* built like that is a soft target, so the timed leg uses
+# -O3 -march=native with contraction allowed, compiled ON THE BOX THAT RUNS IT (the file name carries a hash of that CPU's
+# model and flags: a binary built elsewhere is never picked up).
+NATIVE_FLAGS = "-O3 -march=native -fopenmp -fPIC"
+_NATIVE = False
+
+
+def _cpu_tag() -> str:
+    import hashlib
+    try:
+        txt = open("/proc/cpuinfo").read()
+        keep = [l for l in txt.splitlines() if l.startswith(("model name", "flags"))][:2]
+    except OSError:
+        keep = []
+    return hashlib.sha1("|".join(keep).encode()).hexdigest()[:10]
+
+
+def build_native():
+    tag = _cpu_tag()
+    so = os.path.join(_HERE, f"liboracle_native_{tag}.so")
+    port = os.path.join(_HERE, f"liboracle_port_native_{tag}.so")
+    csrc = os.path.join(os.path.dirname(_HERE), "successiveconvexification_amd", "csrc")
+    deps = [os.path.join(csrc, f) for f in ("scvx_ipm_core.hpp", "scvx_threedof_core.hpp")]
+    if _stale(so, [os.path.join(_HERE, "scvx_oracle.c")]):
+        subprocess.check_call(["gcc", *NATIVE_FLAGS.split(), "-std=c11", "-shared", "-o", so, os.path.join(_HERE, "scvx_oracle.c"), "-lm"])
+    if _stale(port, [os.path.join(_HERE, "scvx_port.cpp")] + deps):
+        subprocess.check_call(["g++", *NATIVE_FLAGS.split(), "-std=c++17", "-shared", "-o", port, os.path.join(_HERE, "scvx_port.cpp"), "-lm"])
+    return so, port
+
+
+def use_native(on: bool = True):
+    """Route lib() / port_lib() to the -O3 -march=native builds (cpu_baseline only; parity tests use the default build)."""
+    global _NATIVE, _LIB, _PORT
+    if on != _NATIVE:
+        _NATIVE, _LIB, _PORT = on, None, None
+
+
 def lib() -> ctypes.CDLL:
     global _LIB
     if _LIB is None:
-        _LIB = ctypes.CDLL(build())
+        _LIB = ctypes.CDLL(build_native()[0] if _NATIVE else build())
     return _LIB
 
 
@@ -60,6 +99,9 @@ _PORT = None
 def port_lib() -> ctypes.CDLL:
     global _PORT
     if _PORT is None:
-        build()
-        _PORT = ctypes.CDLL(os.path.join(_HERE, "liboracle_port.so"))
+        if _NATIVE:
+            _PORT = ctypes.CDLL(build_native()[1])
+        else:
+            build()
+            _PORT = ctypes.CDLL(os.path.join(_HERE, "liboracle_port.so"))
     return _PORT

@@ -101,6 +101,7 @@ SIGNATURES = {
     "scvx_allgather_f64": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "scvx_allgather_i32": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "scvx_socp_solve": (C.c_int, [_vp, _dp, _dp]),
+    "scvx_batch_get_step_stats": (C.c_int, [_vp, _dp, C.c_int]),
     "scvx_batch_set_profiling": (C.c_int, [_vp, C.c_int]),
     "scvx_batch_get_profile": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64)]),
 }

@@ -193,6 +193,12 @@ class ScvxBatch:
                   "scvx_batch_get_solver_stats")
         return st, it, merit, pobj
 
+    def step_stats(self, reset: bool = True):
+        """Totals over the solve_steps enqueued since the last reset (scvx_batch_get_step_stats); synchronises."""
+        o = np.zeros(8)
+        self._chk(self._L.scvx_batch_get_step_stats(self.handle, _p(o), 1 if reset else 0), "scvx_batch_get_step_stats")
+        return dict(zip(("traj_steps", "solves", "ipm_iters", "warm_started", "skipped", "rejected", "failed", "converged"), o.tolist()))
+
     def set_profiling(self, on: bool):
         self._chk(self._L.scvx_batch_set_profiling(self.handle, 1 if on else 0), "scvx_batch_set_profiling")
 

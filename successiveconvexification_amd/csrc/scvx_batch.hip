@@ -346,13 +346,18 @@ struct BlockEx {
     }
 };
 
+// Running totals over the solve_steps enqueued since the last scvx_batch_get_step_stats (one atomic per trajectory per
+// step): what a timed region actually executed -- conic solves, their interior-point iterations, how many were warm-started or
+// skipped, how many steps were rejected / failed.
+enum { ACC_TRAJ_STEPS = 0, ACC_SOLVES, ACC_IPM_ITERS, ACC_WARM, ACC_SKIPPED, ACC_REJECTED, ACC_FAILED, ACC_CONVERGED, ACC_N };
+
 // info[b] = {status, iters, merit, pobj}
 // DS: element type of the linearisation the discretisation kernel wrote (double; float behind scvx_batch_set_linearization_f32)
 template <class Ex, class DS = double>
 __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t work_stride, const double* x, const double* u,
                                           const double* endpoint, const DS* deriv, const double* rk, const double* ic,
                                           const int* active, double* work, double* sol, double* nu, double* info,
-                                          const int* step_status, double* ttr) {
+                                          const int* step_status, double* ttr, double* acc) {
     const int b = blockIdx.x;
     if (b >= B) return;
     if (active && !active[b]) return;
@@ -361,7 +366,7 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t wo
     // radius, the radius row is inactive with a zero multiplier and that optimum still satisfies every KKT condition of
     // the new subproblem: the solve would return it again.  sol / nu / info are left as they are; iters = 0 marks it.
     if (C.pad && step_status[b] == SCVX_ST_REJECTED && ttr[b] <= (1.0 - 1e-6) * rk[b]) {
-        if (threadIdx.x == 0) info[4 * b + 1] = 0.0;
+        if (threadIdx.x == 0) { info[4 * b + 1] = 0.0; atomicAdd(acc + ACC_SKIPPED, 1.0); }
         return;
     }
     const int K = C.K;
@@ -386,6 +391,9 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t wo
         info[4 * b + 2] = r.merit;
         info[4 * b + 3] = r.pobj;
         ttr[b] = S.V[S.L.iTTR];   // the trust-region norm bound at the optimum (Jtr of build_model)
+        atomicAdd(acc + ACC_SOLVES, 1.0);
+        atomicAdd(acc + ACC_IPM_ITERS, (double)r.iters);
+        if (r.warmed) atomicAdd(acc + ACC_WARM, 1.0);
 #if defined(SCVX_IPM_PROF)
         if (b == 0) for (int i = 0; i < 32; i++) work[i] = S.prof[i];  // diagnostic build: section cycles of trajectory 0
 #endif
@@ -411,8 +419,8 @@ __global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_kernel(ipm::Consts C, in
                                                   const int* __restrict__ active, double* __restrict__ work,
                                                   double* __restrict__ sol, double* __restrict__ nu,
                                                   double* __restrict__ info, const int* __restrict__ step_status,
-                                                  double* __restrict__ ttr) {
-    socp_body<WaveEx>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr);
+                                                  double* __restrict__ ttr, double* __restrict__ acc) {
+    socp_body<WaveEx>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr, acc);
 }
 // the same solve on float derivative tiles (scvx_batch_set_linearization_f32)
 __global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_lin32_kernel(ipm::Consts C, int B, size_t work_stride,
@@ -422,8 +430,8 @@ __global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_lin32_kernel(ipm::Consts
                                                   const int* __restrict__ active, double* __restrict__ work,
                                                   double* __restrict__ sol, double* __restrict__ nu,
                                                   double* __restrict__ info, const int* __restrict__ step_status,
-                                                  double* __restrict__ ttr) {
-    socp_body<WaveEx, float>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr);
+                                                  double* __restrict__ ttr, double* __restrict__ acc) {
+    socp_body<WaveEx, float>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr, acc);
 }
 
 // NW wavefronts per trajectory (batches that cannot fill the chip with one wavefront each)
@@ -440,8 +448,8 @@ __global__ __launch_bounds__(64 * NW, SCVX_K4_BLOCK_OCC) void socp_block_kernel(
                                                   const int* __restrict__ active, double* __restrict__ work,
                                                   double* __restrict__ sol, double* __restrict__ nu,
                                                   double* __restrict__ info, const int* __restrict__ step_status,
-                                                  double* __restrict__ ttr) {
-    socp_body<BlockEx<NW>, DS>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr);
+                                                  double* __restrict__ ttr, double* __restrict__ acc) {
+    socp_body<BlockEx<NW>, DS>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr, acc);
 }
 
 // cand = about + step (x, u in one contiguous [B][(K+1)*17+1] trajectory record, sigma last)
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
                                                        double* __restrict__ rk, double* __restrict__ cost,
                                                        int* __restrict__ iter, int* __restrict__ status,
                                                        const int* mask /* may be `active` or `live` itself */, int* active,
-                                                       int* live, double* __restrict__ out) {
+                                                       int* live, double* __restrict__ out, double* __restrict__ acc) {
     const int b = blockIdx.x;
     if (b >= B) return;
     // not stepped by this call (failed earlier, or converged inside scvx_solve): status[b] keeps saying why and
@@ -543,6 +551,10 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
         status[b] = st;
         out[2 * b] = nun;
         out[2 * b + 1] = dJ;
+        atomicAdd(acc + ACC_TRAJ_STEPS, 1.0);
+        if (st == SCVX_ST_REJECTED) atomicAdd(acc + ACC_REJECTED, 1.0);
+        else if (st == SCVX_ST_CONVERGED) atomicAdd(acc + ACC_CONVERGED, 1.0);
+        else if (st != SCVX_ST_RUNNING) atomicAdd(acc + ACC_FAILED, 1.0);
     }
 }
 
@@ -582,6 +594,7 @@ struct scvx_batch {
     float* deriv_f = nullptr;   // the derivative tiles in float (scvx_batch_set_linearization_f32): then `deriv` is not allocated
     double *rk = nullptr, *cost = nullptr, *ic = nullptr, *info = nullptr, *out = nullptr, *work = nullptr;
     double *ttr = nullptr;   // trust-region norm bound at the last optimum (reuse_inactive_tr)
+    double *acc = nullptr;   // scvx::ACC_N running totals (scvx_batch_get_step_stats)
     int *iter = nullptr, *status = nullptr;
     int *active = nullptr;   // 0 once a trajectory has failed (solver / non-finite): never stepped again
     int *live = nullptr;     // active and not yet converged: the trajectories scvx_solve still steps
@@ -645,10 +658,10 @@ template <int NW>
 void launch_socp_block(scvx_batch* b, const int* mask) {
     if (b->deriv_f)
         hipLaunchKernelGGL((scvx::socp_block_kernel<NW, float>), dim3(b->B), dim3(64 * NW), 0, b->ctx->stream, b->C, b->B, b->work_stride,
-                           b->x, b->u, b->endpoint, b->deriv_f, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr);
+                           b->x, b->u, b->endpoint, b->deriv_f, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr, b->acc);
     else
         hipLaunchKernelGGL((scvx::socp_block_kernel<NW, double>), dim3(b->B), dim3(64 * NW), 0, b->ctx->stream, b->C, b->B, b->work_stride,
-                           b->x, b->u, b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr);
+                           b->x, b->u, b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr, b->acc);
 }
 
 // K1 for the batch's iterate, into the derivative buffer of the batch's mode
@@ -667,10 +680,10 @@ int enqueue_socp(scvx_batch* b, const int* mask) {
     else if (w == 2) launch_socp_block<2>(b, mask);
     else if (b->deriv_f)
         hipLaunchKernelGGL(scvx::socp_lin32_kernel, dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
-                           b->endpoint, b->deriv_f, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr);
+                           b->endpoint, b->deriv_f, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr, b->acc);
     else
         hipLaunchKernelGGL(scvx::socp_kernel, dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
-                           b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr);
+                           b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr, b->acc);
     SCVX_HIP(b->ctx, hipGetLastError());
     return SCVX_OK;
 }
@@ -708,7 +721,7 @@ int enqueue_step(scvx_batch* b, const int* mask) {
     SCVX_HIP(ctx, scvx::launch_propagate(ctx, b->B, b->K, b->cx, b->cu, b->csigma, dt, b->xprop, st));
     if ((rc = mark(b))) return rc;
     hipLaunchKernelGGL(scvx::tr_update_kernel, dim3(b->B), dim3(64), 0, st, b->tr, b->B, b->cand, b->xprop, b->nu, b->info,
-                       b->traj, b->rk, b->cost, b->iter, b->status, mask, b->active, b->live, b->out);
+                       b->traj, b->rk, b->cost, b->iter, b->status, mask, b->active, b->live, b->out, b->acc);
     SCVX_HIP(ctx, hipGetLastError());
     if ((rc = mark(b))) return rc;
     rc = split_views(b, b->traj, b->x, b->u, b->sigma);
@@ -804,6 +817,8 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     rc |= dmalloc(ctx, &b->info, nB * 4);
     rc |= dmalloc(ctx, &b->out, nB * 2);
     rc |= dmalloc(ctx, &b->ttr, nB);
+    rc |= dmalloc(ctx, &b->acc, (size_t)scvx::ACC_N);
+    if (!rc && hipMemset(b->acc, 0, sizeof(double) * scvx::ACC_N) != hipSuccess) rc = SCVX_ERR_HIP;
     rc |= dmalloc(ctx, &b->work, nB * b->work_stride);
     rc |= dmalloc(ctx, &b->iter, nB);
     rc |= dmalloc(ctx, &b->status, nB);
@@ -822,7 +837,7 @@ void scvx_batch_destroy(scvx_batch* b) {
     (void)hipSetDevice(b->device);
     for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
     void* ptrs[] = {b->traj0, b->traj, b->cand, b->sol, b->x, b->u, b->sigma, b->cx, b->cu, b->csigma, b->endpoint, b->deriv, b->xprop,
-                    b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active, b->live, b->ttr, b->deriv_f};
+                    b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active, b->live, b->ttr, b->deriv_f, b->acc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete b;
@@ -1125,6 +1140,18 @@ int scvx_debug_ipm_prof(scvx_batch* b, double* out32) {
     return hipMemcpy(out32, b->work, 128 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;   // out32: 128 doubles (wavefronts 0..3)
 }
 #endif
+
+int scvx_batch_get_step_stats(scvx_batch* b, double* out8, int reset) {
+    int rc = check_batch(b, false);
+    if (rc) return rc;
+    if (!out8) return fail(b->ctx, SCVX_ERR_ARG, "null buffer");
+    scvx_ctx* ctx = b->ctx;
+    static_assert(scvx::ACC_N == 8, "scvx_batch_get_step_stats documents eight totals");
+    SCVX_HIP(ctx, hipMemcpyAsync(out8, b->acc, sizeof(double) * scvx::ACC_N, hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) SCVX_HIP(ctx, hipMemsetAsync(b->acc, 0, sizeof(double) * scvx::ACC_N, ctx->stream));
+    SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCVX_OK;
+}
 
 int scvx_batch_set_profiling(scvx_batch* b, int enable) {
     if (!b) return SCVX_ERR_ARG;

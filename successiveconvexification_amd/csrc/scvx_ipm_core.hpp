@@ -302,6 +302,7 @@ struct Result {
     int status;  // see the status table at the top of this file
     int iters;
     double merit, pobj;
+    int warmed;   // the solve started from the kept iterate of the previous solve (SCVX_WARM_SAVE)
 };
 
 template <class Ex, class Stor = double, class DStor = Stor>
@@ -2138,7 +2139,7 @@ struct Solver {
             V[L.nx + 3 * K + 2] = 0.0 - ubar[3 * K + 2];
         }
         ex.sync();
-        Result res; res.status = 1; res.iters = 0; res.merit = INFINITY; res.pobj = 0;
+        Result res; res.status = 1; res.iters = 0; res.merit = INFINITY; res.pobj = 0; res.warmed = 0;
         // Infeasibility that needs no iteration to detect: at node 1 the reference fixes r, v and w (rocketland.jl:109-113) and
         // applies the glideslope and rate cones there (:142-167, k = 1..K): constants against constants.  (The dynamic-
         // pressure extension adds |vIi| <= vmax.)  A violated one has no strictly feasible point.
@@ -2156,6 +2157,7 @@ struct Solver {
         // pulling the kept primal point inside the new radius (a convex combination with the reference point) and keeping
         // the duals breaks down within two iterations on 80 % of such solves: tried, not kept.
         const bool warmed = warm && wh[0] == 1.0 && Vw[L.iTTR] < 0.8 * rk;
+        res.warmed = warmed ? 1 : 0;
         if (warmed) {
             // same subproblem, new radius: restart from the kept iterate; its radius slack is recomputed (and kept interior)
             copy(V, Vw, L.nv); copy(y, yw, L.ny); copy(S, Sw, L.nc); copy(Z, Zw, L.nc);

@@ -282,6 +282,39 @@ def test_config5_shape_K100_B32768_properties():
     b.close(); c.close()
 
 
+def test_config5_shape_with_aero_K100_B32768(aero_tables):
+    """BASELINE configs[4] at its shape WITH the aerodynamic tables (K = 100, B = 32768, seed 20261005): the conic solve's
+    size-independent properties on every trajectory, one solve_step on all of them, and three sampled trajectories against the
+    INDEPENDENT oracle (oracle/scvx.py at K = 100: IPM on the exact build_model rows + RK4 with the spline tables)."""
+    from dataclasses import replace
+    from oracle import model, scvx as oscvx
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.defns import AtmosphericData
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    import bench
+    d, l, t = aero_tables
+    K, B = 100, 32768
+    pp = replace(sp.base_prob_aero_scaled(AtmosphericData(d, l, t)), K=K)
+    po = replace(model.base_prob_scaled(model.AeroData(d, l, t)), K=K)
+    ic = bench.disperse_ics(po, 0, B, 20261005)
+    c = IntegratorCache(pp, npts=10)
+    bs = ScvxBatch(c, 512).init(ic[:512])
+    _check_socp_properties(po, ic[:512], bs, 100.0)      # incl. the linearised dynamics rows (host copy of the tiles)
+    bs.close()
+    b = ScvxBatch(c, B).init(ic)
+    _check_socp_properties(po, ic, b, 100.0, rows=False)
+    st, nun, dj = b.solve_step()
+    assert np.all(st == 1) and np.isfinite(nun).all()
+    xs, us, ss = b.trajectory()
+    for tr in (0, 16384, 32767):
+        it0 = oscvx.create_initial(po, 10, ic[tr, :3], ic[tr, 3:])
+        it1, cnu, cdel = oscvx.solve_step(it0)
+        assert np.abs(xs[tr] - it1.x).max() < 5e-5 and np.abs(us[tr] - it1.u).max() < 5e-5, tr
+        assert abs(ss[tr] - it1.sigma) < 2e-5 and abs(nun[tr] - cnu) < 2e-6
+    b.close(); c.close()
+
+
 def test_aero_B256_dispersed_matches_oracle_on_a_sample(aero_tables):
     """BASELINE configs[2] as written: 6-DoF + aero tables, K = 50, B = 256 dispersed (SURVEY 8d law, seed 20261003).
     Four trajectories are checked against the INDEPENDENT oracle (oracle/scvx.py: IPM on the exact build_model rows +
