@@ -25,6 +25,7 @@ class OracleParams(C.Structure):
         ("aoa0", C.c_double), ("daoa", C.c_double), ("mach0", C.c_double), ("dmach", C.c_double),
         ("force_scalar", C.c_double), ("length_scalar", C.c_double),
         ("cdrag", _dp), ("clift", _dp),
+        ("nu", C.c_int32), ("pad2", C.c_int32),
     ]
 
 
@@ -62,6 +63,8 @@ class Params:
         s.Jinv[:] = list(Ji.flatten(order="F"))
         s.rTB[:] = list(p.rTB)
         s.rFB[:] = list(p.rFB)
+        s.nu = 5 if getattr(p, "fins", False) else 3     # control_dim (fin extension: build-defined)
+        self.nu, self.np = int(s.nu), 14 + 2 * int(s.nu) + 1
         self._keep = []
         if p.aero is None:
             s.aero_kind = 0
@@ -94,7 +97,7 @@ def jac(par: Params, x, u):
     x = np.ascontiguousarray(x, float)
     u = np.ascontiguousarray(u, float)
     A = np.zeros((NX, NX))
-    Bu = np.zeros((NX, NU))
+    Bu = np.zeros((NX, par.nu))
     lib().scvx_oracle_jac(C.byref(par.c), _p(x), _p(u), _p(A), _p(Bu))
     return A, Bu
 
@@ -102,21 +105,22 @@ def jac(par: Params, x, u):
 def segment(par: Params, inp, dt, nsub=10, with_deriv=True):
     inp = np.ascontiguousarray(inp, float)
     e = np.zeros(NX)
-    d = np.zeros((NP, NX)) if with_deriv else None
+    d = np.zeros((par.np, NX)) if with_deriv else None
     lib().scvx_oracle_segment(C.byref(par.c), _p(inp), C.c_double(dt), C.c_int(nsub), _p(e),
                               _p(d) if with_deriv else None)
-    return (e, d.T.copy()) if with_deriv else e  # derivative returned as a 14x21 matrix
+    return (e, d.T.copy()) if with_deriv else e  # derivative returned as a 14 x np matrix
 
 
 def linearize(par: Params, x, u, sigma, dt, nsub=10):
-    """x [B][K+1][14], u [B][K+1][3], sigma [B] -> endpoint [B][K][14], deriv [B][K][21][14]."""
+    """x [B][K+1][14], u [B][K+1][nu], sigma [B] -> endpoint [B][K][14], deriv [B][K][np][14]."""
     x = np.ascontiguousarray(x, float)
     u = np.ascontiguousarray(u, float)
     sigma = np.ascontiguousarray(sigma, float)
     B, K1, _ = x.shape
     K = K1 - 1
     e = np.zeros((B, K, NX))
-    d = np.zeros((B, K, NP, NX))
+    assert u.shape[-1] == par.nu, (u.shape, par.nu)
+    d = np.zeros((B, K, par.np, NX))
     lib().scvx_oracle_linearize(C.byref(par.c), C.c_int(B), C.c_int(K), _p(x), _p(u), _p(sigma),
                                 C.c_double(dt), C.c_int(nsub), _p(e), _p(d))
     return e, d
@@ -128,6 +132,7 @@ def propagate(par: Params, x, u, sigma, dt, nsub=10):
     sigma = np.ascontiguousarray(sigma, float)
     B, K1, _ = x.shape
     K = K1 - 1
+    assert u.shape[-1] == par.nu, (u.shape, par.nu)
     e = np.zeros((B, K, NX))
     lib().scvx_oracle_propagate(C.byref(par.c), C.c_int(B), C.c_int(K), _p(x), _p(u), _p(sigma),
                                 C.c_double(dt), C.c_int(nsub), _p(e))
@@ -147,3 +152,12 @@ def aero_force(par: Params, q, v):
     dF = np.zeros((3, 7))
     lib().scvx_oracle_aero_force(C.byref(par.c), _p(q), _p(v), _p(F), _p(dF))
     return F, dF
+
+
+def fin_dirs(q, v):
+    """fd1 = normalize((C(q) e2) x v), fd2 = fd1 x v (dynamics.jl:60-62) and their derivatives w.r.t. (q, v), 3x7 each."""
+    q = np.ascontiguousarray(q, float)
+    v = np.ascontiguousarray(v, float)
+    f1, f2, d1, d2 = np.zeros(3), np.zeros(3), np.zeros((3, 7)), np.zeros((3, 7))
+    lib().scvx_oracle_fin_dirs(_p(q), _p(v), _p(f1), _p(f2), _p(d1), _p(d2))
+    return f1, f2, d1, d2

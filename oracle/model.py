@@ -78,6 +78,15 @@ class DescentProblem:
     bet: float = 3.2
     sos: float = 5.0
     enforce_dp: bool = False   # build extension: enforce 1/2 rho |v|^2 <= dpMax (the reference leaves it as a todo)
+    # fin extension (BUILD-DEFINED): control_dim = 5, u[4:5] = fin force coordinates along fd1 / fd2
+    # (dynamics.jl:60-63,66,69 as commented there), |u[4:5]| <= finmxf at every node (rocketland.jl:203-209: finmxf is pinned
+    # to 0.01 by a Zeros row in the commented code, in the units of the normalised problem)
+    fins: bool = False
+    finmxf: float = 0.01
+
+    @property
+    def nu(self):
+        return 5 if self.fins else 3
 
 
 def normalize_problem(dp: DescentProblem) -> DescentProblem:
@@ -101,7 +110,8 @@ def normalize_problem(dp: DescentProblem) -> DescentProblem:
         wDS=dp.wDS, wCst=dp.wCst, wTviol=dp.wTviol, delTol=dp.delTol,
         tf_guess=dp.tf_guess / Ut, ri=dp.ri, rh0=dp.rh0, rh1=dp.rh1, rh2=dp.rh2,
         alph=dp.alph, bet=dp.bet, dpMax=dp.dpMax / (Um / (Ul * Ut**2)), rho=dp.rho / (Um / Ul**3),
-        sos=dp.sos / (Ul / Ut), aero=aero)
+        sos=dp.sos / (Ul / Ut), aero=aero, enforce_dp=dp.enforce_dp,
+        fins=dp.fins, finmxf=dp.finmxf)   # finmxf: a constant of build_model (rocketland.jl:205), not rescaled
 
 
 def base_prob(aero=None) -> DescentProblem:
@@ -136,13 +146,13 @@ def rotation_between(a, b):
 
 
 def linear_points(p: DescentProblem, rIi=None, vIi=None):
-    """initial_solve.jl:113-129 -> x[K+1][14], u[K+1][3].  vIf follows the problem (already the
-    scaled vIi in the samples); a dispersed (rIi, vIi) replaces the problem's initial condition."""
+    """initial_solve.jl:113-129 -> x[K+1][14], u[K+1][nu].  vIf follows the problem (already the
+    scaled vIi in the samples); a dispersed (rIi, vIi) replaces the problem's initial condition.  (Fin controls start at 0.)"""
     K = p.K
     rIi = p.rIi if rIi is None else np.asarray(rIi, float)
     vIi = p.vIi if vIi is None else np.asarray(vIi, float)
     x = np.zeros((K + 1, 14))
-    u = np.zeros((K + 1, 3))
+    u = np.zeros((K + 1, p.nu))
     for k in range(K + 1):
         a, b = (K - k) / K, k / K
         mk = a * p.mwet + b * p.mdry

@@ -15,7 +15,7 @@ class Consts(C.Structure):
                 ("tol", C.c_double), ("accept", C.c_double),
                 ("itan", C.c_double), ("sqcm", C.c_double), ("icos", C.c_double), ("Tmax", C.c_double),
                 ("Tmin", C.c_double), ("omMax", C.c_double), ("mdry", C.c_double), ("wNu", C.c_double),
-                ("mwet", C.c_double), ("vmax", C.c_double),
+                ("mwet", C.c_double), ("finmxf", C.c_double), ("vmax", C.c_double),
                 ("rIf", C.c_double * 3), ("vIf", C.c_double * 3), ("qBIf", C.c_double * 4),
                 ("wBi", C.c_double * 3), ("wBf", C.c_double * 3)]
 
@@ -28,6 +28,7 @@ def consts(p: DescentProblem, tol=1e-8, max_iter=60, refine=6, accept=0.0) -> Co
     c.icos = 1.0 / np.cos(np.radians(p.deltaMax))      # :65
     c.Tmax, c.Tmin, c.omMax, c.mdry, c.wNu, c.mwet = p.Tmax, p.Tmin, p.omMax, p.mdry, p.wNu, p.mwet
     c.vmax = float(np.sqrt(2.0 * p.dpMax / p.rho)) if getattr(p, "enforce_dp", False) else 0.0
+    c.finmxf = float(getattr(p, "finmxf", 0.0))
     c.rIf[:] = list(p.rIf); c.vIf[:] = list(p.vIf); c.qBIf[:] = list(p.qBIf)
     c.wBi[:] = list(p.wBi); c.wBf[:] = list(p.wBf)
     return c
@@ -39,8 +40,8 @@ def _p(a):
 
 def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, max_iter=60, refine=6, nthreads=0, accept=0.0,
          f32=False, work=None, warm=None, lin32=False):
-    """Batched: xbar [B][K+1][14], ubar [B][K+1][3], endpoint [B][K][14], deriv [B][K][21][14], rk [B].
-    Returns dict(dx, du, ds, nu, status, iters, merit, pobj)."""
+    """Batched: xbar [B][K+1][14], ubar [B][K+1][nu], endpoint [B][K][14], deriv [B][K][14+2nu+1][14], rk [B]; nu = 3, or 5
+    when p.fins (fin extension).  Returns dict(dx, du, ds, nu, status, iters, merit, pobj)."""
     xbar = np.ascontiguousarray(xbar, float)
     ubar = np.ascontiguousarray(ubar, float)
     endpoint = np.ascontiguousarray(endpoint, float)
@@ -52,10 +53,18 @@ def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, 
         ic = np.tile(np.concatenate([p.rIi, p.vIi]), (B, 1))
     ic = np.ascontiguousarray(ic, float)
     c = consts(p, tol, max_iter, refine, accept)
-    sol = np.zeros((B, (K + 1) * 17 + 1))
+    NU = 5 if getattr(p, "fins", False) else 3
+    assert ubar.shape[-1] == NU and deriv.shape[-2] == 14 + 2 * NU + 1, (ubar.shape, deriv.shape)
+    sol = np.zeros((B, (K + 1) * (14 + NU) + 1))
     nu = np.zeros((B, K, 14))
     info = np.zeros((B, 4))
-    if work is not None:   # persistent per-trajectory workspace + warm flags (the device's warm start after a rejected step)
+    if NU == 5:
+        assert not (f32 or lin32), "the fin twin is built for double storage"
+        wf = np.ascontiguousarray(warm if warm is not None else np.zeros(B), np.int32)
+        port_lib().scvx_port_socp_fin(C.byref(c), C.c_int(B), _p(xbar), _p(ubar), _p(endpoint), _p(deriv), _p(rk), _p(ic), _p(sol), _p(nu),
+                                      _p(info), C.c_int(nthreads), _p(work) if work is not None else None,
+                                      wf.ctypes.data_as(C.POINTER(C.c_int32)))
+    elif work is not None:   # persistent per-trajectory workspace + warm flags (the device's warm start after a rejected step)
         wf = np.ascontiguousarray(warm if warm is not None else np.zeros(B), np.int32)
         port_lib().scvx_port_socp_ws(C.byref(c), C.c_int(B), _p(xbar), _p(ubar), _p(endpoint), _p(deriv), _p(rk), _p(ic), _p(sol), _p(nu),
                                      _p(info), C.c_int(nthreads), _p(work), wf.ctypes.data_as(C.POINTER(C.c_int32)))
@@ -63,7 +72,7 @@ def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, 
       (port_lib().scvx_port_socp_f32 if f32 else (port_lib().scvx_port_socp_lin32 if lin32 else port_lib().scvx_port_socp))(C.byref(c), C.c_int(B), _p(xbar), _p(ubar), _p(endpoint), _p(deriv), _p(rk), _p(ic),
                               _p(sol), _p(nu), _p(info), C.c_int(nthreads))
     nx = 14 * (K + 1)
-    return dict(dx=sol[:, :nx].reshape(B, K + 1, 14), du=sol[:, nx:nx + 3 * (K + 1)].reshape(B, K + 1, 3),
+    return dict(dx=sol[:, :nx].reshape(B, K + 1, 14), du=sol[:, nx:nx + NU * (K + 1)].reshape(B, K + 1, NU),
                 ds=sol[:, -1], nu=nu, status=info[:, 0].astype(int), iters=info[:, 1].astype(int),
                 merit=info[:, 2], pobj=info[:, 3])
 
@@ -80,7 +89,7 @@ def scvx_steps(p: DescentProblem, ic, steps, nsub=10, nthreads=0, tol=1e-8, acce
     K = p.K
     ic = np.ascontiguousarray(ic, float)
     B = ic.shape[0]
-    x = np.zeros((B, K + 1, 14)); u = np.zeros((B, K + 1, 3))
+    x = np.zeros((B, K + 1, 14)); u = np.zeros((B, K + 1, p.nu))
     for t in range(B):
         x[t], u[t] = linear_points(p, ic[t, :3], ic[t, 3:])
     sig = np.full(B, p.tf_guess)
@@ -92,8 +101,8 @@ def scvx_steps(p: DescentProblem, ic, steps, nsub=10, nthreads=0, tol=1e-8, acce
     out = dict(merit=[], status=[], iters=[], rejected=[])
     work = None; was_rej = np.zeros(B, np.int32)
     if warm_start:
-        port_lib().scvx_port_work_doubles.restype = C.c_size_t
-        work = np.zeros((B, port_lib().scvx_port_work_doubles(C.c_int(K), C.c_int(1 if getattr(p, "enforce_dp", False) else 0))))
+        port_lib().scvx_port_work_doubles_nu.restype = C.c_size_t
+        work = np.zeros((B, port_lib().scvx_port_work_doubles_nu(C.c_int(K), C.c_int(1 if getattr(p, "enforce_dp", False) else 0), C.c_int(p.nu))))
     for s in range(steps):
         r = socp(p, x, u, e, d.astype(np.float32).astype(np.float64) if f32 else d, rk, ic, tol=tol, max_iter=max_iter,
                  refine=refine, nthreads=nthreads, accept=accept, f32=f32, work=work, warm=was_rej)

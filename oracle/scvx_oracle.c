@@ -22,6 +22,12 @@
  *   aero_force (symbolic)    aerodynamics.jl:60-77 + shims dynamics.jl:162-207
  *   cubic B-spline tables    aerodynamics.jl:17-21 (Interpolations.jl Cubic(Line(OnGrid())), Flat())
  *
+ * FIN EXTENSION (control_dim = 5; BUILD-DEFINED).  The reference carries the fin model only as commented-out
+ * code: fd1 = normalize((C(q) e2) x v), fd2 = fd1 x v are computed and unused (dynamics.jl:60-62); the force
+ * ff = u[4] fd1 + u[5] fd2 (:63), its place in the acceleration (:66 "aerf + ff") and the torque cross(rFB, ff) (:69) sit in
+ * #= =# comments.  With p->nu == 5 this file enables exactly those three commented expressions (bdy_trq stays zero, as in
+ * the live model); with nu == 3 nothing changes.  fd1 is guarded like the reference's ifnz: (C e2) x v = 0 gives no fin force.
+ *
  * The Jacobian of the discrete RK4 map is obtained by integrating the variational equations with the
  * same RK4 tableau, which is identical to differentiating the discrete map (what
  * sensitivity_zygote, dynamics.jl:311-313, asks forward-mode AD to do).
@@ -32,8 +38,8 @@
 #include <string.h>
 
 #define NX 14
-#define NU 3
-#define NP 21
+#define NU_MAX 5
+#define NP_MAX 25 /* 14 + 2 * 5 + 1 */
 
 typedef struct {
     double alpha, g0, sos;
@@ -46,7 +52,10 @@ typedef struct {
     double force_scalar, length_scalar;
     const double *cdrag; /* prefiltered B-spline coefficients, (n_aoa+2) x (n_mach+2), aoa fastest */
     const double *clift;
+    int32_t nu;   /* control_dim: 3 (the live model) or 5 (fin extension) */
+    int32_t pad2;
 } oracle_params;
+static int nu_of(const oracle_params *p) { return p->nu == 5 ? 5 : 3; }
 
 /* ---------- small helpers ---------- */
 static void dcm(const double q[4], double C[9] /* row-major */) {
@@ -224,12 +233,66 @@ static void aero_force(const oracle_params *p, const double q[4], const double v
     }
 }
 
+/* ---------- fin force (build-defined extension; dynamics.jl:60-63 as commented there) ---------- */
+/* fd1 = normalize((C e2) x v), fd2 = fd1 x v.  If d != NULL: d fd1 / d(q, v) and d fd2 / d(q, v), each 3x7 row-major. */
+static int fin_dirs(const double q[4], const double v[3], const double C[9], double fd1[3], double fd2[3], double *d1, double *d2) {
+    double b2[3] = {C[1], C[4], C[7]}; /* C(q) e2 */
+    double n[3];
+    cross3(b2, v, n);
+    double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (!(nn > 0)) {
+        for (int i = 0; i < 3; i++) fd1[i] = fd2[i] = 0;
+        if (d1) { memset(d1, 0, sizeof(double) * 21); memset(d2, 0, sizeof(double) * 21); }
+        return 0;
+    }
+    for (int i = 0; i < 3; i++) fd1[i] = n[i] / nn;
+    cross3(fd1, v, fd2);
+    if (!d1) return 1;
+    /* d b2 / dq (3x4): b2 = [2(q1q2 - q0q3), 1 - 2(q1^2 + q3^2), 2(q2q3 + q0q1)] */
+    double db2[12] = {-2 * q[3], 2 * q[2], 2 * q[1], -2 * q[0],
+                      0, -4 * q[1], 0, -4 * q[3],
+                      2 * q[1], 2 * q[0], 2 * q[3], 2 * q[2]};
+    double dn[21]; /* d n / d(q, v) */
+    for (int j = 0; j < 4; j++) {
+        double col[3] = {db2[j], db2[4 + j], db2[8 + j]}, c[3];
+        cross3(col, v, c);
+        for (int i = 0; i < 3; i++) dn[i * 7 + j] = c[i];
+    }
+    for (int j = 0; j < 3; j++) { /* d (b2 x v) / d v_j = b2 x e_j */
+        double e[3] = {0, 0, 0}, c[3];
+        e[j] = 1;
+        cross3(b2, e, c);
+        for (int i = 0; i < 3; i++) dn[i * 7 + 4 + j] = c[i];
+    }
+    for (int j = 0; j < 7; j++) {
+        double proj = fd1[0] * dn[j] + fd1[1] * dn[7 + j] + fd1[2] * dn[14 + j];
+        for (int i = 0; i < 3; i++) d1[i * 7 + j] = (dn[i * 7 + j] - fd1[i] * proj) / nn;
+    }
+    for (int j = 0; j < 7; j++) {
+        double col[3] = {d1[j], d1[7 + j], d1[14 + j]}, c[3];
+        cross3(col, v, c);
+        for (int i = 0; i < 3; i++) d2[i * 7 + j] = c[i];
+    }
+    for (int j = 0; j < 3; j++) { /* + fd1 x e_j */
+        double e[3] = {0, 0, 0}, c[3];
+        e[j] = 1;
+        cross3(fd1, e, c);
+        for (int i = 0; i < 3; i++) d2[i * 7 + 4 + j] += c[i];
+    }
+    return 1;
+}
+
 /* ---------- RHS g(x,u) (un-scaled by sigma) and its Jacobians ---------- */
-void scvx_oracle_rhs(const oracle_params *p, const double x[NX], const double u[NU], double g[NX]) {
+void scvx_oracle_rhs(const oracle_params *p, const double x[NX], const double *u /* [nu] */, double g[NX]) {
     const double *q = x + 7, *w = x + 11, *v = x + 4;
-    double C[9], F[3];
+    double C[9], F[3], ff[3] = {0, 0, 0};
     dcm(q, C);
     aero_force(p, q, v, F, 0);
+    if (nu_of(p) == 5) { /* ff = u[4] fd1 + u[5] fd2 (dynamics.jl:63); aero_frc = aerf + ff (:66) */
+        double fd1[3], fd2[3];
+        fin_dirs(q, v, C, fd1, fd2, 0, 0);
+        for (int i = 0; i < 3; i++) { ff[i] = u[3] * fd1[i] + u[4] * fd2[i]; F[i] += ff[i]; }
+    }
     double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
     g[0] = -p->alpha * un;
     g[1] = v[0]; g[2] = v[1]; g[3] = v[2];
@@ -247,13 +310,16 @@ void scvx_oracle_rhs(const oracle_params *p, const double x[NX], const double u[
     mat3v(p->J, w, Jw);
     cross3(w, Jw, wxJw);
     cross3(p->rTB, u, rxu);
-    for (int i = 0; i < 3; i++) t[i] = rxu[i] - wxJw[i];
+    double rxf[3];
+    cross3(p->rFB, ff, rxf); /* aero_trq = cross(rFB, ff) (dynamics.jl:69 as commented there; zero when nu == 3) */
+    for (int i = 0; i < 3; i++) t[i] = rxu[i] + rxf[i] - wxJw[i];
     mat3v(p->Jinv, t, a);
     g[11] = a[0]; g[12] = a[1]; g[13] = a[2];
 }
 
-/* A = dg/dx (14x14 row-major), Bu = dg/du (14x3 row-major) */
-void scvx_oracle_jac(const oracle_params *p, const double x[NX], const double u[NU], double A[NX * NX], double Bu[NX * NU]) {
+/* A = dg/dx (14x14 row-major), Bu = dg/du (14 x nu row-major) */
+void scvx_oracle_jac(const oracle_params *p, const double x[NX], const double *u, double A[NX * NX], double *Bu) {
+    const int NU = nu_of(p);
     memset(A, 0, sizeof(double) * NX * NX);
     memset(Bu, 0, sizeof(double) * NX * NU);
     const double *q = x + 7, *w = x + 11, *v = x + 4;
@@ -262,6 +328,14 @@ void scvx_oracle_jac(const oracle_params *p, const double x[NX], const double u[
     dcm(q, C);
     dcm_u_dq(q, u, D);
     aero_force(p, q, v, F, dF);
+    double fd1[3] = {0, 0, 0}, fd2[3] = {0, 0, 0}, dff[21];
+    memset(dff, 0, sizeof dff);
+    if (NU == 5) {
+        double d1[21], d2[21];
+        fin_dirs(q, v, C, fd1, fd2, d1, d2);
+        for (int i = 0; i < 3; i++) F[i] += u[3] * fd1[i] + u[4] * fd2[i];
+        for (int i = 0; i < 21; i++) { dff[i] = u[3] * d1[i] + u[4] * d2[i]; dF[i] += dff[i]; }
+    }
     double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
     for (int j = 0; j < 3; j++) Bu[0 * NU + j] = (un > 0) ? -p->alpha * u[j] / un : 0.0;
     for (int i = 0; i < 3; i++) A[(1 + i) * NX + 4 + i] = 1.0;
@@ -271,6 +345,7 @@ void scvx_oracle_jac(const oracle_params *p, const double x[NX], const double u[
         for (int j = 0; j < 4; j++) A[(4 + i) * NX + 7 + j] = (D[i * 4 + j] + dF[i * 7 + j]) / m;
         for (int j = 0; j < 3; j++) A[(4 + i) * NX + 4 + j] = dF[i * 7 + 4 + j] / m;
         for (int j = 0; j < 3; j++) Bu[(4 + i) * NU + j] = C[i * 3 + j] / m;
+        if (NU == 5) { Bu[(4 + i) * NU + 3] = fd1[i] / m; Bu[(4 + i) * NU + 4] = fd2[i] / m; }
     }
     /* d qdot / dq = 0.5 Omega(w) */
     double Om[16] = {0, -w[0], -w[1], -w[2], w[0], 0, w[2], -w[1], w[1], -w[2], 0, w[0], w[2], w[1], -w[0], 0};
@@ -307,46 +382,67 @@ void scvx_oracle_jac(const oracle_params *p, const double x[NX], const double u[
             for (int k = 0; k < 3; k++) s += p->Jinv[k * 3 + i] * rx[k * 3 + j];
             Bu[(11 + i) * NU + j] = s;
         }
+    if (NU == 5) { /* wdot += Jinv (rFB x ff): columns q, v of A and u4, u5 of Bu */
+        const double *f = p->rFB;
+        double fx[9] = {0, -f[2], f[1], f[2], 0, -f[0], -f[1], f[0], 0};
+        double G[9]; /* Jinv [rFB]x, row-major */
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += p->Jinv[k * 3 + i] * fx[k * 3 + j];
+                G[i * 3 + j] = s;
+            }
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 7; j++) {
+                double s = G[i * 3] * dff[j] + G[i * 3 + 1] * dff[7 + j] + G[i * 3 + 2] * dff[14 + j];
+                A[(11 + i) * NX + (j < 4 ? 7 + j : j)] += s; /* dff columns: q0..q3 -> 7..10, v1..v3 -> 4..6 */
+            }
+            Bu[(11 + i) * NU + 3] = G[i * 3] * fd1[0] + G[i * 3 + 1] * fd1[1] + G[i * 3 + 2] * fd1[2];
+            Bu[(11 + i) * NU + 4] = G[i * 3] * fd2[0] + G[i * 3 + 1] * fd2[1] + G[i * 3 + 2] * fd2[2];
+        }
+    }
 }
 
 /* time derivative of the augmented (x | S) system at normalised time fraction lkp = t/dt.
  * S is 14x21 row-major here (converted to Julia column-major on output). */
 static void aug_rhs(const oracle_params *p, const double *x, const double *S, const double *uk, const double *up,
                     double sigma, double lkp, double *dx, double *dS) {
-    double lkm = 1.0 - lkp, u[3];
-    for (int i = 0; i < 3; i++) u[i] = uk[i] * lkm + up[i] * lkp; /* dynamics.jl:108-110,144-150 */
+    const int NU = nu_of(p), NP = 14 + 2 * NU + 1;
+    double lkm = 1.0 - lkp, u[NU_MAX];
+    for (int i = 0; i < NU; i++) u[i] = uk[i] * lkm + up[i] * lkp; /* dynamics.jl:108-110,144-150 */
     double g[NX];
     scvx_oracle_rhs(p, x, u, g);
     for (int i = 0; i < NX; i++) dx[i] = sigma * g[i];
     if (!S) return;
-    double A[NX * NX], Bu[NX * NU];
+    double A[NX * NX], Bu[NX * NU_MAX];
     scvx_oracle_jac(p, x, u, A, Bu);
     for (int i = 0; i < NX; i++)
         for (int j = 0; j < NP; j++) {
             double s = 0;
             for (int k = 0; k < NX; k++) s += A[i * NX + k] * S[k * NP + j];
-            if (j >= 14 && j < 17) s += Bu[i * NU + (j - 14)] * lkm;
-            else if (j >= 17 && j < 20) s += Bu[i * NU + (j - 17)] * lkp;
+            if (j >= 14 && j < 14 + NU) s += Bu[i * NU + (j - 14)] * lkm;
+            else if (j >= 14 + NU && j < 14 + 2 * NU) s += Bu[i * NU + (j - 14 - NU)] * lkp;
             s *= sigma;
-            if (j == 20) s += g[i];
+            if (j == NP - 1) s += g[i];
             dS[i * NP + j] = s;
         }
 }
 
-/* one segment: inp[21] -> endpoint[14], deriv (column-major 14x21, may be NULL) */
-void scvx_oracle_segment(const oracle_params *p, const double inp[NP], double dt, int nsub, double *endpoint, double *deriv) {
-    double x[NX], S[NX * NP];
-    const double *uk = inp + 14, *up = inp + 17;
-    double sigma = inp[20];
+/* one segment: inp[np] -> endpoint[14], deriv (column-major 14 x np, may be NULL); np = 14 + 2 nu + 1 */
+void scvx_oracle_segment(const oracle_params *p, const double *inp, double dt, int nsub, double *endpoint, double *deriv) {
+    const int NU = nu_of(p), NP = 14 + 2 * NU + 1;
+    double x[NX], S[NX * NP_MAX];
+    const double *uk = inp + 14, *up = inp + 14 + NU;
+    double sigma = inp[NP - 1];
     memcpy(x, inp, sizeof(double) * NX);
     int withS = deriv != 0;
     if (withS) {
-        memset(S, 0, sizeof(S));
+        memset(S, 0, sizeof(double) * NX * NP);
         for (int i = 0; i < NX; i++) S[i * NP + i] = 1.0;
     }
     double h = dt / nsub;
     double k1x[NX], k2x[NX], k3x[NX], k4x[NX], xt[NX];
-    double k1S[NX * NP], k2S[NX * NP], k3S[NX * NP], k4S[NX * NP], St[NX * NP];
+    double k1S[NX * NP_MAX], k2S[NX * NP_MAX], k3S[NX * NP_MAX], k4S[NX * NP_MAX], St[NX * NP_MAX];
     for (int s = 0; s < nsub; s++) {
         double f0 = (double)s / nsub, fm = (s + 0.5) / nsub, f1 = (double)(s + 1) / nsub;
         aug_rhs(p, x, withS ? S : 0, uk, up, sigma, f0, k1x, k1S);
@@ -371,16 +467,16 @@ void scvx_oracle_segment(const oracle_params *p, const double inp[NP], double dt
 /* Dynamics.linearize_dynamics (dynamics.jl:321-334) over a batch, ABI layouts of include/scvx.h. */
 void scvx_oracle_linearize(const oracle_params *p, int B, int K, const double *x, const double *u, const double *sigma,
                            double dt, int nsub, double *endpoint, double *deriv) {
+    const int NU = nu_of(p), NP = 14 + 2 * NU + 1;
 #pragma omp parallel for schedule(static)
     for (long s = 0; s < (long)B * K; s++) {
         int b = (int)(s / K), k = (int)(s % K);
-        double inp[NP];
+        double inp[NP_MAX];
         const double *xk = x + ((size_t)b * (K + 1) + k) * NX;
         const double *uk = u + ((size_t)b * (K + 1) + k) * NU;
         memcpy(inp, xk, sizeof(double) * NX);
-        memcpy(inp + 14, uk, sizeof(double) * 3);
-        memcpy(inp + 17, uk + 3, sizeof(double) * 3);
-        inp[20] = sigma[b];
+        memcpy(inp + 14, uk, sizeof(double) * 2 * NU); /* u_k then u_{k+1}: adjacent */
+        inp[NP - 1] = sigma[b];
         scvx_oracle_segment(p, inp, dt, nsub, endpoint + (size_t)s * NX, deriv ? deriv + (size_t)s * NX * NP : 0);
     }
 }
@@ -397,4 +493,9 @@ void scvx_oracle_table_eval(const oracle_params *p, int which, double aoa, doubl
 }
 void scvx_oracle_aero_force(const oracle_params *p, const double q[4], const double v[3], double F[3], double dF[21]) {
     aero_force(p, q, v, F, dF);
+}
+void scvx_oracle_fin_dirs(const double q[4], const double v[3], double fd1[3], double fd2[3], double d1[21], double d2[21]) {
+    double C[9];
+    dcm(q, C);
+    fin_dirs(q, v, C, fd1, fd2, d1, d2);
 }

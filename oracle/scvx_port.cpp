@@ -27,6 +27,7 @@ struct HostEx {
     bool all(bool b) { return b; }
     double* scratch() { return sc; }
     static constexpr int kPrefetchRegs = 0;
+    static constexpr int kLanes = 1;
     static constexpr bool kPipelineFactor = false;
     static constexpr bool kTwisted = false;
     // C(14x14) = (acc ? C : 0) + alpha * A(14 x Kd) B(Kd x 14); element strides: C(i,j) = C[i*sci + j*scj],
@@ -117,35 +118,42 @@ size_t scvx_port_work_doubles(int K, int with_dp) {
     L.init(K, with_dp != 0);
     return L.work_doubles();
 }
+size_t scvx_port_work_doubles_nu(int K, int with_dp, int nu) {
+    scvx::ipm::Layout L;
+    L.init(K, with_dp != 0, nu);
+    return L.work_doubles();
+}
 
 }  // extern "C"
 
-// Solve B subproblems.  Layouts as include/scvx.h: xbar [B][K+1][14], ubar [B][K+1][3], endpoint [B][K][14],
-// deriv [B][K][21][14], rk [B], ic [B][6].  Outputs: sol [B][(K+1)*17+1] = dx, du, dsigma ; nu [B][K][14];
+// Solve B subproblems.  Layouts as include/scvx.h: xbar [B][K+1][14], ubar [B][K+1][NU], endpoint [B][K][14],
+// deriv [B][K][14+2NU+1][14], rk [B], ic [B][6].  Outputs: sol [B][(K+1)*(14+NU)+1] = dx, du, dsigma ; nu [B][K][14];
 // info [B][4] = status, iters, merit, pobj.  Stor = storage type of the linearisation and of the solver workspace.
-template <class Stor, class DStor = Stor>
+// NU = 3 (the reference's live model) or 5 (fin extension).
+template <class Stor, class DStor = Stor, int NU = 3>
 static int port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
                      const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
                      int nthreads, Stor* work_all = nullptr, const int* warm = nullptr) {
     const int K = C->K;
     scvx::ipm::Layout L;
-    L.init(K, C->vmax > 0.0);
+    L.init(K, C->vmax > 0.0, NU);
     const size_t nw = L.work_doubles();
+    constexpr int DSZ = 14 * (14 + 2 * NU + 1);
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel
     {
         std::vector<Stor> work(work_all ? 0 : nw);
-        std::vector<DStor> D((size_t)K * 294);
+        std::vector<DStor> D((size_t)K * DSZ);
         HostEx ex;
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < B; b++) {
-            for (size_t i = 0; i < D.size(); i++) D[i] = (DStor)deriv[(size_t)b * K * 294 + i];
-            scvx::ipm::Solver<HostEx, Stor, DStor> S(ex, *C);
+            for (size_t i = 0; i < D.size(); i++) D[i] = (DStor)deriv[(size_t)b * K * DSZ + i];
+            scvx::ipm::Solver<HostEx, Stor, DStor, NU> S(ex, *C);
             Stor* wk = work_all ? work_all + (size_t)b * nw : work.data();   // persistent per-trajectory slab, as on the device
-            scvx::ipm::Result r = S.solve(xbar + (size_t)b * (K + 1) * 14, ubar + (size_t)b * (K + 1) * 3,
+            scvx::ipm::Result r = S.solve(xbar + (size_t)b * (K + 1) * 14, ubar + (size_t)b * (K + 1) * NU,
                                           endpoint + (size_t)b * K * 14, D.data(), rk[b], ic + (size_t)b * 6, wk,
                                           warm && warm[b]);
-            double* so = sol + (size_t)b * ((K + 1) * 17 + 1);
+            double* so = sol + (size_t)b * ((K + 1) * (14 + NU) + 1);
             for (int i = 0; i < L.nx + L.nu_; i++) so[i] = S.V[i];
             so[L.nx + L.nu_] = S.V[L.iS];
             for (int i = 0; i < L.ny; i++) nu[(size_t)b * K * 14 + i] = S.V[L.nx + L.nu_ + i];
@@ -174,6 +182,12 @@ int scvx_port_socp_lin32(const scvx::ipm::Consts* C, int B, const double* xbar, 
                          const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
                          int nthreads) {
     return port_socp<double, float>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads);
+}
+// fin extension (control_dim = 5), optional persistent workspace + warm flags (work == NULL: per-call scratch)
+int scvx_port_socp_fin(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
+                       const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
+                       int nthreads, double* work, const int* warm) {
+    return port_socp<double, double, 5>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads, work, warm);
 }
 // f32 storage: the linearisation and the whole solver workspace are float, arithmetic stays double
 int scvx_port_socp_f32(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,

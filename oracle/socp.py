@@ -6,6 +6,11 @@ with the per-iteration data of solve_step (rocketland.jl:245-269).  Sizes at K=5
 1,742 equalities, 204 linear inequalities, 204 second-order cones of total dimension 2,289
  — checked by tests/test_oracle_socp.py.
 
+FIN EXTENSION (p.fins, control_dim = 5; build-defined): u and du get two more rows, and the commented rows
+of rocketland.jl:203-209 are enabled -- finmxf[n] pinned to p.finmxf (the Zeros row, :205) and SOC(3) on
+[finmxf[n]; u[4:5, n]] at n = 1..K+1 (:208).  (The Nonpositives row :207 on u[4:5] is a second, contradictory sketch of the
+same bound and stays out.)
+
 Cone-program form handed to oracle.ipm:  min c'z  s.t.  A z = b,  G z + s = h,  s in R+^l x Q...
 """
 from dataclasses import dataclass
@@ -14,7 +19,7 @@ import scipy.sparse as sp
 
 from .model import DescentProblem
 
-NX, NU = 14, 3
+NX = 14
 
 
 @dataclass
@@ -35,9 +40,10 @@ class Index:
     ang_sp_help: np.ndarray
     mtk: np.ndarray
     rK: int
+    finmxf: np.ndarray = None   # [K+1], fin extension only
 
 
-def index(K: int) -> Index:
+def index(K: int, NU: int = 3) -> Index:
     pos = 0
 
     def take(shape):
@@ -61,7 +67,8 @@ def index(K: int) -> Index:
     ang_sp_help = take((K,))
     mtk = take((K + 1,))
     rK = int(take((1,))[0])
-    return Index(K, pos, xv, uv, dxv, duv, dsig, nuv, Jvnu, Jtr, Jsig, gshelp, aoa_help, ang_sp_help, mtk, rK)
+    finmxf = take((K + 1,)) if NU == 5 else None
+    return Index(K, pos, xv, uv, dxv, duv, dsig, nuv, Jvnu, Jtr, Jsig, gshelp, aoa_help, ang_sp_help, mtk, rK, finmxf)
 
 
 class _Rows:
@@ -86,7 +93,8 @@ def build(p: DescentProblem, xbar, ubar, endpoint, deriv, rk):
     """xbar [K+1][14], ubar [K+1][3] (iterAbout), endpoint [K][14], deriv [K][21][14] (iterDynam:
     column-major 14x21 per segment), rk = trust radius.  Returns (c, A, b, G, h, l, q, idx)."""
     K = p.K
-    ix = index(K)
+    NU = 5 if getattr(p, "fins", False) else 3
+    ix = index(K, NU)
     n = ix.n
     tggs = np.tan(np.radians(p.gammaGs))                       # rocketland.jl:63
     sqcm = np.sqrt((1 - np.cos(np.radians(p.thetaMax))) / 2)   # :64
@@ -117,7 +125,7 @@ def build(p: DescentProblem, xbar, ubar, endpoint, deriv, rk):
     # linearised dynamics (:117-133):
     # derivative_n [dx_n; du_n; du_{n+1}; dsig] + nu_{n+1} - dx_{n+1} + (endpoint_n - xbar_{n+1}) = 0
     for k in range(K):
-        D = deriv[k].T  # 14x21
+        D = deriv[k].T  # 14 x (14 + 2 NU + 1)
         cols = list(ix.dxv[:, k]) + list(ix.duv[:, k]) + list(ix.duv[:, k + 1]) + [ix.dsig]
         for i in range(NX):
             cc = cols + [ix.nuv[i, k + 1], ix.dxv[i, k + 1]]
@@ -130,6 +138,9 @@ def build(p: DescentProblem, xbar, ubar, endpoint, deriv, rk):
         E.add([ix.aoa_help[k]], [1.0], sqcm)
     for k in range(K):
         E.add([ix.ang_sp_help[k]], [1.0], p.omMax)
+    if NU == 5:   # finmxf[n] - p.finmxf = 0 (rocketland.jl:205 as commented there)
+        for k in range(K + 1):
+            E.add([ix.finmxf[k]], [1.0], p.finmxf)
     A, b = E.mat()
 
     L = _Rows(n)  # G z + s = h with s >= 0
@@ -144,8 +155,8 @@ def build(p: DescentProblem, xbar, ubar, endpoint, deriv, rk):
         L.add([ix.mtk[k], ix.uv[0, k]], [1.0, -1.0 / delMax], 0.0)
     # linearised thrust lower bound (:199-201 and solve_step :261-265)
     for k in range(K + 1):
-        un = np.linalg.norm(ubar[k])
-        L.add(list(ix.duv[:, k]), list(-ubar[k] / un), -(p.Tmin - un))
+        un = np.linalg.norm(ubar[k, :3])   # the thrust part of the control (:199 indexes control[1:3])
+        L.add(list(ix.duv[:3, k]), list(-ubar[k, :3] / un), -(p.Tmin - un))
     # hard trust region Jtr - rk <= 0 (:215-216, :269)
     L.add([ix.Jtr], [1.0], rk)
     l = L.m
@@ -167,7 +178,10 @@ def build(p: DescentProblem, xbar, ubar, endpoint, deriv, rk):
     for k in range(K):
         soc([ix.ang_sp_help[k]] + list(ix.xv[11:14, k]))                                 # :165-167
     for k in range(K + 1):
-        soc([ix.mtk[k]] + list(ix.uv[:, k]))                                             # :190-192
+        soc([ix.mtk[k]] + list(ix.uv[:3, k]))                                            # :190-192
+    if NU == 5:
+        for k in range(K + 1):
+            soc([ix.finmxf[k]] + list(ix.uv[3:5, k]))                                    # :208 as commented there
     # dynamic pressure 1/2 rho |v_k|^2 <= dpMax, k = 1..K, as the cone (vmax; v_k) -- fields master.jl:27,30, constraint a
     # "todo" at rocketland.jl:211-212; only when the problem enables it (build extension)
     if getattr(p, "enforce_dp", False):

@@ -9,9 +9,12 @@
 // The algorithm (Mehrotra predictor-corrector, Nesterov-Todd scaling, CVXOPT-style initial point) and
 // every formula follow the validated numpy twin oracle/ipm_struct.py; see DESIGN.md §SOCP for the maths.
 //
-// Reduced variables  w = (dx[K+1][14], du[K+1][3], nu[K][14], s, tnu, ttr, ts)   ("var vector", NV)
+// Reduced variables  w = (dx[K+1][14], du[K+1][NU], nu[K][14], s, tnu, ttr, ts)   ("var vector", NV); NU = 3, or 5 with the
+// fin extension (build-defined, SURVEY N2: u[4:5] = fin force coordinates, cone |u[4:5]| <= finmxf at every node,
+// rocketland.jl:203-209 as commented there)
 // Cone vector layout ("cone vector", NC):
-//     gs[K][3] tilt[K][3] rate[K][4] mass[K] tb[K+1][4] tc[K+1][4] lb[K+1] dp[ndp][4] nu[14K+1] tr[17(K+1)+1] sg[2] rk[1]
+//     gs[K][3] tilt[K][3] rate[K][4] mass[K] tb[K+1][4] tc[K+1][4] lb[K+1] fin[nfin][3] dp[ndp][4] nu[14K+1] tr[(14+NU)(K+1)+1] sg[2] rk[1]
+//     (fin: nfin = K+1 when NU = 5, else 0)
 //     (dp: the optional dynamic-pressure cones, ndp = K when Consts::vmax > 0, else 0)
 #pragma once
 #include <math.h>
@@ -132,6 +135,7 @@ struct Consts {
     int warm, pad2;   // warm: warm-start the solve that follows a rejected step (scvx_solver_opts.warm_start)
     double tol, accept;   // accept: acceptance band of a floor-limited iterate (status 4), >= tol
     double itan, sqcm, icos, Tmax, Tmin, omMax, mdry, wNu, mwet;
+    double finmxf; // fin extension: |u[4:5]| <= finmxf (rocketland.jl:205; read only by the NU = 5 instantiation)
     double vmax;   // dynamic-pressure limit |v_k| <= sqrt(2 dpMax / rho) (master.jl:27,30; 0 = not enforced, as in the reference)
     double rIf[3], vIf[3], qBIf[4], wBi[3], wBf[3];
 };
@@ -143,29 +147,34 @@ enum { LINV_SZ = 105 };
 SCVX_HD int linv_row(int i) { return i < 7 ? 15 * i : 15 * (13 - i) + (14 - i); }
 
 // compact per-node inverse of the x-block of Hb: [hm | Hr 3x3 | Hv 3x3 | hq | Hq34 2x2 | Hw 3x3] = 33 doubles
-// (Hv is a multiple of the identity unless the dynamic-pressure cone is enforced); NODE_SZ adds the 3x3 u-block
-enum { HX_M = 0, HX_R = 1, HX_V = 10, HX_Q = 19, HX_Q34 = 20, HX_W = 24, HX_SZ = 33, NODE_SZ = HX_SZ + 9 };
+// (Hv is a multiple of the identity unless the dynamic-pressure cone is enforced).  The u-block of a node follows:
+// 3x3 thrust block (9 doubles), and with the fin extension the 2x2 fin block (4 more): hu_size(NU).
+enum { HX_M = 0, HX_R = 1, HX_V = 10, HX_Q = 19, HX_Q34 = 20, HX_W = 24, HX_SZ = 33 };
+SCVX_HD constexpr int hu_size(int nu) { return nu == 5 ? 13 : 9; }
 
 struct Layout {
     int K, nx, nu_, nloc, nv, iS, iTNU, iTTR, iTS;
-    int o_gs, o_tilt, o_rate, o_mass, o_tb, o_tc, o_lb, o_dp, o_nu, o_tr, o_sg, o_rk, nc;
-    int c_gs, c_tilt, c_rate, c_mass, c_tb, c_tc, c_lb, c_dp, c_nu, c_tr, c_sg, c_rk, ncones, nsmall;
-    int ndp;
+    int o_gs, o_tilt, o_rate, o_mass, o_tb, o_tc, o_lb, o_fin, o_dp, o_nu, o_tr, o_sg, o_rk, nc;
+    int c_gs, c_tilt, c_rate, c_mass, c_tb, c_tc, c_lb, c_fin, c_dp, c_nu, c_tr, c_sg, c_rk, ncones, nsmall;
+    int ndp, nfin, NU;
     int ny;
-    SCVX_HD void init(int K_, bool with_dp = false) {
+    SCVX_HD void init(int K_, bool with_dp = false, int nu = 3) {
         K = K_;
+        NU = nu == 5 ? 5 : 3;
         ndp = with_dp ? K_ : 0;
+        nfin = NU == 5 ? K_ + 1 : 0;
         nx = 14 * (K + 1);
-        nu_ = 3 * (K + 1);
+        nu_ = NU * (K + 1);
         nloc = nx + nu_ + 14 * K;
         iS = nloc; iTNU = nloc + 1; iTTR = nloc + 2; iTS = nloc + 3;
         nv = nloc + 4;
         ny = 14 * K;
         o_gs = 0; o_tilt = 3 * K; o_rate = 6 * K; o_mass = 10 * K; o_tb = 11 * K;
-        o_tc = o_tb + 4 * (K + 1); o_lb = o_tc + 4 * (K + 1); o_dp = o_lb + (K + 1); o_nu = o_dp + 4 * ndp;
-        o_tr = o_nu + 14 * K + 1; o_sg = o_tr + 17 * (K + 1) + 1; o_rk = o_sg + 2; nc = o_rk + 1;
+        o_tc = o_tb + 4 * (K + 1); o_lb = o_tc + 4 * (K + 1); o_fin = o_lb + (K + 1); o_dp = o_fin + 3 * nfin; o_nu = o_dp + 4 * ndp;
+        o_tr = o_nu + 14 * K + 1; o_sg = o_tr + (14 + NU) * (K + 1) + 1; o_rk = o_sg + 2; nc = o_rk + 1;
         c_gs = 0; c_tilt = K; c_rate = 2 * K; c_mass = 3 * K; c_tb = 4 * K; c_tc = c_tb + K + 1; c_lb = c_tc + K + 1;
-        c_dp = c_lb + K + 1;
+        c_fin = c_lb + K + 1;
+        c_dp = c_fin + nfin;
         nsmall = c_dp + ndp;
         c_nu = nsmall; c_tr = nsmall + 1; c_sg = nsmall + 2; c_rk = nsmall + 3; ncones = nsmall + 4;
     }
@@ -177,13 +186,13 @@ struct Layout {
         n += (size_t)ny * 10;            // y, ry, dy, r2, cy, tmpy, tmpy2, rp, tq0, tq1
         n += (size_t)nc * 8;             // S, Z, lam, Wv, Wibz, tmpc, Wirz, sd
         n += (size_t)ncones;             // Wbeta
-        n += (size_t)(K + 1) * HX_SZ + (size_t)(K + 1) * 9;  // hx, hu
+        n += (size_t)(K + 1) * HX_SZ + (size_t)(K + 1) * hu_size(NU);  // hx, hu
         n += (size_t)K * (LINV_SZ + 196);  // Linv (packed lower triangle), Nf
         n += (size_t)K * 196;            // At: the state blocks A_k of D transposed (coalesced E' products)
         n += (size_t)ny;                 // tchain
         n += (size_t)ny * 4 + nloc;      // ys, ytr, ynu, rtr, ptl
         n += (size_t)nloc * 2;           // tmpl, tmpl2
-        n += (size_t)3 * (K + 1);        // uhat
+        n += (size_t)3 * (K + 1);        // uhat (thrust part of the control)
         n += (size_t)(K + 1);            // lb0
         n += 64;                         // scalars
         n += (size_t)nv + ny + 2 * (size_t)nc + 8;   // warm-start iterate (Vw, yw, Sw, Zw) + its header
@@ -305,8 +314,19 @@ struct Result {
     int warmed;   // the solve started from the kept iterate of the previous solve (SCVX_WARM_SAVE)
 };
 
-template <class Ex, class Stor = double, class DStor = Stor>
+template <class Ex, class Stor = double, class DStor = Stor, int NU = 3>
 struct Solver {
+    static_assert(NU == 3 || NU == 5, "control_dim 3 (the reference's live model) or 5 (fin extension)");
+    static constexpr int NP = 14 + 2 * NU + 1;      // columns of a derivative tile: [A | B- | B+ | Sigma]
+    static constexpr int DSZ = 14 * NP;             // doubles per tile (column-major 14 x NP)
+    static constexpr int CS = 14 + 2 * NU;          // the sigma column
+    static constexpr int NXU = 14 + NU;             // trust-region rows per node
+    static constexpr int HU_SZ = hu_size(NU);       // node u-block inverse: 3x3 thrust (+ 2x2 fin)
+    static constexpr int NODE_SZ = HX_SZ + HU_SZ;   // compact node inverse
+    static constexpr int TW = 14 + 2 * NU;          // columns of the [TA | TBm | TBp] tile
+    static constexpr int TS = NU == 5 ? 26 : 22;    // its row stride in LDS (conflict-free fragment reads)
+    static constexpr int BPN = 14 * NU;             // a B+ / B- block (column-major 14 x NU)
+    static constexpr int NPW = (DSZ + 63) / 64;     // registers per lane that hold one tile in a 64-lane wavefront
     typedef typename gp<Stor>::ptr gptr;     // workspace (storage type)
     typedef typename gp<Stor>::cptr cgptr;
     typedef typename gp<DStor>::ptr dptr;
@@ -345,7 +365,7 @@ struct Solver {
                        // an inaccurate solve RAISES it, and must not switch the refinement off)
 
     SCVX_HD Solver(Ex& e, const Consts& c) : ex(e), C(c) {
-        L.init(c.K, c.vmax > 0.0);
+        L.init(c.K, c.vmax > 0.0, NU);
 #if defined(SCVX_IPM_PROF)
         for (int i = 0; i < 32; i++) prof[i] = 0.0;
 #endif
@@ -360,7 +380,7 @@ struct Solver {
         S = w; w += nc; Z = w; w += nc; lam = w; w += nc; Wv = w; w += nc;
         Wibz = w; w += nc; tmpc = w; w += nc; Wirz = w; w += nc; sd = w; w += nc;
         Wbeta = w; w += L.ncones;
-        hx = w; w += (size_t)(K + 1) * HX_SZ; hu = w; w += (size_t)(K + 1) * 9;
+        hx = w; w += (size_t)(K + 1) * HX_SZ; hu = w; w += (size_t)(K + 1) * HU_SZ;
         Linv = w; w += (size_t)K * LINV_SZ; Nf = w; w += (size_t)K * 196; At = (dptr)w; w += (size_t)K * 196;
         tchain = w; w += ny;
         ys = w; w += ny; ytr = w; w += ny; ynu = w; w += ny; rtr = w; w += ny; ptl = w; w += nloc;
@@ -376,7 +396,22 @@ struct Solver {
         if (k == L.K) return j != 0;
         return false;
     }
-    SCVX_HD bool fixed_u(int k, int c) const { return k == L.K && c > 0; }
+    SCVX_HD bool fixed_u(int k, int c) const { return k == L.K && (c == 1 || c == 2); }   // u[2:3, K+1] = 0 (rocketland.jl:115)
+
+    // ---- node u-block inverse Hui (compact: 3x3 thrust block row-major at h[0..8], 2x2 fin block at h[9..12]) ----
+    // element (i, c) of  B Hui  for the 14 x NU block of the tile Dt that starts at column c0
+    template <class PH>
+    static SCVX_HD double bhu(const double* Dt, int c0, int i, int c, PH h) {
+        if (NU == 3 || c < 3) return Dt[14 * c0 + i] * h[c] + Dt[14 * (c0 + 1) + i] * h[3 + c] + Dt[14 * (c0 + 2) + i] * h[6 + c];
+        return Dt[14 * (c0 + 3) + i] * h[9 + (c - 3)] + Dt[14 * (c0 + 4) + i] * h[11 + (c - 3)];
+    }
+    // So(i, j) = -TA(i, j) + sum_c TBm(i, c) Bp(j, c)   (T row stride TS, Bp column-major 14 x NU)
+    static SCVX_HD double so_elem(const double* T, const double* Bp, int i, int j) {
+        double a = -T[TS * i + j];
+        SCVX_UNROLL
+        for (int c = 0; c < NU; c++) a += T[TS * i + 14 + c] * Bp[14 * c + j];
+        return a;
+    }
 
     // ---- parallel vector helpers ----
     // Streaming loop over [i0, n) with U independent elements in flight per lane: ld(i) gathers the inputs of element
@@ -431,14 +466,14 @@ struct Solver {
         double n2 = 0;
         for (int r = ex.lane(); r < 14 * K; r += ex.nlanes()) {
             const int k = r / 14, i = r - 14 * k;
-            dcptr Dk = D + (size_t)k * 294 + i;
+            dcptr Dk = D + (size_t)k * DSZ + i;
             cgptr dx = v + 14 * k;
-            cgptr du = v + L.nx + 3 * k;
+            cgptr du = v + L.nx + NU * k;
             const double ad = add ? add[r] : 0.0;   // issued with the batch of loads below, not after it
             double a = 0;
             for (int j = 0; j < 14; j++) a += Dk[14 * j] * dx[j];
-            for (int j = 0; j < 6; j++) a += Dk[14 * (14 + j)] * du[j];  // du_k then du_{k+1} are adjacent
-            a += Dk[14 * 20] * s;
+            for (int j = 0; j < 2 * NU; j++) a += Dk[14 * (14 + j)] * du[j];  // du_k then du_{k+1} are adjacent
+            a += Dk[14 * CS] * s;
             a += v[L.nx + L.nu_ + r] - v[14 * (k + 1) + i];
             a += sa * ad;
             out[r] = a;
@@ -471,16 +506,16 @@ struct Solver {
             g[t] = a;
         }
         for (int t = ex.lane(); t < L.nu_; t += ex.nlanes()) {
-            const int k = t / 3, c = t - 3 * k;
+            const int k = t / NU, c = t - NU * k;
             const double b0 = mode ? base[L.nx + t] - (corr ? pc * Pt[L.nx + t] : 0.0) : 0.0;
             double a = 0;
             if (k < K) {
-                dcptr col = D + (size_t)k * 294 + 14 * (14 + c);
+                dcptr col = D + (size_t)k * DSZ + 14 * (14 + c);
                 cgptr yk = yy + 14 * k;
                 for (int i = 0; i < 14; i++) a += col[i] * yk[i];
             }
             if (k > 0) {
-                dcptr col = D + (size_t)(k - 1) * 294 + 14 * (17 + c);
+                dcptr col = D + (size_t)(k - 1) * DSZ + 14 * (14 + NU + c);
                 cgptr yk = yy + 14 * (k - 1);
                 for (int i = 0; i < 14; i++) a += col[i] * yk[i];
             }
@@ -491,10 +526,10 @@ struct Solver {
         {
             const dcptr D_ = D; cgptr bn = mode ? base + L.nx + L.nu_ : yy; const gptr gn = g + L.nx + L.nu_;
             if (corr)
-                stream(0, 14 * K, [&](int r) { const int k = r / 14, i = r - 14 * k; return D4{yy[r], bn[r], D_[(size_t)k * 294 + 14 * 20 + i], Pn[r]}; },
+                stream(0, 14 * K, [&](int r) { const int k = r / 14, i = r - 14 * k; return D4{yy[r], bn[r], D_[(size_t)k * DSZ + 14 * CS + i], Pn[r]}; },
                        [&](int r, const D4& w) { gn[r] = (w.b - pn * w.d) - w.a; sg += w.c * w.a; });
             else
-            stream(0, 14 * K, [&](int r) { const int k = r / 14, i = r - 14 * k; return D3{yy[r], bn[r], D_[(size_t)k * 294 + 14 * 20 + i]}; },
+            stream(0, 14 * K, [&](int r) { const int k = r / 14, i = r - 14 * k; return D3{yy[r], bn[r], D_[(size_t)k * DSZ + 14 * CS + i]}; },
                    [&](int r, const D3& w) { gn[r] = mode == 0 ? w.a : (mode == 1 ? w.b - w.a : w.a - w.b); sg += w.c * w.a; });
         }
         ex.sync();
@@ -510,10 +545,10 @@ struct Solver {
         const double af = affine ? 1.0 : 0.0;
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
             cgptr dx = v + 14 * k;
-            cgptr du = v + L.nx + 3 * k;
-            double x[14], u[3];
+            cgptr du = v + L.nx + NU * k;
+            double x[14], u[NU];
             for (int j = 0; j < 14; j++) x[j] = af * xbar[14 * k + j] + dx[j];
-            for (int c = 0; c < 3; c++) u[c] = af * ubar[3 * k + c] + du[c];
+            for (int c = 0; c < NU; c++) u[c] = af * ubar[NU * k + c] + du[c];
             if (k < K) {
                 gptr g = out + L.o_gs + 3 * k;
                 g[0] = x[1] * C.itan; g[1] = x[2]; g[2] = x[3];
@@ -532,6 +567,10 @@ struct Solver {
             gptr tc = out + L.o_tc + 4 * k;
             tc[0] = u[0] * C.icos; tc[1] = u[0]; tc[2] = u[1]; tc[3] = u[2];
             out[L.o_lb + k] = uhat[3 * k] * du[0] + uhat[3 * k + 1] * du[1] + uhat[3 * k + 2] * du[2] - af * lb0[k];
+            if constexpr (NU == 5) {
+                gptr f = out + L.o_fin + 3 * k;
+                f[0] = af * C.finmxf; f[1] = u[3]; f[2] = u[4];
+            }
         }
         {
             cgptr vn = v + L.nx + L.nu_; gptr on = out + L.o_nu + 1; gptr ot = out + L.o_tr + 1;
@@ -553,7 +592,7 @@ struct Solver {
         SCVX_T0();
         const int K = L.K;
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
-            double gl[17];   // the node's rows are assembled in registers and stored once
+            double gl[NXU];   // the node's rows are assembled in registers and stored once
             cgptr trx = z + L.o_tr + 1 + 14 * k;
             for (int j = 0; j < 14; j++) gl[j] = trx[j];
             if (k >= 1) gl[0] += z[L.o_mass + (k - 1)];
@@ -569,22 +608,26 @@ struct Solver {
                     gl[4] += d[1]; gl[5] += d[2]; gl[6] += d[3];
                 }
             }
-            cgptr tru = z + L.o_tr + 1 + L.nx + 3 * k;
+            cgptr tru = z + L.o_tr + 1 + L.nx + NU * k;
             cgptr tb = z + L.o_tb + 4 * k;
             cgptr tc = z + L.o_tc + 4 * k;
             const double zl = z[L.o_lb + k];
             for (int c = 0; c < 3; c++) gl[14 + c] = tru[c] + tb[1 + c] + tc[1 + c] + zl * uhat[3 * k + c];
             gl[14] += tc[0] * C.icos;
-            gptr gx_ = g + 14 * k; gptr gu = g + L.nx + 3 * k;
+            if constexpr (NU == 5) {
+                cgptr f = z + L.o_fin + 3 * k;
+                gl[17] = tru[3] + f[1]; gl[18] = tru[4] + f[2];
+            }
+            gptr gx_ = g + 14 * k; gptr gu = g + L.nx + NU * k;
             if (sub) {
-                double sb[17];
+                double sb[NXU];
                 for (int j = 0; j < 14; j++) sb[j] = sub[14 * k + j];
-                for (int c = 0; c < 3; c++) sb[14 + c] = sub[L.nx + 3 * k + c];
+                for (int c = 0; c < NU; c++) sb[14 + c] = sub[L.nx + NU * k + c];
                 for (int j = 0; j < 14; j++) gx_[j] = -sb[j] - gl[j];
-                for (int c = 0; c < 3; c++) gu[c] = -sb[14 + c] - gl[14 + c];
+                for (int c = 0; c < NU; c++) gu[c] = -sb[14 + c] - gl[14 + c];
             } else {
                 for (int j = 0; j < 14; j++) gx_[j] = gl[j];
-                for (int c = 0; c < 3; c++) gu[c] = gl[14 + c];
+                for (int c = 0; c < NU; c++) gu[c] = gl[14 + c];
             }
         }
         {
@@ -611,7 +654,7 @@ struct Solver {
             if (fixed_x(0, j)) g[j] = 0.0;
             if (fixed_x(L.K, j)) g[14 * L.K + j] = 0.0;
         }
-        if (ex.lane() == 0) { g[L.nx + 3 * L.K + 1] = 0.0; g[L.nx + 3 * L.K + 2] = 0.0; }
+        if (ex.lane() == 0) { g[L.nx + NU * L.K + 1] = 0.0; g[L.nx + NU * L.K + 2] = 0.0; }
         ex.sync();
     }
 
@@ -645,6 +688,7 @@ struct Solver {
         each_small<1>(L.o_mass, L.c_mass, K, f);
         each_small<4>(L.o_tb, L.c_tb, 2 * (K + 1), f);      // tb, tc are adjacent
         each_small<1>(L.o_lb, L.c_lb, K + 1, f);
+        each_small<3>(L.o_fin, L.c_fin, L.nfin, f);
         each_small<4>(L.o_dp, L.c_dp, L.ndp, f);
         if (with_sg) { each_small<2>(L.o_sg, L.c_sg, 1, f); each_small<1>(L.o_rk, L.c_rk, 1, f); }
     }
@@ -674,7 +718,7 @@ struct Solver {
             }
         }, true);
         big_W(L.o_nu, 14 * L.K + 1, L.c_nu, in, out, inverse);
-        big_W(L.o_tr, 17 * (L.K + 1) + 1, L.c_tr, in, out, inverse);
+        big_W(L.o_tr, NXU * (L.K + 1) + 1, L.c_tr, in, out, inverse);
         ex.sync();
         SCVX_T1(8);
     }
@@ -690,7 +734,7 @@ struct Solver {
     // cones are swept cooperatively: reductions first (their scalars enter every element), then one apply sweep.
     // a(v) / J v of a small cone are gathered straight from the variable vector (no cone-shaped temporary).
     // ------------------------------------------------------------------------------------------------
-    enum { G_GS3 = 0, G_RATE = 1, G_MASS = 2, G_T4 = 3, G_LB = 4, G_SG = 5, G_RK = 6, G_DP = 7 };
+    enum { G_GS3 = 0, G_RATE = 1, G_MASS = 2, G_T4 = 3, G_LB = 4, G_SG = 5, G_RK = 6, G_DP = 7, G_FIN = 8 };
     template <int GRP, int D, class F>
     SCVX_HD void each_small_g(int off0, int c0, int n, F&& f) {
         for (int q = ex.lane(); q < n; q += ex.nlanes())
@@ -705,6 +749,7 @@ struct Solver {
         each_small_g<G_MASS, 1>(L.o_mass, L.c_mass, K, f);
         each_small_g<G_T4, 4>(L.o_tb, L.c_tb, 2 * (K + 1), f);       // tb, tc are adjacent
         each_small_g<G_LB, 1>(L.o_lb, L.c_lb, K + 1, f);
+        if constexpr (NU == 5) each_small_g<G_FIN, 3>(L.o_fin, L.c_fin, L.nfin, f);
         each_small_g<G_DP, 4>(L.o_dp, L.c_dp, L.ndp, f);
         each_small_g<G_SG, 2>(L.o_sg, L.c_sg, 1, f);
         each_small_g<G_RK, 1>(L.o_rk, L.c_rk, 1, f);
@@ -732,14 +777,19 @@ struct Solver {
         } else if constexpr (GRP == G_T4) {
             const bool tb = q <= K;
             const int k = tb ? q : q - (K + 1);
-            cgptr du = v + L.nx + 3 * k; cdptr ub = ubar + 3 * k;
+            cgptr du = v + L.nx + NU * k; cdptr ub = ubar + NU * k;
             double u[3];
             for (int c = 0; c < 3; c++) u[c] = af * ub[c] + du[c];
             o[0] = tb ? af * C.Tmax : u[0] * C.icos;
             o[1] = u[0]; o[2] = u[1]; o[3] = u[2];
         } else if constexpr (GRP == G_LB) {
-            cgptr du = v + L.nx + 3 * q;
+            cgptr du = v + L.nx + NU * q;
             o[0] = uhat[3 * q] * du[0] + uhat[3 * q + 1] * du[1] + uhat[3 * q + 2] * du[2] - af * lb0[q];
+        } else if constexpr (GRP == G_FIN) {
+            cgptr du = v + L.nx + NU * q; cdptr ub = ubar + NU * q;
+            o[0] = af * C.finmxf;
+            o[1] = af * ub[3] + du[3];
+            o[2] = af * ub[4] + du[4];
         } else if constexpr (GRP == G_DP) {
             cgptr dx = v + 14 * q; cdptr xb = xbar + 14 * q;
             o[0] = af * C.vmax;
@@ -754,7 +804,7 @@ struct Solver {
     struct BigCone { int off, dim, cidx, head, body; };
     SCVX_HD BigCone big_cone(int q) const {
         return q == 0 ? BigCone{L.o_nu, 14 * L.K + 1, L.c_nu, L.iTNU, L.nx + L.nu_}
-                      : BigCone{L.o_tr, 17 * (L.K + 1) + 1, L.c_tr, L.iTTR, 0};
+                      : BigCone{L.o_tr, NXU * (L.K + 1) + 1, L.c_tr, L.iTTR, 0};
     }
     struct D6 { double a, b, c, d, e, f; };
 
@@ -1052,7 +1102,12 @@ struct Solver {
         {
             cgptr gu = g + L.nx; gptr ou = out + L.nx;
             stream(0, L.nu_,
-                   [&](int t) { const int k = t / 3; cgptr h = hu_ + 3 * t; cgptr x = gu + 3 * k; return D6{h[0], h[1], h[2], x[0], x[1], x[2]}; },
+                   [&](int t) {
+                       const int k = t / NU, c = t - NU * k;
+                       if (NU == 3 || c < 3) { cgptr h = hu_ + HU_SZ * k + 3 * c; cgptr x = gu + NU * k; return D6{h[0], h[1], h[2], x[0], x[1], x[2]}; }
+                       cgptr h = hu_ + HU_SZ * k + 9 + 2 * (c - 3); cgptr x = gu + NU * k + 3;   // row c - 3 of the 2x2 fin block
+                       return D6{h[0], h[1], 0.0, x[0], x[1], 0.0};
+                   },
                    [&](int t, const D6& w) { ou[t] = w.a * w.d + w.b * w.e + w.c * w.f; });
         }
         {
@@ -1195,11 +1250,11 @@ struct Solver {
         const int K = L.K;
         for (int r = ex.lane(); r < 14 * K; r += ex.nlanes()) {
             const int k = r / 14, i = r - 14 * k;
-            dcptr Dk = D + (size_t)k * 294 + i;
+            dcptr Dk = D + (size_t)k * DSZ + i;
             const double ad = add1[r];
             double a = 0, b = 0;
             for (int j = 0; j < 14; j++) { const double d = Dk[14 * j]; a += d * v0[14 * k + j]; b += d * v1[14 * k + j]; }
-            for (int j = 0; j < 6; j++) { const double d = Dk[14 * (14 + j)]; a += d * v0[L.nx + 3 * k + j]; b += d * v1[L.nx + 3 * k + j]; }
+            for (int j = 0; j < 2 * NU; j++) { const double d = Dk[14 * (14 + j)]; a += d * v0[L.nx + NU * k + j]; b += d * v1[L.nx + NU * k + j]; }
             a += v0[L.nx + L.nu_ + r] - v0[14 * (k + 1) + i];
             b += v1[L.nx + L.nu_ + r] - v1[14 * (k + 1) + i];
             out0[r] = a;
@@ -1230,27 +1285,25 @@ struct Solver {
         double* Li = Wp + 588;           // 2 x 196: Linv ring (chain writes k; the post stage reads k-1)
         double* Mq = Li + 392;           // post stage: Nf product
         double* Dt = Mq + 196;           // producer: D_k tile
-        double* T = Dt + 294;            // producer: [TA | TBm | TBp], row stride 22
-        double* Bp = T + 308;            // producer: Bp_k kept across the tile swap
-        double* Hh = Bp + 42;            // producer: node inverses k | k+1
+        double* T = Dt + DSZ;            // producer: [TA | TBm | TBp], row stride 22
+        double* Bp = T + 14 * TS;            // producer: Bp_k kept across the tile swap
+        double* Hh = Bp + BPN;            // producer: node inverses k | k+1
         double* Hd = Hh + 2 * NODE_SZ;   // producer: dense Hxi_{k+1}
-        constexpr int TS = 22;
         const int w = ex.wave(), l = ex.wlane();
         bool ok = true;
         auto node_elem = [&](int node, int e) -> double {
-            return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[9 * node + (e - HX_SZ)];
+            return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[HU_SZ * node + (e - HX_SZ)];
         };
         if (w == 1) {   // producer prologue: D_0, node 0 -> TA_0, TBm_0
-            for (int e = l; e < 294; e += 64) Dt[e] = D_[e];
+            for (int e = l; e < DSZ; e += 64) Dt[e] = D_[e];
             for (int e = l; e < NODE_SZ; e += 64) Hh[NODE_SZ + e] = node_elem(0, e);
             ex.w_sync_lds();
             for (int e = l; e < 196; e += 64) Hd[e] = hxi_entry(Hh + NODE_SZ, e / 14, e % 14);
             ex.w_sync_lds();
             ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
-            for (int q = l; q < 42; q += 64) {
-                const int i = q / 3, c = q - 3 * i;
-                const double* h = Hh + NODE_SZ + HX_SZ;
-                T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
+            for (int q = l; q < BPN; q += 64) {
+                const int i = q / NU, c = q - NU * i;
+                T[TS * i + 14 + c] = bhu(Dt, 14, i, c, Hh + NODE_SZ + HX_SZ);
             }
             ex.w_sync_lds();
         }
@@ -1262,49 +1315,47 @@ struct Solver {
                 SCVX_TS(tp0_);
                 double* Sdk = Sd + 196 * (k & 1); double* Sok = So + 196 * (k & 1);
                 // next tile into registers while this segment is assembled
-                double pre[5];
-                dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
+                double pre[NPW];
+                dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * DSZ;
                 SCVX_UNROLL
-                for (int q = 0; q < 5; q++) { const int e = l + 64 * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
+                for (int q = 0; q < NPW; q++) { const int e = l + 64 * q; pre[q] = e < DSZ ? Dn[e] : 0.0; }
                 for (int e = l; e < NODE_SZ; e += 64) { Hh[e] = Hh[NODE_SZ + e]; }
                 ex.w_sync_lds();
                 if (l < NODE_SZ) Hh[NODE_SZ + l] = hnext;                          // node k + 1, requested a step ago
                 hnext = l < NODE_SZ ? node_elem(k + 2 <= K ? k + 2 : K, l) : 0.0;   // node k + 2 for the next step
                 ex.w_sync_lds();
-                for (int e = l; e < 196 + 42; e += 64) {
+                for (int e = l; e < 196 + BPN; e += 64) {
                     if (e < 196) {
                         const int i = e / 14, j = e - 14 * i;
                         const double h = hxi_entry(Hh + NODE_SZ, i, j);
                         Hd[e] = h;
                         Sdk[e] = h + (i == j ? hnui_ : 0.0);
                     } else {
-                        const int q = e - 196, i = q / 3, c = q - 3 * i;
-                        const double* h = Hh + NODE_SZ + HX_SZ;
-                        T[TS * i + 17 + c] = Dt[14 * 17 + i] * h[c] + Dt[14 * 18 + i] * h[3 + c] + Dt[14 * 19 + i] * h[6 + c];
+                        const int q = e - 196, i = q / NU, c = q - NU * i;
+                        T[TS * i + 14 + NU + c] = bhu(Dt, 14 + NU, i, c, Hh + NODE_SZ + HX_SZ);
                     }
                 }
                 ex.w_sync_lds();
                 SCVX_TE(tp0_, 24);
                 SCVX_TS(tp1_);
-                ex.w_tile_gemm(Sdk, 14, 1, T, TS, 1, Dt, 14, 1, 20, 1.0, true);
+                ex.w_tile_gemm(Sdk, 14, 1, T, TS, 1, Dt, 14, 1, TW, 1.0, true);
                 SCVX_TE(tp1_, 25);
                 SCVX_TS(tp2_);
                 if (k + 1 < K) {
-                    for (int q = l; q < 42; q += 64) Bp[q] = Dt[14 * 17 + q];
+                    for (int q = l; q < BPN; q += 64) Bp[q] = Dt[14 * (14 + NU) + q];
                     ex.w_sync_lds();
                     SCVX_UNROLL
-                    for (int q = 0; q < 5; q++) { const int e = l + 64 * q; if (e < 294) Dt[e] = pre[q]; }
+                    for (int q = 0; q < NPW; q++) { const int e = l + 64 * q; if (e < DSZ) Dt[e] = pre[q]; }
                     ex.w_sync_lds();
                     ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
-                    for (int q = l; q < 42; q += 64) {
-                        const int i = q / 3, c = q - 3 * i;
-                        const double* h = Hh + NODE_SZ + HX_SZ;
-                        T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
+                    for (int q = l; q < BPN; q += 64) {
+                        const int i = q / NU, c = q - NU * i;
+                        T[TS * i + 14 + c] = bhu(Dt, 14, i, c, Hh + NODE_SZ + HX_SZ);
                     }
                     ex.w_sync_lds();
                     for (int e = l; e < 196; e += 64) {
                         const int i = e / 14, j = e - 14 * i;
-                        Sok[e] = -T[TS * i + j] + T[TS * i + 14] * Bp[j] + T[TS * i + 15] * Bp[14 + j] + T[TS * i + 16] * Bp[28 + j];
+                        Sok[e] = so_elem(T, Bp, i, j);
                     }
                 }
                 ex.w_sync_lds();
@@ -1374,15 +1425,14 @@ struct Solver {
         double* Li = Wp + 588;           // 2 x 196: Linv ring
         double* Mq = Li + 392;           // N tile product
         double* Dt = Mq + 196;           // producer: D_k tile
-        double* T = Dt + 294;            // producer: [TA | TBm | TBp], row stride 22
-        double* Bp = T + 308;            // producer: Bp of the neighbouring tile
-        double* Hh = Bp + 42;            // producer: node inverses (two slots)
+        double* T = Dt + DSZ;            // producer: [TA | TBm | TBp], row stride 22
+        double* Bp = T + 14 * TS;            // producer: Bp of the neighbouring tile
+        double* Hh = Bp + BPN;            // producer: node inverses (two slots)
         double* Hd = Hh + 2 * NODE_SZ;   // producer: dense Hxi (bottom: two of them, by step parity)
         double* Mp = Hd + 392;           // producer: N tile of the node the chain finished one step ago
-        constexpr int TS = 22;
         bool ok = true;
         auto node_elem = [&](int node, int e) -> double {
-            return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[9 * node + (e - HX_SZ)];
+            return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[HU_SZ * node + (e - HX_SZ)];
         };
         auto store_linv = [&](int k, const double* Lik) {
             for (int e = l; e < LINV_SZ; e += 64) {
@@ -1408,24 +1458,23 @@ struct Solver {
         };
         // ---- prologues ----
         if (w == 1) {   // top producer: D_0, node 0 -> TA_0, TBm_0 (as factor_pipelined)
-            for (int e = l; e < 294; e += 64) Dt[e] = D_[e];
+            for (int e = l; e < DSZ; e += 64) Dt[e] = D_[e];
             for (int e = l; e < NODE_SZ; e += 64) Hh[NODE_SZ + e] = node_elem(0, e);
             ex.w_sync_lds();
             for (int e = l; e < 196; e += 64) Hd[e] = hxi_entry(Hh + NODE_SZ, e / 14, e % 14);
             ex.w_sync_lds();
             ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
-            for (int q = l; q < 42; q += 64) {
-                const int i = q / 3, c = q - 3 * i;
-                const double* h = Hh + NODE_SZ + HX_SZ;
-                T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
+            for (int q = l; q < BPN; q += 64) {
+                const int i = q / NU, c = q - NU * i;
+                T[TS * i + 14 + c] = bhu(Dt, 14, i, c, Hh + NODE_SZ + HX_SZ);
             }
             ex.w_sync_lds();
         }
         if (w == 3) {   // bottom producer: tile K-1, nodes K-1 (slot 0) and K (slot 1), Bp of tile K-2, dense Hxi_K
-            dcptr Dk = D_ + (size_t)(K - 1) * 294;
-            for (int e = l; e < 294; e += 64) Dt[e] = Dk[e];
+            dcptr Dk = D_ + (size_t)(K - 1) * DSZ;
+            for (int e = l; e < DSZ; e += 64) Dt[e] = Dk[e];
             for (int e = l; e < NODE_SZ; e += 64) { Hh[e] = node_elem(K - 1, e); Hh[NODE_SZ + e] = node_elem(K, e); }
-            for (int q = l; q < 42; q += 64) Bp[q] = D_[(size_t)(K - 2) * 294 + 14 * 17 + q];
+            for (int q = l; q < BPN; q += 64) Bp[q] = D_[(size_t)(K - 2) * DSZ + 14 * (14 + NU) + q];
             ex.w_sync_lds();
             for (int e = l; e < 196; e += 64) Hd[196 + e] = hxi_entry(Hh + NODE_SZ, e / 14, e % 14);   // parity 1 = "step -1"
             ex.w_sync_lds();
@@ -1438,45 +1487,43 @@ struct Solver {
                 const int k = t;
                 SCVX_TS(ta_);
                 double* Sdk = Sd + 196 * (k & 1); double* Sok = So + 196 * (k & 1);
-                double pre[5];
-                dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
+                double pre[NPW];
+                dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * DSZ;
                 SCVX_UNROLL
-                for (int q = 0; q < 5; q++) { const int e = l + 64 * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
+                for (int q = 0; q < NPW; q++) { const int e = l + 64 * q; pre[q] = e < DSZ ? Dn[e] : 0.0; }
                 for (int e = l; e < NODE_SZ; e += 64) { Hh[e] = Hh[NODE_SZ + e]; }
                 ex.w_sync_lds();
                 if (l < NODE_SZ) Hh[NODE_SZ + l] = hnext;                          // node k + 1, requested a step ago
                 hnext = l < NODE_SZ ? node_elem(k + 2 <= K ? k + 2 : K, l) : 0.0;   // node k + 2 for the next step
                 ex.w_sync_lds();
-                for (int e = l; e < 196 + 42; e += 64) {
+                for (int e = l; e < 196 + BPN; e += 64) {
                     if (e < 196) {
                         const int i = e / 14, j = e - 14 * i;
                         const double h = hxi_entry(Hh + NODE_SZ, i, j);
                         Hd[e] = h;
                         Sdk[e] = h + (i == j ? hnui_ : 0.0);
                     } else {
-                        const int q = e - 196, i = q / 3, c = q - 3 * i;
-                        const double* h = Hh + NODE_SZ + HX_SZ;
-                        T[TS * i + 17 + c] = Dt[14 * 17 + i] * h[c] + Dt[14 * 18 + i] * h[3 + c] + Dt[14 * 19 + i] * h[6 + c];
+                        const int q = e - 196, i = q / NU, c = q - NU * i;
+                        T[TS * i + 14 + NU + c] = bhu(Dt, 14 + NU, i, c, Hh + NODE_SZ + HX_SZ);
                     }
                 }
                 ex.w_sync_lds();
-                ex.w_tile_gemm(Sdk, 14, 1, T, TS, 1, Dt, 14, 1, 20, 1.0, true);
+                ex.w_tile_gemm(Sdk, 14, 1, T, TS, 1, Dt, 14, 1, TW, 1.0, true);
                 if (k < m) {
-                    for (int q = l; q < 42; q += 64) Bp[q] = Dt[14 * 17 + q];
+                    for (int q = l; q < BPN; q += 64) Bp[q] = Dt[14 * (14 + NU) + q];
                     ex.w_sync_lds();
                     SCVX_UNROLL
-                    for (int q = 0; q < 5; q++) { const int e = l + 64 * q; if (e < 294) Dt[e] = pre[q]; }
+                    for (int q = 0; q < NPW; q++) { const int e = l + 64 * q; if (e < DSZ) Dt[e] = pre[q]; }
                     ex.w_sync_lds();
                     ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
-                    for (int q = l; q < 42; q += 64) {
-                        const int i = q / 3, c = q - 3 * i;
-                        const double* h = Hh + NODE_SZ + HX_SZ;
-                        T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
+                    for (int q = l; q < BPN; q += 64) {
+                        const int i = q / NU, c = q - NU * i;
+                        T[TS * i + 14 + c] = bhu(Dt, 14, i, c, Hh + NODE_SZ + HX_SZ);
                     }
                     ex.w_sync_lds();
                     for (int e = l; e < 196; e += 64) {
                         const int i = e / 14, j = e - 14 * i;
-                        Sok[e] = -T[TS * i + j] + T[TS * i + 14] * Bp[j] + T[TS * i + 15] * Bp[14 + j] + T[TS * i + 16] * Bp[28 + j];
+                        Sok[e] = so_elem(T, Bp, i, j);
                     }
                 }
                 ex.w_sync_lds();
@@ -1507,12 +1554,14 @@ struct Solver {
                 const double* Hd1 = Hd + 196 * ((u + 1) & 1);   // dense Hxi_{k+1}: the previous step's Hd0
                 // the next step's inputs into registers: tile k-1, node k-1, Bp of tile k-2 (indices clamped at the end of the half)
                 const int kn = k - 1 > m ? k - 1 : k, kb2 = kn - 1;
-                double pre[5];
-                dcptr Dn = D_ + (size_t)kn * 294;
+                double pre[NPW];
+                dcptr Dn = D_ + (size_t)kn * DSZ;
                 SCVX_UNROLL
-                for (int q = 0; q < 5; q++) { const int e = l + 64 * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
+                for (int q = 0; q < NPW; q++) { const int e = l + 64 * q; pre[q] = e < DSZ ? Dn[e] : 0.0; }
                 const double hn = l < NODE_SZ ? node_elem(kn, l) : 0.0;
-                const double bpn = l < 42 ? (double)D_[(size_t)kb2 * 294 + 14 * 17 + l] : 0.0;
+                double bpn[(BPN + 63) / 64];
+                SCVX_UNROLL
+                for (int q = 0; q < (BPN + 63) / 64; q++) { const int e = l + 64 * q; bpn[q] = e < BPN ? (double)D_[(size_t)kb2 * DSZ + 14 * (14 + NU) + e] : 0.0; }
                 for (int e = l; e < 196; e += 64) {
                     const int i = e / 14, j = e - 14 * i;
                     Hd0[e] = hxi_entry(Hh, i, j);
@@ -1520,27 +1569,28 @@ struct Solver {
                 }
                 ex.w_sync_lds();
                 ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd0, 14, 1, 14, 1.0, false);     // TA_k = A_k Hxi_k
-                for (int q = l; q < 84; q += 64) {
-                    const bool pls = q >= 42;
-                    const int qq = pls ? q - 42 : q, i = qq / 3, c = qq - 3 * i;
+                for (int q = l; q < 2 * BPN; q += 64) {
+                    const bool pls = q >= BPN;
+                    const int qq = pls ? q - BPN : q, i = qq / NU, c = qq - NU * i;
                     const double* h = Hh + (pls ? NODE_SZ : 0) + HX_SZ;            // Hui_k for TBm_k, Hui_{k+1} for TBp_k
-                    const int c0 = pls ? 17 : 14;
-                    T[TS * i + c0 + c] = Dt[14 * c0 + i] * h[c] + Dt[14 * (c0 + 1) + i] * h[3 + c] + Dt[14 * (c0 + 2) + i] * h[6 + c];
+                    const int c0 = pls ? 14 + NU : 14;
+                    T[TS * i + c0 + c] = bhu(Dt, c0, i, c, h);
                 }
                 ex.w_sync_lds();
-                ex.w_tile_gemm(Sdk, 14, 1, T, TS, 1, Dt, 14, 1, 20, 1.0, true);
+                ex.w_tile_gemm(Sdk, 14, 1, T, TS, 1, Dt, 14, 1, TW, 1.0, true);
                 for (int e = l; e < 196; e += 64) {
                     const int i = e / 14, j = e - 14 * i;
-                    Sok[e] = -T[TS * i + j] + T[TS * i + 14] * Bp[j] + T[TS * i + 15] * Bp[14 + j] + T[TS * i + 16] * Bp[28 + j];   // So_{k-1}
+                    Sok[e] = so_elem(T, Bp, i, j);   // So_{k-1}
                 }
                 ex.w_sync_lds();
                 // rotate: node k becomes "k+1" of the next step, the prefetched tile / node / Bp move in
                 if (l < NODE_SZ) { Hh[NODE_SZ + l] = Hh[l]; }
                 ex.w_sync_lds();
                 if (l < NODE_SZ) Hh[l] = hn;
-                if (l < 42) Bp[l] = bpn;
                 SCVX_UNROLL
-                for (int q = 0; q < 5; q++) { const int e = l + 64 * q; if (e < 294) Dt[e] = pre[q]; }
+                for (int q = 0; q < (BPN + 63) / 64; q++) { const int e = l + 64 * q; if (e < BPN) Bp[e] = bpn[q]; }
+                SCVX_UNROLL
+                for (int q = 0; q < NPW; q++) { const int e = l + 64 * q; if (e < DSZ) Dt[e] = pre[q]; }
                 ex.w_sync_lds();
                 SCVX_TE(tc_, 24);
             }
@@ -1602,7 +1652,7 @@ struct Solver {
         const int K = L.K;
         // big-cone scalars
         {
-            const int dn = 14 * K + 1, dt = 17 * (K + 1) + 1;
+            const int dn = 14 * K + 1, dt = NXU * (K + 1) + 1;
             double n1 = 0, n2 = 0;
             {
                 cgptr wn = Wv + L.o_nu; cgptr wt = Wv + L.o_tr;
@@ -1701,11 +1751,17 @@ struct Solver {
                 const double il2 = 1.0 / (wl * wl);
                 for (int a = 0; a < 3; a++)
                     for (int b = 0; b < 3; b++) M[3 * a + b] += il2 * uhat[3 * k + a] * uhat[3 * k + b];
-                gptr hi = hu + 9 * k;
+                gptr hi = hu + HU_SZ * k;
                 if (last) {
                     for (int i = 0; i < 9; i++) hi[i] = 0.0;
                     hi[0] = 1.0 / M[0];
                 } else inv3(M, hi);
+                if constexpr (NU == 5) {
+                    // fin block: trust region + the cone (finmxf; u4, u5); free at every node (u[2:3, K+1] = 0 fixes thrust only)
+                    cgptr vf = Wv + L.o_fin + 3 * k;
+                    soc_w2(vf[0], vf[1] * vf[1] + vf[2] * vf[2], Wbeta[L.c_fin + k], h00, h01, h11, b2);
+                    inv2(dtr + b2 + h11 * vf[1] * vf[1], h11 * vf[1] * vf[2], dtr + b2 + h11 * vf[2] * vf[2], hi + 9);
+                }
             }
         }
         ex.sync();
@@ -1729,11 +1785,10 @@ struct Solver {
         double* Wp = M + 196;           // 196  Wb[k-1]
         double* Li = Wp + 196;          // 196  Linv[k]
         double* Dt = Li + 196;          // 294  D_k tile (column-major 14x21: element (i,j) at 14 j + i)
-        double* T = Dt + 294;           // 308  [TA | TBm | TBp] = [A_k Hxi_k | Bm_k Hui_k | Bp_k Hui_{k+1}], 14 x 20, row stride 22
-        double* Bp = T + 308;           // 42   copy of Bp_k (column-major 14x3) kept across the D tile swap
-        double* Hh = Bp + 42;           // 84   hx_k (33) hu_k (9) | hx_{k+1} (33) hu_{k+1} (9)
+        double* T = Dt + DSZ;           // 308  [TA | TBm | TBp] = [A_k Hxi_k | Bm_k Hui_k | Bp_k Hui_{k+1}], 14 x 20, row stride 22
+        double* Bp = T + 14 * TS;           // 42   copy of Bp_k (column-major 14x3) kept across the D tile swap
+        double* Hh = Bp + BPN;           // 84   hx_k (33) hu_k (9) | hx_{k+1} (33) hu_{k+1} (9)
         double* Hd = Hh + 2 * NODE_SZ;           // 196  dense Hxi of the node being multiplied
-        constexpr int TS = 22;          // row stride of T (22: conflict-free fragment reads; 20 would be 2-way)
         bool ok = true;
         if constexpr (Ex::kPipelineFactor) {
             if constexpr (Ex::kTwisted) {
@@ -1744,36 +1799,35 @@ struct Solver {
         // All 14x14xK products below go through ex.tile_gemm: FP64 MFMA (v_mfma_f64_16x16x4) on the device — one A and
         // one B element per lane per instruction instead of 2 LDS reads per multiply-add — plain loops on the host.
         // prologue: D_0, hx_0/hu_0 -> LDS; TA_0, TBm_0
-        for (int e = ex.lane(); e < 294; e += ex.nlanes()) Dt[e] = D_[e];
+        for (int e = ex.lane(); e < DSZ; e += ex.nlanes()) Dt[e] = D_[e];
         for (int e = ex.lane(); e < NODE_SZ; e += ex.nlanes()) Hh[NODE_SZ + e] = e < HX_SZ ? hx_[e] : hu_[e - HX_SZ];
         ex.sync_lds();
         for (int e = ex.lane(); e < 196; e += ex.nlanes()) Hd[e] = hxi_entry(Hh + NODE_SZ, e / 14, e % 14);
         ex.sync_lds();
         ex.tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);          // TA_0 = A_0 Hxi_0
-        for (int q = ex.lane(); q < 42; q += ex.nlanes()) {
-            const int i = q / 3, c = q - 3 * i;
-            const double* h = Hh + NODE_SZ + HX_SZ;
-            T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
+        for (int q = ex.lane(); q < BPN; q += ex.nlanes()) {
+            const int i = q / NU, c = q - NU * i;
+            T[TS * i + 14 + c] = bhu(Dt, 14, i, c, Hh + NODE_SZ + HX_SZ);
         }
         ex.sync_lds();
         // the compact node inverses (42 doubles) are requested one segment ahead as well: lane e holds element e of node
         // k + 1 while segment k - 1 is processed (register-prefetching executors have at least 42 lanes)
         auto node_elem = [&](int node, int e) -> double {
-            return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[9 * node + (e - HX_SZ)];
+            return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[HU_SZ * node + (e - HX_SZ)];
         };
         double hn = 0.0;
         if (Ex::kPrefetchRegs > 0 && ex.lane() < NODE_SZ) hn = node_elem(1, ex.lane());
         for (int k = 0; k < K; k++) {
             SCVX_TS(ta_);
             // prefetch the next segment's tile
-            constexpr int NPRE = Ex::kPrefetchRegs;
+            constexpr int NPRE = Ex::kPrefetchRegs > 0 ? (DSZ + Ex::kLanes - 1) / Ex::kLanes : 0;
             double hn2 = 0.0;
             if (NPRE > 0 && ex.lane() < NODE_SZ) hn2 = node_elem(k + 2 <= K ? k + 2 : K, ex.lane());
             double pre[NPRE > 0 ? NPRE : 1];
-            dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * 294;
+            dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * DSZ;
             if (NPRE > 0) {
                 SCVX_UNROLL
-                for (int q = 0; q < NPRE; q++) { const int e = ex.lane() + ex.nlanes() * q; pre[q] = e < 294 ? Dn[e] : 0.0; }
+                for (int q = 0; q < NPRE; q++) { const int e = ex.lane() + ex.nlanes() * q; pre[q] = e < DSZ ? Dn[e] : 0.0; }
             }
             // node inverses: slot 0 <- slot 1 (k), slot 1 <- k+1, dense tile of k+1
             for (int e = ex.lane(); e < NODE_SZ; e += ex.nlanes()) {
@@ -1783,23 +1837,22 @@ struct Solver {
             }
             hn = hn2;
             ex.sync_lds();
-            for (int e = ex.lane(); e < 196 + 42; e += ex.nlanes()) {
+            for (int e = ex.lane(); e < 196 + BPN; e += ex.nlanes()) {
                 if (e < 196) {
                     const int i = e / 14, j = e - 14 * i;
                     const double h = hxi_entry(Hh + NODE_SZ, i, j);
                     Hd[e] = h;
                     M[e] = h + (i == j ? hnui_ : 0.0);   // pivot tile starts from Hxi_{k+1} + hnui I
                 } else {  // TBp_k = Bp_k Hui_{k+1}
-                    const int q = e - 196, i = q / 3, c = q - 3 * i;
-                    const double* h = Hh + NODE_SZ + HX_SZ;
-                    T[TS * i + 17 + c] = Dt[14 * 17 + i] * h[c] + Dt[14 * 18 + i] * h[3 + c] + Dt[14 * 19 + i] * h[6 + c];
+                    const int q = e - 196, i = q / NU, c = q - NU * i;
+                    T[TS * i + 14 + NU + c] = bhu(Dt, 14 + NU, i, c, Hh + NODE_SZ + HX_SZ);
                 }
             }
             ex.sync_lds();
             SCVX_TE(ta_, 2);
             SCVX_TS(tb_);
             // pivot tile: M += [TA|TBm|TBp] [A|Bm|Bp]'  -  Wb_{k-1} Wb_{k-1}'
-            ex.tile_gemm(M, 14, 1, T, TS, 1, Dt, 14, 1, 20, 1.0, true);
+            ex.tile_gemm(M, 14, 1, T, TS, 1, Dt, 14, 1, TW, 1.0, true);
             if (k > 0) ex.tile_gemm(M, 14, 1, Wp, 14, 1, Wp, 1, 14, 14, -1.0, true);
             ex.sync_lds();
             SCVX_TE(tb_, 5);
@@ -1822,27 +1875,26 @@ struct Solver {
             SCVX_TS(te_);
             if (k + 1 < K) {
                 // keep Bp_k, swap in D_{k+1}
-                for (int q = ex.lane(); q < 42; q += ex.nlanes()) Bp[q] = Dt[14 * 17 + q];
+                for (int q = ex.lane(); q < BPN; q += ex.nlanes()) Bp[q] = Dt[14 * (14 + NU) + q];
                 ex.sync_lds();
                 if (NPRE > 0) {
                     SCVX_UNROLL
-                    for (int q = 0; q < NPRE; q++) { const int e = ex.lane() + ex.nlanes() * q; if (e < 294) Dt[e] = pre[q]; }
+                    for (int q = 0; q < NPRE; q++) { const int e = ex.lane() + ex.nlanes() * q; if (e < DSZ) Dt[e] = pre[q]; }
                 } else {
-                    for (int e = ex.lane(); e < 294; e += ex.nlanes()) Dt[e] = Dn[e];
+                    for (int e = ex.lane(); e < DSZ; e += ex.nlanes()) Dt[e] = Dn[e];
                 }
                 ex.sync_lds();
                 // TA_{k+1} = A_{k+1} Hxi_{k+1}, TBm_{k+1}
                 ex.tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
-                for (int q = ex.lane(); q < 42; q += ex.nlanes()) {
-                    const int i = q / 3, c = q - 3 * i;
-                    const double* h = Hh + NODE_SZ + HX_SZ;
-                    T[TS * i + 14 + c] = Dt[14 * 14 + i] * h[c] + Dt[14 * 15 + i] * h[3 + c] + Dt[14 * 16 + i] * h[6 + c];
+                for (int q = ex.lane(); q < BPN; q += ex.nlanes()) {
+                    const int i = q / NU, c = q - NU * i;
+                    T[TS * i + 14 + c] = bhu(Dt, 14, i, c, Hh + NODE_SZ + HX_SZ);
                 }
                 ex.sync_lds();
                 // So[k] = -TA_{k+1} + TBm_{k+1} Bp_k'
                 for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
                     const int i = e / 14, j = e - 14 * i;
-                    M[e] = -T[TS * i + j] + T[TS * i + 14] * Bp[j] + T[TS * i + 15] * Bp[14 + j] + T[TS * i + 16] * Bp[28 + j];
+                    M[e] = so_elem(T, Bp, i, j);
                 }
                 ex.sync_lds();
                 ex.tile_gemm(Wp, 14, 1, M, 14, 1, Li, 1, 14, 14, 1.0, false);      // Wb_k = So Linv'
@@ -1879,7 +1931,7 @@ struct Solver {
             }
             {
                 gptr ty = tmpy; gptr r2_ = r2; cgptr wn = Wv + L.o_nu + 1;
-                stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D2{D_[(size_t)k * 294 + 14 * 20 + i], wn[r]}; },
+                stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D2{D_[(size_t)k * DSZ + 14 * CS + i], wn[r]}; },
                        [&](int r, const D2& v) { ty[r] = v.a; r2_[r] = hnui_ * v.b; });   // r_s = +Sg, r_nu
             }
             ex.sync();
@@ -1903,7 +1955,7 @@ struct Solver {
             for (int q = 0; q < 9; q++) a[q] = 0.0;
             {
                 cgptr y0 = ys; cgptr y1 = ytr; cgptr y2 = ynu; cgptr rt = rtr; cgptr wn = Wv + L.o_nu + 1;
-                stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D6{D_[(size_t)k * 294 + 14 * 20 + i], y0[r], y1[r], y2[r], rt[r], wn[r]}; },
+                stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D6{D_[(size_t)k * DSZ + 14 * CS + i], y0[r], y1[r], y2[r], rt[r], wn[r]}; },
                        [&](int, const D6& v) {
                            a[0] += v.a * v.b; a[1] += v.a * v.c; a[2] += v.a * v.d;
                            a[3] += v.e * v.b; a[4] += v.e * v.c; a[5] += v.e * v.d;
@@ -1934,7 +1986,7 @@ struct Solver {
         double a = 0, bt = 0, bn = 0, gn = 0;
         {
             const dcptr D_ = D; cgptr rt = rtr; cgptr wn = Wv + L.o_nu + 1; cgptr gnu = g + L.nx + L.nu_;
-            stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D5{D_[(size_t)k * 294 + 14 * 20 + i], dyv[r], rt[r], wn[r], gnu[r]}; },
+            stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D5{D_[(size_t)k * DSZ + 14 * CS + i], dyv[r], rt[r], wn[r], gnu[r]}; },
                    [&](int, const D5& v) { a += v.a * v.b; bt += v.c * v.b; bn += v.d * v.b; gn += v.d * v.e; });
         }
         const double c0s = ex.sum(a);
@@ -2023,7 +2075,7 @@ struct Solver {
             const double sgy = Et_apply(dy, tmpl);
             double e1 = 0, e2 = 0, e3 = 0;
             for (int i = 0; i < L.nloc; i++) { double r = gx[i] - r1[i] - tmpl[i]; bool fx = false;
-                if (i < 14) fx = fixed_x(0, i); else if (i >= 14 * L.K && i < L.nx) fx = fixed_x(L.K, i - 14 * L.K); else if (i == L.nx + 3 * L.K + 1 || i == L.nx + 3 * L.K + 2) fx = true;
+                if (i < 14) fx = fixed_x(0, i); else if (i >= 14 * L.K && i < L.nx) fx = fixed_x(L.K, i - 14 * L.K); else if (i == L.nx + NU * L.K + 1 || i == L.nx + NU * L.K + 2) fx = true;
                 if (!fx) { if (i < L.nx + L.nu_) e1 += r * r; else e2 += r * r; } }
             E_apply(dw, tmpy2, true);
             for (int i = 0; i < L.ny; i++) { double r = -ry[i] - tmpy2[i]; e3 += r * r; }
@@ -2086,7 +2138,7 @@ struct Solver {
         }, true);
         t = -ex.min(-t);
         const int offs[2] = {L.o_nu, L.o_tr};
-        const int dims[2] = {14 * L.K + 1, 17 * (L.K + 1) + 1};
+        const int dims[2] = {14 * L.K + 1, NXU * (L.K + 1) + 1};
         for (int q = 0; q < 2; q++) {
             double n = 0;
             for (int i = 1 + ex.lane(); i < dims[q]; i += ex.nlanes()) n += X[offs[q] + i] * X[offs[q] + i];
@@ -2116,11 +2168,11 @@ struct Solver {
         for (int r = ex.lane(); r < L.ny; r += ex.nlanes()) dk[r] = endpoint[r] - xbar[14 + r];
         {   // A_k' once per subproblem: element (i, j) of A_k sits at 14 j + i in D (column-major), at 14 i + j here
             const dcptr D_ = D; const dptr At_ = At;
-            stream(0, 196 * K, [&](int e) { const int k = e / 196, r = e - 196 * k, i = r / 14, j = r - 14 * i; return D_[(size_t)k * 294 + 14 * j + i]; },
+            stream(0, 196 * K, [&](int e) { const int k = e / 196, r = e - 196 * k, i = r / 14, j = r - 14 * i; return D_[(size_t)k * DSZ + 14 * j + i]; },
                    [&](int e, double v) { At_[e] = v; });
         }
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
-            cdptr u = ubar + 3 * k;
+            cdptr u = ubar + NU * k;   // the thrust part of the control (rocketland.jl:199 indexes control[1:3])
             const double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
             for (int c = 0; c < 3; c++) uhat[3 * k + c] = u[c] / un;  // rocketland.jl:199 (un = 0 -> NaN, as in the reference)
             lb0[k] = C.Tmin - un;
@@ -2135,8 +2187,8 @@ struct Solver {
             gptr vK = V + 14 * K;
             for (int i = 0; i < 3; i++) { vK[1 + i] = C.rIf[i] - xK[1 + i]; vK[4 + i] = C.vIf[i] - xK[4 + i]; vK[11 + i] = C.wBf[i] - xK[11 + i]; }
             for (int i = 0; i < 4; i++) vK[7 + i] = C.qBIf[i] - xK[7 + i];
-            V[L.nx + 3 * K + 1] = 0.0 - ubar[3 * K + 1];
-            V[L.nx + 3 * K + 2] = 0.0 - ubar[3 * K + 2];
+            V[L.nx + NU * K + 1] = 0.0 - ubar[NU * K + 1];
+            V[L.nx + NU * K + 2] = 0.0 - ubar[NU * K + 2];
         }
         ex.sync();
         Result res; res.status = 1; res.iters = 0; res.merit = INFINITY; res.pobj = 0; res.warmed = 0;
