@@ -18,6 +18,14 @@
  *   augmented input inp[21] = [x; u_k; u_{k+1}; sigma]
  *   LinRes.derivative is Julia column-major 14x21: element (i,j) at j*14 + i   (master.jl:90-93)
  *
+ * FIN EXTENSION (model_flags & SCVX_MODEL_FINS; BASELINE configs[4] "6-DoF + fin aero").  The reference carries the fin model
+ * only as commented-out code, so the model is DEFINED BY THIS BUILD from exactly those comments: control_dim = 5,
+ * u[4:5] = coordinates of the fin force along fd1 = normalize((C(q) e2) x v) and fd2 = fd1 x v (dynamics.jl:60-63), the force
+ * added to the aerodynamic force (:66) and its torque cross(rFB, ff) to the body torque (:69), and the cone
+ * |u[4:5]| <= finmxf at every node (rocketland.jl:203-209).  Every array below then uses NU = 5:
+ *   u [B][K+1][5], inp[25], derivative 14x25 ([A | B- (5) | B+ (5) | Sigma]), trajectory record [(K+1)*19 + 1].
+ * scvx_control_dim(ctx) returns NU.
+ *
  * All pointers named *_dev are device (HBM) pointers valid on the context's device; all others are
  * host pointers.  Device entry points are asynchronous on the context's stream (scvx_set_stream);
  * the *_host entry points copy in, run, copy out and synchronise.  Every function returns 0 on
@@ -36,6 +44,8 @@ extern "C" {
 #define SCVX_NX 14
 #define SCVX_NU 3
 #define SCVX_NP 21 /* 14 + 3 + 3 + 1 */
+#define SCVX_NU_FINS 5
+#define SCVX_NP_FINS 25 /* 14 + 5 + 5 + 1 */
 
 #define SCVX_OK 0
 #define SCVX_ERR_ARG -1
@@ -56,6 +66,8 @@ extern "C" {
  * |v_k| <= sqrt(2 dpMax / rho) (fields master.jl:27,30; the constraint is a "todo" at rocketland.jl:211-212).  The
  * initial velocity must satisfy it. */
 #define SCVX_MODEL_DPMAX 1
+/* model_flags: the fin extension described at the top of this file (control_dim = 5).  Needs finmxf > 0. */
+#define SCVX_MODEL_FINS 2
 
 /* Flat image of DescentProblem (master.jl:17-71) + the aero scalars of AtmosphericData (master.jl:10-16).
  * Angles in degrees exactly as the reference stores them.  jB is column-major 3x3. */
@@ -71,6 +83,7 @@ typedef struct scvx_problem {
     double wNu, wID, wDS, wCst, wTviol, nuTol, delTol, tf_guess;
     double ri, rh0, rh1, rh2, alph, bet;
     double force_scalar, length_scalar; /* AtmosphericData scalars; ignored when aero_kind == 0 */
+    double finmxf; /* fin extension: bound of |u[4:5]| (rocketland.jl:205 pins it to 0.01 in the commented code); read only with SCVX_MODEL_FINS */
     int32_t K, imax;
     int32_t aero_kind; /* 0 = ExoatmosphericData, 1 = AtmosphericData */
     int32_t model_flags; /* SCVX_MODEL_* bits: constraints the reference sketches but never wired up; 0 = the reference's model */
@@ -107,6 +120,8 @@ typedef struct scvx_batch scvx_batch; /* owns the batched iterate (ProblemIterat
 int scvx_ctx_create(const scvx_problem *p, int device, scvx_ctx **out);
 void scvx_ctx_destroy(scvx_ctx *ctx);
 const char *scvx_last_error(const scvx_ctx *ctx);
+/* control_dim of the context's model: 3, or 5 with SCVX_MODEL_FINS.  Sizes every u / derivative / trajectory array. */
+int scvx_control_dim(const scvx_ctx *ctx);
 /* Stream every kernel and copy of the context is enqueued on.  NULL selects the context's OWN stream (created
  * hipStreamNonBlocking: it does not synchronise with HIP's default stream) -- a caller that produces or consumes
  * device buffers on another stream orders against it with scvx_get_stream + events, or scvx_synchronize.
@@ -124,7 +139,7 @@ int scvx_set_aero_table(scvx_ctx *ctx, const double *drag, const double *lift, c
                         int n_aoa, int n_mach, double aoa0, double daoa, double mach0, double dmach);
 
 /* ---- discretisation: Dynamics.linearize_dynamics / predict_state ---------------------------- */
-/* x [B][K+1][14], u [B][K+1][3], sigma [B]; endpoint [B][K][14]; deriv [B][K][21][14]. */
+/* x [B][K+1][14], u [B][K+1][NU], sigma [B]; endpoint [B][K][14]; deriv [B][K][14+2NU+1][14]  (NU = scvx_control_dim). */
 int scvx_linearize_f64(scvx_ctx *ctx, int B, int K, const double *x_dev, const double *u_dev,
                        const double *sigma_dev, double dt, double *endpoint_dev, double *deriv_dev);
 int scvx_linearize_f64_host(scvx_ctx *ctx, int B, int K, const double *x, const double *u,
@@ -216,7 +231,7 @@ int scvx_solve_step_async(scvx_batch *b);
 int scvx_solve(scvx_batch *b, int32_t *status, int32_t *iters, double *nu_norm, double *dJ);
 
 /* ---- iterate access (the batched ProblemIteration) ------------------------------------------ */
-/* traj [B][(K+1)*17 + 1]: per trajectory x[K+1][14], u[K+1][3], sigma.  */
+/* traj [B][(K+1)*(14+NU) + 1]: per trajectory x[K+1][14], u[K+1][NU], sigma  (NU = 3: 17 per node).  */
 int scvx_batch_get_trajectory(scvx_batch *b, double *traj);
 int scvx_batch_set_trajectory(scvx_batch *b, const double *traj);
 /* device pointer to the same layout (zero-copy views; scvx_allgather_trajectories gathers it); valid until destroy */
@@ -270,7 +285,7 @@ int scvx_comm_unique_id(void *id_out /* SCVX_COMM_ID_BYTES */);
 int scvx_comm_create(scvx_ctx *ctx, const void *unique_id, int rank, int world);
 int scvx_comm_destroy(scvx_ctx *ctx);
 int scvx_comm_info(const scvx_ctx *ctx, int *rank, int *world); /* world = 0: no communicator */
-/* out_dev [world][B][(K+1)*17+1]: every rank's trajectory records (all ranks hold the same B), asynchronous on the
+/* out_dev [world][B][(K+1)*(14+NU)+1]: every rank's trajectory records (all ranks hold the same B), asynchronous on the
  * context's stream; status_out_dev / iters_out_dev [world][B] (either may be NULL). */
 int scvx_allgather_trajectories(scvx_batch *b, double *out_dev);
 int scvx_allgather_status(scvx_batch *b, int32_t *status_out_dev, int32_t *iters_out_dev);
@@ -279,7 +294,7 @@ int scvx_allgather_f64(scvx_ctx *ctx, const double *send_dev, double *recv_dev, 
 int scvx_allgather_i32(scvx_ctx *ctx, const int32_t *send_dev, int32_t *recv_dev, int64_t count);
 
 /* ---- the conic subproblem alone (replaces MOI.optimize!, rocketland.jl:271) ------------------ */
-/* Solves the trust-region SOCP at the batch's current (about, dynam, rk).  sol [B][(K+1)*17+1] as
+/* Solves the trust-region SOCP at the batch's current (about, dynam, rk).  sol [B][(K+1)*(14+NU)+1] as
  * the trajectory layout but sigma slot holds sigma + dsigma; nu [B][K][14] (nu_2..nu_{K+1}). */
 int scvx_socp_solve(scvx_batch *b, double *sol, double *nu);
 

@@ -127,6 +127,13 @@ def base_prob_scaled(aero=None) -> DescentProblem:
     return normalize_problem(base_prob(aero))
 
 
+def base_prob_fin_scaled(aero=None) -> DescentProblem:
+    """The sample problem with the fin extension (control_dim = 5; build-defined).  rFB is a length and is scaled
+    by 1/Ul here (normalize_problem's 1/Ut, sample_problems.jl:16, would put the fins 2 km from the centre of mass)."""
+    b = base_prob(aero)
+    return replace(normalize_problem(replace(b, fins=True)), rFB=b.rFB / float(np.max(b.rIi)))
+
+
 def rotation_between(a, b):
     """Rotations.rotation_between as a scalar-first unit quaternion."""
     a = np.asarray(a, float)

@@ -31,7 +31,7 @@ class ScvxProblem(C.Structure):
         ("wTviol", C.c_double), ("nuTol", C.c_double), ("delTol", C.c_double), ("tf_guess", C.c_double),
         ("ri", C.c_double), ("rh0", C.c_double), ("rh1", C.c_double), ("rh2", C.c_double),
         ("alph", C.c_double), ("bet", C.c_double),
-        ("force_scalar", C.c_double), ("length_scalar", C.c_double),
+        ("force_scalar", C.c_double), ("length_scalar", C.c_double), ("finmxf", C.c_double),
         ("K", C.c_int32), ("imax", C.c_int32), ("aero_kind", C.c_int32), ("model_flags", C.c_int32),
     ]
 
@@ -52,6 +52,7 @@ SIGNATURES = {
     "scvx_ctx_create": (C.c_int, [C.POINTER(ScvxProblem), C.c_int, C.POINTER(_vp)]),
     "scvx_ctx_destroy": (None, [_vp]),
     "scvx_last_error": (C.c_char_p, [_vp]),
+    "scvx_control_dim": (C.c_int, [_vp]),
     "scvx_set_stream": (C.c_int, [_vp, _vp]),
     "scvx_use_null_stream": (C.c_int, [_vp]),
     "scvx_get_stream": (C.c_int, [_vp, C.POINTER(_vp)]),

@@ -31,7 +31,8 @@ class ScvxBatch:
         self.cache = cache
         self.B = int(B)
         self.K = cache.problem.K
-        self.nrec = (self.K + 1) * 17 + 1
+        self.nu = cache.nu                               # control_dim: 3, or 5 with the fin extension
+        self.nrec = (self.K + 1) * (14 + self.nu) + 1
         self._L = cache._L
         h = C.c_void_p()
         _lib.check(cache.handle, self._L.scvx_batch_create(cache.handle, self.B, C.byref(h)), "scvx_batch_create")
@@ -117,7 +118,7 @@ class ScvxBatch:
     def _split(self, rec):
         K, B = self.K, self.B
         nx = (K + 1) * 14
-        return (rec[:, :nx].reshape(B, K + 1, 14).copy(), rec[:, nx:nx + (K + 1) * 3].reshape(B, K + 1, 3).copy(),
+        return (rec[:, :nx].reshape(B, K + 1, 14).copy(), rec[:, nx:nx + (K + 1) * self.nu].reshape(B, K + 1, self.nu).copy(),
                 rec[:, -1].copy())
 
     def trajectory(self):
@@ -145,7 +146,7 @@ class ScvxBatch:
 
     def linearization(self):
         e = np.zeros((self.B, self.K, 14))
-        d = np.zeros((self.B, self.K, 21, 14))
+        d = np.zeros((self.B, self.K, 14 + 2 * self.nu + 1, 14))
         self._chk(self._L.scvx_batch_get_linearization(self.handle, _p(e), _p(d)), "scvx_batch_get_linearization")
         return e, d
 

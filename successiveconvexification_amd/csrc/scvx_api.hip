@@ -41,6 +41,18 @@ void fill_dyn(const scvx_problem& p, scvx::DynParams& d) {
             for (int k = 0; k < 3; k++) s += d.Jinv[3 * i + k] * rx[3 * k + j];
             d.JrT[3 * i + j] = s;
         }
+    // fin extension (SCVX_MODEL_FINS): torque arm of the fin force, Jinv [rFB]x
+    d.fin = (p.model_flags & SCVX_MODEL_FINS) ? 1 : 0;
+    {
+        const double* f = p.rFB;
+        const double fx[9] = {0, -f[2], f[1], f[2], 0, -f[0], -f[1], f[0], 0};
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += d.Jinv[3 * i + k] * fx[3 * k + j];
+                d.JrF[3 * i + j] = s;
+            }
+    }
     d.aero = 0;  // becomes 1 only once tables are uploaded (scvx_set_aero_table)
     d.n_aoa = d.n_mach = 0;
     d.aoa0 = d.inv_daoa = d.mach0 = d.inv_dmach = 0.0;
@@ -113,6 +125,7 @@ int scvx_ctx_create(const scvx_problem* p, int device, scvx_ctx** out) {
     if (!p || !out) return SCVX_ERR_ARG;
     *out = nullptr;
     if (p->K < 1) return SCVX_ERR_ARG;
+    if ((p->model_flags & SCVX_MODEL_FINS) && !(p->finmxf > 0.0)) return SCVX_ERR_ARG;   // the fin cone needs its bound
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || device < 0 || device >= ndev) return SCVX_ERR_HIP;
     scvx_ctx* ctx = new (std::nothrow) scvx_ctx();
@@ -145,6 +158,8 @@ void scvx_ctx_destroy(scvx_ctx* ctx) {
 }
 
 const char* scvx_last_error(const scvx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int scvx_control_dim(const scvx_ctx* ctx) { return ctx && (ctx->prob.model_flags & SCVX_MODEL_FINS) ? 5 : 3; }
 
 int scvx_set_stream(scvx_ctx* ctx, void* hip_stream) {
     if (!ctx) return SCVX_ERR_ARG;
@@ -272,8 +287,9 @@ static int disc_host_f32(scvx_ctx* ctx, int B, int K, const float* x, const floa
     if (B == 0) return SCVX_OK;
     if (with_deriv && !deriv) return fail(ctx, SCVX_ERR_ARG, "null buffer");
     SCVX_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t nx = (size_t)B * (K + 1) * 14, nu = (size_t)B * (K + 1) * 3, ne = (size_t)B * K * 14,
-                 nd = (size_t)B * K * 294;
+    const int NU = scvx_control_dim(ctx);
+    const size_t nx = (size_t)B * (K + 1) * 14, nu = (size_t)B * (K + 1) * NU, ne = (size_t)B * K * 14,
+                 nd = (size_t)B * K * 14 * (14 + 2 * NU + 1);
     DevBufF dx, du, ds, de, dd;
     SCVX_HIP(ctx, hipMalloc(&dx.p, nx * 4));
     SCVX_HIP(ctx, hipMalloc(&du.p, nu * 4));
@@ -320,8 +336,9 @@ static int disc_host(scvx_ctx* ctx, int B, int K, const double* x, const double*
     if (B == 0) return SCVX_OK;
     if (with_deriv && !deriv) return fail(ctx, SCVX_ERR_ARG, "null buffer");
     SCVX_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t nx = (size_t)B * (K + 1) * 14, nu = (size_t)B * (K + 1) * 3, ne = (size_t)B * K * 14,
-                 nd = (size_t)B * K * 294;
+    const int NU = scvx_control_dim(ctx);
+    const size_t nx = (size_t)B * (K + 1) * 14, nu = (size_t)B * (K + 1) * NU, ne = (size_t)B * K * 14,
+                 nd = (size_t)B * K * 14 * (14 + 2 * NU + 1);
     DevBuf dx, du, ds, de, dd;
     SCVX_HIP(ctx, hipMalloc(&dx.p, nx * 8));
     SCVX_HIP(ctx, hipMalloc(&du.p, nu * 8));

@@ -37,6 +37,13 @@ namespace scvx {
 // address space, and every LDS access becomes a flat_load/flat_store that also waits on the global loads and
 // stores in flight (vmcnt) — which serialises the tile arithmetic behind the HBM traffic it is meant to overlap.
 __shared__ __attribute__((aligned(16))) double g_socp_lds[1552];
+// ... and of the fin instantiation (control_dim = 5: 14 x 25 tiles, 24-column [TA | TBm | TBp]); separate symbols so that the
+// kernels of the reference's model keep their LDS footprint
+__shared__ __attribute__((aligned(16))) double g_socp_lds5[1704];
+#define SCVX_PIPE_LDS5 (2 * 392 + 588 + 392 + 196 + 350 + 364 + 70 + 2 * 46 + 3 * 196 + 8)
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds5[SCVX_PIPE_LDS5];
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds25[SCVX_PIPE_LDS5];
+template <int NU> __device__ __forceinline__ double* socp_lds() { if constexpr (NU == 5) return g_socp_lds5; else return g_socp_lds; }
 // tiles of the two-wavefront factorisation pipeline (multi-wavefront kernels only: a kernel that never references the
 // symbol does not get the allocation)
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 3 * 196 + 8];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
@@ -50,8 +57,12 @@ __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds2[2 * 392 + 588 + 
 #ifndef SCVX_K4_TWISTED
 #define SCVX_K4_TWISTED 1
 #endif
+template <int NU> __device__ __forceinline__ double* socp_pipe_lds() { if constexpr (NU == 5) return g_socp_pipe_lds5; else return g_socp_pipe_lds; }
+template <int NU> __device__ __forceinline__ double* socp_pipe_lds2() { if constexpr (NU == 5) return g_socp_pipe_lds25; else return g_socp_pipe_lds2; }
 
-struct WaveEx {
+template <int NU_>
+struct WaveExT {
+    static constexpr int kLanes = 64;
     __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63); }   // lane in the wavefront (BlockEx runs tile work on any of its wavefronts)
     __device__ __forceinline__ int nlanes() const { return 64; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
@@ -74,7 +85,7 @@ struct WaveEx {
         return x;
     }
     __device__ __forceinline__ bool all(bool b) { return __all(b) != 0; }
-    __device__ __forceinline__ double* scratch() { return g_socp_lds; }
+    __device__ __forceinline__ double* scratch() { return socp_lds<NU_>(); }
 
     // value of x in lane `src` (src wave-uniform) delivered to every lane: two v_readlane_b32, no LDS
     static __device__ __forceinline__ double bcast(double x, int src) {
@@ -83,7 +94,7 @@ struct WaveEx {
         return __hiloint2double(hi, lo);
     }
 
-    static constexpr int kPrefetchRegs = 5;  // ceil(294 / 64): next D tile held in registers while segment k is processed
+    static constexpr int kPrefetchRegs = 1;  // > 0: the next D tile is held in registers (ceil(tile / 64) per lane) while segment k is processed
     static constexpr bool kTwisted = false;
     static constexpr bool kPipelineFactor = false;
 
@@ -275,16 +286,19 @@ struct WaveEx {
 // 64 NW lanes; the 14x14 tile arithmetic and the block recurrences stay on wavefront 0 (they are sequential in k), with
 // workgroup barriers where the single-wavefront executor needs none.  Reductions go through LDS in a fixed order, so
 // every lane of the workgroup sees bit-identical scalars (uniform control flow, as in WaveEx).
-template <int NW>
+typedef WaveExT<3> WaveEx;
+
+template <int NW, int NU_ = 3>
 struct BlockEx {
-    WaveEx w0;
-    static constexpr int kPrefetchRegs = (294 + 64 * NW - 1) / (64 * NW);
+    WaveExT<NU_> w0;
+    static constexpr int kLanes = 64 * NW;
+    static constexpr int kPrefetchRegs = 1;
     // the factorisation loop as a producer / consumer pair of wavefronts (Solver::factor_pipelined)
     static constexpr bool kPipelineFactor = SCVX_K4_PIPELINE != 0;
     // two-ended (twisted) factorisation and solve: the chain is eliminated from both ends towards the middle block by two
     // producer / consumer pairs, and the solve's recurrences run on wavefronts 0 and 2 side by side (Solver::factor_twisted)
     static constexpr bool kTwisted = NW == 4 && SCVX_K4_PIPELINE != 0 && SCVX_K4_TWISTED != 0;
-    __device__ __forceinline__ double* pipe_scratch2() { return g_socp_pipe_lds2; }
+    __device__ __forceinline__ double* pipe_scratch2() { return socp_pipe_lds2<NU_>(); }
     template <int NR>
     __device__ __forceinline__ void chain_range_n(int wv, int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
                                                      bool reverse, int k0, int ns, bool store_first) {
@@ -292,7 +306,7 @@ struct BlockEx {
     }
     __device__ __forceinline__ int wave() const { return (int)(threadIdx.x >> 6); }
     __device__ __forceinline__ int wlane() const { return (int)(threadIdx.x & 63); }
-    __device__ __forceinline__ double* pipe_scratch() { return g_socp_pipe_lds; }
+    __device__ __forceinline__ double* pipe_scratch() { return socp_pipe_lds<NU_>(); }
     __device__ __forceinline__ void w_sync_lds() { w0.sync_lds(); }
     __device__ __forceinline__ void w_tile_gemm(double* Cm, int sci, int scj, const double* A, int sai, int sak, const double* B,
                                                 int sbk, int sbj, int Kd, double alpha, bool acc) {
@@ -303,14 +317,14 @@ struct BlockEx {
     __device__ __forceinline__ int nlanes() const { return 64 * NW; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
     __device__ __forceinline__ void sync_lds() { __syncthreads(); }
-    __device__ __forceinline__ double* scratch() { return g_socp_lds; }
+    __device__ __forceinline__ double* scratch() { return socp_lds<NU_>(); }
     __device__ __forceinline__ bool first() const { return threadIdx.x < 64; }
     // slots 0..NW-1 of the scratch header hold the per-wavefront partials, slot 16 a flag
     template <class OP>
     __device__ __forceinline__ double reduce(double x, OP op) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) x = op(x, __shfl_xor(x, o, 64));
-        double* red = g_socp_lds;
+        double* red = socp_lds<NU_>();
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
         __syncthreads();
         double r = red[0];
@@ -327,7 +341,7 @@ struct BlockEx {
         if (first()) w0.tile_gemm(Cm, sci, scj, A, sai, sak, B, sbk, sbj, Kd, alpha, acc);
     }
     __device__ __forceinline__ bool chol_inv14(const double* M, double* Li) {
-        double* flag = g_socp_lds + 16;
+        double* flag = socp_lds<NU_>() + 16;
         if (first()) {
             const bool ok = w0.chol_inv14(M, Li);
             if (threadIdx.x == 0) *flag = ok ? 1.0 : 0.0;
@@ -353,7 +367,7 @@ enum { ACC_TRAJ_STEPS = 0, ACC_SOLVES, ACC_IPM_ITERS, ACC_WARM, ACC_SKIPPED, ACC
 
 // info[b] = {status, iters, merit, pobj}
 // DS: element type of the linearisation the discretisation kernel wrote (double; float behind scvx_batch_set_linearization_f32)
-template <class Ex, class DS = double>
+template <class Ex, class DS = double, int NU = 3>
 __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t work_stride, const double* x, const double* u,
                                           const double* endpoint, const DS* deriv, const double* rk, const double* ic,
                                           const int* active, double* work, double* sol, double* nu, double* info,
@@ -371,12 +385,12 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t wo
     }
     const int K = C.K;
     Ex ex;
-    ipm::Solver<Ex, double, DS> S(ex, C);
+    ipm::Solver<Ex, double, DS, NU> S(ex, C);
     // kernel arguments are HBM pointers: hand them to the solver typed as such (see ipm::gptr)
     // warm start: the last solve in this slab was for the same about / dynam (its step was rejected) and is still valid
     const bool warm = C.warm && step_status[b] == SCVX_ST_REJECTED && ttr[b] < 1e300;
-    const ipm::Result r = S.solve((ipm::cgptr)(x + (size_t)b * (K + 1) * 14), (ipm::cgptr)(u + (size_t)b * (K + 1) * 3),
-                                  (ipm::cgptr)(endpoint + (size_t)b * K * 14), (typename ipm::gp<DS>::cptr)(deriv + (size_t)b * K * 294), rk[b],
+    const ipm::Result r = S.solve((ipm::cgptr)(x + (size_t)b * (K + 1) * 14), (ipm::cgptr)(u + (size_t)b * (K + 1) * NU),
+                                  (ipm::cgptr)(endpoint + (size_t)b * K * 14), (typename ipm::gp<DS>::cptr)(deriv + (size_t)b * K * (14 * (14 + 2 * NU + 1))), rk[b],
                                   (ipm::cgptr)(ic + (size_t)b * 6), (ipm::gptr)(work + (size_t)b * work_stride), warm);
     const int nxu = S.L.nx + S.L.nu_;
     const int nl = ex.nlanes();
@@ -412,6 +426,18 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t wo
 // registers did.  4 (128 VGPRs) is 17 % slower, 1 is 40 % slower at the full batch.
 #define SCVX_K4_OCC 2
 #endif
+template <class DS, int NU>
+__global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_kernel_t(ipm::Consts C, int B, size_t work_stride,
+                                                  const double* __restrict__ x, const double* __restrict__ u,
+                                                  const double* __restrict__ endpoint, const DS* __restrict__ deriv,
+                                                  const double* __restrict__ rk, const double* __restrict__ ic,
+                                                  const int* __restrict__ active, double* __restrict__ work,
+                                                  double* __restrict__ sol, double* __restrict__ nu,
+                                                  double* __restrict__ info, const int* __restrict__ step_status,
+                                                  double* __restrict__ ttr, double* __restrict__ acc) {
+    socp_body<WaveExT<NU>, DS, NU>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr, acc);
+}
+// the reference's model (control_dim = 3) keeps its two named kernels: profiles and tools refer to them
 __global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_kernel(ipm::Consts C, int B, size_t work_stride,
                                                   const double* __restrict__ x, const double* __restrict__ u,
                                                   const double* __restrict__ endpoint, const double* __restrict__ deriv,
@@ -440,7 +466,7 @@ __global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_lin32_kernel(ipm::Consts
 #ifndef SCVX_K4_BLOCK_OCC
 #define SCVX_K4_BLOCK_OCC 2
 #endif
-template <int NW, class DS = double>
+template <int NW, class DS = double, int NU = 3>
 __global__ __launch_bounds__(64 * NW, SCVX_K4_BLOCK_OCC) void socp_block_kernel(ipm::Consts C, int B, size_t work_stride,
                                                   const double* __restrict__ x, const double* __restrict__ u,
                                                   const double* __restrict__ endpoint, const DS* __restrict__ deriv,
@@ -449,7 +475,7 @@ __global__ __launch_bounds__(64 * NW, SCVX_K4_BLOCK_OCC) void socp_block_kernel(
                                                   double* __restrict__ sol, double* __restrict__ nu,
                                                   double* __restrict__ info, const int* __restrict__ step_status,
                                                   double* __restrict__ ttr, double* __restrict__ acc) {
-    socp_body<BlockEx<NW>, DS>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr, acc);
+    socp_body<BlockEx<NW, NU>, DS, NU>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr, acc);
 }
 
 // cand = about + step (x, u in one contiguous [B][(K+1)*17+1] trajectory record, sigma last)
@@ -460,9 +486,9 @@ __global__ void candidate_kernel(int B, int nrec, const double* __restrict__ tra
 }
 
 // split / join between the contiguous trajectory record and the (x, u, sigma) arrays the kernels read
-__global__ void unpack_kernel(int B, int K, const double* __restrict__ rec, double* __restrict__ x,
+__global__ void unpack_kernel(int B, int K, int NU, const double* __restrict__ rec, double* __restrict__ x,
                               double* __restrict__ u, double* __restrict__ sigma) {
-    const int nrec = (K + 1) * 17 + 1, nx = (K + 1) * 14, nu = (K + 1) * 3;
+    const int nrec = (K + 1) * (14 + NU) + 1, nx = (K + 1) * 14, nu = (K + 1) * NU;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * nrec) return;
     const size_t b = i / nrec;
@@ -475,7 +501,7 @@ __global__ void unpack_kernel(int B, int K, const double* __restrict__ rec, doub
 
 struct TrParams {
     double wNu, rh0, rh1, rh2, alph, bet, ri, nuTol, delTol;
-    int K, imax;
+    int K, imax, NU, pad;
 };
 
 // One wavefront per trajectory: rocketland.jl:286-313 plus the commit of the accepted candidate.
@@ -492,7 +518,7 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
     // not stepped by this call (failed earlier, or converged inside scvx_solve): status[b] keeps saying why and
     // out[b] keeps the (nu, dJ) of the last step this trajectory did take
     if (!mask[b]) return;
-    const int K = P.K, nrec = (K + 1) * 17 + 1;
+    const int K = P.K, nrec = (K + 1) * (14 + P.NU) + 1;
     const double* c = cand + (size_t)b * nrec;
     const double* xp = xprop + (size_t)b * K * 14;
     const double* nv = nu + (size_t)b * K * 14;
@@ -581,6 +607,7 @@ __global__ void copy_flags_kernel(int B, const int* __restrict__ src, int* __res
 struct scvx_batch {
     scvx_ctx* ctx = nullptr;
     int B = 0, K = 0, nrec = 0;
+    int NU = 3, dsz = 294;   // control_dim of the context's model; doubles per derivative tile, 14 * (14 + 2 NU + 1)
     scvx_solver_opts opts{};
     scvx::ipm::Consts C{};
     scvx::TrParams tr{};
@@ -632,7 +659,7 @@ int dmalloc(scvx_ctx* ctx, T** p, size_t n) {
 
 int split_views(scvx_batch* b, const double* rec, double* x, double* u, double* sigma) {
     const size_t n = (size_t)b->B * b->nrec;
-    hipLaunchKernelGGL(scvx::unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->ctx->stream, b->B, b->K,
+    hipLaunchKernelGGL(scvx::unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->ctx->stream, b->B, b->K, b->NU,
                        rec, x, u, sigma);
     SCVX_HIP(b->ctx, hipGetLastError());
     return SCVX_OK;
@@ -654,13 +681,13 @@ int socp_waves(int B, int num_cus) {
     return B <= 2 * cus ? 4 : (B <= 4 * cus ? 2 : 1);
 }
 
-template <int NW>
+template <int NW, int NU = 3>
 void launch_socp_block(scvx_batch* b, const int* mask) {
     if (b->deriv_f)
-        hipLaunchKernelGGL((scvx::socp_block_kernel<NW, float>), dim3(b->B), dim3(64 * NW), 0, b->ctx->stream, b->C, b->B, b->work_stride,
+        hipLaunchKernelGGL((scvx::socp_block_kernel<NW, float, NU>), dim3(b->B), dim3(64 * NW), 0, b->ctx->stream, b->C, b->B, b->work_stride,
                            b->x, b->u, b->endpoint, b->deriv_f, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr, b->acc);
     else
-        hipLaunchKernelGGL((scvx::socp_block_kernel<NW, double>), dim3(b->B), dim3(64 * NW), 0, b->ctx->stream, b->C, b->B, b->work_stride,
+        hipLaunchKernelGGL((scvx::socp_block_kernel<NW, double, NU>), dim3(b->B), dim3(64 * NW), 0, b->ctx->stream, b->C, b->B, b->work_stride,
                            b->x, b->u, b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr, b->acc);
 }
 
@@ -676,7 +703,16 @@ int enqueue_socp(scvx_batch* b, const int* mask) {
     // scvx_solve's tail: once few trajectories are still live the solve is latency-bound again, and the executors with
     // several wavefronts per trajectory (dead blocks return at once) finish a step in half the time
     const int w = socp_waves(b->nlive_hint >= 0 && b->nlive_hint < b->B ? (b->nlive_hint > 0 ? b->nlive_hint : 1) : b->B, b->ctx->num_cus);
-    if (w == 4) launch_socp_block<4>(b, mask);
+    if (b->NU == 5) {   // fin extension: the same three executors, instantiated for control_dim = 5
+        if (w == 4) launch_socp_block<4, 5>(b, mask);
+        else if (w == 2) launch_socp_block<2, 5>(b, mask);
+        else if (b->deriv_f)
+            hipLaunchKernelGGL((scvx::socp_kernel_t<float, 5>), dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
+                               b->endpoint, b->deriv_f, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr, b->acc);
+        else
+            hipLaunchKernelGGL((scvx::socp_kernel_t<double, 5>), dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
+                               b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr, b->acc);
+    } else if (w == 4) launch_socp_block<4>(b, mask);
     else if (w == 2) launch_socp_block<2>(b, mask);
     else if (b->deriv_f)
         hipLaunchKernelGGL(scvx::socp_lin32_kernel, dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
@@ -771,7 +807,9 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     const scvx_problem& p = ctx->prob;
     const int K = p.K;
     b->K = K;
-    b->nrec = (K + 1) * 17 + 1;
+    b->NU = scvx_control_dim(ctx);
+    b->dsz = 14 * (14 + 2 * b->NU + 1);
+    b->nrec = (K + 1) * (14 + b->NU) + 1;
     scvx_solver_default_opts(&b->opts);
     scvx::ipm::Consts& C = b->C;
     const double d2r = M_PI / 180.0;
@@ -787,13 +825,14 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     // dynamic pressure 1/2 rho |v|^2 <= dpMax (master.jl:27,30 carry the fields, rocketland.jl:211 leaves the constraint
     // as a todo): enforced only when the problem asks for it
     C.vmax = (p.model_flags & SCVX_MODEL_DPMAX) ? std::sqrt(2.0 * p.dpMax / p.rho) : 0.0;
+    C.finmxf = p.finmxf;
     for (int i = 0; i < 3; i++) { C.rIf[i] = p.rIf[i]; C.vIf[i] = p.vIf[i]; C.wBi[i] = p.wBi[i]; C.wBf[i] = p.wBf[i]; }
     for (int i = 0; i < 4; i++) C.qBIf[i] = p.qBIf[i];
     scvx::TrParams& T = b->tr;
     T.wNu = p.wNu; T.rh0 = p.rh0; T.rh1 = p.rh1; T.rh2 = p.rh2; T.alph = p.alph; T.bet = p.bet; T.ri = p.ri;
-    T.nuTol = p.nuTol; T.delTol = p.delTol; T.K = K; T.imax = p.imax;
+    T.nuTol = p.nuTol; T.delTol = p.delTol; T.K = K; T.imax = p.imax; T.NU = b->NU; T.pad = 0;
     scvx::ipm::Layout L;
-    L.init(K, C.vmax > 0.0);
+    L.init(K, C.vmax > 0.0, b->NU);
     b->work_stride = (L.work_doubles() + 7) & ~(size_t)7;
     const size_t nB = (size_t)B;
     int rc = 0;
@@ -802,13 +841,13 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     rc |= dmalloc(ctx, &b->traj0, nB * b->nrec);
     rc |= dmalloc(ctx, &b->sol, nB * b->nrec);
     rc |= dmalloc(ctx, &b->x, nB * (K + 1) * 14);
-    rc |= dmalloc(ctx, &b->u, nB * (K + 1) * 3);
+    rc |= dmalloc(ctx, &b->u, nB * (K + 1) * b->NU);
     rc |= dmalloc(ctx, &b->sigma, nB);
     rc |= dmalloc(ctx, &b->cx, nB * (K + 1) * 14);
-    rc |= dmalloc(ctx, &b->cu, nB * (K + 1) * 3);
+    rc |= dmalloc(ctx, &b->cu, nB * (K + 1) * b->NU);
     rc |= dmalloc(ctx, &b->csigma, nB);
     rc |= dmalloc(ctx, &b->endpoint, nB * K * 14);
-    rc |= dmalloc(ctx, &b->deriv, nB * K * 294);
+    rc |= dmalloc(ctx, &b->deriv, nB * K * b->dsz);
     rc |= dmalloc(ctx, &b->xprop, nB * K * 14);
     rc |= dmalloc(ctx, &b->nu, nB * K * 14);
     rc |= dmalloc(ctx, &b->rk, nB);
@@ -885,7 +924,8 @@ int scvx_batch_init(scvx_batch* b, const double* ic) {
                 xk[11 + i] = 0.0;
             }
             rotation_between_e1(nv, xk + 7);
-            U[3 * k] = mk * p.g; U[3 * k + 1] = 0.0; U[3 * k + 2] = 0.0;
+            for (int c = 0; c < b->NU; c++) U[b->NU * k + c] = 0.0;   // fin controls (if any) start at zero
+            U[b->NU * k] = mk * p.g;
         }
         r[nrec - 1] = p.tf_guess;
     }
@@ -1051,7 +1091,7 @@ int scvx_batch_get_linearization(scvx_batch* b, double* endpoint, double* deriv)
     if (rc) return rc;
     scvx_ctx* ctx = b->ctx;
     if (endpoint) SCVX_HIP(ctx, hipMemcpyAsync(endpoint, b->endpoint, (size_t)b->B * b->K * 14 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    const size_t nd = (size_t)b->B * b->K * 294;
+    const size_t nd = (size_t)b->B * b->K * b->dsz;
     if (deriv && b->deriv_f) {   // float tiles: widened on the host (the values the conic solve reads)
         std::vector<float> tmp(nd);
         SCVX_HIP(ctx, hipMemcpyAsync(tmp.data(), b->deriv_f, nd * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1075,7 +1115,7 @@ int scvx_batch_set_linearization_f32(scvx_batch* b, int on) {
     SCVX_HIP(ctx, hipSetDevice(ctx->device));
     if ((on != 0) == (b->deriv_f != nullptr)) return SCVX_OK;
     SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const size_t nd = (size_t)b->B * b->K * 294;
+    const size_t nd = (size_t)b->B * b->K * b->dsz;
     if (on) {
         if ((rc = dmalloc(ctx, &b->deriv_f, nd))) return rc;
         (void)hipFree(b->deriv);

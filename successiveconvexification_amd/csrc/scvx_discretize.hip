@@ -29,8 +29,12 @@ constexpr int WAVES_PER_BLOCK = 4;
 //          except r' = sigma v, so six columns are closed form under RK4 (exact for polynomials in t):
 //            d x(dt)/d r_k = [0; I; 0; 0; 0],   d x(dt)/d v_k = [0; sigma dt I; I; 0; 0]
 //          and only the columns of m, q(4), w(3), u_k(3), u_{k+1}(3), sigma are integrated.
-template <bool AERO> struct K1Map { static constexpr int LPS = 21, SPW = 3; };
-template <> struct K1Map<false> { static constexpr int LPS = 15, SPW = 4; };
+//   fins : 25 lanes (control_dim = 5: 14 + 5 + 5 + 1 columns), 2 segments per wave (50 lanes); the fin force depends on the
+//          velocity, so no column is closed form.
+template <bool AERO, bool FIN = false> struct K1Map {
+    static constexpr int LPS = FIN ? 25 : (AERO ? 21 : 15), SPW = FIN ? 2 : (AERO ? 3 : 4);
+    static constexpr int NU = FIN ? 5 : 3, NP = 14 + 2 * NU + 1, DSZ = 14 * NP, HV = DSZ / 2;   // tile: DSZ values = HV 16-byte pairs
+};
 __device__ __forceinline__ int exo_slot_to_col(int slot) {  // 0 -> m, 1..7 -> q,w, 8..14 -> u_k,u_{k+1},sigma
     return slot == 0 ? 0 : slot + 6;
 }
@@ -212,26 +216,33 @@ __device__ double g_k1prof[2 * 16];
 #else
 #define K1_BAR() lds_barrier()
 #endif
+template <bool AERO, bool FIN, typename R>
+__device__ __forceinline__ void column_deriv_rec_any(const DynP<R>& p, const R* rec, int stride, const R* c, const R* wc, R gsel,
+                                                     R sigma, R* dc) {
+    if constexpr (FIN) column_deriv_rec_fin<AERO, R>(p, rec, stride, c, wc, gsel, sigma, dc);
+    else column_deriv_rec<AERO, R>(p, rec, stride, c, wc, gsel, sigma, dc);
+}
 constexpr int PC_GROUP = 4;              // stages published per barrier (one RK4 substep)
 // SG (stage-granular, the default): one barrier per RK stage and the producer one STAGE ahead (2-slot ring) instead of
 // one barrier per substep and the producer one substep ahead: the pipeline fills after one stage instead of four (at
 // npts = 1 the substep-granular form does not overlap at all), which outweighs the 4x barrier count at every npts.
 // O = element type of the derivative tiles in HBM: R, or float under double arithmetic (scvx_batch_set_linearization_f32:
 // the conic solve reads them as float; rounded once, at the store)
-template <bool AERO, bool SG, typename R, typename O = R>
+template <bool AERO, bool SG, typename R, typename O = R, bool FIN = false>
 __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
     DynP<R> p, long nseg, int K, const R* __restrict__ x, const R* __restrict__ u,
     const R* __restrict__ sigma, R dt, int nsub, R* __restrict__ endpoint,
     O* __restrict__ deriv, const int* __restrict__ skip) {
-    constexpr int LPS = K1Map<AERO>::LPS, SPW = K1Map<AERO>::SPW;
+    constexpr int LPS = K1Map<AERO, FIN>::LPS, SPW = K1Map<AERO, FIN>::SPW;
+    constexpr int NU = K1Map<AERO, FIN>::NU, NP = K1Map<AERO, FIN>::NP, DSZ = K1Map<AERO, FIN>::DSZ, HV = K1Map<AERO, FIN>::HV;
     typedef typename Vec2<R>::type VEC2;
     typedef typename Vec2<O>::type OVEC2;
     constexpr int NC = PC_WAVES - 1;
     if (block_unchanged(skip, (long)blockIdx.x * (NC * SPW), NC * SPW, nseg, K)) return;
     constexpr int NS = NC * SPW;               // segments per block
-    constexpr int NR = StageRec<AERO>::N;
+    constexpr int NR = StageRec<AERO, FIN>::N;
     constexpr int RING = SG ? 2 : 2 * PC_GROUP;   // stage records in flight: the producer runs one stage / one substep ahead
-    constexpr int RING_D = RING * NR * NS, TILE_D = NC * SPW * 294;
+    constexpr int RING_D = RING * NR * NS, TILE_D = NC * SPW * DSZ;
     // one LDS slab: the coefficient ring during the integration, the output tiles afterwards
     __shared__ __attribute__((aligned(16))) R lds[RING_D > TILE_D ? RING_D : TILE_D];
     const int lane = threadIdx.x & 63;
@@ -249,12 +260,14 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
         const long b = seg / K;
         const int k = (int)(seg - b * K);
         const R* xk = x + ((size_t)b * (K + 1) + k) * 14;
-        const R* uk = u + ((size_t)b * (K + 1) + k) * 3;
+        const R* uk = u + ((size_t)b * (K + 1) + k) * NU;
         const R sig = sigma[b];
         R xs[14], xa[14], xt[14];
 #pragma unroll
         for (int i = 0; i < 14; i++) { xs[i] = xk[i]; xa[i] = xs[i]; xt[i] = xs[i]; }
-        const R uk0 = uk[0], uk1 = uk[1], uk2 = uk[2], up0 = uk[3], up1 = uk[4], up2 = uk[5];
+        R ukv[NU], upv[NU];
+#pragma unroll
+        for (int j = 0; j < NU; j++) { ukv[j] = uk[j]; upv[j] = uk[NU + j]; }
         const int l = live ? lane : 0;
         for (int s = 0; s <= nsub; s++) {
             if (s < nsub) {
@@ -262,10 +275,12 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
                 for (int stg = 0; stg < 4; stg++) {
                     const R lkp = (R(s) + (stg == 0 ? R(0.0) : (stg == 3 ? R(1.0) : R(0.5)))) * inv_n;
                     const R lkm = R(1.0) - lkp;
-                    R uu[3] = {fma(uk0, lkm, up0 * lkp), fma(uk1, lkm, up1 * lkp), fma(uk2, lkm, up2 * lkp)};
-                    Stage<AERO, R> st;
-                    stage_eval<AERO>(p, xt, uu, st);
-                    if (live) stage_publish<AERO>(p, st, xt, uu, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + l, NS);
+                    R uu[NU];
+#pragma unroll
+                    for (int j = 0; j < NU; j++) uu[j] = fma(ukv[j], lkm, upv[j] * lkp);
+                    Stage<AERO, R, FIN> st;
+                    stage_eval<AERO, FIN>(p, xt, uu, st);
+                    if (live) stage_publish<AERO, FIN>(p, st, xt, uu, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + l, NS);
                     const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
                     const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
 #pragma unroll
@@ -294,7 +309,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
     const int cw = wave < PC_PROD ? wave : wave - 1;
     const int sl = lane / LPS;
     const int slot = lane - sl * LPS;
-    const int col = AERO ? slot : exo_slot_to_col(slot);
+    const int col = (AERO || FIN) ? slot : exo_slot_to_col(slot);
     const bool lane_live = sl < SPW;
     const int ls = cw * SPW + (lane_live ? sl : 0);   // local segment index in the block
     long seg = seg_base + ls;
@@ -303,11 +318,13 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
     R c[14], ca[14], ct[14];
 #pragma unroll
     for (int i = 0; i < 14; i++) { c[i] = (col == i) ? R(1.0) : R(0.0); ca[i] = c[i]; ct[i] = c[i]; }
-    const bool is_uk = (col >= 14) && (col < 17);
-    const bool is_up = (col >= 17) && (col < 20);
-    const int comp = is_uk ? col - 14 : (is_up ? col - 17 : -1);
-    const R gsel = (col == 20) ? R(1.0) : R(0.0);
-    const R e0 = (comp == 0) ? R(1.0) : R(0.0), e1 = (comp == 1) ? R(1.0) : R(0.0), e2 = (comp == 2) ? R(1.0) : R(0.0);
+    const bool is_uk = (col >= 14) && (col < 14 + NU);
+    const bool is_up = (col >= 14 + NU) && (col < 14 + 2 * NU);
+    const int comp = is_uk ? col - 14 : (is_up ? col - 14 - NU : -1);
+    const R gsel = (col == NP - 1) ? R(1.0) : R(0.0);
+    R ec[NU];
+#pragma unroll
+    for (int j = 0; j < NU; j++) ec[j] = (comp == j) ? R(1.0) : R(0.0);
     __syncthreads();  // records of substep 0 are ready
     for (int s = 0; s < nsub; s++) {
 #pragma unroll
@@ -315,9 +332,11 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
             const R lkp = (R(s) + (stg == 0 ? R(0.0) : (stg == 3 ? R(1.0) : R(0.5)))) * inv_n;
             const R lkm = R(1.0) - lkp;
             const R wk = is_uk ? lkm : (is_up ? lkp : R(0.0));
-            const R wc[3] = {e0 * wk, e1 * wk, e2 * wk};
+            R wc[NU];
+#pragma unroll
+            for (int j = 0; j < NU; j++) wc[j] = ec[j] * wk;
             R dc[14];
-            column_deriv_rec<AERO>(p, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + ls, NS, ct, wc, gsel, sig, dc);
+            column_deriv_rec_any<AERO, FIN>(p, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + ls, NS, ct, wc, gsel, sig, dc);
             const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
             const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
 #pragma unroll
@@ -332,13 +351,13 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
         if (!SG) __syncthreads();
     }
     // ---- epilogue: columns into the LDS tile (the ring is dead now) -> coalesced 16-byte stores ----
-    R* t = lds + cw * SPW * 294;
+    R* t = lds + cw * SPW * DSZ;
     if (lane_live) {
 #pragma unroll
-        for (int i = 0; i < 14; i++) t[sl * 294 + col * 14 + i] = c[i];
-        if (!AERO && slot < 6) {
+        for (int i = 0; i < 14; i++) t[sl * DSZ + col * 14 + i] = c[i];
+        if (!AERO && !FIN && slot < 6) {
             const int j = slot < 3 ? slot : slot - 3;
-            R* cc = t + sl * 294 + (slot < 3 ? 1 + j : 4 + j) * 14;
+            R* cc = t + sl * DSZ + (slot < 3 ? 1 + j : 4 + j) * 14;
 #pragma unroll
             for (int i = 0; i < 14; i++) cc[i] = R(0.0);
             if (slot < 3) cc[1 + j] = R(1.0);
@@ -350,11 +369,11 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
     if (seg0 < nseg) {
         const long rem = nseg - seg0;
         const int nvalid = rem < SPW ? (int)rem : SPW;
-        const int n2 = nvalid * 147;
-        OVEC2* out = reinterpret_cast<OVEC2*>(deriv + (size_t)seg0 * 294);
+        const int n2 = nvalid * HV;
+        OVEC2* out = reinterpret_cast<OVEC2*>(deriv + (size_t)seg0 * DSZ);
         const VEC2* src = reinterpret_cast<const VEC2*>(t);
 #pragma unroll
-        for (int r = 0; r < (SPW * 147 + 63) / 64; r++) {
+        for (int r = 0; r < (SPW * HV + 63) / 64; r++) {
             const int e = lane + 64 * r;
             if (e < n2) { const VEC2 v = src[e]; OVEC2 o; o.x = O(v.x); o.y = O(v.y); out[e] = o; }
         }
@@ -362,20 +381,21 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
 }
 
 // The same producer/consumer pipeline (stage-granular) as a PERSISTENT block, used from 3 substeps up.
-template <bool AERO, typename R, typename O = R>
+template <bool AERO, typename R, typename O = R, bool FIN = false>
 __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
     DynP<R> p, long nseg, int K, const R* __restrict__ x, const R* __restrict__ u,
     const R* __restrict__ sigma, R dt, int nsub, R* __restrict__ endpoint,
     O* __restrict__ deriv, const int* __restrict__ skip) {
-    constexpr int LPS = K1Map<AERO>::LPS, SPW = K1Map<AERO>::SPW;
+    constexpr int LPS = K1Map<AERO, FIN>::LPS, SPW = K1Map<AERO, FIN>::SPW;
+    constexpr int NU = K1Map<AERO, FIN>::NU, NP = K1Map<AERO, FIN>::NP, DSZ = K1Map<AERO, FIN>::DSZ, HV = K1Map<AERO, FIN>::HV;
     typedef typename Vec2<R>::type VEC2;
     typedef typename Vec2<O>::type OVEC2;
     constexpr bool SG = true;
     constexpr int NC = PC_WAVES - 1;
     constexpr int NS = NC * SPW;               // segments per group
-    constexpr int NR = StageRec<AERO>::N;
+    constexpr int NR = StageRec<AERO, FIN>::N;
     constexpr int RING = SG ? 2 : 2 * PC_GROUP;   // stage records in flight: the producer runs one stage / one substep ahead
-    constexpr int RING_D = RING * NR * NS, TILE_D = NC * SPW * 294;
+    constexpr int RING_D = RING * NR * NS, TILE_D = NC * SPW * DSZ;
     // PERSISTENT block: it walks the groups of NS segments blockIdx.x, blockIdx.x + gridDim.x, ...  The output tiles of a
     // group leave through 16-byte global stores that nothing waits for: every barrier in here orders LDS only
     // (lds_barrier), so the 2.4 KB per segment of group g drain to HBM while group g + 1 integrates -- with one block per
@@ -409,18 +429,18 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
         // ---------------- producer: lane = segment ----------------
         const bool live = lane < NS;
         const int l = live ? lane : 0;
-        R nx[14], nu6[6], nsig = R(0.0);
+        R nx[14], nu6[2 * NU], nsig = R(0.0);
         auto fetch = [&](long g) {
             long seg = g * NS + l;
             if (seg >= nseg) seg = nseg - 1;
             const long b = seg / K;
             const int k = (int)(seg - b * K);
             const R* xk = x + ((size_t)b * (K + 1) + k) * 14;
-            const R* uk = u + ((size_t)b * (K + 1) + k) * 3;
+            const R* uk = u + ((size_t)b * (K + 1) + k) * NU;
 #pragma unroll
             for (int i = 0; i < 14; i++) nx[i] = xk[i];
 #pragma unroll
-            for (int i = 0; i < 6; i++) nu6[i] = uk[i];
+            for (int i = 0; i < 2 * NU; i++) nu6[i] = uk[i];
             nsig = sigma[b];
         };
         if (grp < ngrp) fetch(grp);
@@ -432,17 +452,21 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
             R xs[14], xa[14], xt[14];
 #pragma unroll
             for (int i = 0; i < 14; i++) { xs[i] = nx[i]; xa[i] = xs[i]; xt[i] = xs[i]; }
-            const R uk0 = nu6[0], uk1 = nu6[1], uk2 = nu6[2], up0 = nu6[3], up1 = nu6[4], up2 = nu6[5];
+            R ukv[NU], upv[NU];
+#pragma unroll
+            for (int j = 0; j < NU; j++) { ukv[j] = nu6[j]; upv[j] = nu6[NU + j]; }
             for (int s = 0; s <= nsub; s++) {
                 if (s < nsub) {
 #pragma unroll
                     for (int stg = 0; stg < 4; stg++) {
                         const R lkp = (R(s) + (stg == 0 ? R(0.0) : (stg == 3 ? R(1.0) : R(0.5)))) * inv_n;
                         const R lkm = R(1.0) - lkp;
-                        R uu[3] = {fma(uk0, lkm, up0 * lkp), fma(uk1, lkm, up1 * lkp), fma(uk2, lkm, up2 * lkp)};
-                        Stage<AERO, R> st;
-                        stage_eval<AERO>(p, xt, uu, st);
-                        if (live) stage_publish<AERO>(p, st, xt, uu, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + l, NS);
+                        R uu[NU];
+#pragma unroll
+                        for (int j = 0; j < NU; j++) uu[j] = fma(ukv[j], lkm, upv[j] * lkp);
+                        Stage<AERO, R, FIN> st;
+                        stage_eval<AERO, FIN>(p, xt, uu, st);
+                        if (live) stage_publish<AERO, FIN>(p, st, xt, uu, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + l, NS);
                         const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
                         const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
 #pragma unroll
@@ -478,14 +502,16 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
     const int cw = wave < PC_PROD ? wave : wave - 1;
     const int sl = lane / LPS;
     const int slot = lane - sl * LPS;
-    const int col = AERO ? slot : exo_slot_to_col(slot);
+    const int col = (AERO || FIN) ? slot : exo_slot_to_col(slot);
     const bool lane_live = sl < SPW;
     const int ls = cw * SPW + (lane_live ? sl : 0);   // local segment index in the group
-    const bool is_uk = (col >= 14) && (col < 17);
-    const bool is_up = (col >= 17) && (col < 20);
-    const int comp = is_uk ? col - 14 : (is_up ? col - 17 : -1);
-    const R gsel = (col == 20) ? R(1.0) : R(0.0);
-    const R e0 = (comp == 0) ? R(1.0) : R(0.0), e1 = (comp == 1) ? R(1.0) : R(0.0), e2 = (comp == 2) ? R(1.0) : R(0.0);
+    const bool is_uk = (col >= 14) && (col < 14 + NU);
+    const bool is_up = (col >= 14 + NU) && (col < 14 + 2 * NU);
+    const int comp = is_uk ? col - 14 : (is_up ? col - 14 - NU : -1);
+    const R gsel = (col == NP - 1) ? R(1.0) : R(0.0);
+    R ec[NU];
+#pragma unroll
+    for (int j = 0; j < NU; j++) ec[j] = (comp == j) ? R(1.0) : R(0.0);
     auto sigma_of = [&](long g) {
         long seg = g * NS + ls;
         if (seg >= nseg) seg = nseg - 1;
@@ -506,9 +532,11 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
                 const R lkp = (R(s) + (stg == 0 ? R(0.0) : (stg == 3 ? R(1.0) : R(0.5)))) * inv_n;
                 const R lkm = R(1.0) - lkp;
                 const R wk = is_uk ? lkm : (is_up ? lkp : R(0.0));
-                const R wc[3] = {e0 * wk, e1 * wk, e2 * wk};
+                R wc[NU];
+#pragma unroll
+            for (int j = 0; j < NU; j++) wc[j] = ec[j] * wk;
                 R dc[14];
-                column_deriv_rec<AERO>(p, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + ls, NS, ct, wc, gsel, sig, dc);
+                column_deriv_rec_any<AERO, FIN>(p, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + ls, NS, ct, wc, gsel, sig, dc);
                 const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
                 const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
 #pragma unroll
@@ -524,13 +552,13 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
         }
         if (nxt < ngrp) nsig = sigma_of(nxt);
         // ---- epilogue: columns into this wavefront's LDS tile -> coalesced 16-byte stores ----
-        R* t = tiles + cw * SPW * 294;
+        R* t = tiles + cw * SPW * DSZ;
         if (lane_live) {
 #pragma unroll
-            for (int i = 0; i < 14; i++) t[sl * 294 + col * 14 + i] = c[i];
-            if (!AERO && slot < 6) {
+            for (int i = 0; i < 14; i++) t[sl * DSZ + col * 14 + i] = c[i];
+            if (!AERO && !FIN && slot < 6) {
                 const int j = slot < 3 ? slot : slot - 3;
-                R* cc = t + sl * 294 + (slot < 3 ? 1 + j : 4 + j) * 14;
+                R* cc = t + sl * DSZ + (slot < 3 ? 1 + j : 4 + j) * 14;
 #pragma unroll
                 for (int i = 0; i < 14; i++) cc[i] = R(0.0);
                 if (slot < 3) cc[1 + j] = R(1.0);
@@ -542,11 +570,11 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
         if (seg0 < nseg) {
             const long rem = nseg - seg0;
             const int nvalid = rem < SPW ? (int)rem : SPW;
-            const int n2 = nvalid * 147;
-            OVEC2* out = reinterpret_cast<OVEC2*>(deriv + (size_t)seg0 * 294);
+            const int n2 = nvalid * HV;
+            OVEC2* out = reinterpret_cast<OVEC2*>(deriv + (size_t)seg0 * DSZ);
             const VEC2* src = reinterpret_cast<const VEC2*>(t);
 #pragma unroll
-            for (int r = 0; r < (SPW * 147 + 63) / 64; r++) {
+            for (int r = 0; r < (SPW * HV + 63) / 64; r++) {
                 const int e = lane + 64 * r;
                 if (e < n2) { const VEC2 v = src[e]; OVEC2 o; o.x = O(v.x); o.y = O(v.y); out[e] = o; }
             }
@@ -559,7 +587,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
 #endif
 }
 
-template <bool AERO, typename R>
+template <bool AERO, typename R, bool FIN = false>
 __global__ __launch_bounds__(256) void propagate_kernel(DynP<R> p, long nseg, int K, const R* __restrict__ x,
                                                         const R* __restrict__ u,
                                                         const R* __restrict__ sigma, R dt, int nsub,
@@ -569,13 +597,15 @@ __global__ __launch_bounds__(256) void propagate_kernel(DynP<R> p, long nseg, in
     const long b = seg / K;
     const int k = (int)(seg - b * K);
     const R* xk = x + ((size_t)b * (K + 1) + k) * 14;
-    const R* uk = u + ((size_t)b * (K + 1) + k) * 3;
+    constexpr int NU = FIN ? 5 : 3;
+    const R* uk = u + ((size_t)b * (K + 1) + k) * NU;
     const R sig = sigma[b];
     R xs[14];
 #pragma unroll
     for (int i = 0; i < 14; i++) xs[i] = xk[i];
-    const R uk0 = uk[0], uk1 = uk[1], uk2 = uk[2];
-    const R up0 = uk[3], up1 = uk[4], up2 = uk[5];
+    R ukv[NU], upv[NU];
+#pragma unroll
+    for (int j = 0; j < NU; j++) { ukv[j] = uk[j]; upv[j] = uk[NU + j]; }
     const R h = dt / R(nsub);
     const R inv_n = R(1.0) / R(nsub);
     for (int s = 0; s < nsub; s++) {
@@ -589,9 +619,11 @@ __global__ __launch_bounds__(256) void propagate_kernel(DynP<R> p, long nseg, in
         for (int stg = 0; stg < 4; stg++) {
             const R lkp = (R(s) + (stg == 0 ? R(0.0) : (stg == 3 ? R(1.0) : R(0.5)))) * inv_n;
             const R lkm = R(1.0) - lkp;
-            R uu[3] = {fma(uk0, lkm, up0 * lkp), fma(uk1, lkm, up1 * lkp), fma(uk2, lkm, up2 * lkp)};
+            R uu[NU];
+#pragma unroll
+            for (int j = 0; j < NU; j++) uu[j] = fma(ukv[j], lkm, upv[j] * lkp);
             R g[14];
-            rhs_only<AERO>(p, xt, uu, g);
+            rhs_only<AERO, FIN>(p, xt, uu, g);
             const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
             const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
 #pragma unroll
@@ -632,9 +664,10 @@ hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, con
                               O* deriv, hipStream_t st, const int* skip = nullptr) {
     const long nseg = (long)B * K;
     if (nseg == 0) return hipSuccess;
+    const bool fin = ctx->dyn.fin != 0;
     if constexpr (std::is_same<R, O>::value)
-        if (ctx->k1_variant == 0) return launch_linearize_simple<R>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st, skip);
-    const int ns = (PC_WAVES - 1) * (ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW);
+        if (ctx->k1_variant == 0 && !fin) return launch_linearize_simple<R>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st, skip);
+    const int ns = (PC_WAVES - 1) * (fin ? K1Map<true, true>::SPW : (ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW));
     // stage-granular pipeline by default (faster at every npts measured: 0.70 -> 0.60 ms at npts 1, 3.05 -> 2.96 ms
     // at npts 10, B = 8192, fp64); SCVX_K1_SG=0 selects the substep-granular form
     const bool sg = ctx->k1_sg != 0;
@@ -642,11 +675,19 @@ hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, con
     const long cap = (long)(ctx->num_cus > 0 ? ctx->num_cus : 256) * PC_BLOCKS_PER_CU;   // persistent blocks, one per CU (LDS and VGPRs allow no more)
     // persistent kernel from 3 substeps up (measured, B = 8192 fp64: npts 10 3.21 -> 2.95 ms; npts 1: 0.59 -> 0.67, npts 2:
     // 0.87 -> 0.90 -- a group is latency-bound there, pipeline fill + epilogue); SCVX_K1_PERSIST = 0 / 1 forces
-    const bool persist = sg && (ctx->k1_persist < 0 ? ctx->nsub >= 3 : ctx->k1_persist != 0);
+    const bool persist = (sg || fin) && (ctx->k1_persist < 0 ? ctx->nsub >= 3 : ctx->k1_persist != 0);
     const unsigned grid = (unsigned)(!persist || ngrp < cap ? ngrp : cap);
     const dim3 g(grid), blk(64 * PC_WAVES);
     const DynP<R> dp(ctx->dyn);
-    if (persist) {
+    if (fin) {   // control_dim = 5: the stage-granular pipeline (persistent from 3 substeps up), exo or aero
+        if (persist) {
+            if (ctx->dyn.aero) hipLaunchKernelGGL((linearize_pcp_kernel<true, R, O, true>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+            else hipLaunchKernelGGL((linearize_pcp_kernel<false, R, O, true>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+        } else {
+            if (ctx->dyn.aero) hipLaunchKernelGGL((linearize_pc_kernel<true, true, R, O, true>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+            else hipLaunchKernelGGL((linearize_pc_kernel<false, true, R, O, true>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+        }
+    } else if (persist) {
         if (ctx->dyn.aero) hipLaunchKernelGGL((linearize_pcp_kernel<true, R, O>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
         else hipLaunchKernelGGL((linearize_pcp_kernel<false, R, O>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
     } else if (ctx->dyn.aero) {
@@ -676,7 +717,7 @@ hipError_t launch_linearize_f32(const scvx_ctx* ctx, int B, int K, const float* 
                                 float dt, float* endpoint, float* deriv, hipStream_t st) {
     // measured at B = 8192 (profiles/r02_k1.md): up to two substeps the column-per-lane form wins in float (0.37 vs 0.43 ms
     // at npts 1: the producer/consumer pipeline pays a barrier per RK stage), beyond that the producer/consumer form does
-    if (ctx->nsub <= 2 && ctx->k1_variant != 0) return launch_linearize_simple<float>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st);
+    if (ctx->nsub <= 2 && ctx->k1_variant != 0 && !ctx->dyn.fin) return launch_linearize_simple<float>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st);
     return launch_linearize_t<float>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st);
 }
 
@@ -687,7 +728,10 @@ hipError_t launch_propagate_t(const scvx_ctx* ctx, int B, int K, const R* x, con
     if (nseg == 0) return hipSuccess;
     const unsigned grid = (unsigned)((nseg + 255) / 256);
     const DynP<R> dp(ctx->dyn);
-    if (ctx->dyn.aero)
+    if (ctx->dyn.fin) {
+        if (ctx->dyn.aero) hipLaunchKernelGGL((propagate_kernel<true, R, true>), dim3(grid), dim3(256), 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, xnext);
+        else hipLaunchKernelGGL((propagate_kernel<false, R, true>), dim3(grid), dim3(256), 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, xnext);
+    } else if (ctx->dyn.aero)
         hipLaunchKernelGGL((propagate_kernel<true, R>), dim3(grid), dim3(256), 0, st, dp, nseg, K, x, u, sigma, dt,
                            ctx->nsub, xnext);
     else

@@ -5,6 +5,9 @@
 //   first-order-hold control  current_control           dynamics.jl:108-110, 144-150
 //   aerodynamic force         Aerodynamics.aero_force   aerodynamics.jl:60-77 + shims dynamics.jl:162-207
 //   table interpolation       load_aerodata             aerodynamics.jl:17-21 (cubic B-spline, Flat)
+//   fin force (FIN = true)    the commented expressions of dynamics.jl:60-63, 66, 69: fd1 = normalize((C e2) x v),
+//                             fd2 = fd1 x v, ff = u[4] fd1 + u[5] fd2 added to the aerodynamic force, torque rFB x ff
+//                             (build-defined model; control_dim = 5)
 // The reference obtains Jacobians by forward-mode AD over generated code (dynamics.jl:245-256); here
 // they are written out analytically and applied column-wise: a lane never forms the 14x14 matrix, it
 // applies the ~48 structural non-zeros of df/dx directly to the sensitivity column it owns.
@@ -21,7 +24,8 @@ struct DynParams {
     double JrT[9];   // row-major Jinv * [rTB]x  (d wdot / du, constant)
     int aero;        // 0 exo, 1 atmospheric
     int n_aoa, n_mach;
-    int pad;
+    int fin;         // 1: fin extension (control_dim = 5)
+    double JrF[9];   // row-major Jinv * [rFB]x  (d wdot / d ff, constant)
     double aoa0, inv_daoa, mach0, inv_dmach, force_scalar;
     const double* cdrag;  // prefiltered coefficients, (n_mach+2) x (n_aoa+2), aoa fastest
     const double* clift;
@@ -34,7 +38,7 @@ struct DynParams {
 template <typename R>
 struct DynP {
     R alpha, g0, sos;
-    R J[9], Jinv[9], rTB[3], JrT[9];
+    R J[9], Jinv[9], rTB[3], JrT[9], JrF[9];
     int aero, n_aoa, n_mach;
     R aoa0, inv_daoa, mach0, inv_dmach, force_scalar;
     const double* cdrag;   // prefiltered coefficients stay double in memory (shared by both precisions, cache-resident)
@@ -44,23 +48,75 @@ struct DynP {
           inv_daoa((R)p.inv_daoa), mach0((R)p.mach0), inv_dmach((R)p.inv_dmach), force_scalar((R)p.force_scalar),
           cdrag(p.cdrag), clift(p.clift) {
 #pragma unroll
-        for (int i = 0; i < 9; i++) { J[i] = (R)p.J[i]; Jinv[i] = (R)p.Jinv[i]; JrT[i] = (R)p.JrT[i]; }
+        for (int i = 0; i < 9; i++) { J[i] = (R)p.J[i]; Jinv[i] = (R)p.Jinv[i]; JrT[i] = (R)p.JrT[i]; JrF[i] = (R)p.JrF[i]; }
 #pragma unroll
         for (int i = 0; i < 3; i++) rTB[i] = (R)p.rTB[i];
     }
 };
 
 // Everything one RK stage needs about the state trajectory, evaluated once per stage per lane.
-template <bool AERO, typename R = double>
+template <bool AERO, typename R = double, bool FIN = false>
 struct Stage {
     R g[14];      // un-scaled RHS
     R C[9];       // DCM, row-major
     R invm;
     R am[3];      // d vdot / d m
     R Dq[12];     // d vdot / d q   (3x4 row-major)
-    R Dv[AERO ? 9 : 1];  // d vdot / d v (aero only)
+    R Dv[(AERO || FIN) ? 9 : 1];  // d vdot / d v (aero / fins)
     R Mw[9];      // d wdot / d w
+    // fin extension: force directions, d wdot / d q and d v through the fin torque, d wdot / d (u4, u5)
+    R fd1[FIN ? 3 : 1], fd2[FIN ? 3 : 1], Wq[FIN ? 12 : 1], Wv[FIN ? 9 : 1], Gf1[FIN ? 3 : 1], Gf2[FIN ? 3 : 1];
 };
+
+// fd1 = normalize((C e2) x v), fd2 = fd1 x v (dynamics.jl:60-62); JAC: d fd1, d fd2 / d (q0..q3, v1..v3), 3x7 row-major each.
+// (C e2) x v = 0 gives no fin force (the reference's ifnz convention for its other normalised directions).
+template <bool JAC, typename R>
+__device__ __forceinline__ void fin_dirs(const R* q, const R* v, const R* C, R fd1[3], R fd2[3], R d1[21], R d2[21]) {
+    const R b2[3] = {C[1], C[4], C[7]};
+    const R n[3] = {b2[1] * v[2] - b2[2] * v[1], b2[2] * v[0] - b2[0] * v[2], b2[0] * v[1] - b2[1] * v[0]};
+    const R nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    const bool ok = nn > R(0.0);
+    const R inn = ok ? R(1.0) / nn : R(0.0);
+#pragma unroll
+    for (int i = 0; i < 3; i++) fd1[i] = n[i] * inn;
+    fd2[0] = fd1[1] * v[2] - fd1[2] * v[1];
+    fd2[1] = fd1[2] * v[0] - fd1[0] * v[2];
+    fd2[2] = fd1[0] * v[1] - fd1[1] * v[0];
+    if (!JAC) return;
+    // d b2 / d q (3x4): b2 = [2(q1q2 - q0q3), 1 - 2(q1^2 + q3^2), 2(q2q3 + q0q1)]
+    const R db2[12] = {-R(2.0) * q[3], R(2.0) * q[2], R(2.0) * q[1], -R(2.0) * q[0],
+                       R(0.0), -R(4.0) * q[1], R(0.0), -R(4.0) * q[3],
+                       R(2.0) * q[1], R(2.0) * q[0], R(2.0) * q[3], R(2.0) * q[2]};
+    R dn[21];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {   // (d b2 / d q_j) x v
+        const R c0 = db2[j], c1 = db2[4 + j], c2 = db2[8 + j];
+        dn[j] = c1 * v[2] - c2 * v[1];
+        dn[7 + j] = c2 * v[0] - c0 * v[2];
+        dn[14 + j] = c0 * v[1] - c1 * v[0];
+    }
+    // d (b2 x v) / d v = [b2]x
+    dn[4] = R(0.0);  dn[5] = -b2[2]; dn[6] = b2[1];
+    dn[11] = b2[2];  dn[12] = R(0.0); dn[13] = -b2[0];
+    dn[18] = -b2[1]; dn[19] = b2[0];  dn[20] = R(0.0);
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        const R proj = fd1[0] * dn[j] + fd1[1] * dn[7 + j] + fd1[2] * dn[14 + j];
+#pragma unroll
+        for (int i = 0; i < 3; i++) d1[i * 7 + j] = ok ? (dn[i * 7 + j] - fd1[i] * proj) * inn : R(0.0);
+    }
+#pragma unroll
+    for (int j = 0; j < 7; j++) {   // (d fd1) x v
+        const R c0 = d1[j], c1 = d1[7 + j], c2 = d1[14 + j];
+        d2[j] = c1 * v[2] - c2 * v[1];
+        d2[7 + j] = c2 * v[0] - c0 * v[2];
+        d2[14 + j] = c0 * v[1] - c1 * v[0];
+    }
+    // + fd1 x e_j = [fd1]x columns
+    d2[5] -= fd1[2];  d2[6] += fd1[1];
+    d2[11] += fd1[2]; d2[13] -= fd1[0];
+    d2[18] -= fd1[1]; d2[19] += fd1[0];
+}
 
 template <typename R>
 __device__ __forceinline__ void bspline_weights(R t, int n, int& i0, R w[4], R dw[4]) {
@@ -226,14 +282,20 @@ __device__ __forceinline__ void dcm(const R* q, R* C) {
 }
 
 // RHS only (K2 propagate and the state part of K1).
-template <bool AERO, typename R>
+template <bool AERO, bool FIN = false, typename R>
 __device__ __forceinline__ void rhs_only(const DynP<R>& p, const R* x, const R* u, R* g) {
     const R* v = x + 4;
     const R* q = x + 7;
     const R* w = x + 11;
-    R C[9], F[3] = {R(0.0), R(0.0), R(0.0)};
+    R C[9], F[3] = {R(0.0), R(0.0), R(0.0)}, ff[3] = {R(0.0), R(0.0), R(0.0)};
     dcm(q, C);
     if (AERO) aero_force<false, R>(p, q, v, C, F, nullptr);
+    if (FIN) {
+        R fd1[3], fd2[3];
+        fin_dirs<false, R>(q, v, C, fd1, fd2, nullptr, nullptr);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { ff[i] = u[3] * fd1[i] + u[4] * fd2[i]; F[i] += ff[i]; }
+    }
     const R invm = R(1.0) / x[0];
     g[0] = -p.alpha * sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
     g[1] = v[0]; g[2] = v[1]; g[3] = v[2];
@@ -251,19 +313,46 @@ __device__ __forceinline__ void rhs_only(const DynP<R>& p, const R* x, const R* 
     t[1] = (p.rTB[2] * u[0] - p.rTB[0] * u[2]) - (w[2] * Jw[0] - w[0] * Jw[2]);
     t[2] = (p.rTB[0] * u[1] - p.rTB[1] * u[0]) - (w[0] * Jw[1] - w[1] * Jw[0]);
 #pragma unroll
-    for (int i = 0; i < 3; i++) g[11 + i] = p.Jinv[3 * i] * t[0] + p.Jinv[3 * i + 1] * t[1] + p.Jinv[3 * i + 2] * t[2];
+    for (int i = 0; i < 3; i++) {
+        g[11 + i] = p.Jinv[3 * i] * t[0] + p.Jinv[3 * i + 1] * t[1] + p.Jinv[3 * i + 2] * t[2];
+        if (FIN) g[11 + i] += p.JrF[3 * i] * ff[0] + p.JrF[3 * i + 1] * ff[1] + p.JrF[3 * i + 2] * ff[2];   // Jinv (rFB x ff)
+    }
 }
 
 // RHS + the structural non-zeros of df/dx at (x,u).
-template <bool AERO, typename R>
-__device__ __forceinline__ void stage_eval(const DynP<R>& p, const R* x, const R* u, Stage<AERO, R>& s) {
+template <bool AERO, bool FIN = false, typename R>
+__device__ __forceinline__ void stage_eval(const DynP<R>& p, const R* x, const R* u, Stage<AERO, R, FIN>& s) {
     const R* v = x + 4;
     const R* q = x + 7;
     const R* w = x + 11;
     dcm(q, s.C);
     R F[3] = {R(0.0), R(0.0), R(0.0)};
-    R dF[AERO ? 21 : 1];
+    R dF[(AERO || FIN) ? 21 : 1];
     if (AERO) aero_force<true>(p, q, v, s.C, F, dF);
+    R ff[3] = {R(0.0), R(0.0), R(0.0)};
+    if (FIN) {
+        R d1[21], d2[21];
+        fin_dirs<true, R>(q, v, s.C, s.fd1, s.fd2, d1, d2);
+        R dff[21];
+#pragma unroll
+        for (int i = 0; i < 21; i++) {
+            dff[i] = u[3] * d1[i] + u[4] * d2[i];
+            dF[i] = AERO ? dF[i] + dff[i] : dff[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            ff[i] = u[3] * s.fd1[i] + u[4] * s.fd2[i];
+            F[i] += ff[i];
+            s.Gf1[i] = p.JrF[3 * i] * s.fd1[0] + p.JrF[3 * i + 1] * s.fd1[1] + p.JrF[3 * i + 2] * s.fd1[2];
+            s.Gf2[i] = p.JrF[3 * i] * s.fd2[0] + p.JrF[3 * i + 1] * s.fd2[1] + p.JrF[3 * i + 2] * s.fd2[2];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                s.Wq[4 * i + j] = p.JrF[3 * i] * dff[j] + p.JrF[3 * i + 1] * dff[7 + j] + p.JrF[3 * i + 2] * dff[14 + j];
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                s.Wv[3 * i + j] = p.JrF[3 * i] * dff[4 + j] + p.JrF[3 * i + 1] * dff[11 + j] + p.JrF[3 * i + 2] * dff[18 + j];
+        }
+    }
     const R invm = R(1.0) / x[0];
     s.invm = invm;
     s.g[0] = -p.alpha * sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
@@ -290,8 +379,8 @@ __device__ __forceinline__ void stage_eval(const DynP<R>& p, const R* x, const R
         s.g[4 + i] = acc;
         s.am[i] = -acc * invm;
 #pragma unroll
-        for (int j = 0; j < 4; j++) s.Dq[4 * i + j] = (D[4 * i + j] + (AERO ? dF[7 * i + j] : R(0.0))) * invm;
-        if (AERO) {
+        for (int j = 0; j < 4; j++) s.Dq[4 * i + j] = (D[4 * i + j] + ((AERO || FIN) ? dF[7 * i + j] : R(0.0))) * invm;
+        if (AERO || FIN) {
 #pragma unroll
             for (int j = 0; j < 3; j++) s.Dv[3 * i + j] = dF[7 * i + 4 + j] * invm;
         }
@@ -308,7 +397,10 @@ __device__ __forceinline__ void stage_eval(const DynP<R>& p, const R* x, const R
     t[1] = (p.rTB[2] * u1 - p.rTB[0] * u3) - (w[2] * Jw[0] - w[0] * Jw[2]);
     t[2] = (p.rTB[0] * u2 - p.rTB[1] * u1) - (w[0] * Jw[1] - w[1] * Jw[0]);
 #pragma unroll
-    for (int i = 0; i < 3; i++) s.g[11 + i] = p.Jinv[3 * i] * t[0] + p.Jinv[3 * i + 1] * t[1] + p.Jinv[3 * i + 2] * t[2];
+    for (int i = 0; i < 3; i++) {
+        s.g[11 + i] = p.Jinv[3 * i] * t[0] + p.Jinv[3 * i + 1] * t[1] + p.Jinv[3 * i + 2] * t[2];
+        if (FIN) s.g[11 + i] += p.JrF[3 * i] * ff[0] + p.JrF[3 * i + 1] * ff[1] + p.JrF[3 * i + 2] * ff[2];
+    }
     // T = [w]x J - [Jw]x ; Mw = -Jinv T
     R T[9];
 #pragma unroll
@@ -376,11 +468,12 @@ __device__ __forceinline__ void column_deriv(const DynP<R>& p, const Stage<AERO,
 
 // ---- producer / consumer form of the stage: what a column needs to know about the state trajectory ----
 // Coefficient record of one RK stage of one segment (NCOEF doubles, stored [field][segment] in LDS):
-//   g[14] | C[9] | invm | am[3] | Dq[12] | Mw[9] | q[4] | w[3] | ku[3] = -alpha u/|u| | (aero) Dv[9]
-template <bool AERO> struct StageRec { static constexpr int N = AERO ? 67 : 58; };
+//   g[14] | C[9] | invm | am[3] | Dq[12] | Mw[9] | q[4] | w[3] | ku[3] = -alpha u/|u| | (aero / fins) Dv[9]
+//   | (fins) fd1[3] fd2[3] Wq[12] Wv[9] Gf1[3] Gf2[3]
+template <bool AERO, bool FIN = false> struct StageRec { static constexpr int N = FIN ? 100 : (AERO ? 67 : 58); };
 
-template <bool AERO, typename R>
-__device__ __forceinline__ void stage_publish(const DynP<R>& p, const Stage<AERO, R>& s, const R* x, const R* u,
+template <bool AERO, bool FIN = false, typename R>
+__device__ __forceinline__ void stage_publish(const DynP<R>& p, const Stage<AERO, R, FIN>& s, const R* x, const R* u,
                                               R* rec, int stride) {
     int o = 0;
 #pragma unroll
@@ -402,10 +495,102 @@ __device__ __forceinline__ void stage_publish(const DynP<R>& p, const Stage<AERO
     const R k = un > R(0.0) ? -p.alpha / un : R(0.0);
 #pragma unroll
     for (int i = 0; i < 3; i++) rec[(o++) * stride] = k * u[i];
-    if (AERO) {
+    if (AERO || FIN) {
 #pragma unroll
         for (int i = 0; i < 9; i++) rec[(o++) * stride] = s.Dv[i];
     }
+    if (FIN) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) rec[(o++) * stride] = s.fd1[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) rec[(o++) * stride] = s.fd2[i];
+#pragma unroll
+        for (int i = 0; i < 12; i++) rec[(o++) * stride] = s.Wq[i];
+#pragma unroll
+        for (int i = 0; i < 9; i++) rec[(o++) * stride] = s.Wv[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) rec[(o++) * stride] = s.Gf1[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) rec[(o++) * stride] = s.Gf2[i];
+    }
+}
+
+// Fin model: d/dt of one sensitivity column from a published stage record (100 values).  The record is read in three
+// batches (translational rows | rotational rows | the RHS itself) so that at most ~45 of its values are live at once:
+// holding all 100 next to the column's own 42 values would spill.  wc[5]: FOH weights of this column's control component.
+template <bool AERO, typename R>
+__device__ __forceinline__ void column_deriv_rec_fin(const DynP<R>& p, const R* rec, int stride, const R* c,
+                                                     const R* wc, R gsel, R sigma, R* dc) {
+    constexpr int oC = 14, oInvm = 23, oAm = 24, oDq = 27, oMw = 39, oQ = 48, oW = 52, oKu = 55, oDv = 58;
+    constexpr int oF1 = 67, oF2 = 70, oWq = 73, oWv = 85, oG1 = 94, oG2 = 97;
+    auto RR = [&](int i) { return rec[i * stride]; };
+    R a[14];
+    {   // ---- mass, position and velocity rows ----
+        R C[9], am[3], Dq[12], Dv[9], f1[3], f2[3], ku[3];
+#pragma unroll
+        for (int i = 0; i < 9; i++) { C[i] = RR(oC + i); Dv[i] = RR(oDv + i); }
+#pragma unroll
+        for (int i = 0; i < 12; i++) Dq[i] = RR(oDq + i);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { am[i] = RR(oAm + i); f1[i] = RR(oF1 + i); f2[i] = RR(oF2 + i); ku[i] = RR(oKu + i); }
+        const R invm = RR(oInvm);
+        a[0] = ku[0] * wc[0] + ku[1] * wc[1] + ku[2] * wc[2];
+        a[1] = c[4]; a[2] = c[5]; a[3] = c[6];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            R t = am[i] * c[0];
+            t = fma(Dq[4 * i], c[7], t);
+            t = fma(Dq[4 * i + 1], c[8], t);
+            t = fma(Dq[4 * i + 2], c[9], t);
+            t = fma(Dq[4 * i + 3], c[10], t);
+            t = fma(Dv[3 * i], c[4], t);
+            t = fma(Dv[3 * i + 1], c[5], t);
+            t = fma(Dv[3 * i + 2], c[6], t);
+            t = fma((C[3 * i] * wc[0] + C[3 * i + 1] * wc[1] + C[3 * i + 2] * wc[2] + f1[i] * wc[3] + f2[i] * wc[4]), invm, t);
+            a[4 + i] = t;
+        }
+    }
+    {   // ---- attitude and rate rows ----
+        R q[4], w[3], Mw[9], Wq[12], Wv[9], g1[3], g2[3];
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] = RR(oQ + i);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { w[i] = RR(oW + i); g1[i] = RR(oG1 + i); g2[i] = RR(oG2 + i); }
+#pragma unroll
+        for (int i = 0; i < 9; i++) { Mw[i] = RR(oMw + i); Wv[i] = RR(oWv + i); }
+#pragma unroll
+        for (int i = 0; i < 12; i++) Wq[i] = RR(oWq + i);
+        const R cq0 = c[7], cq1 = c[8], cq2 = c[9], cq3 = c[10];
+        const R cw0 = c[11], cw1 = c[12], cw2 = c[13];
+        a[7] = R(0.5) * (-w[0] * cq1 - w[1] * cq2 - w[2] * cq3 - q[1] * cw0 - q[2] * cw1 - q[3] * cw2);
+        a[8] = R(0.5) * (w[0] * cq0 + w[2] * cq2 - w[1] * cq3 + q[0] * cw0 - q[3] * cw1 + q[2] * cw2);
+        a[9] = R(0.5) * (w[1] * cq0 - w[2] * cq1 + w[0] * cq3 + q[3] * cw0 + q[0] * cw1 - q[1] * cw2);
+        a[10] = R(0.5) * (w[2] * cq0 + w[1] * cq1 - w[0] * cq2 - q[2] * cw0 + q[1] * cw1 + q[0] * cw2);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            R t = Mw[3 * i] * cw0;
+            t = fma(Mw[3 * i + 1], cw1, t);
+            t = fma(Mw[3 * i + 2], cw2, t);
+            t = fma(Wq[4 * i], cq0, t);
+            t = fma(Wq[4 * i + 1], cq1, t);
+            t = fma(Wq[4 * i + 2], cq2, t);
+            t = fma(Wq[4 * i + 3], cq3, t);
+            t = fma(Wv[3 * i], c[4], t);
+            t = fma(Wv[3 * i + 1], c[5], t);
+            t = fma(Wv[3 * i + 2], c[6], t);
+            t = fma(p.JrT[3 * i], wc[0], t);
+            t = fma(p.JrT[3 * i + 1], wc[1], t);
+            t = fma(p.JrT[3 * i + 2], wc[2], t);
+            t = fma(g1[i], wc[3], t);
+            t = fma(g2[i], wc[4], t);
+            a[11 + i] = t;
+        }
+    }
+    R g[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) g[i] = RR(i);
+#pragma unroll
+    for (int i = 0; i < 14; i++) dc[i] = fma(sigma, a[i], gsel * g[i]);
 }
 
 // d/dt of one sensitivity column from a published stage record (same arithmetic as column_deriv)

@@ -30,7 +30,7 @@ namespace scvx {
 
 struct NcclId { char internal[SCVX_COMM_ID_BYTES]; };   // layout of ncclUniqueId (rccl.h), passed by value to RCCL
 
-// K1: endpoint[B*K][14], deriv[B*K][21][14] from x[B][K+1][14], u[B][K+1][3], sigma[B].
+// K1: endpoint[B*K][14], deriv[B*K][14+2NU+1][14] from x[B][K+1][14], u[B][K+1][NU], sigma[B]  (NU = scvx_control_dim).
 hipError_t launch_linearize(const scvx_ctx* ctx, int B, int K, const double* x, const double* u, const double* sigma,
                             double dt, double* endpoint, double* deriv, hipStream_t st, const int* skip = nullptr);
 // K1 in double arithmetic with the derivative tiles stored as float (scvx_batch_set_linearization_f32)
@@ -47,7 +47,7 @@ hipError_t launch_propagate_f32(const scvx_ctx* ctx, int B, int K, const float* 
                                 float dt, float* xnext, hipStream_t st);
 
 // K0 (scvx_threedof.hip): the batched 3-DoF landing SOCP on device arrays, enqueued on ctx->stream; sol [B][(K+1)*15+1],
-// info [B][6] = status, iters, pobj, gap, pres, dres.  threedof_to_record overwrites the trajectory records [B][(K+1)*17+1]
+// info [B][6] = status, iters, pobj, gap, pres, dres.  threedof_to_record overwrites the trajectory records [B][(K+1)*(14+NU)+1]
 // of the trajectories whose solve is optimal with the LinPoints of initial_solve.jl:90-105.
 int threedof_solve_dev(scvx_ctx* ctx, int B, const double* ic_dev, const scvx_threedof_opts* opts, double* sol_dev,
                        double* info_dev);

@@ -139,16 +139,17 @@ __device__ void rotation_between_e1_dev(const double* b, double* q) {
 
 // initial_solve.jl:90-105: LinPoints from the 3-DoF optimum -- state (ma, r, v, rotation_between(e1, -T), 0), control
 // (|T|, 0, 0) -- written over the trajectory record of every trajectory whose 3-DoF solve is optimal
-__global__ void threedof_to_record_kernel(int B, int K, const double* __restrict__ sol, const double* __restrict__ info,
+__global__ void threedof_to_record_kernel(int B, int K, int NU, const double* __restrict__ sol, const double* __restrict__ info,
                                           double sigma, double tsign, double* __restrict__ rec) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * (K + 1)) return;
     const int b = i / (K + 1), k = i - b * (K + 1);
     if (info[(size_t)b * 6] != 0.0) return;
-    const int nrec = (K + 1) * 17 + 1;
+    const int nrec = (K + 1) * (14 + NU) + 1;
     const double* z = sol + (size_t)b * td::out_doubles(K) + (size_t)k * td::NV;
     double* x = rec + (size_t)b * nrec + 14 * k;
-    double* u = rec + (size_t)b * nrec + (size_t)(K + 1) * 14 + 3 * k;
+    double* u = rec + (size_t)b * nrec + (size_t)(K + 1) * 14 + NU * k;
+    for (int c = 3; c < NU; c++) u[c] = 0.0;   // fin controls start at zero
     x[0] = z[6];
     for (int j = 0; j < 3; j++) { x[1 + j] = z[j]; x[4 + j] = z[3 + j]; x[11 + j] = 0.0; }
     const double nT[3] = {tsign * z[7], tsign * z[8], tsign * z[9]};
@@ -251,7 +252,7 @@ int threedof_solve_dev(scvx_ctx* ctx, int B, const double* ic_dev, const scvx_th
 
 int threedof_to_record(scvx_ctx* ctx, int B, int K, const double* sol_dev, const double* info_dev, double* rec_dev, int attitude) {
     const int n = B * (K + 1);
-    hipLaunchKernelGGL(threedof_to_record_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, B, K, sol_dev, info_dev,
+    hipLaunchKernelGGL(threedof_to_record_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, B, K, scvx_control_dim(ctx), sol_dev, info_dev,
                        ctx->prob.tf_guess, attitude == 1 ? 1.0 : -1.0, rec_dev);
     SCVX_HIP(ctx, hipGetLastError());
     return SCVX_OK;

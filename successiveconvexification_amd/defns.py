@@ -84,7 +84,18 @@ class DescentProblem:
     alph: float = 2.0
     bet: float = 3.2
     sos: float = 5.0
-    model_flags: int = 0   # not a reference field: 1 (SCVX_MODEL_DPMAX) enforces the dpMax / rho constraint the reference leaves as a todo
+    model_flags: int = 0   # not a reference field: 1 (SCVX_MODEL_DPMAX) enforces the dpMax / rho constraint the reference leaves as a todo;
+                           # 2 (SCVX_MODEL_FINS) enables the fin extension: control_dim = 5 (dynamics.jl:60-69 / rocketland.jl:203-209 as commented there)
+    finmxf: float = 0.01   # fin extension: bound of |u[4:5]| (rocketland.jl:205)
+
+    @property
+    def fins(self) -> bool:
+        return bool(int(self.model_flags) & 2)
+
+    @property
+    def nu(self) -> int:
+        """control_dim: 3, or 5 with the fin extension."""
+        return 5 if self.fins else 3
 
     def to_c(self) -> ScvxProblem:
         s = ScvxProblem()
@@ -100,6 +111,7 @@ class DescentProblem:
             getattr(s, name)[:] = list(a)
         s.K, s.imax = int(self.K), int(self.imax)
         s.model_flags = int(getattr(self, "model_flags", 0))
+        s.finmxf = float(self.finmxf)
         if isinstance(self.aero, AtmosphericData):
             s.aero_kind = 1
             s.force_scalar, s.length_scalar = float(self.aero.force_scalar), float(self.aero.length_scalar)
@@ -130,13 +142,13 @@ class ProbInfo:
 @dataclass
 class LinPoint:
     state: np.ndarray    # [14]
-    control: np.ndarray  # [3]
+    control: np.ndarray  # [3]  ([5] with the fin extension)
 
 
 @dataclass
 class LinRes:
     endpoint: np.ndarray    # [14]
-    derivative: np.ndarray  # [14][21]
+    derivative: np.ndarray  # [14][21]  ([14][25] with the fin extension)
 
 
 @dataclass

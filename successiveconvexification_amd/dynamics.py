@@ -37,9 +37,11 @@ class IntegratorCache:
         h = C.c_void_p()
         rc = self._L.scvx_ctx_create(C.byref(self._c_prob), int(device), C.byref(h))
         if rc != 0:
-            raise _lib.ScvxError(f"scvx_ctx_create failed ({rc}): is a HIP device visible?")
+            raise _lib.ScvxError(f"scvx_ctx_create failed ({rc}): is a HIP device visible? (rc -1: bad problem, e.g. fins without finmxf > 0)")
         self.handle = h
         self.device = device
+        self.nu = int(self._L.scvx_control_dim(h))        # 3, or 5 with the fin extension (SCVX_MODEL_FINS)
+        self.np = 14 + 2 * self.nu + 1
         self.set_npts(npts)
         if isinstance(prob.aero, AtmosphericData):
             a = prob.aero
@@ -80,16 +82,16 @@ class IntegratorCache:
 
 
 def linearize_batch(cache: IntegratorCache, x, u, sigma, dt):
-    """x [B][K+1][14], u [B][K+1][3], sigma [B] (host) -> endpoint [B][K][14], deriv [B][K][21][14]."""
+    """x [B][K+1][14], u [B][K+1][nu], sigma [B] (host) -> endpoint [B][K][14], deriv [B][K][14+2nu+1][14]  (nu = cache.nu)."""
     x = np.ascontiguousarray(x, np.float64)
     u = np.ascontiguousarray(u, np.float64)
     sigma = np.ascontiguousarray(sigma, np.float64)
     B, K1, nx = x.shape
     K = K1 - 1
-    if nx != 14 or u.shape != (B, K1, 3) or sigma.shape != (B,):
-        raise ValueError("shape mismatch: x [B][K+1][14], u [B][K+1][3], sigma [B]")
+    if nx != 14 or u.shape != (B, K1, cache.nu) or sigma.shape != (B,):
+        raise ValueError("shape mismatch: x [B][K+1][14], u [B][K+1][%d], sigma [B]" % cache.nu)
     e = np.empty((B, K, 14))
-    d = np.empty((B, K, 21, 14))
+    d = np.empty((B, K, cache.np, 14))
     _lib.check(cache.handle, cache._L.scvx_linearize_f64_host(cache.handle, B, K, _p(x), _p(u), _p(sigma), float(dt),
                                                               _p(e), _p(d)), "scvx_linearize_f64_host")
     return e, d
@@ -101,8 +103,8 @@ def propagate_batch(cache: IntegratorCache, x, u, sigma, dt):
     sigma = np.ascontiguousarray(sigma, np.float64)
     B, K1, nx = x.shape
     K = K1 - 1
-    if nx != 14 or u.shape != (B, K1, 3) or sigma.shape != (B,):
-        raise ValueError("shape mismatch: x [B][K+1][14], u [B][K+1][3], sigma [B]")
+    if nx != 14 or u.shape != (B, K1, cache.nu) or sigma.shape != (B,):
+        raise ValueError("shape mismatch: x [B][K+1][14], u [B][K+1][%d], sigma [B]" % cache.nu)
     e = np.empty((B, K, 14))
     _lib.check(cache.handle, cache._L.scvx_propagate_f64_host(cache.handle, B, K, _p(x), _p(u), _p(sigma), float(dt),
                                                               _p(e)), "scvx_propagate_f64_host")
@@ -120,10 +122,10 @@ def linearize_batch_f32(cache: IntegratorCache, x, u, sigma, dt):
     sigma = np.ascontiguousarray(sigma, np.float32)
     B, K1, nx = x.shape
     K = K1 - 1
-    if nx != 14 or u.shape != (B, K1, 3) or sigma.shape != (B,):
-        raise ValueError("shape mismatch: x [B][K+1][14], u [B][K+1][3], sigma [B]")
+    if nx != 14 or u.shape != (B, K1, cache.nu) or sigma.shape != (B,):
+        raise ValueError("shape mismatch: x [B][K+1][14], u [B][K+1][%d], sigma [B]" % cache.nu)
     e = np.empty((B, K, 14), np.float32)
-    d = np.empty((B, K, 21, 14), np.float32)
+    d = np.empty((B, K, cache.np, 14), np.float32)
     _lib.check(cache.handle, cache._L.scvx_linearize_f32_host(cache.handle, B, K, _pf(x), _pf(u), _pf(sigma), float(dt),
                                                               _pf(e), _pf(d)), "scvx_linearize_f32_host")
     return e, d
@@ -135,8 +137,8 @@ def propagate_batch_f32(cache: IntegratorCache, x, u, sigma, dt):
     sigma = np.ascontiguousarray(sigma, np.float32)
     B, K1, nx = x.shape
     K = K1 - 1
-    if nx != 14 or u.shape != (B, K1, 3) or sigma.shape != (B,):
-        raise ValueError("shape mismatch: x [B][K+1][14], u [B][K+1][3], sigma [B]")
+    if nx != 14 or u.shape != (B, K1, cache.nu) or sigma.shape != (B,):
+        raise ValueError("shape mismatch: x [B][K+1][14], u [B][K+1][%d], sigma [B]" % cache.nu)
     e = np.empty((B, K, 14), np.float32)
     _lib.check(cache.handle, cache._L.scvx_propagate_f32_host(cache.handle, B, K, _pf(x), _pf(u), _pf(sigma), float(dt),
                                                               _pf(e)), "scvx_propagate_f32_host")
@@ -159,7 +161,7 @@ def linearize_dynamics(states, tf_guess: float, base_dt: float, cache: Integrato
 def predict_state(initial_state, uk, up, sigma, dt, pinfo, cache: IntegratorCache):
     """dynamics.jl:315-317: state at the end of one segment."""
     x = np.zeros((1, 2, 14))
-    u = np.zeros((1, 2, 3))
+    u = np.zeros((1, 2, cache.nu))
     x[0, 0] = initial_state
     u[0, 0] = uk
     u[0, 1] = up

@@ -33,7 +33,9 @@ def linear_points(problem: DescentProblem):
         rIk = (K - k) / K * problem.rIi + (k / K) * problem.rIf
         vIk = (K - k) / K * problem.vIi + (k / K) * problem.vIf
         q = rotation_between([1, 0, 0], -vIk)
-        pts.append(LinPoint(np.concatenate([[mk], rIk, vIk, q, [0.0, 0, 0]]), np.array([mk * problem.g, 0, 0])))
+        ctrl = np.zeros(getattr(problem, "nu", 3))   # fin controls (control_dim = 5) start at zero
+        ctrl[0] = mk * problem.g
+        pts.append(LinPoint(np.concatenate([[mk], rIk, vIk, q, [0.0, 0, 0]]), ctrl))
     return pts
 
 
@@ -105,5 +107,7 @@ def solve_initial(problem: DescentProblem, cache, **opts):
         Tk = sol["T"][0, :, k]
         q = rotation_between([1, 0, 0], -Tk)
         state = np.concatenate([[sol["ma"][0, k]], sol["r"][0, :, k], sol["v"][0, :, k], q, [0.0, 0, 0]])
-        pts.append(LinPoint(state, np.array([np.linalg.norm(Tk), 0, 0])))
+        ctrl = np.zeros(getattr(problem, "nu", 3))
+        ctrl[0] = np.linalg.norm(Tk)
+        pts.append(LinPoint(state, ctrl))
     return pts, dynamics.linearize_dynamics(pts, problem.tf_guess, 1 / (problem.K + 1), cache)

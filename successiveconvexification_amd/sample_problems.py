@@ -28,7 +28,8 @@ def normalize_problem(dp: DescentProblem) -> DescentProblem:
         wDS=dp.wDS, wCst=dp.wCst, wTviol=dp.wTviol, delTol=dp.delTol,
         tf_guess=dp.tf_guess / Ut, ri=dp.ri, rh0=dp.rh0, rh1=dp.rh1,
         rh2=dp.rh2, alph=dp.alph, bet=dp.bet, dpMax=dp.dpMax / (Um / (Ul * Ut**2)), rho=dp.rho / (Um / Ul**3),
-        sos=dp.sos / (Ul / Ut), aero=rescale_aerodata(dp.aero, Ul, Ut, Um))
+        sos=dp.sos / (Ul / Ut), aero=rescale_aerodata(dp.aero, Ul, Ut, Um),
+        model_flags=dp.model_flags, finmxf=dp.finmxf)   # build extensions pass through (finmxf is a constant of build_model, rocketland.jl:205)
 
 
 def _base(aero) -> DescentProblem:
@@ -50,3 +51,15 @@ def base_prob_aero(aero_info) -> DescentProblem:
 
 def base_prob_aero_scaled(aero_info) -> DescentProblem:
     return normalize_problem(base_prob_aero(aero_info))
+
+
+def base_prob_fin_scaled(aero_info=None) -> DescentProblem:
+    """BASELINE configs[4] "6-DoF + fin aero": the sample problem with the fin extension (control_dim = 5).  The model is
+    DEFINED BY THIS BUILD from the reference's commented-out fin code (include/scvx.h).  One deliberate
+    departure from normalize_problem: it scales rFB by 1/Ut (sample_problems.jl:16, harmless there because rFB is unused),
+    which would put the fins 2 normalised length units = 2 km from the centre of mass; the fin torque arm is a length, so it
+    is scaled by 1/Ul here like rTB."""
+    from .defns import ExoatmosphericData
+    b = _base(aero_info if aero_info is not None else ExoatmosphericData())
+    p = normalize_problem(replace(b, model_flags=b.model_flags | 2))
+    return replace(p, rFB=b.rFB * (1.0 / float(np.max(b.rIi))))
