@@ -27,20 +27,24 @@ struct CProblem
     wBi::NTuple{3,Cdouble}; wBf::NTuple{3,Cdouble}
     wNu::Cdouble; wID::Cdouble; wDS::Cdouble; wCst::Cdouble; wTviol::Cdouble; nuTol::Cdouble; delTol::Cdouble; tf_guess::Cdouble
     ri::Cdouble; rh0::Cdouble; rh1::Cdouble; rh2::Cdouble; alph::Cdouble; bet::Cdouble
-    force_scalar::Cdouble; length_scalar::Cdouble
+    force_scalar::Cdouble; length_scalar::Cdouble; finmxf::Cdouble
     K::Int32; imax::Int32; aero_kind::Int32; model_flags::Int32
 end
+
+const MODEL_DPMAX = 1   # SCVX_MODEL_DPMAX: enforce 1/2 rho |v|^2 <= dpMax (fields master.jl:27,30; a todo at rocketland.jl:211)
+const MODEL_FINS = 2    # SCVX_MODEL_FINS: the fin extension, control_dim = 5 -- the model the reference sketches in comments
+                        # (dynamics.jl:60-69, rocketland.jl:203-209) and include/scvx.h defines; LinPoint.control then has 5 entries
 
 t3(v) = (Float64(v[1]), Float64(v[2]), Float64(v[3]))
 t4(v) = (Float64(v[1]), Float64(v[2]), Float64(v[3]), Float64(v[4]))
 
-function CProblem(p::DescentProblem; model_flags::Integer=0)   # model_flags = 1: enforce dpMax (SCVX_MODEL_DPMAX)
+function CProblem(p::DescentProblem; model_flags::Integer=0, finmxf::Real=0.01)   # model_flags: MODEL_DPMAX | MODEL_FINS
     aero = p.aero isa AtmosphericData
     CProblem(p.g, p.mdry, p.mwet, p.Tmin, p.Tmax, p.deltaMax, p.thetaMax, p.gammaGs, p.omMax, p.dpMax,
              Tuple(Float64.(vec(p.jB))), p.alpha, p.rho, p.sos, t3(p.rTB), t3(p.rFB), t3(p.rIi), t3(p.rIf), t3(p.vIi), t3(p.vIf),
              t4(p.qBIi), t4(p.qBIf), t3(p.wBi), t3(p.wBf),
              p.wNu, p.wID, p.wDS, p.wCst, p.wTviol, p.nuTol, p.delTol, p.tf_guess, p.ri, p.rh0, p.rh1, p.rh2, p.alph, p.bet,
-             aero ? p.aero.force_scalar : 1.0, aero ? p.aero.length_scalar : 1.0,
+             aero ? p.aero.force_scalar : 1.0, aero ? p.aero.length_scalar : 1.0, Float64(finmxf),
              Int32(p.K), Int32(p.imax), Int32(aero ? 1 : 0), Int32(model_flags))
 end
 
@@ -50,7 +54,9 @@ check(ctx, rc, what) = rc == 0 || error("$what failed ($rc): " * unsafe_string(c
 mutable struct Cache
     ctx::Ptr{Cvoid}
     problem::DescentProblem
+    nu::Int          # control_dim of the context's model (scvx_control_dim): 3, or 5 with MODEL_FINS
 end
+control_dim(c::Cache) = c.nu
 
 # The raw table values behind AtmosphericData's interpolation objects (aerodynamics.jl:17-21): the three 181 x 61 grids
 # `reshape(col, 181, 61)` of lift_drag.csv, cos(AoA) fastest.  Interpolations.jl keeps the prefiltered coefficients, so
@@ -67,12 +73,13 @@ end
 
 # IntegratorCache(prob, info, lin_mod) of the recipe: `info` and the generated module are not needed (the RHS and its
 # Jacobians are compiled into the library); `tables` = (drag, lift, trq) raw grids for an AtmosphericData problem.
-function Cache(prob::DescentProblem, info=nothing, lin_mod=nothing; device::Int=0, npts::Int=10, tables=nothing)
+function Cache(prob::DescentProblem, info=nothing, lin_mod=nothing; device::Int=0, npts::Int=10, tables=nothing,
+               model_flags::Integer=0, finmxf::Real=0.01)
     ref = Ref{Ptr{Cvoid}}(C_NULL)
-    cp = Ref(CProblem(prob))
+    cp = Ref(CProblem(prob; model_flags=model_flags, finmxf=finmxf))
     rc = ccall((:scvx_ctx_create, LIB), Cint, (Ref{CProblem}, Cint, Ref{Ptr{Cvoid}}), cp, device, ref)
     rc == 0 || error("scvx_ctx_create failed ($rc)")
-    c = Cache(ref[], prob)
+    c = Cache(ref[], prob, Int(ccall((:scvx_control_dim, LIB), Cint, (Ptr{Cvoid},), ref[])))
     check(c.ctx, ccall((:scvx_set_nsub, LIB), Cint, (Ptr{Cvoid}, Cint), c.ctx, npts), "scvx_set_nsub")
     if prob.aero isa AtmosphericData
         tables === nothing && error("AtmosphericData problem: pass tables=(drag, lift, trq), the 181x61 grids of lift_drag.csv")
@@ -87,9 +94,10 @@ make_dynamics_module(info) = nothing   # dynamics.jl:141: code generation is rep
 function linearize_dynamics(states::Array{LinPoint,1}, tf_guess::Float64, base_dt::Float64, cache::Cache)
     K = length(states) - 1
     x = hcat((s.state for s in states)...)       # 14 x (K+1), column-major == [K+1][14]
-    u = hcat((s.control for s in states)...)     # 3 x (K+1)
+    u = hcat((s.control for s in states)...)     # NU x (K+1)
+    size(u, 1) == cache.nu || error("LinPoint.control has $(size(u, 1)) entries, the context's model has control_dim $(cache.nu)")
     endpoint = Matrix{Float64}(undef, 14, K)
-    deriv = Array{Float64,3}(undef, 14, 21, K)   # column-major 14x21 per segment == [K][21][14]
+    deriv = Array{Float64,3}(undef, 14, 14 + 2 * cache.nu + 1, K)   # column-major 14x21 (14x25) per segment == [K][21][14]
     check(cache.ctx, ccall((:scvx_linearize_f64_host, LIB), Cint,
         (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}),
         cache.ctx, 1, K, x, u, [tf_guess], base_dt, endpoint, deriv), "scvx_linearize_f64_host")
@@ -132,14 +140,14 @@ linearization_f32!(b::Batch, on::Bool=true) =
 
 # snapshot of trajectory t (1-based) of a batch as the reference's ProblemIteration
 function iteration(b::Batch, t::Int=1)
-    K = b.cache.problem.K; nrec = (K + 1) * 17 + 1
+    K = b.cache.problem.K; NU = b.cache.nu; nrec = (K + 1) * (14 + NU) + 1
     rec = Matrix{Float64}(undef, nrec, b.B)
     check(b.cache.ctx, ccall((:scvx_batch_get_trajectory, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), b.h, rec), "scvx_batch_get_trajectory")
-    endpoint = Array{Float64,3}(undef, 14, K, b.B); deriv = Array{Float64,4}(undef, 14, 21, K, b.B)
+    endpoint = Array{Float64,3}(undef, 14, K, b.B); deriv = Array{Float64,4}(undef, 14, 14 + 2NU + 1, K, b.B)
     check(b.cache.ctx, ccall((:scvx_batch_get_linearization, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), b.h, endpoint, deriv), "scvx_batch_get_linearization")
     rk = Vector{Float64}(undef, b.B); cost = Vector{Float64}(undef, b.B); it = Vector{Int32}(undef, b.B)
     check(b.cache.ctx, ccall((:scvx_batch_get_scalars, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}), b.h, rk, cost, it), "scvx_batch_get_scalars")
-    x = reshape(rec[1:14(K+1), t], 14, K + 1); u = reshape(rec[14(K+1)+1:17(K+1), t], 3, K + 1)
+    x = reshape(rec[1:14(K+1), t], 14, K + 1); u = reshape(rec[14(K+1)+1:(14+NU)*(K+1), t], NU, K + 1)
     Iteration(b.cache.problem, b.cache, rec[end, t],
               [LinPoint(x[:, k], u[:, k]) for k = 1:K+1], [LinRes(endpoint[:, k, t], deriv[:, :, k, t]) for k = 1:K],
               b, it[t], rk[t], cost[t])
@@ -238,7 +246,72 @@ end
 unique_id() = (id = Vector{UInt8}(undef, 128); ccall((:scvx_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id) == 0 || error("RCCL unavailable"); id)
 comm_create!(c::Cache, id::Vector{UInt8}, rank::Int, world::Int) =
     check(c.ctx, ccall((:scvx_comm_create, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), c.ctx, id, rank, world), "scvx_comm_create")
-# out_dev: device pointer to world x B x ((K+1)*17+1) doubles (e.g. an AMDGPU.jl ROCArray)
+# out_dev: device pointer to world x B x ((K+1)*(14+NU)+1) doubles (e.g. an AMDGPU.jl ROCArray)
 allgather_trajectories!(b::Batch, out_dev::Ptr{Cdouble}) =
     check(b.cache.ctx, ccall((:scvx_allgather_trajectories, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), b.h, out_dev), "scvx_allgather_trajectories")
+
+# ---- drop-in by dispatch: the reference's OWN call sites run unedited -----------------------------------------------------
+# install!() defines methods IN the reference's modules with the reference's exact argument lists (dynamics.jl:141, 258, 315,
+# 321; rocketland.jl:34, 226, 432), so that the recipe of rocketland.jl:26-32
+#     Dynamics.make_dynamics_module(RocketlandDefns.ProbInfo(prob))
+#     cache = Dynamics.IntegratorCache(prob, RocketlandDefns.ProbInfo(prob), Linearizer)
+#     pi = Rocketland.create_initial(prob, cache);  pi, nu, dJ = Rocketland.solve_step(pi, cache)
+# reaches the HIP path.  The reference's IntegratorCache (master.jl:113-120) has untyped fields: the device Cache rides in
+# `sim_prob`.  ProblemIteration.model is a ProblemModel of MOI handles (master.jl:96-111): a placeholder is built whose untyped
+# `debug` field carries the device Batch.  An AtmosphericData problem needs its raw tables once: ScvxAMD.TABLES[] = (drag, lift, trq).
+const TABLES = Ref{Any}(nothing)
+const HOST = parentmodule(@__MODULE__)     # where master.jl included Dynamics / Rocketland / FirstRound
+device_cache(c::IntegratorCache) = c.sim_prob::Cache
+device_batch(it::ProblemIteration) = it.model.debug::Batch
+
+function placeholder_model(b::Batch)
+    MOI = HOST.RocketlandDefns.MOI
+    vi = MOI.VariableIndex(0); va = Array{MOI.VariableIndex,2}(undef, 0, 0)
+    ci = MOI.ConstraintIndex{MOI.VectorAffineFunction{Float64},MOI.Zeros}(0)
+    ProblemModel(MOI.Utilities.Model{Float64}(), va, va, va, va, vi, va, vi, ci, ci, MOI.ConstraintIndex[], ci, ci, b)
+end
+reference_iteration(it::Iteration, cache::IntegratorCache) =
+    ProblemIteration(it.problem, cache, it.sigma, it.about, it.dynam, placeholder_model(it.model), it.iter, it.rk, it.cost)
+
+function install!()
+    @eval HOST.Dynamics begin
+        function make_dynamics_module(info::ProbInfo)
+            Core.eval(Main, :(Linearizer = nothing))     # the recipe passes `Linearizer` on: nothing is generated on this path
+            return nothing
+        end
+        function (::Type{IntegratorCache})(prob::DescentProblem, info::ProbInfo, lin_mod)
+            dc = $(@__MODULE__).Cache(prob; tables=$(@__MODULE__).TABLES[])
+            return IntegratorCache(dc, nothing, nothing, nothing, nothing, info)
+        end
+        function predict_state(initial_state, uk, up, sigma, dt, pinfo, cache)
+            return $(@__MODULE__).predict_state(initial_state, uk, up, sigma, dt, pinfo, $(@__MODULE__).device_cache(cache))
+        end
+        function linearize_dynamics(states::Array{LinPoint,1}, tf_guess::Float64, base_dt::Float64, cache::IntegratorCache)
+            return $(@__MODULE__).linearize_dynamics(states, tf_guess, base_dt, $(@__MODULE__).device_cache(cache))
+        end
+    end
+    @eval HOST.Rocketland begin
+        function create_initial(problem::DescentProblem, linear_cache::IntegratorCache)
+            it = $(@__MODULE__).create_initial(problem, $(@__MODULE__).device_cache(linear_cache))
+            return $(@__MODULE__).reference_iteration(it, linear_cache)
+        end
+        function solve_step(iteration::ProblemIteration, linear_cache::IntegratorCache)
+            b = $(@__MODULE__).device_batch(iteration)
+            st, nu, dj = $(@__MODULE__).step!(b)
+            st[1] in (3, 4, 5) && error("Non-optimal result $($(@__MODULE__).STATUS_NAME[st[1]]) exiting")   # rocketland.jl:273-276
+            return $(@__MODULE__).reference_iteration($(@__MODULE__).iteration(b), linear_cache), nu[1], dj[1]
+        end
+        # rocketland.jl:432 types `cache::LinearCache`, a name that exists nowhere at HEAD (SURVEY F4): the working type is used
+        function solve_problem(iprob::DescentProblem, cache::IntegratorCache)
+            prob = create_initial(iprob, cache)
+            cnu = Inf; cdel = Inf; iter = 1
+            while (iprob.nuTol < cnu || iprob.delTol < cdel) && iter < iprob.imax
+                prob, cnu, cdel = solve_step(prob, cache)
+                iter = iter + 1
+            end
+            return prob, cnu, cdel
+        end
+    end
+    return nothing
+end
 end

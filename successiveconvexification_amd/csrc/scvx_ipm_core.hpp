@@ -47,6 +47,13 @@
 //                        reference treats anything but OPTIMAL as an error, rocketland.jl:273-276 -- set accept = tol
 //                        to get exactly that)
 // iterations without a new best merit (below 1e-5) after which the iterate is taken to sit on its numerical floor
+// The r block and the thrust block of a node: assembled and Cholesky-factorised (0, default) or inverted from their square-root
+// factors by a Householder QR (1).  Measured on the twin, first failures over 60 random classes / 40 fin classes
+// (tools/k4_fuzz.py, profiles/r03_k4_fuzz.md): 1.77 % / 1.30 % assembled, 2.09 % / 1.26 % square-root -- no gain: what limits
+// those solves is the elimination of dz (W^-2 has condition ~ v0^4), not the factorisation of the 3x3 blocks.  Kept as a switch.
+#ifndef SCVX_NODE_QR
+#define SCVX_NODE_QR 0
+#endif
 #ifndef SCVX_STALL_ITERS
 #define SCVX_STALL_ITERS 3
 #endif
@@ -98,6 +105,9 @@
 #define SCVX_T1(slot) SCVX_TE(t0_, slot)
 #if defined(SCVX_IPM_DEBUG) && !defined(__HIPCC__)
 #include <stdio.h>
+#ifndef SCVX_DBG_NODE
+#define SCVX_DBG_NODE -1
+#endif
 #define SCVX_DBG(...) fprintf(stderr, __VA_ARGS__)
 #else
 #define SCVX_DBG(...)
@@ -282,6 +292,87 @@ SCVX_HD void inv2(double a, double b, double d, PO Mi) {  // [[a b],[b d]] SPD
     const double l00 = sqrt(a), l10 = b / l00, l11 = sqrt(piv_floor(d - l10 * l10, d));
     const double i00 = 1.0 / l00, i11 = 1.0 / l11, i10 = -l10 * i00 * i11;
     Mi[0] = i00 * i00 + i10 * i10; Mi[1] = Mi[2] = i10 * i11; Mi[3] = i11 * i11;
+}
+
+// ---- node blocks in SQUARE-ROOT form -------------------------------------------------------------------------------
+// A node block of Hb is  M = a I + sum_c Jc' W_c^-2 Jc  over the cones that touch the node's variables.  Near the end of a
+// solve an active cone contributes entries of size v0^4 / beta^2 ~ 1e15 while the block's small eigenvalues stay O(1): assembled
+// and factorised as a matrix (cond ~ 1e16) the small pivots of a Cholesky factorisation are differences of those huge entries
+// and come out as noise -- for the two cones whose head row is a VARIABLE (glideslope: r1 / tan(gamma); gimbal: u1 / cos(delta))
+// the assembled form even contains an indefinite part (b2 (I - icos^2 e1 e1')) that only the rank-one term makes definite.
+// That inconsistency between Hb^-1 and the operator form J' W^-1 W^-1 J was the first-row residual 1e5 that no refinement
+// pass could contract (a trajectory frozen with SCVX_ST_SOLVER; profiles/r02_k4_fuzz.md rows 13/16/22/23).
+//   * blocks of the form  a I + kappa v v'  (rate, tilt, dynamic pressure, fins, Tmax) are inverted in closed form, every entry
+//     a sum of positive terms;
+//   * the r block and the thrust block are never assembled: M = A'A with A = [sqrt(a) I; W_c^-1 Jc; ...] (6 or 9 rows), and
+//     M^-1 = R^-1 R^-T from the Householder QR of A -- the conditioning of A is the square root of M's.
+// inverse of a I + kappa v v' (3x3, row-major out)
+template <class PO>
+SCVX_HD void inv_iso_rank1_3(double a, double kappa, double v0, double v1, double v2, PO Mi) {
+    const double n2 = v0 * v0 + v1 * v1 + v2 * v2;
+    const double den = 1.0 / (a + kappa * n2), ia = 1.0 / a;
+    const double off = -kappa * ia * den;
+    Mi[0] = (a + kappa * (v1 * v1 + v2 * v2)) * ia * den;
+    Mi[4] = (a + kappa * (v0 * v0 + v2 * v2)) * ia * den;
+    Mi[8] = (a + kappa * (v0 * v0 + v1 * v1)) * ia * den;
+    Mi[1] = Mi[3] = off * v0 * v1;
+    Mi[2] = Mi[6] = off * v0 * v2;
+    Mi[5] = Mi[7] = off * v1 * v2;
+}
+template <class PO>
+SCVX_HD void inv_iso_rank1_2(double a, double kappa, double v0, double v1, PO Mi) {
+    const double den = 1.0 / (a + kappa * (v0 * v0 + v1 * v1)), ia = 1.0 / a;
+    Mi[0] = (a + kappa * v1 * v1) * ia * den;
+    Mi[3] = (a + kappa * v0 * v0) * ia * den;
+    Mi[1] = Mi[2] = -kappa * v0 * v1 * ia * den;
+}
+// row r of W^-1 Jc for a cone of dimension D whose scaling is (v, beta): x = column of Jc (D entries) -> W^-1 x
+template <int D>
+SCVX_HD void soc_Winv_col(const double* v, double ibeta, const double* x, double* y) {
+    double vx = v[0] * x[0];
+    for (int i = 1; i < D; i++) vx -= v[i] * x[i];
+    y[0] = (2.0 * vx * v[0] - x[0]) * ibeta;
+    for (int i = 1; i < D; i++) y[i] = (-2.0 * vx * v[i] + x[i]) * ibeta;
+}
+// (A'A)^-1 for A = NR x 3 (row-major, destroyed): Householder QR, then R^-1 R^-T.  Mi row-major 3x3.
+template <int NR, class PO>
+SCVX_HD void qr_inv3(double (&A)[NR][3], PO Mi) {
+    double R[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int j = 0; j < 3; j++) {
+        double nrm2 = 0;
+        for (int r = j; r < NR; r++) nrm2 += A[r][j] * A[r][j];
+        const double nrm = sqrt(nrm2);
+        const double x0 = A[j][j];
+        const double alpha = x0 > 0.0 ? -nrm : nrm;
+        R[j][j] = alpha;
+        const double v0 = x0 - alpha;                       // v = x - alpha e1 (no cancellation: alpha has the opposite sign)
+        const double vtv = nrm2 - x0 * x0 + v0 * v0;
+        if (vtv > 0.0) {
+            const double tv = 2.0 / vtv;
+            for (int c = j + 1; c < 3; c++) {
+                double d = v0 * A[j][c];
+                for (int r = j + 1; r < NR; r++) d += A[r][j] * A[r][c];
+                d *= tv;
+                R[j][c] = A[j][c] - d * v0;
+                for (int r = j + 1; r < NR; r++) A[r][c] -= d * A[r][j];
+            }
+        } else {
+            for (int c = j + 1; c < 3; c++) R[j][c] = A[j][c];
+        }
+    }
+    // guard: a zero column cannot occur (sqrt(a) I is part of A), but keep the pivots finite
+    for (int j = 0; j < 3; j++) if (!(fabs(R[j][j]) > 1e-300)) R[j][j] = 1e-300;
+    const double i00 = 1.0 / R[0][0], i11 = 1.0 / R[1][1], i22 = 1.0 / R[2][2];
+    const double i01 = -R[0][1] * i00 * i11;
+    const double i12 = -R[1][2] * i11 * i22;
+    const double i02 = -(R[0][1] * i12 + R[0][2] * i22) * i00;
+    // Mi = Ri Ri'  (Ri upper triangular)
+    Mi[0] = i00 * i00 + i01 * i01 + i02 * i02;
+    Mi[1] = Mi[3] = i01 * i11 + i02 * i12;
+    Mi[2] = Mi[6] = i02 * i22;
+    Mi[4] = i11 * i11 + i12 * i12;
+    Mi[5] = Mi[7] = i12 * i22;
+    Mi[8] = i22 * i22;
 }
 
 template <class PH>
@@ -1686,6 +1777,23 @@ struct Solver {
             }
             if (!first && !last) {
                 // r block with glideslope cone
+#if SCVX_NODE_QR
+                // M = dtr I + Jc' W^-2 Jc, Jc = diag(1 / tan(gamma), 1, 1): square-root form (see qr_inv3)
+                cgptr v = Wv + L.o_gs + 3 * k;
+                double h00, h01, h11, b2;
+                {
+                    const double vv[3] = {v[0], v[1], v[2]};
+                    const double ib = 1.0 / Wbeta[L.c_gs + k], sq = sqrt(dtr);
+                    double A[6][3] = {{sq, 0, 0}, {0, sq, 0}, {0, 0, sq}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+                    for (int c = 0; c < 3; c++) {
+                        const double x[3] = {c == 0 ? C.itan : 0.0, c == 1 ? 1.0 : 0.0, c == 2 ? 1.0 : 0.0};
+                        double y[3];
+                        soc_Winv_col<3>(vv, ib, x, y);
+                        A[3][c] = y[0]; A[4][c] = y[1]; A[5][c] = y[2];
+                    }
+                    qr_inv3<6>(A, h + HX_R);
+                }
+#else
                 cgptr v = Wv + L.o_gs + 3 * k;
                 double h00, h01, h11, b2;
                 soc_w2(v[0], v[1] * v[1] + v[2] * v[2], Wbeta[L.c_gs + k], h00, h01, h11, b2);
@@ -1697,13 +1805,12 @@ struct Solver {
                 M[5] = M[7] = h11 * v[1] * v[2];
                 M[8] = dtr + b2 + h11 * v[2] * v[2];
                 inv3(M, h + HX_R);
+#endif
                 // v block: dtr I, plus the dynamic-pressure cone (vmax; v_k) when it is enforced
                 if (k < L.ndp) {
                     cgptr vd = Wv + L.o_dp + 4 * k;
                     soc_w2(vd[0], vd[1] * vd[1] + vd[2] * vd[2] + vd[3] * vd[3], Wbeta[L.c_dp + k], h00, h01, h11, b2);
-                    for (int a = 0; a < 3; a++)
-                        for (int b = 0; b < 3; b++) M[3 * a + b] = h11 * vd[1 + a] * vd[1 + b] + (a == b ? dtr + b2 : 0.0);
-                    inv3(M, h + HX_V);
+                    inv_iso_rank1_3(dtr + b2, h11, vd[1], vd[2], vd[3], h + HX_V);
                 } else {
                     h[HX_V] = h[HX_V + 4] = h[HX_V + 8] = 1.0 / dtr;
                 }
@@ -1713,17 +1820,46 @@ struct Solver {
                 cgptr v = Wv + L.o_tilt + 3 * k;
                 double h00, h01, h11, b2;
                 soc_w2(v[0], v[1] * v[1] + v[2] * v[2], Wbeta[L.c_tilt + k], h00, h01, h11, b2);
-                inv2(dtr + b2 + h11 * v[1] * v[1], h11 * v[1] * v[2], dtr + b2 + h11 * v[2] * v[2], h + HX_Q34);
+                inv_iso_rank1_2(dtr + b2, h11, v[1], v[2], h + HX_Q34);
             }
             if (!first && !last) {
                 cgptr v = Wv + L.o_rate + 4 * k;
                 double h00, h01, h11, b2;
                 soc_w2(v[0], v[1] * v[1] + v[2] * v[2] + v[3] * v[3], Wbeta[L.c_rate + k], h00, h01, h11, b2);
-                double M[9];
-                for (int a = 0; a < 3; a++)
-                    for (int b = 0; b < 3; b++) M[3 * a + b] = h11 * v[1 + a] * v[1 + b] + (a == b ? dtr + b2 : 0.0);
-                inv3(M, h + HX_W);
+                inv_iso_rank1_3(dtr + b2, h11, v[1], v[2], v[3], h + HX_W);
             }
+#if SCVX_NODE_QR
+            // u block (thrust part): M = dtr I + [Tmax cone: b2 I + h11 v1 v1'] + [gimbal cone: Jc' W^-2 Jc, Jc = [e1' / cos(delta); I]]
+            //                         + (1 / wl^2) uhat uhat'   -- never assembled: M = A'A, see qr_inv3
+            {
+                cgptr v = Wv + L.o_tb + 4 * k;
+                double h00, h01, h11, b2;
+                soc_w2(v[0], v[1] * v[1] + v[2] * v[2] + v[3] * v[3], Wbeta[L.c_tb + k], h00, h01, h11, b2);
+                const double sq = sqrt(dtr + b2), sh = sqrt(h11);
+                const double wl = Wbeta[L.c_lb + k], iwl = 1.0 / wl;
+                double A[9][3] = {{sq, 0, 0}, {0, sq, 0}, {0, 0, sq},
+                                  {sh * v[1], sh * v[2], sh * v[3]},
+                                  {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0},
+                                  {iwl * uhat[3 * k], iwl * uhat[3 * k + 1], iwl * uhat[3 * k + 2]}};
+                {
+                    cgptr vc = Wv + L.o_tc + 4 * k;
+                    const double vv[4] = {vc[0], vc[1], vc[2], vc[3]};
+                    const double ib = 1.0 / Wbeta[L.c_tc + k];
+                    for (int c = 0; c < 3; c++) {
+                        const double x[4] = {c == 0 ? C.icos : 0.0, c == 0 ? 1.0 : 0.0, c == 1 ? 1.0 : 0.0, c == 2 ? 1.0 : 0.0};
+                        double y[4];
+                        soc_Winv_col<4>(vv, ib, x, y);
+                        for (int r = 0; r < 4; r++) A[4 + r][c] = y[r];
+                    }
+                }
+                gptr hi = hu + HU_SZ * k;
+                if (last) {   // only u1 is free at the last node (u[2:3, K+1] = 0): its 1x1 block = |column 0 of A|^2
+                    double m00 = 0;
+                    for (int r = 0; r < 9; r++) m00 += A[r][0] * A[r][0];
+                    for (int i = 0; i < 9; i++) hi[i] = 0.0;
+                    hi[0] = 1.0 / m00;
+                } else qr_inv3<9>(A, hi);
+#else
             // u block
             {
                 double M[9];
@@ -1756,11 +1892,21 @@ struct Solver {
                     for (int i = 0; i < 9; i++) hi[i] = 0.0;
                     hi[0] = 1.0 / M[0];
                 } else inv3(M, hi);
+#endif
+#if defined(SCVX_IPM_DEBUG) && !defined(__HIPCC__)
+                if (k == SCVX_DBG_NODE) {
+                    cgptr vb = Wv + L.o_tb + 4 * k; cgptr vc = Wv + L.o_tc + 4 * k;
+                    SCVX_DBG("UBLK dtr %.17g tb %.17g %.17g %.17g %.17g %.17g tc %.17g %.17g %.17g %.17g %.17g lb %.17g uhat %.17g %.17g %.17g icos %.17g HI %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n",
+                             dtr, (double)vb[0], (double)vb[1], (double)vb[2], (double)vb[3], (double)Wbeta[L.c_tb + k], (double)vc[0], (double)vc[1], (double)vc[2], (double)vc[3],
+                             (double)Wbeta[L.c_tc + k], (double)wl, (double)uhat[3 * k], (double)uhat[3 * k + 1], (double)uhat[3 * k + 2], C.icos,
+                             (double)hi[0], (double)hi[1], (double)hi[2], (double)hi[3], (double)hi[4], (double)hi[5], (double)hi[6], (double)hi[7], (double)hi[8]);
+                }
+#endif
                 if constexpr (NU == 5) {
                     // fin block: trust region + the cone (finmxf; u4, u5); free at every node (u[2:3, K+1] = 0 fixes thrust only)
                     cgptr vf = Wv + L.o_fin + 3 * k;
                     soc_w2(vf[0], vf[1] * vf[1] + vf[2] * vf[2], Wbeta[L.c_fin + k], h00, h01, h11, b2);
-                    inv2(dtr + b2 + h11 * vf[1] * vf[1], h11 * vf[1] * vf[2], dtr + b2 + h11 * vf[2] * vf[2], hi + 9);
+                    inv_iso_rank1_2(dtr + b2, h11, vf[1], vf[2], hi + 9);
                 }
             }
         }
@@ -2107,6 +2253,15 @@ struct Solver {
             // accurate enough skips the correction, one that is not gets up to C.refine of them.
             const double nr1 = sqrt(sumsq(r1, L.nv));
             SCVX_DBG("      refine %d: |r1| %.3e\n", it, nr1);
+#if defined(SCVX_IPM_DEBUG) && !defined(__HIPCC__)
+            if (it == 0) {   // where the residual of the first solve sits: (block, node, component)
+                int am = 0; double mx = 0;
+                for (int i = 0; i < L.nv; i++) if (fabs((double)r1[i]) > mx) { mx = fabs((double)r1[i]); am = i; }
+                if (am < L.nx) SCVX_DBG("        max at x node %d comp %d (%.3e)\n", am / 14, am % 14, mx);
+                else if (am < L.nx + L.nu_) SCVX_DBG("        max at u node %d comp %d (%.3e)\n", (am - L.nx) / NU, (am - L.nx) % NU, mx);
+                else SCVX_DBG("        max at index %d of nv %d (%.3e)\n", am, L.nv, mx);
+            }
+#endif
             if (nr1 <= SCVX_REFINE_STOP * C.tol * (C.wNu > 1.0 ? C.wNu : 1.0)) break;
             if (it > 0 && !(nr1 < 0.5 * nr_prev)) break;   // the corrections have stopped contracting: precision floor
             nr_prev = nr1;
@@ -2338,7 +2493,20 @@ struct Solver {
             const double sig = (om * om) * (om * om);
 #endif
             SCVX_DBG("    aff alpha %.6e |dw|^2 %.6e ds %.6e dtnu %.6e dttr %.6e\n", alpha, dot(dw, dw, L.nv), dw[L.iS], dw[L.iTNU], dw[L.iTTR]);
-            corr_rhs_pass(sig * mu);
+            // Do not aim below the gap the tolerance asks for: the NT scalings of the active cones grow like 1 / sqrt(mu) and the
+            // Newton system (entries v0^4 / beta^2) passes the precision of a double a little below mu = tol |pobj| / degree; a
+            // predictor that finds alpha_aff ~ 1 there would target 1e-4 mu and the step that follows pollutes the dual residual
+            // beyond repair (the solves that used to end "stalled at merit 1.0..5e-8").
+            double smu = sig * mu;
+#ifndef SCVX_MU_FLOOR
+#define SCVX_MU_FLOOR 0.5   // of tol |pobj| / degree.  Twin, first failures on 60 random classes: 0 -> 2.25 %, 0.25 -> 1.77 %, 0.5 -> 1.71 %, 1 -> 4.4 %
+#endif
+            {
+                const double apo = fabs(pobj) > 1.0 ? fabs(pobj) : 1.0;
+                const double mu_floor = SCVX_MU_FLOOR * C.tol * apo / degree;
+                if (smu < mu_floor) smu = mu_floor < mu ? mu_floor : mu;
+            }
+            corr_rhs_pass(smu);
             { SCVX_TS(tN_); newton_solve(false); SCVX_TE(tN_, 10); }
             alpha = SCVX_STEP_FRAC * dir_pass<false>();
             if (alpha > 1.0) alpha = 1.0;

@@ -9,14 +9,14 @@
  *     predict_state(x4, u4, u5, sigma, dt, info, cache)                scvx_propagate_f64_host
  *
  * with the argument layouts the shim passes: the problem BY POINTER as the flat scvx_problem struct, states as
- * column-major 14 x (K+1) arrays, LinRes.derivative as column-major 14 x 21 per segment.  Julia is not in the build
+ * column-major 14 x (K+1) arrays, LinRes.derivative as column-major 14 x 21 per segment (14 x 25 and 5-row controls with the fin extension).  Julia is not in the build
  * image; this harness is how the binding's use of the ABI is executed on the GPU.  The test
  * (tests/test_abi_harness.py) writes the inputs, runs this program, and compares its outputs BIT FOR BIT with the same
  * sequence driven through the Python ctypes layer.
  *
  *     abi_harness <in.bin> <out.bin>
  * in.bin : scvx_problem | int32 n_aoa, n_mach, nsub, nstep | double aoa0, daoa, mach0, dmach | drag | lift | trq
- * out.bin: for create_initial and after each step: traj[(K+1)*17+1] endpoint[K*14] deriv[K*294] rk cost (double)iter ;
+ * out.bin: for create_initial and after each step: traj[(K+1)*(14+NU)+1] endpoint[K*14] deriv[K*14*(14+2NU+1)] rk cost (double)iter ;
  *          per step additionally (double)status nu dJ ; then linearize endpoint[K*14] deriv[K*294], predict_state x[14]
  */
 #include <stdio.h>
@@ -34,14 +34,15 @@
     } while (0)
 
 static int dump_iteration(scvx_ctx *ctx, scvx_batch *b, int K, FILE *fo) {
-    const size_t nrec = (size_t)(K + 1) * 17 + 1;
-    double *rec = malloc(nrec * 8), *e = malloc((size_t)K * 14 * 8), *d = malloc((size_t)K * 294 * 8);
+    const int NU = scvx_control_dim(ctx), DSZ = 14 * (14 + 2 * NU + 1);   /* 3 / 294, or 5 / 350 with SCVX_MODEL_FINS */
+    const size_t nrec = (size_t)(K + 1) * (14 + NU) + 1;
+    double *rec = malloc(nrec * 8), *e = malloc((size_t)K * 14 * 8), *d = malloc((size_t)K * DSZ * 8);
     double rk, cost;
     int32_t it;
     CHECK(ctx, scvx_batch_get_trajectory(b, rec));
     CHECK(ctx, scvx_batch_get_linearization(b, e, d));
     CHECK(ctx, scvx_batch_get_scalars(b, &rk, &cost, &it));
-    fwrite(rec, 8, nrec, fo); fwrite(e, 8, (size_t)K * 14, fo); fwrite(d, 8, (size_t)K * 294, fo);
+    fwrite(rec, 8, nrec, fo); fwrite(e, 8, (size_t)K * 14, fo); fwrite(d, 8, (size_t)K * DSZ, fo);
     double sc[3] = {rk, cost, (double)it};
     fwrite(sc, 8, 3, fo);
     free(rec); free(e); free(d);
@@ -89,16 +90,17 @@ int main(int argc, char **argv) {
 
     /* Dynamics.linearize_dynamics(pi.about, pi.sigma, 1/(K+1), cache) and predict_state on segment 4 */
     {
-        const size_t nrec = (size_t)(K + 1) * 17 + 1;
-        double *rec = malloc(nrec * 8), *e = malloc((size_t)K * 14 * 8), *d = malloc((size_t)K * 294 * 8);
+        const int NU = scvx_control_dim(ctx), DSZ = 14 * (14 + 2 * NU + 1);
+        const size_t nrec = (size_t)(K + 1) * (14 + NU) + 1;
+        double *rec = malloc(nrec * 8), *e = malloc((size_t)K * 14 * 8), *d = malloc((size_t)K * DSZ * 8);
         CHECK(ctx, scvx_batch_get_trajectory(b, rec));
-        const double *x = rec, *u = rec + (size_t)(K + 1) * 14;   /* 14 x (K+1) and 3 x (K+1), column-major */
+        const double *x = rec, *u = rec + (size_t)(K + 1) * 14;   /* 14 x (K+1) and NU x (K+1), column-major */
         double sigma = rec[nrec - 1], dt = 1.0 / (K + 1);
         CHECK(ctx, scvx_linearize_f64_host(ctx, 1, K, x, u, &sigma, dt, e, d));
-        fwrite(e, 8, (size_t)K * 14, fo); fwrite(d, 8, (size_t)K * 294, fo);
-        double xs[28], us[6], out[14];
+        fwrite(e, 8, (size_t)K * 14, fo); fwrite(d, 8, (size_t)K * DSZ, fo);
+        double xs[28], us[10], out[14];
         memcpy(xs, x + 14 * 3, 14 * 8); memset(xs + 14, 0, 14 * 8);   /* hcat(initial_state, zeros(14)) */
-        memcpy(us, u + 3 * 3, 6 * 8);                                  /* hcat(uk, up) */
+        memcpy(us, u + NU * 3, (size_t)2 * NU * 8);                    /* hcat(uk, up) */
         CHECK(ctx, scvx_propagate_f64_host(ctx, 1, 1, xs, us, &sigma, dt, out));
         fwrite(out, 8, 14, fo);
         free(rec); free(e); free(d);

@@ -48,15 +48,18 @@ def test_julia_shim_struct_matches_header():
 
 
 @pytest.mark.gpu
-def test_harness_replays_the_julia_call_sequence_bit_for_bit(tmp_path, aero_tables):
+@pytest.mark.parametrize("fins", [False, True])
+def test_harness_replays_the_julia_call_sequence_bit_for_bit(tmp_path, aero_tables, fins):
     from successiveconvexification_amd import _lib, sample_problems as sp
     from successiveconvexification_amd.batch import ScvxBatch
     from successiveconvexification_amd.defns import AtmosphericData
     from successiveconvexification_amd.dynamics import IntegratorCache
     exe = _compile(tmp_path)
     d, l, t = aero_tables
-    prob = sp.base_prob_aero_scaled(AtmosphericData(d, l, t))
+    prob = sp.base_prob_fin_scaled(AtmosphericData(d, l, t)) if fins else sp.base_prob_aero_scaled(AtmosphericData(d, l, t))
     K, nsub, nstep = prob.K, 10, 2
+    NU = prob.nu
+    DSZ = 14 * (14 + 2 * NU + 1)
     cache = IntegratorCache(prob, npts=nsub)
     cp = cache.cproblem()                       # the flat struct the Python layer hands to scvx_ctx_create
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
@@ -70,10 +73,10 @@ def test_harness_replays_the_julia_call_sequence_bit_for_bit(tmp_path, aero_tabl
     r = subprocess.run([exe, fin, fout], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     out = np.fromfile(fout)
-    nrec = (K + 1) * 17 + 1
-    per_iter = nrec + K * 14 + K * 294 + 3
+    nrec = (K + 1) * (14 + NU) + 1
+    per_iter = nrec + K * 14 + K * DSZ + 3
     n3 = (K + 1) * 15 + 1
-    assert out.size == per_iter * (nstep + 1) + 3 * nstep + K * 14 + K * 294 + 14 + n3 + 6
+    assert out.size == per_iter * (nstep + 1) + 3 * nstep + K * 14 + K * DSZ + 14 + n3 + 6
 
     b = ScvxBatch(cache, 1).init(None)
 
@@ -97,7 +100,7 @@ def test_harness_replays_the_julia_call_sequence_bit_for_bit(tmp_path, aero_tabl
     x, u, s = b.trajectory()
     e2, d2 = linearize_batch(cache, x, u, s, 1.0 / (K + 1))
     assert np.array_equal(out[pos:pos + K * 14], e2.ravel()); pos += K * 14
-    assert np.array_equal(out[pos:pos + K * 294], d2.ravel()); pos += K * 294
+    assert np.array_equal(out[pos:pos + K * DSZ], d2.ravel()); pos += K * DSZ
     xs = np.zeros((1, 2, 14)); xs[0, 0] = x[0, 3]
     xp = propagate_batch(cache, xs, u[:, 3:5], s, 1.0 / (K + 1))
     assert np.array_equal(out[pos:pos + 14], xp[0, 0]); pos += 14
@@ -112,3 +115,34 @@ def test_harness_replays_the_julia_call_sequence_bit_for_bit(tmp_path, aero_tabl
     assert np.array_equal(out[pos:pos + n3], rec, equal_nan=True); pos += n3
     assert np.array_equal(out[pos:pos + 6], np.concatenate([[float(st3[0])], info]), equal_nan=True)
     b.close(); cache.close()
+
+
+# the reference's own function lines for the hot path (dynamics.jl:141, 258, 315, 321; rocketland.jl:34, 226, 432): name -> argument list
+_REF_SIGNATURES = {
+    "make_dynamics_module": "info::ProbInfo",
+    "(::Type{IntegratorCache})": "prob::DescentProblem, info::ProbInfo, lin_mod",
+    "predict_state": "initial_state, uk, up, sigma, dt, pinfo, cache",
+    "linearize_dynamics": "states::Array{LinPoint,1}, tf_guess::Float64, base_dt::Float64, cache::IntegratorCache",
+    "create_initial": "problem::DescentProblem, linear_cache::IntegratorCache",
+    "solve_step": "iteration::ProblemIteration, linear_cache::IntegratorCache",
+    "solve_problem": "iprob::DescentProblem, cache::IntegratorCache",   # the reference types cache::LinearCache, undefined at HEAD
+}
+
+
+def test_julia_install_defines_the_references_own_signatures():
+    """ScvxAMD.install!() adds methods to Dynamics / Rocketland with the reference's exact argument lists,
+    so the recipe of rocketland.jl:26-32 runs unedited.  Parsed, not executed (no Julia in the image); the expected argument
+    lists are checked against /root/reference when it is present (this container), and held above otherwise."""
+    import re
+    jl = open(os.path.join(ROOT, "julia", "ScvxAMD.jl")).read()
+    body = jl[jl.index("function install!()"):]
+    found = dict(re.findall(r"^\s+function (\(::Type\{IntegratorCache\}\)|\w+)\(([^)]*)\)\s*$", body, flags=re.M))
+    assert found == _REF_SIGNATURES, found
+    assert "@eval HOST.Dynamics" in body and "@eval HOST.Rocketland" in body
+    ref = "/root/reference"
+    if os.path.isdir(ref):
+        src = {f: open(os.path.join(ref, f)).read() for f in ("dynamics.jl", "rocketland.jl")}
+        for name, args in _REF_SIGNATURES.items():
+            fn = "dynamics.jl" if name in ("make_dynamics_module", "(::Type{IntegratorCache})", "predict_state", "linearize_dynamics") else "rocketland.jl"
+            want = args if name != "solve_problem" else args.replace("cache::IntegratorCache", "cache::LinearCache")
+            assert ("function " + name + "(" + want + ")") in src[fn], (name, fn)

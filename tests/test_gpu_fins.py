@@ -114,7 +114,12 @@ def test_fin_socp_matches_independent_oracle_on_every_executor(with_aero, K, aer
             assert st[0] == 0 and merit[0] < 1e-8
             assert np.abs(xs[0] - xo).max() < 2e-5 and np.abs(us[0] - uo).max() < 2e-5, (waves, np.abs(xs[0] - xo).max(), np.abs(us[0] - uo).max())
             assert abs(ss[0] - (it0.sigma + sol.x[ix.dsig])) < 2e-5
-            assert abs(pobj[0] - sol.pobj) < 1e-8 * max(1.0, abs(sol.pobj))
+            xb, ub = it0.x, it0.u
+            obj = (-xs[0, -1, 0] + po.wNu * np.linalg.norm(nu[0]) + 0.5 * np.linalg.norm(np.concatenate([(xs[0] - xb).ravel(), (us[0] - ub).ravel()]))
+                   + abs(ss[0] - it0.sigma))
+            # objective parity is much tighter than solution parity; 1e-7 relative (5e-8 seen): wNu = 1e4 multiplies |nu|, which
+            # carries the equality residual of a solve that stops at 1e-8
+            assert abs(obj - sol.pobj) < 1e-7 * abs(sol.pobj)
             assert np.linalg.norm(us[0][:, 3:], axis=1).max() > 0.5 * po.finmxf      # the fins are used
             b.close()
     finally:

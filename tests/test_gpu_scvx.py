@@ -218,7 +218,7 @@ def _check_socp_properties(po, ic, b, rk, tol=1e-6, rows=True):
     assert np.abs(x[:, 0, 0] - po.mwet).max() < 1e-12
     assert np.abs(x[:, 0, 1:4] - ic[:, :3]).max() < 1e-12 and np.abs(x[:, 0, 4:7] - ic[:, 3:]).max() < 1e-12
     assert np.abs(x[:, K, 1:4] - po.rIf).max() < 1e-12 and np.abs(x[:, K, 7:11] - po.qBIf).max() < 1e-12
-    assert np.abs(u[:, K, 1:]).max() < 1e-12
+    assert np.abs(u[:, K, 1:3]).max() < 1e-12          # u[2:3, K+1] = 0 (rocketland.jl:115); fin controls, if any, are free
     # dynamics rows (:117-133)
     dx, du = x - xb, u - ub
     if rows:   # needs the whole linearisation on the host: 118 KB per trajectory at K = 50
@@ -231,10 +231,10 @@ def _check_socp_properties(po, ic, b, rk, tol=1e-6, rows=True):
     assert (x[:, :K, 1] / np.tan(np.radians(po.gammaGs)) - np.linalg.norm(x[:, :K, 2:4], axis=-1)).min() > -tol
     assert (np.sqrt((1 - np.cos(np.radians(po.thetaMax))) / 2) - np.linalg.norm(x[:, :K, 9:11], axis=-1)).min() > -tol
     assert (po.omMax - np.linalg.norm(x[:, :K, 11:14], axis=-1)).min() > -tol
-    un = np.linalg.norm(u, axis=-1)
+    un = np.linalg.norm(u[..., :3], axis=-1)
     assert (po.Tmax - un).min() > -tol and (u[..., 0] / np.cos(np.radians(po.deltaMax)) - un).min() > -tol
-    ubn = np.linalg.norm(ub, axis=-1)
-    assert (np.sum(ub / ubn[..., None] * du, axis=-1) - (po.Tmin - ubn)).min() > -tol
+    ubn = np.linalg.norm(ub[..., :3], axis=-1)
+    assert (np.sum(ub[..., :3] / ubn[..., None] * du[..., :3], axis=-1) - (po.Tmin - ubn)).min() > -tol
     assert (np.sqrt(np.sum(dx**2, axis=(1, 2)) + np.sum(du**2, axis=(1, 2))) - rk).max() < tol
     return x, u, snew, nu, its, merit
 

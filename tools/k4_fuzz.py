@@ -1,6 +1,8 @@
 """The 6-DoF conic solve (K4's solver core, on the CPU twin) on RANDOM problem classes: constraint parameters, mass ratio,
 horizon, dispersion and model flags drawn at random around the sample problem; several solve_steps each.
-    python tools/k4_fuzz.py [--n 30] [--B 16] [--steps 8] [--seed 1]"""
+    python tools/k4_fuzz.py [--n 30] [--B 16] [--steps 8] [--seed 1] [--fins] [--lib path/to/liboracle_port.so]
+"attempted" = conic solves of trajectories that had not failed before (a failed trajectory is frozen: the reference stops with
+an error there, rocketland.jl:273-276); "failed" = the first non-optimal solve of a trajectory."""
 import argparse
 import os
 import sys
@@ -19,12 +21,19 @@ def main():
     ap.add_argument("--B", type=int, default=16)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--fins", action="store_true", help="every class with the fin extension (control_dim = 5)")
+    ap.add_argument("--lib", default=None, help="a variant build of liboracle_port.so")
     a = ap.parse_args()
+    import oracle
+    if a.lib:
+        import ctypes
+        oracle._PORT = ctypes.CDLL(a.lib)
     from oracle import model, port
     rng = np.random.default_rng(a.seed)
     base = model.base_prob_scaled()
     tot = {}
     worst = 0.0
+    attempted = failed = 0
     print("| # | K | mdry | Tmin/Tmax | deltaMax | thetaMax | gammaGs | omMax | tf_guess | dp | status counts (solver) | IPM its mean / max | merit max |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for n in range(a.n):
@@ -32,6 +41,8 @@ def main():
         p = replace(base, K=K, mdry=float(base.mwet * rng.uniform(0.4, 0.999)), Tmin=float(base.Tmax * rng.uniform(0.05, 0.6)),
                     deltaMax=float(rng.uniform(5.0, 30.0)), thetaMax=float(rng.uniform(30.0, 120.0)), gammaGs=float(rng.uniform(5.0, 45.0)),
                     omMax=float(rng.uniform(20.0, 120.0)), tf_guess=float(rng.uniform(0.5, 12.0)), enforce_dp=bool(rng.integers(0, 2)))
+        if a.fins:
+            p = replace(p, fins=True, rFB=model.base_prob().rFB / 1000.0, finmxf=float(rng.uniform(0.002, 0.02)))
         ic = model.disperse_ics(p, a.B, 500 + n, 0.3)
         try:
             o = port.scvx_steps(p, ic, a.steps, nsub=4, warm_start=True)
@@ -39,6 +50,12 @@ def main():
             print("| %d | %d | error: %s |" % (n, K, e))
             continue
         st = np.concatenate(o["status"]); it = np.concatenate(o["iters"]); m = np.concatenate(o["merit"])
+        S = np.stack(o["status"])                                    # [steps][B]
+        bad = (S != 0)
+        alive = np.vstack([np.ones((1, S.shape[1]), bool), ~np.maximum.accumulate(bad, axis=0)[:-1]])   # not failed before this step
+        feas = S[0] != 5                                             # status 5 = infeasible initial condition: not a solver failure
+        attempted += int((alive & feas[None, :]).sum())
+        failed += int((alive & bad & feas[None, :]).sum())
         for k, v in zip(*np.unique(st, return_counts=True)):
             tot[int(k)] = tot.get(int(k), 0) + int(v)
         okm = m[(st == 0) | (st == 4)]
@@ -47,6 +64,8 @@ def main():
             n, K, p.mdry, p.Tmin / p.Tmax, p.deltaMax, p.thetaMax, p.gammaGs, p.omMax, p.tf_guess, int(p.enforce_dp),
             {int(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))}, it.mean(), it.max(), m.max()), flush=True)
     print("\nsolver status totals:", tot, " worst merit among optimal / almost optimal: %.2e" % worst)
+    print("attempted solves on live trajectories: %d, first failures: %d (%.3f %%), optimal: %.3f %%" % (
+        attempted, failed, 100.0 * failed / max(attempted, 1), 100.0 * (1 - failed / max(attempted, 1))))
 
 
 if __name__ == "__main__":
