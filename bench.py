@@ -176,6 +176,7 @@ def traj_linf_vs_oracle(cache_cls, batch_cls, prob, npts):
 
 
 def k1_by_npts(cache, batch, torch, K, B, default_npts, sweep=(1, 2, 4, 10), with_f32=True):
+    nu, npc = cache.nu, cache.np   # control_dim and columns of a derivative tile (3 / 21; 5 / 25 with the fin extension)
     """K1 alone on the batch's current trajectories for rk4 npts in (1, 2, 4, 10): the HBM fraction of the discretisation
     kernel depends on how much FP64 work a segment carries (SURVEY.md 8d), so the bench states it per npts.  Device
     pointers through the C ABI (scvx_linearize_f64), HIP events on the stream the kernel runs on; outside the timed region."""
@@ -183,7 +184,7 @@ def k1_by_npts(cache, batch, torch, K, B, default_npts, sweep=(1, 2, 4, 10), wit
     x, u, s = batch.trajectory()
     xd, ud, sd = (torch.tensor(np.ascontiguousarray(a), device="cuda") for a in (x, u, s))
     e = torch.empty((B, K, 14), dtype=torch.float64, device="cuda")
-    d = torch.empty((B, K, 21, 14), dtype=torch.float64, device="cuda")
+    d = torch.empty((B, K, npc, 14), dtype=torch.float64, device="cuda")
     L, out = cache._L, {}
     ts = torch.cuda.Stream()            # torch's events only see kernels on a torch stream: run K1 on one for this leg
     cache.set_stream(ts.cuda_stream)
@@ -204,12 +205,12 @@ def k1_by_npts(cache, batch, torch, K, B, default_npts, sweep=(1, 2, 4, 10), wit
         t1.record(ts)
         torch.cuda.synchronize()
         ms = t0.elapsed_time(t1) / 5
-        out[str(npts)] = {"ms": ms, "achieved_GBps": k1_alg_bytes(K) * B / (ms * 1e-3) / 1e9,
-                          "frac": k1_alg_bytes(K) * B / (ms * 1e-3) / HBM_PEAK}
+        out[str(npts)] = {"ms": ms, "achieved_GBps": k1_alg_bytes(K, nu) * B / (ms * 1e-3) / 1e9,
+                          "frac": k1_alg_bytes(K, nu) * B / (ms * 1e-3) / HBM_PEAK}
     # fp32 entry point (scvx_linearize_f32: column-per-lane kernel in float arithmetic, float arrays): SURVEY 8d's fp32 row
     xf, uf, sf = xd.float(), ud.float(), sd.float()
     ef = torch.empty((B, K, 14), dtype=torch.float32, device="cuda")
-    df = torch.empty((B, K, 21, 14), dtype=torch.float32, device="cuda")
+    df = torch.empty((B, K, npc, 14), dtype=torch.float32, device="cuda")
     out32 = {}
     for npts in (sweep if with_f32 else ()):
         cache.set_npts(npts)
@@ -227,8 +228,8 @@ def k1_by_npts(cache, batch, torch, K, B, default_npts, sweep=(1, 2, 4, 10), wit
         t1.record(ts)
         torch.cuda.synchronize()
         ms = t0.elapsed_time(t1) / 5
-        out32[str(npts)] = {"ms": ms, "achieved_GBps": k1_alg_bytes(K, s=4) * B / (ms * 1e-3) / 1e9,
-                            "frac": k1_alg_bytes(K, s=4) * B / (ms * 1e-3) / HBM_PEAK}
+        out32[str(npts)] = {"ms": ms, "achieved_GBps": k1_alg_bytes(K, nu, s=4) * B / (ms * 1e-3) / 1e9,
+                            "frac": k1_alg_bytes(K, nu, s=4) * B / (ms * 1e-3) / HBM_PEAK}
     cache.set_npts(default_npts)
     cache.set_stream(None)   # back to the context's own stream
     return out, out32
@@ -244,16 +245,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=14)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8192, help="trajectories per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (weak scaling); default 8192 (32768 with --config5)")
     ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: total trajectories, split over the ranks")
     ap.add_argument("--npts", type=int, default=10, help="RK4 substeps per segment (Dynamics.rk4 npts)")
     ap.add_argument("--seed", type=int, default=20261004)
     ap.add_argument("--aero", action="store_true", help="SampleProblems.base_prob_aero_scaled (lift_drag tables): BASELINE configs[2] model; NOT the headline workload")
+    ap.add_argument("--config5", action="store_true", help="BASELINE configs[4] as named: 6-DoF + aero tables + the fin extension "
+                    "(control_dim = 5, a BUILD-DEFINED model: the reference only sketches it in comments), K = 100, seed 20261005; NOT the headline workload")
     ap.add_argument("--no-reset", action="store_true", help="do not return to create_initial every imax-1 steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traj-check", action="store_true", help="skip the B=1 full-solve parity figure (profiling runs)")
     ap.add_argument("--no-k1-sweep", action="store_true", help="skip the K1-by-npts leg (profiling runs)")
     args = ap.parse_args()
+    if not args.batch:
+        args.batch = 32768 if args.config5 else 8192
+    if args.config5 and args.seed == 20261004:
+        args.seed = 20261005          # config 5's dispersion seed
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -280,7 +287,13 @@ def main():
     from successiveconvexification_amd.batch import ScvxBatch
     from successiveconvexification_amd.dynamics import IntegratorCache
 
-    if args.aero:
+    if args.config5:
+        from dataclasses import replace
+        from successiveconvexification_amd.defns import AtmosphericData
+        z = np.load(os.path.join(ROOT, "tests", "golden", "lift_drag_tables.npz"))   # the reference's aero/lift_drag.csv, repacked
+        p = replace(sp.base_prob_fin_scaled(AtmosphericData(z["drag"], z["lift"], z["torque"])), K=100)
+        args.aero = True    # not the headline: the legs that belong to the headline workload are skipped
+    elif args.aero:
         from successiveconvexification_amd.defns import AtmosphericData
         z = np.load(os.path.join(ROOT, "tests", "golden", "lift_drag_tables.npz"))   # the reference's aero/lift_drag.csv, repacked
         p = sp.base_prob_aero_scaled(AtmosphericData(z["drag"], z["lift"], z["torque"]))
@@ -375,13 +388,15 @@ def main():
         k1_full, _ = k1_by_npts(cache, batch, torch, K, B, args.npts, sweep=(args.npts,), with_f32=False)
         k1_ms = k1_full[str(args.npts)]["ms"]
         k4_ms = prof["socp"] / max(nprof, 1)
-        alg = k1_alg_bytes(K) * B
+        alg = k1_alg_bytes(K, p.nu) * B
         achieved = alg / (k1_ms * 1e-3) if k1_ms > 0 else 0.0
         traffic = k1_measured_traffic(B)
         k4t = k4_measured_traffic(B)
         k1_flops = K1_FLOP_PER_SEG_SUBSTEP * K * args.npts * B
+        # K4's algorithmic bytes per trajectory: the linearisation + the iterate in, the solution out = 137 KB at K = 50, NU = 3
+        socp_alg = SOCP_ALG_BYTES if (K == 50 and p.nu == 3) else k1_alg_bytes(K, p.nu) + 8 * ((K + 1) * (14 + p.nu) + 1 + 14 * K)
         line = {
-            "metric": "6-DoF K=50 SCvx iterations/sec (batch)",
+            "metric": "6-DoF K=50 SCvx iterations/sec (batch)" if not args.config5 else "6-DoF + fin aero K=100 SCvx iterations/sec (batch) -- BASELINE configs[4], NOT the headline metric",
             "value": done_all / elapsed,
             "unit": "traj-iter/s",
             "n_gpus": world,
@@ -394,10 +409,15 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "6-DoF K=50 SCvx, Monte-Carlo dispersed ICs (BASELINE configs[3] shape, SURVEY 8d law, seed %d), "
-                            "SampleProblems.%s, fp64; solve_problem mix: create_initial again every "
-                            "%d steps%s" % (args.seed, "base_prob_aero normalised (lift_drag tables)" if args.aero else "base_prob normalised (exo)",
-                                            period, " (disabled)" if args.no_reset else ""),
+                "workload": ("6-DoF K=%d SCvx, Monte-Carlo dispersed ICs (BASELINE configs[%d] shape, SURVEY 8d law, seed %d), "
+                             "SampleProblems.%s, fp64; solve_problem mix: create_initial again every "
+                             "%d steps%s" % (K, 4 if args.config5 else 3, args.seed,
+                                             "base_prob_aero normalised + FIN EXTENSION (control_dim = 5): a BUILD-DEFINED model -- the reference carries "
+                                             "the fin force only as commented-out code (dynamics.jl:60-69, rocketland.jl:203-209; SURVEY N2), include/scvx.h "
+                                             "states what was enabled; parity is against this build's own oracle of the same stated model" if args.config5
+                                             else ("base_prob_aero normalised (lift_drag tables)" if args.aero else "base_prob normalised (exo)"),
+                                             period, " (disabled)" if args.no_reset else "")),
+                "control_dim": p.nu,
                 "K": K, "batch_per_gpu": B, "global_batch": shard.global_batch, "rk4_npts": args.npts,
                 "solver": "interior-point (NT scaling): optimal = merit < 1e-8, anything else freezes the trajectory as the "
                           "reference's error() does (accept_tol = tol, the default); the solve that "
@@ -436,9 +456,9 @@ def main():
             "roofline_socp": None if k4_ms <= 0 else {
                 "kernel": "scvx::socp_kernel (K4, the conic solve: 97 % of the step)", "bound": "hbm", "unit": "GB/s",
                 "peak": HBM_PEAK / 1e9, "avg_launch_ms": k4_ms,
-                "alg_bytes_per_launch": SOCP_ALG_BYTES * B,
-                "achieved": SOCP_ALG_BYTES * B / (k4_ms * 1e-3) / 1e9,
-                "frac": SOCP_ALG_BYTES * B / (k4_ms * 1e-3) / HBM_PEAK,
+                "alg_bytes_per_launch": socp_alg * B,
+                "achieved": socp_alg * B / (k4_ms * 1e-3) / 1e9,
+                "frac": socp_alg * B / (k4_ms * 1e-3) / HBM_PEAK,
                 "traffic": k4t["hi"] if k4t else None,
                 "traffic_lo": k4t["lo"] if k4t else None, "traffic_hi": k4t["hi"] if k4t else None,
                 "traffic_source": k4t["source"] if k4t else None,

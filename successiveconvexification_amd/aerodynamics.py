@@ -47,6 +47,17 @@ def load_fin_table(finforce: str):
     return mach, aoa, data["lift"][order].reshape(shape), data["drag"][order].reshape(shape)
 
 
+def fin_force_bound(fin_table, mach: float, force_scalar: float = 1.0) -> float:
+    """Largest fin force the table offers at `mach`, max over the deflection axis of |lift| (linear in Mach between the table's
+    rows, flat outside), times the AtmosphericData force scalar: a data-derived value for DescentProblem.finmxf, the bound of
+    the fin cone |u[4:5]| <= finmxf.  (The reference's commented code pins finmxf to the constant 0.01, rocketland.jl:205,
+    and never uses fin.csv; this is the one place this build gives the file a meaning, and it is opt-in:
+    sample_problems.base_prob_fin_scaled(aero, fin_table=...).)"""
+    mach_ax, _, lift, _ = fin_table
+    peak = np.abs(lift).max(axis=1)
+    return float(np.interp(mach, mach_ax, peak)) * float(force_scalar)
+
+
 def rescale_aerodata(data, Ul: float, Ut: float, Um: float):
     if isinstance(data, ExoatmosphericData):
         return data

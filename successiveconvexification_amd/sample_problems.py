@@ -53,13 +53,19 @@ def base_prob_aero_scaled(aero_info) -> DescentProblem:
     return normalize_problem(base_prob_aero(aero_info))
 
 
-def base_prob_fin_scaled(aero_info=None) -> DescentProblem:
+def base_prob_fin_scaled(aero_info=None, fin_table=None) -> DescentProblem:
     """BASELINE configs[4] "6-DoF + fin aero": the sample problem with the fin extension (control_dim = 5).  The model is
     DEFINED BY THIS BUILD from the reference's commented-out fin code (include/scvx.h).  One deliberate
     departure from normalize_problem: it scales rFB by 1/Ut (sample_problems.jl:16, harmless there because rFB is unused),
     which would put the fins 2 normalised length units = 2 km from the centre of mass; the fin torque arm is a length, so it
-    is scaled by 1/Ul here like rTB."""
-    from .defns import ExoatmosphericData
+    is scaled by 1/Ul here like rTB.  fin_table (aerodynamics.load_fin_table of aero/fin.csv), if given, replaces the constant
+    finmxf = 0.01 of rocketland.jl:205 by the table's largest fin force at the initial Mach number (aerodynamics.fin_force_bound)."""
+    from .aerodynamics import fin_force_bound
+    from .defns import AtmosphericData, ExoatmosphericData
     b = _base(aero_info if aero_info is not None else ExoatmosphericData())
     p = normalize_problem(replace(b, model_flags=b.model_flags | 2))
-    return replace(p, rFB=b.rFB * (1.0 / float(np.max(b.rIi))))
+    p = replace(p, rFB=b.rFB * (1.0 / float(np.max(b.rIi))))
+    if fin_table is not None:
+        fs = p.aero.force_scalar if isinstance(p.aero, AtmosphericData) else 1.0 / (float(np.max(b.rIi)) * b.mwet / b.tf_guess**2)
+        p = replace(p, finmxf=fin_force_bound(fin_table, float(np.linalg.norm(p.vIi)) / p.sos, fs))
+    return p

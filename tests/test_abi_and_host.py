@@ -194,6 +194,14 @@ def test_aero_csv_loader_and_fin_table(tmp_path, aero_tables):
     m2, a2, lift, drag = ae.load_fin_table(str(fin))
     assert np.allclose(m2, fm) and np.allclose(a2, fa) and lift.shape == (3, 4)
     assert np.allclose(lift, fm[:, None] * fa[None, :]) and np.allclose(drag, -fm[:, None] * fa[None, :] ** 2)
+    # the fin table's one use: a data-derived bound for the fin cone (opt-in; the reference's commented code has the constant 0.01)
+    assert np.isclose(ae.fin_force_bound((m2, a2, lift, drag), 0.035, 2.0), 2.0 * 0.035 * 0.3)
+    assert np.isclose(ae.fin_force_bound((m2, a2, lift, drag), 0.0475, 1.0), 0.0475 * 0.3)      # linear in Mach between rows
+    assert np.isclose(ae.fin_force_bound((m2, a2, lift, drag), 9.0, 1.0), 0.06 * 0.3)           # flat outside
+    from successiveconvexification_amd import sample_problems as sp
+    pf = sp.base_prob_fin_scaled(a, fin_table=(m2, a2, lift, drag))
+    assert pf.nu == 5 and pf.model_flags & 2 and 0 < pf.finmxf < 1e-6 and sp.base_prob_fin_scaled().finmxf == 0.01
+    assert np.allclose(pf.rFB, [0.002, 0, 0])
     bad = tmp_path / "bad.csv"
     np.savetxt(bad, np.array(rows[:-1]), delimiter=",", header="lift,drag,mach,aoa", comments="")
     with pytest.raises(ValueError):
