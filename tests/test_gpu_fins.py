@@ -199,6 +199,7 @@ def test_fin_f32_linearisation_and_full_solve(aero_tables):
         b32.close()
         if B == 24:
             st, it, nu, dj = b64.solve()
-            assert np.all((st == 0) | (st == 1) | (st == 2)) and np.all(it == pp.imax - 1)
+            # no conic solve fails (the reference would stop with an error there); imax - 1 more steps after the one above
+            assert np.all((st == 0) | (st == 1) | (st == 2)) and np.all(it == pp.imax)
         b64.close()
     c.close()
