@@ -219,8 +219,7 @@ __device__ double g_k1prof[2 * 16];
 template <bool AERO, bool FIN, typename R>
 __device__ __forceinline__ void column_deriv_rec_any(const DynP<R>& p, const R* rec, int stride, const R* c, const R* wc, R gsel,
                                                      R sigma, R* dc) {
-    if constexpr (FIN) column_deriv_rec_fin<AERO, R>(p, rec, stride, c, wc, gsel, sigma, dc);
-    else column_deriv_rec<AERO, R>(p, rec, stride, c, wc, gsel, sigma, dc);
+    column_deriv_rec_pieces<AERO, FIN, R>(p, rec, stride, c, wc, gsel, sigma, dc);
 }
 constexpr int PC_GROUP = 4;              // stages published per barrier (one RK4 substep)
 // SG (stage-granular, the default): one barrier per RK stage and the producer one STAGE ahead (2-slot ring) instead of
@@ -278,9 +277,8 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
                     R uu[NU];
 #pragma unroll
                     for (int j = 0; j < NU; j++) uu[j] = fma(ukv[j], lkm, upv[j] * lkp);
-                    Stage<AERO, R, FIN> st;
-                    stage_eval<AERO, FIN>(p, xt, uu, st);
-                    if (live) stage_publish<AERO, FIN>(p, st, xt, uu, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + l, NS);
+                    struct { R g[14]; } st;
+                    stage_eval_publish<AERO, FIN>(p, xt, uu, st.g, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + l, NS, live);
                     const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
                     const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
 #pragma unroll
@@ -464,9 +462,8 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
                         R uu[NU];
 #pragma unroll
                         for (int j = 0; j < NU; j++) uu[j] = fma(ukv[j], lkm, upv[j] * lkp);
-                        Stage<AERO, R, FIN> st;
-                        stage_eval<AERO, FIN>(p, xt, uu, st);
-                        if (live) stage_publish<AERO, FIN>(p, st, xt, uu, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + l, NS);
+                        struct { R g[14]; } st;
+                        stage_eval_publish<AERO, FIN>(p, xt, uu, st.g, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + l, NS, live);
                         const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
                         const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
 #pragma unroll

@@ -13,6 +13,7 @@
 // applies the ~48 structural non-zeros of df/dx directly to the sensitivity column it owns.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace scvx {
 
@@ -472,67 +473,298 @@ __device__ __forceinline__ void column_deriv(const DynP<R>& p, const Stage<AERO,
 //   | (fins) fd1[3] fd2[3] Wq[12] Wv[9] Gf1[3] Gf2[3]
 template <bool AERO, bool FIN = false> struct StageRec { static constexpr int N = FIN ? 100 : (AERO ? 67 : 58); };
 
-template <bool AERO, bool FIN = false, typename R>
-__device__ __forceinline__ void stage_publish(const DynP<R>& p, const Stage<AERO, R, FIN>& s, const R* x, const R* u,
-                                              R* rec, int stride) {
-    int o = 0;
+// ---- column-wise force derivatives for the producer ----
+// The producer needs d F / d (q0..q3, v1..v3) only to fold it, column by column, into the record's Dq / Dv (and Wq / Wv) entries.
+// aero_force<true> and fin_dirs<true> return the whole 3x7 arrays (plus 3x7 temporaries): ~90 values live at once.  Here the
+// column-independent part is prepared once (AeroPrep / FinPrep) and column j is produced, used and dropped.
+template <typename R>
+struct AeroPrep {
+    bool on, clamped, has_lift;
+    R F[3], bv[3], l[3];
+    R ivn, vn2, c, iln, drag, lift, fs_td1, fs_td2, fs_tl1, fs_tl2, isos;
+};
+template <typename R>
+__device__ __forceinline__ void aero_prep(const DynP<R>& p, const R* v, const R* C, AeroPrep<R>& A) {
+    A.F[0] = A.F[1] = A.F[2] = R(0.0);
+    A.bv[0] = C[0]; A.bv[1] = C[3]; A.bv[2] = C[6];
+    A.vn2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const R vn = sqrt(A.vn2);
+    A.on = vn > R(0.0);
+    A.clamped = false; A.has_lift = false;
+    A.ivn = A.on ? R(1.0) / vn : R(0.0);
+    A.c = A.bv[0] * v[0] + A.bv[1] * v[1] + A.bv[2] * v[2];
+    A.isos = R(1.0) / p.sos;
+    A.iln = R(0.0); A.drag = A.lift = R(0.0);
+    A.fs_td1 = A.fs_td2 = A.fs_tl1 = A.fs_tl2 = R(0.0);
+    A.l[0] = A.l[1] = A.l[2] = R(0.0);
+    if (!A.on) return;
+    const R mach = vn * A.isos;
+    R arg = A.c / (mach * p.sos);
+    if (arg < -R(1.0)) { arg = -R(1.0); A.clamped = true; }
+    if (arg > R(1.0)) { arg = R(1.0); A.clamped = true; }
+    R td[3], tl[3];
+    aero_tables(p, arg, mach, td, tl);
+    const R fs = p.force_scalar;
+    A.drag = td[0] * fs; A.lift = tl[0] * fs;
+    A.fs_td1 = fs * td[1]; A.fs_td2 = fs * td[2]; A.fs_tl1 = fs * tl[1]; A.fs_tl2 = fs * tl[2];
+    R ld[3];
 #pragma unroll
-    for (int i = 0; i < 14; i++) rec[(o++) * stride] = s.g[i];
+    for (int i = 0; i < 3; i++) ld[i] = A.c * v[i] - A.vn2 * A.bv[i];
+    const R ln = sqrt(ld[0] * ld[0] + ld[1] * ld[1] + ld[2] * ld[2]);
+    A.has_lift = ln > R(0.0);
+    A.iln = A.has_lift ? R(1.0) / ln : R(0.0);
 #pragma unroll
-    for (int i = 0; i < 9; i++) rec[(o++) * stride] = s.C[i];
-    rec[(o++) * stride] = s.invm;
+    for (int i = 0; i < 3; i++) {
+        A.l[i] = ld[i] * A.iln;
+        A.F[i] = A.drag * v[i] * A.ivn + (A.has_lift ? A.lift * A.l[i] : R(0.0));
+    }
+}
+// column j (0..3: q0..q3, 4..6: v1..v3) of d F_aero / d (q, v): the arithmetic of aero_force<true>, one column at a time
+template <int J, typename R>
+__device__ __forceinline__ void aero_col(const R* q, const R* v, const AeroPrep<R>& A, R d[3]) {
+    d[0] = d[1] = d[2] = R(0.0);
+    if (!A.on) return;
+    R dbv[3] = {R(0.0), R(0.0), R(0.0)};
+    if (J == 0) { dbv[1] = R(2.0) * q[3]; dbv[2] = -R(2.0) * q[2]; }
+    if (J == 1) { dbv[1] = R(2.0) * q[2]; dbv[2] = R(2.0) * q[3]; }
+    if (J == 2) { dbv[0] = -R(4.0) * q[2]; dbv[1] = R(2.0) * q[1]; dbv[2] = -R(2.0) * q[0]; }
+    if (J == 3) { dbv[0] = -R(4.0) * q[3]; dbv[1] = R(2.0) * q[0]; dbv[2] = R(2.0) * q[1]; }
+    const R ivn = A.ivn;
+    R dc = R(0.0), darg, dmach;
+    if (J < 4) {
+        dc = dbv[0] * v[0] + dbv[1] * v[1] + dbv[2] * v[2];
+        darg = A.clamped ? R(0.0) : dc * ivn;
+        dmach = R(0.0);
+    } else {
+        darg = A.clamped ? R(0.0) : (A.bv[J - 4] * ivn - A.c * v[J - 4] * ivn * ivn * ivn);
+        dmach = v[J - 4] * ivn * A.isos;
+    }
+    const R ddrag = A.fs_td1 * darg + A.fs_td2 * dmach;
+    const R dlift = A.fs_tl1 * darg + A.fs_tl2 * dmach;
 #pragma unroll
-    for (int i = 0; i < 3; i++) rec[(o++) * stride] = s.am[i];
+    for (int i = 0; i < 3; i++) {
+        d[i] = ddrag * v[i] * ivn;
+        if (J >= 4) d[i] += A.drag * ((i == J - 4 ? ivn : R(0.0)) - v[i] * v[J - 4] * ivn * ivn * ivn);
+    }
+    if (A.has_lift) {
+        R dld[3];
 #pragma unroll
-    for (int i = 0; i < 12; i++) rec[(o++) * stride] = s.Dq[i];
+        for (int i = 0; i < 3; i++) {
+            if (J < 4) dld[i] = v[i] * dc - A.vn2 * dbv[i];
+            else dld[i] = (i == J - 4 ? A.c : R(0.0)) + v[i] * A.bv[J - 4] - R(2.0) * A.bv[i] * v[J - 4];
+        }
+        const R proj = A.l[0] * dld[0] + A.l[1] * dld[1] + A.l[2] * dld[2];
 #pragma unroll
-    for (int i = 0; i < 9; i++) rec[(o++) * stride] = s.Mw[i];
+        for (int i = 0; i < 3; i++) d[i] += dlift * A.l[i] + A.lift * (dld[i] - A.l[i] * proj) * A.iln;
+    }
+}
+template <typename R>
+struct FinPrep {
+    bool ok;
+    R fd1[3], fd2[3], b2[3], inn;
+};
+template <typename R>
+__device__ __forceinline__ void fin_prep(const R* v, const R* C, FinPrep<R>& Fp) {
+    Fp.b2[0] = C[1]; Fp.b2[1] = C[4]; Fp.b2[2] = C[7];
+    const R n[3] = {Fp.b2[1] * v[2] - Fp.b2[2] * v[1], Fp.b2[2] * v[0] - Fp.b2[0] * v[2], Fp.b2[0] * v[1] - Fp.b2[1] * v[0]};
+    const R nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    Fp.ok = nn > R(0.0);
+    Fp.inn = Fp.ok ? R(1.0) / nn : R(0.0);
 #pragma unroll
-    for (int i = 0; i < 4; i++) rec[(o++) * stride] = x[7 + i];
+    for (int i = 0; i < 3; i++) Fp.fd1[i] = n[i] * Fp.inn;
+    Fp.fd2[0] = Fp.fd1[1] * v[2] - Fp.fd1[2] * v[1];
+    Fp.fd2[1] = Fp.fd1[2] * v[0] - Fp.fd1[0] * v[2];
+    Fp.fd2[2] = Fp.fd1[0] * v[1] - Fp.fd1[1] * v[0];
+}
+// column j of d ff / d (q, v), ff = u4 fd1 + u5 fd2: the arithmetic of fin_dirs<true>, one column at a time
+template <int J, typename R>
+__device__ __forceinline__ void fin_col(const R* q, const R* v, const FinPrep<R>& Fp, R u4, R u5, R d[3]) {
+    R dn[3];
+    if (J < 4) {
+        R c0, c1, c2;
+        if (J == 0) { c0 = -R(2.0) * q[3]; c1 = R(0.0); c2 = R(2.0) * q[1]; }
+        if (J == 1) { c0 = R(2.0) * q[2]; c1 = -R(4.0) * q[1]; c2 = R(2.0) * q[0]; }
+        if (J == 2) { c0 = R(2.0) * q[1]; c1 = R(0.0); c2 = R(2.0) * q[3]; }
+        if (J == 3) { c0 = -R(2.0) * q[0]; c1 = -R(4.0) * q[3]; c2 = R(2.0) * q[2]; }
+        dn[0] = c1 * v[2] - c2 * v[1];
+        dn[1] = c2 * v[0] - c0 * v[2];
+        dn[2] = c0 * v[1] - c1 * v[0];
+    } else {   // b2 x e_j
+        if (J == 4) { dn[0] = R(0.0); dn[1] = Fp.b2[2]; dn[2] = -Fp.b2[1]; }
+        if (J == 5) { dn[0] = -Fp.b2[2]; dn[1] = R(0.0); dn[2] = Fp.b2[0]; }
+        if (J == 6) { dn[0] = Fp.b2[1]; dn[1] = -Fp.b2[0]; dn[2] = R(0.0); }
+    }
+    const R proj = Fp.fd1[0] * dn[0] + Fp.fd1[1] * dn[1] + Fp.fd1[2] * dn[2];
+    R d1[3], d2[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) rec[(o++) * stride] = x[11 + i];
-    const R un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-    const R k = un > R(0.0) ? -p.alpha / un : R(0.0);
+    for (int i = 0; i < 3; i++) d1[i] = Fp.ok ? (dn[i] - Fp.fd1[i] * proj) * Fp.inn : R(0.0);
+    d2[0] = d1[1] * v[2] - d1[2] * v[1];
+    d2[1] = d1[2] * v[0] - d1[0] * v[2];
+    d2[2] = d1[0] * v[1] - d1[1] * v[0];
+    if (J == 4) { d2[1] += Fp.fd1[2]; d2[2] -= Fp.fd1[1]; }     // + fd1 x e_j
+    if (J == 5) { d2[0] -= Fp.fd1[2]; d2[2] += Fp.fd1[0]; }
+    if (J == 6) { d2[0] += Fp.fd1[1]; d2[1] -= Fp.fd1[0]; }
 #pragma unroll
-    for (int i = 0; i < 3; i++) rec[(o++) * stride] = k * u[i];
-    if (AERO || FIN) {
+    for (int i = 0; i < 3; i++) d[i] = u4 * d1[i] + u5 * d2[i];
+}
+
+// ---- producer: evaluate one RK stage and PUBLISH each group of the record as soon as it exists ----
+// (stage_eval + stage_publish keep the whole Stage -- 48 to 90 values -- live next to the producer's three copies of the
+// state until the publish at the end; here a group is stored to LDS right after it is computed, the force derivatives are
+// produced one column at a time, and only g[14] survives, which the state update needs.)  Record layout: StageRec.
+// `live` = this lane owns a segment of the group.
+template <bool AERO, bool FIN, typename R>
+__device__ __forceinline__ void stage_eval_publish(const DynP<R>& p, const R* x, const R* u, R* g, R* rec, int stride, bool live) {
+    constexpr int oC = 14, oInvm = 23, oAm = 24, oDq = 27, oMw = 39, oQ = 48, oW = 52, oKu = 55, oDv = 58;
+    constexpr int oF1 = 67, oF2 = 70, oWq = 73, oWv = 85, oG1 = 94, oG2 = 97;
+    const R* v = x + 4;
+    const R* q = x + 7;
+    const R* w = x + 11;
+    auto PUT = [&](int i, R val) { if (live) rec[i * stride] = val; };
+    R C[9];
+    dcm(q, C);
 #pragma unroll
-        for (int i = 0; i < 9; i++) rec[(o++) * stride] = s.Dv[i];
+    for (int i = 0; i < 9; i++) PUT(oC + i, C[i]);
+    const R invm = R(1.0) / x[0];
+    PUT(oInvm, invm);
+    const R q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const R u1 = u[0], u2 = u[1], u3 = u[2];
+    R F[3] = {R(0.0), R(0.0), R(0.0)}, ff[3] = {R(0.0), R(0.0), R(0.0)};
+    AeroPrep<R> A;
+    FinPrep<R> Fp;
+    if (AERO) {
+        aero_prep(p, v, C, A);
+#pragma unroll
+        for (int i = 0; i < 3; i++) F[i] = A.F[i];
     }
     if (FIN) {
+        fin_prep(v, C, Fp);
 #pragma unroll
-        for (int i = 0; i < 3; i++) rec[(o++) * stride] = s.fd1[i];
+        for (int i = 0; i < 3; i++) {
+            ff[i] = u[3] * Fp.fd1[i] + u[4] * Fp.fd2[i];
+            F[i] += ff[i];
+            PUT(oF1 + i, Fp.fd1[i]);
+            PUT(oF2 + i, Fp.fd2[i]);
+            PUT(oG1 + i, p.JrF[3 * i] * Fp.fd1[0] + p.JrF[3 * i + 1] * Fp.fd1[1] + p.JrF[3 * i + 2] * Fp.fd1[2]);
+            PUT(oG2 + i, p.JrF[3 * i] * Fp.fd2[0] + p.JrF[3 * i + 1] * Fp.fd2[1] + p.JrF[3 * i + 2] * Fp.fd2[2]);
+        }
+    }
+    // one column of the velocity / rate rows at a time: d(C u)/dq column + force-derivative column -> Dq | Dv (and Wq | Wv)
+    auto column = [&](auto Jt) {
+        constexpr int J = decltype(Jt)::value;
+        R d[3] = {R(0.0), R(0.0), R(0.0)};
+        if (AERO) aero_col<J>(q, v, A, d);
+        if (FIN) {
+            R df[3];
+            fin_col<J>(q, v, Fp, u[3], u[4], df);
 #pragma unroll
-        for (int i = 0; i < 3; i++) rec[(o++) * stride] = s.fd2[i];
+            for (int i = 0; i < 3; i++) {
+                d[i] += df[i];
+                PUT((J < 4 ? oWq + 4 * i + J : oWv + 3 * i + (J - 4)), p.JrF[3 * i] * df[0] + p.JrF[3 * i + 1] * df[1] + p.JrF[3 * i + 2] * df[2]);
+            }
+        }
+        if (J < 4) {
+            R D[3];   // column J of d(C u)/dq
+            if (J == 0) { D[0] = R(2.0) * (-q3 * u2 + q2 * u3); D[1] = R(2.0) * (q3 * u1 - q1 * u3); D[2] = R(2.0) * (-q2 * u1 + q1 * u2); }
+            if (J == 1) { D[0] = R(2.0) * (q2 * u2 + q3 * u3); D[1] = R(2.0) * (q2 * u1 - R(2.0) * q1 * u2 - q0 * u3); D[2] = R(2.0) * (q3 * u1 + q0 * u2 - R(2.0) * q1 * u3); }
+            if (J == 2) { D[0] = R(2.0) * (-R(2.0) * q2 * u1 + q1 * u2 + q0 * u3); D[1] = R(2.0) * (q1 * u1 + q3 * u3); D[2] = R(2.0) * (-q0 * u1 + q3 * u2 - R(2.0) * q2 * u3); }
+            if (J == 3) { D[0] = R(2.0) * (-R(2.0) * q3 * u1 - q0 * u2 + q1 * u3); D[1] = R(2.0) * (q0 * u1 - R(2.0) * q3 * u2 + q2 * u3); D[2] = R(2.0) * (q1 * u1 + q2 * u2); }
 #pragma unroll
-        for (int i = 0; i < 12; i++) rec[(o++) * stride] = s.Wq[i];
+            for (int i = 0; i < 3; i++) PUT(oDq + 4 * i + J, (D[i] + d[i]) * invm);
+        } else if (AERO || FIN) {
 #pragma unroll
-        for (int i = 0; i < 9; i++) rec[(o++) * stride] = s.Wv[i];
+            for (int i = 0; i < 3; i++) PUT(oDv + 3 * i + (J - 4), d[i] * invm);
+        }
+    };
+    column(std::integral_constant<int, 0>()); column(std::integral_constant<int, 1>());
+    column(std::integral_constant<int, 2>()); column(std::integral_constant<int, 3>());
+    if (AERO || FIN) {
+        column(std::integral_constant<int, 4>()); column(std::integral_constant<int, 5>()); column(std::integral_constant<int, 6>());
+    }
+    g[0] = -p.alpha * sqrt(u1 * u1 + u2 * u2 + u3 * u3);
+    g[1] = v[0]; g[2] = v[1]; g[3] = v[2];
 #pragma unroll
-        for (int i = 0; i < 3; i++) rec[(o++) * stride] = s.Gf1[i];
+    for (int i = 0; i < 3; i++) {
+        const R acc = (C[3 * i] * u1 + C[3 * i + 1] * u2 + C[3 * i + 2] * u3 + F[i]) * invm;
+        g[4 + i] = acc;
+        PUT(oAm + i, -acc * invm);
+    }
+    g[4] -= p.g0;
+    g[7] = R(0.5) * (-w[0] * q1 - w[1] * q2 - w[2] * q3);
+    g[8] = R(0.5) * (w[0] * q0 + w[2] * q2 - w[1] * q3);
+    g[9] = R(0.5) * (w[1] * q0 - w[2] * q1 + w[0] * q3);
+    g[10] = R(0.5) * (w[2] * q0 + w[1] * q1 - w[0] * q2);
+    {
+        R Jw[3], t[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++) rec[(o++) * stride] = s.Gf2[i];
+        for (int i = 0; i < 3; i++) Jw[i] = p.J[3 * i] * w[0] + p.J[3 * i + 1] * w[1] + p.J[3 * i + 2] * w[2];
+        t[0] = (p.rTB[1] * u3 - p.rTB[2] * u2) - (w[1] * Jw[2] - w[2] * Jw[1]);
+        t[1] = (p.rTB[2] * u1 - p.rTB[0] * u3) - (w[2] * Jw[0] - w[0] * Jw[2]);
+        t[2] = (p.rTB[0] * u2 - p.rTB[1] * u1) - (w[0] * Jw[1] - w[1] * Jw[0]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            g[11 + i] = p.Jinv[3 * i] * t[0] + p.Jinv[3 * i + 1] * t[1] + p.Jinv[3 * i + 2] * t[2];
+            if (FIN) g[11 + i] += p.JrF[3 * i] * ff[0] + p.JrF[3 * i + 1] * ff[1] + p.JrF[3 * i + 2] * ff[2];
+        }
+        // T = [w]x J - [Jw]x ; Mw = -Jinv T
+        R T[9];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            T[0 + j] = -w[2] * p.J[3 + j] + w[1] * p.J[6 + j];
+            T[3 + j] = w[2] * p.J[0 + j] - w[0] * p.J[6 + j];
+            T[6 + j] = -w[1] * p.J[0 + j] + w[0] * p.J[3 + j];
+        }
+        T[1] += Jw[2]; T[2] -= Jw[1];
+        T[3] -= Jw[2]; T[5] += Jw[0];
+        T[6] += Jw[1]; T[7] -= Jw[0];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                PUT(oMw + 3 * i + j, -(p.Jinv[3 * i] * T[j] + p.Jinv[3 * i + 1] * T[3 + j] + p.Jinv[3 * i + 2] * T[6 + j]));
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) PUT(i, g[i]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) PUT(oQ + i, q[i]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) PUT(oW + i, w[i]);
+    {
+        const R un = sqrt(u1 * u1 + u2 * u2 + u3 * u3);
+        const R k = un > R(0.0) ? -p.alpha / un : R(0.0);
+        PUT(oKu, k * u1); PUT(oKu + 1, k * u2); PUT(oKu + 2, k * u3);
     }
 }
 
-// Fin model: d/dt of one sensitivity column from a published stage record (100 values).  The record is read in three
-// batches (translational rows | rotational rows | the RHS itself) so that at most ~45 of its values are live at once:
-// holding all 100 next to the column's own 42 values would spill.  wc[5]: FOH weights of this column's control component.
-template <bool AERO, typename R>
-__device__ __forceinline__ void column_deriv_rec_fin(const DynP<R>& p, const R* rec, int stride, const R* c,
-                                                     const R* wc, R gsel, R sigma, R* dc) {
+// d/dt of one sensitivity column from a published stage record, read in THREE BATCHES (mass / position / velocity rows | attitude
+// and rate rows | the RHS itself): at most ~45 of the record's 58 / 67 / 100 values are live at once next to the column's own 42
+// (c, its RK accumulator and stage value).  Reading the whole record in one batch (round 2's column_deriv_rec) keeps one LDS round
+// trip per stage but spilled (round 2: 97 / 240 VGPRs in the persistent kernel, exo / aero).
+// wc[NU]: FOH weights of this column's control component (NU = 5 with FIN, else 3).
+template <bool AERO, bool FIN, typename R>
+__device__ __forceinline__ void column_deriv_rec_pieces(const DynP<R>& p, const R* rec, int stride, const R* c,
+                                                        const R* wc, R gsel, R sigma, R* dc) {
+    constexpr bool DV = AERO || FIN;
     constexpr int oC = 14, oInvm = 23, oAm = 24, oDq = 27, oMw = 39, oQ = 48, oW = 52, oKu = 55, oDv = 58;
     constexpr int oF1 = 67, oF2 = 70, oWq = 73, oWv = 85, oG1 = 94, oG2 = 97;
     auto RR = [&](int i) { return rec[i * stride]; };
     R a[14];
     {   // ---- mass, position and velocity rows ----
-        R C[9], am[3], Dq[12], Dv[9], f1[3], f2[3], ku[3];
+        R C[9], am[3], Dq[12], Dv[DV ? 9 : 1], f1[FIN ? 3 : 1], f2[FIN ? 3 : 1], ku[3];
 #pragma unroll
-        for (int i = 0; i < 9; i++) { C[i] = RR(oC + i); Dv[i] = RR(oDv + i); }
+        for (int i = 0; i < 9; i++) C[i] = RR(oC + i);
+        if (DV) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) Dv[i] = RR(oDv + i);
+        }
 #pragma unroll
         for (int i = 0; i < 12; i++) Dq[i] = RR(oDq + i);
 #pragma unroll
-        for (int i = 0; i < 3; i++) { am[i] = RR(oAm + i); f1[i] = RR(oF1 + i); f2[i] = RR(oF2 + i); ku[i] = RR(oKu + i); }
+        for (int i = 0; i < 3; i++) { am[i] = RR(oAm + i); ku[i] = RR(oKu + i); }
+        if (FIN) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { f1[i] = RR(oF1 + i); f2[i] = RR(oF2 + i); }
+        }
         const R invm = RR(oInvm);
         a[0] = ku[0] * wc[0] + ku[1] * wc[1] + ku[2] * wc[2];
         a[1] = c[4]; a[2] = c[5]; a[3] = c[6];
@@ -543,23 +775,33 @@ __device__ __forceinline__ void column_deriv_rec_fin(const DynP<R>& p, const R* 
             t = fma(Dq[4 * i + 1], c[8], t);
             t = fma(Dq[4 * i + 2], c[9], t);
             t = fma(Dq[4 * i + 3], c[10], t);
-            t = fma(Dv[3 * i], c[4], t);
-            t = fma(Dv[3 * i + 1], c[5], t);
-            t = fma(Dv[3 * i + 2], c[6], t);
-            t = fma((C[3 * i] * wc[0] + C[3 * i + 1] * wc[1] + C[3 * i + 2] * wc[2] + f1[i] * wc[3] + f2[i] * wc[4]), invm, t);
+            if (DV) {
+                t = fma(Dv[3 * i], c[4], t);
+                t = fma(Dv[3 * i + 1], c[5], t);
+                t = fma(Dv[3 * i + 2], c[6], t);
+            }
+            R cw_ = C[3 * i] * wc[0] + C[3 * i + 1] * wc[1] + C[3 * i + 2] * wc[2];
+            if (FIN) cw_ += f1[i] * wc[3] + f2[i] * wc[4];
+            t = fma(cw_, invm, t);
             a[4 + i] = t;
         }
     }
     {   // ---- attitude and rate rows ----
-        R q[4], w[3], Mw[9], Wq[12], Wv[9], g1[3], g2[3];
+        R q[4], w[3], Mw[9], Wq[FIN ? 12 : 1], Wv[FIN ? 9 : 1], g1[FIN ? 3 : 1], g2[FIN ? 3 : 1];
 #pragma unroll
         for (int i = 0; i < 4; i++) q[i] = RR(oQ + i);
 #pragma unroll
-        for (int i = 0; i < 3; i++) { w[i] = RR(oW + i); g1[i] = RR(oG1 + i); g2[i] = RR(oG2 + i); }
+        for (int i = 0; i < 3; i++) w[i] = RR(oW + i);
 #pragma unroll
-        for (int i = 0; i < 9; i++) { Mw[i] = RR(oMw + i); Wv[i] = RR(oWv + i); }
+        for (int i = 0; i < 9; i++) Mw[i] = RR(oMw + i);
+        if (FIN) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) Wq[i] = RR(oWq + i);
+            for (int i = 0; i < 3; i++) { g1[i] = RR(oG1 + i); g2[i] = RR(oG2 + i); }
+#pragma unroll
+            for (int i = 0; i < 9; i++) Wv[i] = RR(oWv + i);
+#pragma unroll
+            for (int i = 0; i < 12; i++) Wq[i] = RR(oWq + i);
+        }
         const R cq0 = c[7], cq1 = c[8], cq2 = c[9], cq3 = c[10];
         const R cw0 = c[11], cw1 = c[12], cw2 = c[13];
         a[7] = R(0.5) * (-w[0] * cq1 - w[1] * cq2 - w[2] * cq3 - q[1] * cw0 - q[2] * cw1 - q[3] * cw2);
@@ -571,18 +813,22 @@ __device__ __forceinline__ void column_deriv_rec_fin(const DynP<R>& p, const R* 
             R t = Mw[3 * i] * cw0;
             t = fma(Mw[3 * i + 1], cw1, t);
             t = fma(Mw[3 * i + 2], cw2, t);
-            t = fma(Wq[4 * i], cq0, t);
-            t = fma(Wq[4 * i + 1], cq1, t);
-            t = fma(Wq[4 * i + 2], cq2, t);
-            t = fma(Wq[4 * i + 3], cq3, t);
-            t = fma(Wv[3 * i], c[4], t);
-            t = fma(Wv[3 * i + 1], c[5], t);
-            t = fma(Wv[3 * i + 2], c[6], t);
+            if (FIN) {
+                t = fma(Wq[4 * i], cq0, t);
+                t = fma(Wq[4 * i + 1], cq1, t);
+                t = fma(Wq[4 * i + 2], cq2, t);
+                t = fma(Wq[4 * i + 3], cq3, t);
+                t = fma(Wv[3 * i], c[4], t);
+                t = fma(Wv[3 * i + 1], c[5], t);
+                t = fma(Wv[3 * i + 2], c[6], t);
+            }
             t = fma(p.JrT[3 * i], wc[0], t);
             t = fma(p.JrT[3 * i + 1], wc[1], t);
             t = fma(p.JrT[3 * i + 2], wc[2], t);
-            t = fma(g1[i], wc[3], t);
-            t = fma(g2[i], wc[4], t);
+            if (FIN) {
+                t = fma(g1[i], wc[3], t);
+                t = fma(g2[i], wc[4], t);
+            }
             a[11 + i] = t;
         }
     }
@@ -591,59 +837,6 @@ __device__ __forceinline__ void column_deriv_rec_fin(const DynP<R>& p, const R* 
     for (int i = 0; i < 14; i++) g[i] = RR(i);
 #pragma unroll
     for (int i = 0; i < 14; i++) dc[i] = fma(sigma, a[i], gsel * g[i]);
-}
-
-// d/dt of one sensitivity column from a published stage record (same arithmetic as column_deriv)
-template <bool AERO, typename R>
-__device__ __forceinline__ void column_deriv_rec(const DynP<R>& p, const R* rec, int stride, const R* c,
-                                                 const R* wc, R gsel, R sigma, R* dc) {
-    // the whole record into registers first: 58 (67) independent LDS reads in flight, one wait — read one at a
-    // time each multiply-add would expose a full LDS latency with only two waves per SIMD to hide it
-    constexpr int NR = StageRec<AERO>::N;
-    R rr[NR];
-#pragma unroll
-    for (int i = 0; i < NR; i++) rr[i] = rec[i * stride];
-    auto RR = [&](int i) { return rr[i]; };
-    const int oC = 14, oInvm = 23, oAm = 24, oDq = 27, oMw = 39, oQ = 48, oW = 52, oKu = 55, oDv = 58;
-    R a[14];
-    a[0] = RR(oKu) * wc[0] + RR(oKu + 1) * wc[1] + RR(oKu + 2) * wc[2];
-    a[1] = c[4]; a[2] = c[5]; a[3] = c[6];
-    const R invm = RR(oInvm);
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        R t = RR(oAm + i) * c[0];
-        t = fma(RR(oDq + 4 * i), c[7], t);
-        t = fma(RR(oDq + 4 * i + 1), c[8], t);
-        t = fma(RR(oDq + 4 * i + 2), c[9], t);
-        t = fma(RR(oDq + 4 * i + 3), c[10], t);
-        if (AERO) {
-            t = fma(RR(oDv + 3 * i), c[4], t);
-            t = fma(RR(oDv + 3 * i + 1), c[5], t);
-            t = fma(RR(oDv + 3 * i + 2), c[6], t);
-        }
-        t = fma((RR(oC + 3 * i) * wc[0] + RR(oC + 3 * i + 1) * wc[1] + RR(oC + 3 * i + 2) * wc[2]), invm, t);
-        a[4 + i] = t;
-    }
-    const R q0 = RR(oQ), q1 = RR(oQ + 1), q2 = RR(oQ + 2), q3 = RR(oQ + 3);
-    const R w0 = RR(oW), w1 = RR(oW + 1), w2 = RR(oW + 2);
-    const R cq0 = c[7], cq1 = c[8], cq2 = c[9], cq3 = c[10];
-    const R cw0 = c[11], cw1 = c[12], cw2 = c[13];
-    a[7] = R(0.5) * (-w0 * cq1 - w1 * cq2 - w2 * cq3 - q1 * cw0 - q2 * cw1 - q3 * cw2);
-    a[8] = R(0.5) * (w0 * cq0 + w2 * cq2 - w1 * cq3 + q0 * cw0 - q3 * cw1 + q2 * cw2);
-    a[9] = R(0.5) * (w1 * cq0 - w2 * cq1 + w0 * cq3 + q3 * cw0 + q0 * cw1 - q1 * cw2);
-    a[10] = R(0.5) * (w2 * cq0 + w1 * cq1 - w0 * cq2 - q2 * cw0 + q1 * cw1 + q0 * cw2);
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        R t = RR(oMw + 3 * i) * cw0;
-        t = fma(RR(oMw + 3 * i + 1), cw1, t);
-        t = fma(RR(oMw + 3 * i + 2), cw2, t);
-        t = fma(p.JrT[3 * i], wc[0], t);
-        t = fma(p.JrT[3 * i + 1], wc[1], t);
-        t = fma(p.JrT[3 * i + 2], wc[2], t);
-        a[11 + i] = t;
-    }
-#pragma unroll
-    for (int i = 0; i < 14; i++) dc[i] = fma(sigma, a[i], gsel * RR(i));
 }
 
 }  // namespace scvx
