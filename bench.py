@@ -256,6 +256,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traj-check", action="store_true", help="skip the B=1 full-solve parity figure (profiling runs)")
     ap.add_argument("--no-k1-sweep", action="store_true", help="skip the K1-by-npts leg (profiling runs)")
+    ap.add_argument("--dump-gathered", default=None, help="rank 0 saves the gathered trajectory records [world*B][(K+1)*(14+NU)+1] as .npy (tests)")
     args = ap.parse_args()
     if not args.batch:
         args.batch = 32768 if args.config5 else 8192
@@ -374,11 +375,15 @@ def main():
                 mine, dev = mine.cpu(), "cpu"
             out = mc.gather_records(mine, dist)
         gathered = tuple(out.shape)
+        gathered_arr = out
         # every rank sees every shard: rank r's first record must be what rank r holds
         assert torch.equal(out[rank].to(mine.device), mine), "all-gather returned a different local shard"
         elapsed, done_all = mc.reduce_clock(elapsed, done, dist, dev)
     else:
         done_all = done
+    if args.dump_gathered and rank == 0:
+        rec_all = gathered_arr.reshape(-1, gathered_arr.shape[-1]).cpu().numpy() if dist is not None else batch.trajectory_record()
+        np.save(args.dump_gathered, rec_all)
 
     if rank == 0:
         st, its, merit, pobj = batch.solver_stats()

@@ -512,7 +512,8 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
                                                        double* __restrict__ rk, double* __restrict__ cost,
                                                        int* __restrict__ iter, int* __restrict__ status,
                                                        const int* mask /* may be `active` or `live` itself */, int* active,
-                                                       int* live, double* __restrict__ out, double* __restrict__ acc) {
+                                                       int* live, double* __restrict__ out, double* __restrict__ acc,
+                                                       int* __restrict__ nlive) {
     const int b = blockIdx.x;
     if (b >= B) return;
     // not stepped by this call (failed earlier, or converged inside scvx_solve): status[b] keeps saying why and
@@ -564,6 +565,7 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
     if (threadIdx.x == 0) {
         const int it = iter[b] + 1;
         iter[b] = it;
+        const int was_live = live[b];
         if (st == SCVX_ST_SOLVER || st == SCVX_ST_NONFINITE || st == SCVX_ST_INFEASIBLE) {
             active[b] = 0;   // frozen: the reference stops with an error here
             live[b] = 0;
@@ -574,6 +576,7 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
             // scvx_solve acts on it (live); solve_step itself has no notion of convergence and keeps stepping.
             if (accept && nun <= P.nuTol && dJ <= P.delTol) { st = SCVX_ST_CONVERGED; live[b] = 0; }
         }
+        if (was_live && !live[b]) atomicSub(nlive, 1);   // device-side count of the trajectories scvx_solve still steps
         status[b] = st;
         out[2 * b] = nun;
         out[2 * b + 1] = dJ;
@@ -595,10 +598,13 @@ __global__ void reset_scalars_kernel(int B, double* __restrict__ rk, double* __r
     for (int q = 0; q < 4; q++) info[4 * i + q] = 0.0;
 }
 
-// live = active (start of a solve_problem loop)
-__global__ void copy_flags_kernel(int B, const int* __restrict__ src, int* __restrict__ dst) {
+// live = active (start of a solve_problem loop); *nlive (zeroed by the caller) = how many
+__global__ void copy_flags_kernel(int B, const int* __restrict__ src, int* __restrict__ dst, int* __restrict__ nlive) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) dst[i] = src[i];
+    const int v = i < B ? src[i] : 0;
+    if (i < B) dst[i] = v;
+    const unsigned long long m = __ballot(v != 0);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(nlive, (int)__popcll(m));
 }
 
 }  // namespace scvx
@@ -622,6 +628,9 @@ struct scvx_batch {
     double *rk = nullptr, *cost = nullptr, *ic = nullptr, *info = nullptr, *out = nullptr, *work = nullptr;
     double *ttr = nullptr;   // trust-region norm bound at the last optimum (reuse_inactive_tr)
     double *acc = nullptr;   // scvx::ACC_N running totals (scvx_batch_get_step_stats)
+    int *d_nlive = nullptr;  // device-side count of live trajectories (scvx_solve), mirrored asynchronously into pinned h_nlive[2]
+    int *h_nlive = nullptr;
+    hipEvent_t ev_nlive[2] = {nullptr, nullptr};
     int *iter = nullptr, *status = nullptr;
     int *active = nullptr;   // 0 once a trajectory has failed (solver / non-finite): never stepped again
     int *live = nullptr;     // active and not yet converged: the trajectories scvx_solve still steps
@@ -757,7 +766,7 @@ int enqueue_step(scvx_batch* b, const int* mask) {
     SCVX_HIP(ctx, scvx::launch_propagate(ctx, b->B, b->K, b->cx, b->cu, b->csigma, dt, b->xprop, st));
     if ((rc = mark(b))) return rc;
     hipLaunchKernelGGL(scvx::tr_update_kernel, dim3(b->B), dim3(64), 0, st, b->tr, b->B, b->cand, b->xprop, b->nu, b->info,
-                       b->traj, b->rk, b->cost, b->iter, b->status, mask, b->active, b->live, b->out, b->acc);
+                       b->traj, b->rk, b->cost, b->iter, b->status, mask, b->active, b->live, b->out, b->acc, b->d_nlive);
     SCVX_HIP(ctx, hipGetLastError());
     if ((rc = mark(b))) return rc;
     rc = split_views(b, b->traj, b->x, b->u, b->sigma);
@@ -857,6 +866,10 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     rc |= dmalloc(ctx, &b->out, nB * 2);
     rc |= dmalloc(ctx, &b->ttr, nB);
     rc |= dmalloc(ctx, &b->acc, (size_t)scvx::ACC_N);
+    rc |= dmalloc(ctx, &b->d_nlive, (size_t)1);
+    if (!rc && (hipHostMalloc((void**)&b->h_nlive, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&b->ev_nlive[0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&b->ev_nlive[1], hipEventDisableTiming) != hipSuccess)) rc = SCVX_ERR_HIP;
     if (!rc && hipMemset(b->acc, 0, sizeof(double) * scvx::ACC_N) != hipSuccess) rc = SCVX_ERR_HIP;
     rc |= dmalloc(ctx, &b->work, nB * b->work_stride);
     rc |= dmalloc(ctx, &b->iter, nB);
@@ -875,8 +888,10 @@ void scvx_batch_destroy(scvx_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : b->ev_nlive) if (e) (void)hipEventDestroy(e);
+    if (b->h_nlive) (void)hipHostFree(b->h_nlive);
     void* ptrs[] = {b->traj0, b->traj, b->cand, b->sol, b->x, b->u, b->sigma, b->cx, b->cu, b->csigma, b->endpoint, b->deriv, b->xprop,
-                    b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active, b->live, b->ttr, b->deriv_f, b->acc};
+                    b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active, b->live, b->ttr, b->deriv_f, b->acc, b->d_nlive};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete b;
@@ -1030,24 +1045,31 @@ int scvx_solve(scvx_batch* b, int32_t* status, int32_t* iters, double* nu_norm, 
     const int B = b->B;
     // Rocketland.solve_problem (rocketland.jl:432-443): cnu = cdel = Inf, iter = 1, loop while not converged and
     // iter < imax.  Per trajectory: `live` starts as `active`, tr_update clears it on convergence or failure, and only
-    // live trajectories are stepped.  The host looks at the flags every few steps only (a step with nothing live is
-    // a handful of empty launches), so the loop is not serialised on a read-back per step.
-    hipLaunchKernelGGL(scvx::copy_flags_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, ctx->stream, B, b->active, b->live);
+    // live trajectories are stepped.
+    SCVX_HIP(ctx, hipMemsetAsync(b->d_nlive, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(scvx::copy_flags_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, ctx->stream, B, b->active, b->live, b->d_nlive);
     SCVX_HIP(ctx, hipGetLastError());
-    std::vector<int> lv(B);
-    constexpr int CHECK_EVERY = 2;
+    // The count of live trajectories is kept ON THE DEVICE (tr_update decrements it) and mirrored into pinned host memory by an
+    // asynchronous 4-byte copy after every step.  Before step `it` is enqueued the host waits only for the copy made after step
+    // it - 2: step it - 1 is still queued or running, so the device never idles on the host, and the host never runs more than
+    // two steps ahead of a count it has not seen (the count picks the conic solver's executor for the tail and ends the loop
+    // when nothing is live).  There is no read-back of the per-trajectory flags inside the loop.
     b->nlive_hint = -1;
+    bool pending[2] = {false, false};
     for (int it = 1; it < ctx->prob.imax; it++) {
-        rc = enqueue_step(b, b->live);
-        if (rc) { b->nlive_hint = -1; return rc; }
-        if (it % CHECK_EVERY == 0 && it + 1 < ctx->prob.imax) {
-            SCVX_HIP(ctx, hipMemcpyAsync(lv.data(), b->live, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-            SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            int nlive = 0;
-            for (int t = 0; t < B; t++) nlive += lv[t] != 0;
+        const int q = it & 1;
+        if (pending[q]) {
+            SCVX_HIP(ctx, hipEventSynchronize(b->ev_nlive[q]));
+            pending[q] = false;
+            const int nlive = b->h_nlive[q];
             if (nlive == 0) break;
             b->nlive_hint = nlive;
         }
+        rc = enqueue_step(b, b->live);
+        if (rc) { b->nlive_hint = -1; return rc; }
+        SCVX_HIP(ctx, hipMemcpyAsync(&b->h_nlive[q], b->d_nlive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SCVX_HIP(ctx, hipEventRecord(b->ev_nlive[q], ctx->stream));
+        pending[q] = true;
     }
     b->nlive_hint = -1;
     if (iters) {

@@ -875,3 +875,70 @@ def test_warm_start_after_rejected_steps_changes_nothing_but_the_iteration_count
     assert its_w.sum() < 0.85 * its_k.sum()                      # -23 % iterations over the sample problem's 14 steps
     assert (its_w[ar] < 0.5 * its_k[ar]).mean() > 0.6            # most solves after a rejection: under half the iterations
     w.close(); k.close(); c.close()
+
+
+def test_two_rank_bench_on_one_gpu_matches_the_single_process_run(tmp_path):
+    """the N > 1 path of bench.py end to end on the one GPU of this box -- two ranks (fresh child processes,
+    torch.distributed over gloo: SCVX_DIST_BACKEND=gloo) sharing the card, strong scaling of a 2,048-trajectory batch, two
+    solve_steps, the final all-gather -- against a single-process run of the same 2,048 trajectories.  With the conic solver's
+    executor pinned (SCVX_K4_WAVES=1: 1,024 and 2,048 trajectories would otherwise pick different executors, whose sums are
+    ordered differently) every trajectory's arithmetic is independent of its batch: the gathered records must be equal BIT FOR BIT."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SCVX_DIST_BACKEND="gloo", SCVX_K4_WAVES="1", MASTER_ADDR="127.0.0.1")
+    common = ["--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-traj-check", "--no-k1-sweep"]
+    f2, f1 = str(tmp_path / "two.npy"), str(tmp_path / "one.npy")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--global-batch", "2048",
+                         "--dump-gathered", f2] + common, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    line2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert line2["n_gpus"] == 2 and line2["scaling"] == "strong" and line2["config"]["batch_per_gpu"] == 1024
+    assert line2["config"]["all_gather_shape"] == [2, 1024, 51 * 17 + 1] and line2["config"]["traj_iters_timed"] == 2 * 2048
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--batch", "2048", "--dump-gathered", f1] + common,
+                        env=dict(env, SCVX_DIST_BACKEND="nccl"), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    a, b = np.load(f2), np.load(f1)
+    assert a.shape == b.shape == (2048, 51 * 17 + 1)
+    assert np.array_equal(a, b)
+
+
+def test_fuzz_class_that_used_to_stall_matches_independent_oracle():
+    """class 16 of tools/k4_fuzz.py (K = 25, 41 % propellant, glideslope 36 deg, tf_guess 9.2 -- round 2's
+    profiles/r02_k4_fuzz.md rows 13/16/22/23 are the classes that stalled) on the device against oracle/ipm.py.  Trajectory 11 of
+    its dispersed batch ended "stalled at merit 1.09e-8" before the centring floor (SCVX_MU_FLOOR); it and two neighbours must be
+    OPTIMAL now and agree with the independent solver.  5e-5 on the minimiser: the optimum of this class is flatter than the
+    sample problem's (2.2e-5 seen on the twin)."""
+    import os
+    import sys
+    from dataclasses import replace
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import k4_fuzz
+    from oracle import model, scvx as oscvx
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    rng = np.random.default_rng(1)
+    base = model.base_prob_scaled()
+    for _ in range(17):
+        po = k4_fuzz.draw_class(rng, base)
+    assert po.K == 25 and not po.enforce_dp
+    pp = replace(sp.base_prob_scaled, K=po.K, mdry=po.mdry, Tmin=po.Tmin, deltaMax=po.deltaMax, thetaMax=po.thetaMax,
+                 gammaGs=po.gammaGs, omMax=po.omMax, tf_guess=po.tf_guess)
+    ic = model.disperse_ics(po, 16, 516, 0.3)
+    c = IntegratorCache(pp, npts=4)
+    b = ScvxBatch(c, 16).init(ic)
+    xs, us, ss, nu = b.socp_solve()
+    st, its, merit, _ = b.solver_stats()
+    assert np.all(st == 0) and merit.max() < 1e-8, (st, merit)
+    for tr in (11, 0, 2):
+        it0 = oscvx.create_initial(po, 4, ic[tr, :3], ic[tr, 3:])
+        sol, ix = oscvx.solve_socp(it0)
+        assert sol.status == "optimal"
+        assert np.abs(xs[tr] - sol.x[ix.xv].T).max() < 5e-5 and np.abs(us[tr] - sol.x[ix.uv].T).max() < 5e-5, tr
+    b.close(); c.close()

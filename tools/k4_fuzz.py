@@ -15,6 +15,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
+def draw_class(rng, base, fins=False):
+    """One random problem class around `base` (an oracle.model.DescentProblem): the law of this tool."""
+    from oracle import model
+    K = int(rng.choice([12, 25, 50, 64]))
+    p = replace(base, K=K, mdry=float(base.mwet * rng.uniform(0.4, 0.999)), Tmin=float(base.Tmax * rng.uniform(0.05, 0.6)),
+                deltaMax=float(rng.uniform(5.0, 30.0)), thetaMax=float(rng.uniform(30.0, 120.0)), gammaGs=float(rng.uniform(5.0, 45.0)),
+                omMax=float(rng.uniform(20.0, 120.0)), tf_guess=float(rng.uniform(0.5, 12.0)), enforce_dp=bool(rng.integers(0, 2)))
+    if fins:
+        p = replace(p, fins=True, rFB=model.base_prob().rFB / 1000.0, finmxf=float(rng.uniform(0.002, 0.02)))
+    return p
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=30)
@@ -37,12 +49,8 @@ def main():
     print("| # | K | mdry | Tmin/Tmax | deltaMax | thetaMax | gammaGs | omMax | tf_guess | dp | status counts (solver) | IPM its mean / max | merit max |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for n in range(a.n):
-        K = int(rng.choice([12, 25, 50, 64]))
-        p = replace(base, K=K, mdry=float(base.mwet * rng.uniform(0.4, 0.999)), Tmin=float(base.Tmax * rng.uniform(0.05, 0.6)),
-                    deltaMax=float(rng.uniform(5.0, 30.0)), thetaMax=float(rng.uniform(30.0, 120.0)), gammaGs=float(rng.uniform(5.0, 45.0)),
-                    omMax=float(rng.uniform(20.0, 120.0)), tf_guess=float(rng.uniform(0.5, 12.0)), enforce_dp=bool(rng.integers(0, 2)))
-        if a.fins:
-            p = replace(p, fins=True, rFB=model.base_prob().rFB / 1000.0, finmxf=float(rng.uniform(0.002, 0.02)))
+        p = draw_class(rng, base, a.fins)
+        K = p.K
         ic = model.disperse_ics(p, a.B, 500 + n, 0.3)
         try:
             o = port.scvx_steps(p, ic, a.steps, nsub=4, warm_start=True)
