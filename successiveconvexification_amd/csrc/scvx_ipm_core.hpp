@@ -2506,6 +2506,11 @@ struct Solver {
                 const double apo = fabs(pobj) > 1.0 ? fabs(pobj) : 1.0;
                 const double mu_floor = SCVX_MU_FLOOR * C.tol * apo / degree;
                 if (smu < mu_floor) smu = mu_floor < mu ? mu_floor : mu;
+#if defined(SCVX_HOLD_MU)
+                // gap and primal residual already meet the tolerance, only the dual residual is left: a pure centring step
+                // (target = the current mu) restores feasibility without pushing the scalings further
+                if (relgap < C.tol && pres < C.tol) smu = mu;
+#endif
             }
             corr_rhs_pass(smu);
             { SCVX_TS(tN_); newton_solve(false); SCVX_TE(tN_, 10); }

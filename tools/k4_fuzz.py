@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--fins", action="store_true", help="every class with the fin extension (control_dim = 5)")
     ap.add_argument("--lib", default=None, help="a variant build of liboracle_port.so")
+    ap.add_argument("--accept", type=float, default=0.0, help="accept_tol of the solver (default = tol: OPTIMAL or failure; 1e-5 = MOSEK's "
+                    "MSK_DPAR_INTPNT_CO_TOL_NEAR_REL = 1000 rule, under which a stalled solve within 1000 tol is still reported OPTIMAL)")
     a = ap.parse_args()
     import oracle
     if a.lib:
@@ -53,13 +55,13 @@ def main():
         K = p.K
         ic = model.disperse_ics(p, a.B, 500 + n, 0.3)
         try:
-            o = port.scvx_steps(p, ic, a.steps, nsub=4, warm_start=True)
+            o = port.scvx_steps(p, ic, a.steps, nsub=4, warm_start=True, accept=a.accept)
         except Exception as e:  # noqa: BLE001
             print("| %d | %d | error: %s |" % (n, K, e))
             continue
         st = np.concatenate(o["status"]); it = np.concatenate(o["iters"]); m = np.concatenate(o["merit"])
         S = np.stack(o["status"])                                    # [steps][B]
-        bad = (S != 0)
+        bad = (S != 0) & (S != 4)      # 4 = stalled inside the acceptance band (only with --accept > tol)
         alive = np.vstack([np.ones((1, S.shape[1]), bool), ~np.maximum.accumulate(bad, axis=0)[:-1]])   # not failed before this step
         feas = S[0] != 5                                             # status 5 = infeasible initial condition: not a solver failure
         attempted += int((alive & feas[None, :]).sum())

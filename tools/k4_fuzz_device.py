@@ -28,6 +28,7 @@ def main():
     print("|---|---|---|---|---|---|")
     worst = 0.0
     ndiff = 0
+    att = {"1": 0, "4": 0}; fail = {"1": 0, "4": 0}
     for n in range(a.n):
         K = int(rng.choice([12, 25, 31, 50, 64]))
         p = replace(base, K=K, mdry=float(base.mwet * rng.uniform(0.4, 0.999)), Tmin=float(base.Tmax * rng.uniform(0.05, 0.6)),
@@ -45,6 +46,10 @@ def main():
                 s, it, m, _ = b.solver_stats()
                 sts.append(s.copy()); its.append(it.copy())
             res[waves] = (np.array(sts), np.array(its), b.trajectory()[0])
+            S = np.array(sts); bad = S != 0                       # solver status per step: a failed trajectory is frozen afterwards
+            alive = np.vstack([np.ones((1, S.shape[1]), bool), ~np.maximum.accumulate(bad, axis=0)[:-1]])
+            feas = S[0] != 5
+            att[waves] += int((alive & feas[None, :]).sum()); fail[waves] += int((alive & bad & feas[None, :]).sum())
             b.close(); c.close()
         s1, s4 = res["1"][0], res["4"][0]
         d = (s1 != s4).any(axis=1).sum()
@@ -56,6 +61,9 @@ def main():
         print("| %d | %d | %s / %s | %d | %.1f / %.1f | %.1e |" % (n, K, cnt(s1), cnt(s4), d, res["1"][1].mean(), res["4"][1].mean(), dx), flush=True)
     os.environ.pop("SCVX_K4_WAVES", None)
     print("\nsolves with different status between the executors: %d; worst final-x difference where all statuses agree: %.2e" % (ndiff, worst))
+    for w in ("1", "4"):
+        print("%s-wavefront executor: attempted solves on live trajectories %d, first failures %d (%.3f %%), optimal %.3f %%" % (
+            w, att[w], fail[w], 100.0 * fail[w] / max(att[w], 1), 100.0 * (1 - fail[w] / max(att[w], 1))))
 
 
 if __name__ == "__main__":
