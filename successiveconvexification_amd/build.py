@@ -24,11 +24,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB] + sources()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+        flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
+    # one hipcc per translation unit, side by side (the conic solver's file alone takes ~70 s), then one link
+    objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        jobs.append((src, obj, subprocess.Popen([hipcc] + flags + ["-c", src, "-o", obj])))
+    failed = [src for src, _, pr in jobs if pr.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [obj for _, obj, _ in jobs])
     return LIB
 
 

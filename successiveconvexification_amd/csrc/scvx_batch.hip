@@ -20,423 +20,13 @@
 #include <limits>
 #include <new>
 #include <vector>
-#include "scvx_internal.hpp"
-#include "scvx_ipm_core.hpp"
+
+#include "scvx_socp.hpp"
 
 using scvx::fail;
 
-#ifndef SCVX_CHAIN_R
-#define SCVX_CHAIN_R 8   // steps of the block recurrence whose operands are in flight (10 VGPRs each)
-#endif
-
 namespace scvx {
 
-// The tile scratch of socp_kernel (one wavefront per block).  File scope on purpose: every routine of the solver
-// reaches it through WaveEx::scratch() as a known LDS symbol, so tile accesses compile to ds_read/ds_write (lgkmcnt
-// only).  A pointer carried in the executor object is reloaded from memory in each non-inlined routine, loses its
-// address space, and every LDS access becomes a flat_load/flat_store that also waits on the global loads and
-// stores in flight (vmcnt) — which serialises the tile arithmetic behind the HBM traffic it is meant to overlap.
-__shared__ __attribute__((aligned(16))) double g_socp_lds[1552];
-// ... and of the fin instantiation (control_dim = 5: 14 x 25 tiles, 24-column [TA | TBm | TBp]); separate symbols so that the
-// kernels of the reference's model keep their LDS footprint
-__shared__ __attribute__((aligned(16))) double g_socp_lds5[1704];
-#define SCVX_PIPE_LDS5 (2 * 392 + 588 + 392 + 196 + 350 + 364 + 70 + 2 * 46 + 3 * 196 + 8)
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds5[SCVX_PIPE_LDS5];
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds25[SCVX_PIPE_LDS5];
-template <int NU> __device__ __forceinline__ double* socp_lds() { if constexpr (NU == 5) return g_socp_lds5; else return g_socp_lds; }
-// tiles of the two-wavefront factorisation pipeline (multi-wavefront kernels only: a kernel that never references the
-// symbol does not get the allocation)
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 3 * 196 + 8];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
-#ifndef SCVX_K4_PIPELINE
-#define SCVX_K4_PIPELINE 1
-#endif
-// second tile set of the TWO-ENDED factorisation (four-wavefront blocks only: wavefronts 2 / 3 eliminate the bottom half of
-// the chain upwards while 0 / 1 eliminate the top half downwards); a separate symbol so that the two-wavefront kernel, which
-// never references it, keeps its LDS footprint (4 blocks per CU)
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds2[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 3 * 196 + 8];
-#ifndef SCVX_K4_TWISTED
-#define SCVX_K4_TWISTED 1
-#endif
-template <int NU> __device__ __forceinline__ double* socp_pipe_lds() { if constexpr (NU == 5) return g_socp_pipe_lds5; else return g_socp_pipe_lds; }
-template <int NU> __device__ __forceinline__ double* socp_pipe_lds2() { if constexpr (NU == 5) return g_socp_pipe_lds25; else return g_socp_pipe_lds2; }
-
-template <int NU_>
-struct WaveExT {
-    static constexpr int kLanes = 64;
-    __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63); }   // lane in the wavefront (BlockEx runs tile work on any of its wavefronts)
-    __device__ __forceinline__ int nlanes() const { return 64; }
-    __device__ __forceinline__ void sync() { __syncthreads(); }
-    // LDS-only ordering inside the single wavefront of the block: a release/acquire pair restricted to the local
-    // address space compiles to `s_waitcnt lgkmcnt(0)` — global loads (prefetches) and stores stay in flight,
-    // whereas __syncthreads() / an unrestricted workgroup fence drains vmcnt(0) at every phase boundary.
-    __device__ __forceinline__ void sync_lds() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    }
-    __device__ __forceinline__ double sum(double x) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-        return x;
-    }
-    __device__ __forceinline__ double min(double x) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o, 64));
-        return x;
-    }
-    __device__ __forceinline__ bool all(bool b) { return __all(b) != 0; }
-    __device__ __forceinline__ double* scratch() { return socp_lds<NU_>(); }
-
-    // value of x in lane `src` (src wave-uniform) delivered to every lane: two v_readlane_b32, no LDS
-    static __device__ __forceinline__ double bcast(double x, int src) {
-        const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
-        const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
-        return __hiloint2double(hi, lo);
-    }
-
-    static constexpr int kPrefetchRegs = 1;  // > 0: the next D tile is held in registers (ceil(tile / 64) per lane) while segment k is processed
-    static constexpr bool kTwisted = false;
-    static constexpr bool kPipelineFactor = false;
-
-    // C(14x14) = (acc ? C : 0) + alpha * A(14 x Kd) B(Kd x 14) on the FP64 matrix pipe: ceil(Kd/4) x
-    // v_mfma_f64_16x16x4_f64, tiles in LDS with arbitrary element strides (so transposes are free).
-    // Fragment maps (cdna guide §3, f64 form): A: lane l holds A[l&15][l>>4], B: lane l holds B[l>>4][l&15],
-    // C/D: register r of lane l is C[(l>>4) + 4r][l&15].  Rows/columns 14,15 and k >= Kd are fed zeros.
-    typedef double v4f64 __attribute__((ext_vector_type(4)));
-    __device__ __forceinline__ void tile_gemm(double* Cm, int sci, int scj, const double* A, int sai, int sak,
-                                              const double* B, int sbk, int sbj, int Kd, double alpha, bool acc) {
-        const int l = lane();
-        const int rc = l & 15, kq = l >> 4;
-        v4f64 c = {0.0, 0.0, 0.0, 0.0};
-        const bool in = rc < 14;
-        for (int k0 = 0; k0 < Kd; k0 += 4) {
-            const int k = k0 + kq;
-            const bool kin = in && (k < Kd);
-            const double a = kin ? A[rc * sai + k * sak] : 0.0;
-            const double b = kin ? B[k * sbk + rc * sbj] : 0.0;
-            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-        }
-        if (in) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = kq + 4 * r;
-                if (row < 14) {
-                    double* p = Cm + row * sci + rc * scj;
-                    *p = (acc ? *p : 0.0) + alpha * c[r];
-                }
-            }
-        }
-    }
-
-    // Li = L^-1 (row-major, lower) where L L' = M, for the 14x14 SPD pivot tile in LDS.  Lane i keeps row i of
-    // M/L in VGPRs; pivots, column entries and the rows needed by the inversion travel by readlane:
-    // 105 broadcasts for the factorisation, 105 for the inverse, no barrier inside.
-    __device__ __forceinline__ bool chol_inv14(const double* M, double* Li) {
-        const int i = lane();
-        const int r = i < 14 ? i : 13;
-        double m[14];
-#pragma unroll
-        for (int c = 0; c < 14; c++) m[c] = M[14 * r + c];
-        // dynamic regularisation (same rule as the host executor): pivots below 1e-13 * max diagonal are clamped
-        double dmax = 0.0;
-#pragma unroll
-        for (int j = 0; j < 14; j++) dmax = fmax(dmax, M[15 * j]);   // same address in every lane: LDS broadcast reads
-        const double floor_ = fmax(1e-13 * dmax, 1e-300);
-        bool ok = dmax > 0.0;
-        double ipv[14];   // 1 / L[j][j], identical in every lane: the inverse below multiplies instead of dividing
-#pragma unroll
-        for (int j = 0; j < 14; j++) {
-            const double d0 = bcast(m[j], j);
-            ok = ok && (d0 == d0);
-            const double d = fmax(d0, floor_);          // NaN-safe: fmax returns the non-NaN operand
-            // 1/sqrt(d) from v_rsq_f64 and two Newton steps (d is a clamped positive pivot: no special cases) — the
-            // library sqrt + division pair is ~50 dependent instructions on this critical path, this is 9
-            double ip = __builtin_amdgcn_rsq(d);
-            const double hd = 0.5 * d;
-            ip = fma(ip, fma(-hd * ip, ip, 0.5), ip);
-            ip = fma(ip, fma(-hd * ip, ip, 0.5), ip);
-            ipv[j] = ip;
-            m[j] = (i == j) ? d * ip : m[j] * ip;       // rows above j hold junk in column j, never read
-#pragma unroll
-            for (int c = j + 1; c < 14; c++) {
-                const double lcj = bcast(m[j], c);
-                m[c] = fma(-m[j], lcj, m[c]);   // rows i < c update junk (their upper triangle is never read): no select
-            }
-        }
-        // inverse: lane c owns column c of L^-1: x[i] = (delta_ic - sum_{t=c}^{i-1} L[i][t] x[t]) / L[i][i]
-        double x[14];
-#pragma unroll
-        for (int a = 0; a < 14; a++) {
-            double acc = (a == i) ? 1.0 : 0.0;
-#pragma unroll
-            for (int t = 0; t < a; t++) {
-                const double lat = bcast(m[t], a);  // L[a][t]
-                acc = fma(-lat, x[t], acc);         // x[t] = 0 for t < i: no select
-            }
-            x[a] = (a >= i) ? acc * ipv[a] : 0.0;
-        }
-        if (i < 14) {
-#pragma unroll
-            for (int a = 0; a < 14; a++) Li[14 * a + i] = x[a];
-        }
-        return ok;
-    }
-
-    // out_k = z_k + N_k out_{k-1} (forward) / out_k = z_k + N_{k+1}' out_{k+1} (reverse) for NR right-hand sides at
-    // once: the only sequential part of the block-tridiagonal solve, run entirely on the FP64 matrix pipe.
-    // (N_k is the NEGATED coupling tile, stored TRANSPOSED: element (i, j) at 14 j + i — see Solver::S_solve.)
-    //
-    // One step is  D = Z_k E + N_k T_{k-1}  as five v_mfma_f64_16x16x4:  T holds the NR running 14-vectors as columns
-    // 0..NR-1.  With the fragment maps of tile_gemm, register r of lane (g = l>>4, n = l&15) of the result is
-    // D[g + 4r][n]; feeding MFMA c the k-slots {g + 4c} makes its B operand B[g + 4c][n] = register c of the SAME lane
-    // of the previous result — the recurrence never leaves the accumulator registers: no LDS, no cross-lane traffic,
-    // no barrier.  The A operands are plain loads from the tile (forward, lane (g, row): element (g + 4c) * 14 + row,
-    // 4 runs of 14 consecutive doubles per instruction; reverse: the transposed element 14 row + g + 4c), and z rides in a fifth MFMA against a constant selector
-    // (A[row][16 + g] = z_g[row], B[16 + g][n] = delta(g, n)), issued ahead of the dependent four.  Operands for step
-    // s + R are requested while step s runs (R x 10 VGPRs in flight).
-    template <int NR>
-    __device__ __forceinline__ void chain_n(int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
-                                               bool reverse) {
-        chain_range_n<NR>(K, z, N, o, reverse, reverse ? K - 1 : 0, K, true);
-    }
-    // The same recurrence over ns nodes starting at node k0 (the first one without a coupling term), for the two-ended
-    // solve of BlockEx<4>: K is only the number of tiles (the reverse form reads the tile of node k + 1).
-    template <int NR>
-    __device__ __forceinline__ void chain_range_n(int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
-                                                     bool reverse, int k0, int ns, bool store_first) {
-        static_assert(NR >= 1 && NR <= 4, "right-hand sides ride in k-slots 16..19");
-        constexpr int R = SCVX_CHAIN_R;
-        const int l = lane(), n = l & 15, g = l >> 4;
-        const bool rin = n < 14;   // for the A operands n is the tile row
-        // every lane loads from a valid (clamped) address and masks the value afterwards: a predicated load would
-        // compile to a branch around each of the five loads of a step
-        int offA[4];
-        double mA[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int kk = g + 4 * c;
-            const bool in = rin && kk < 14;
-            offA[c] = in ? (reverse ? 14 * n + kk : kk * 14 + n) : 0;
-            mA[c] = in ? 1.0 : 0.0;
-        }
-        const bool zin = rin && g < NR;
-        const int offZ = zin ? n : 0;
-        ipm::cgptr zp = z[0];
-        ipm::gptr op = o[0];
-#pragma unroll
-        for (int q = 1; q < NR; q++) {
-            if (g == q) zp = z[q];
-            if (n == q) op = o[q];
-        }
-        const double bsel = (g == n) ? 1.0 : 0.0;
-        const bool oin = n < NR;
-        const bool oin3 = oin && g < 2;   // register 3 holds row g + 12
-        const int dk = reverse ? -1 : 1;
-        double st[R][5];
-        auto issue = [&](int s, double (&f)[5]) {
-            const int k = k0 + dk * s;
-            ipm::cgptr base = N + (size_t)(reverse ? (k + 1 < K ? k + 1 : k) : k) * 196;   // reverse: the tile of node k + 1
-#pragma unroll
-            for (int c = 0; c < 4; c++) f[c] = base[offA[c]];
-            f[4] = zp[14 * k + offZ];
-        };
-#pragma unroll
-        for (int q = 0; q < R; q++)
-            if (q < ns) issue(q, st[q]);
-        v4f64 d = {0.0, 0.0, 0.0, 0.0};
-        for (int s0 = 0; s0 < ns; s0 += R) {
-#pragma unroll
-            for (int q = 0; q < R; q++) {
-                const int s = s0 + q;
-                if (s < ns) {
-                    // the first node has no coupling term (its tile is never written: mask, don't multiply)
-                    const double m0 = s > 0 ? 1.0 : 0.0;
-                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(zin ? st[q][4] : 0.0, bsel, acc, 0, 0, 0);
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const double a = (mA[c] * m0 != 0.0) ? st[q][c] : 0.0;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, d[c], acc, 0, 0, 0);
-                    }
-                    d = acc;
-                    // operands of step s + R go into the registers this step has just consumed
-                    if (s + R < ns) issue(s + R, st[q]);
-                    const int k = k0 + dk * s;
-                    const bool st_ = store_first || s > 0;
-                    if (oin && st_) {
-                        op[14 * k + g] = d[0];
-                        op[14 * k + g + 4] = d[1];
-                        op[14 * k + g + 8] = d[2];
-                    }
-                    if (oin3 && st_) op[14 * k + g + 12] = d[3];
-                }
-            }
-        }
-    }
-    __device__ __forceinline__ void chain(int K, ipm::cgptr z, ipm::cgptr N, ipm::gptr out, bool reverse) {
-        const ipm::cgptr zs[1] = {z};
-        const ipm::gptr os[1] = {out};
-        chain_n<1>(K, zs, N, os, reverse);
-    }
-};
-
-// Small batches: NW wavefronts cooperate on ONE trajectory (a lone wavefront per trajectory leaves most of the chip idle
-// below a few hundred trajectories and each solve is latency-bound: 26 ms per subproblem).  The streaming sweeps, the
-// E / E' products and the node loops of the solver are written against lane()/nlanes(), so they simply spread over
-// 64 NW lanes; the 14x14 tile arithmetic and the block recurrences stay on wavefront 0 (they are sequential in k), with
-// workgroup barriers where the single-wavefront executor needs none.  Reductions go through LDS in a fixed order, so
-// every lane of the workgroup sees bit-identical scalars (uniform control flow, as in WaveEx).
-typedef WaveExT<3> WaveEx;
-
-template <int NW, int NU_ = 3>
-struct BlockEx {
-    WaveExT<NU_> w0;
-    static constexpr int kLanes = 64 * NW;
-    static constexpr int kPrefetchRegs = 1;
-    // the factorisation loop as a producer / consumer pair of wavefronts (Solver::factor_pipelined)
-    static constexpr bool kPipelineFactor = SCVX_K4_PIPELINE != 0;
-    // two-ended (twisted) factorisation and solve: the chain is eliminated from both ends towards the middle block by two
-    // producer / consumer pairs, and the solve's recurrences run on wavefronts 0 and 2 side by side (Solver::factor_twisted)
-    static constexpr bool kTwisted = NW == 4 && SCVX_K4_PIPELINE != 0 && SCVX_K4_TWISTED != 0;
-    __device__ __forceinline__ double* pipe_scratch2() { return socp_pipe_lds2<NU_>(); }
-    template <int NR>
-    __device__ __forceinline__ void chain_range_n(int wv, int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
-                                                     bool reverse, int k0, int ns, bool store_first) {
-        if (wave() == wv) w0.template chain_range_n<NR>(K, z, N, o, reverse, k0, ns, store_first);
-    }
-    __device__ __forceinline__ int wave() const { return (int)(threadIdx.x >> 6); }
-    __device__ __forceinline__ int wlane() const { return (int)(threadIdx.x & 63); }
-    __device__ __forceinline__ double* pipe_scratch() { return socp_pipe_lds<NU_>(); }
-    __device__ __forceinline__ void w_sync_lds() { w0.sync_lds(); }
-    __device__ __forceinline__ void w_tile_gemm(double* Cm, int sci, int scj, const double* A, int sai, int sak, const double* B,
-                                                int sbk, int sbj, int Kd, double alpha, bool acc) {
-        w0.tile_gemm(Cm, sci, scj, A, sai, sak, B, sbk, sbj, Kd, alpha, acc);
-    }
-    __device__ __forceinline__ bool w_chol_inv14(const double* M, double* Li) { return w0.chol_inv14(M, Li); }
-    __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
-    __device__ __forceinline__ int nlanes() const { return 64 * NW; }
-    __device__ __forceinline__ void sync() { __syncthreads(); }
-    __device__ __forceinline__ void sync_lds() { __syncthreads(); }
-    __device__ __forceinline__ double* scratch() { return socp_lds<NU_>(); }
-    __device__ __forceinline__ bool first() const { return threadIdx.x < 64; }
-    // slots 0..NW-1 of the scratch header hold the per-wavefront partials, slot 16 a flag
-    template <class OP>
-    __device__ __forceinline__ double reduce(double x, OP op) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x = op(x, __shfl_xor(x, o, 64));
-        double* red = socp_lds<NU_>();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
-        __syncthreads();
-        double r = red[0];
-#pragma unroll
-        for (int q = 1; q < NW; q++) r = op(r, red[q]);
-        __syncthreads();   // the partials may be overwritten by the next reduction
-        return r;
-    }
-    __device__ __forceinline__ double sum(double x) { return reduce(x, [](double a, double b) { return a + b; }); }
-    __device__ __forceinline__ double min(double x) { return reduce(x, [](double a, double b) { return fmin(a, b); }); }
-    __device__ __forceinline__ bool all(bool b) { return __syncthreads_and(b ? 1 : 0) != 0; }
-    __device__ __forceinline__ void tile_gemm(double* Cm, int sci, int scj, const double* A, int sai, int sak, const double* B,
-                                              int sbk, int sbj, int Kd, double alpha, bool acc) {
-        if (first()) w0.tile_gemm(Cm, sci, scj, A, sai, sak, B, sbk, sbj, Kd, alpha, acc);
-    }
-    __device__ __forceinline__ bool chol_inv14(const double* M, double* Li) {
-        double* flag = socp_lds<NU_>() + 16;
-        if (first()) {
-            const bool ok = w0.chol_inv14(M, Li);
-            if (threadIdx.x == 0) *flag = ok ? 1.0 : 0.0;
-        }
-        __syncthreads();
-        const bool ok = *flag != 0.0;
-        __syncthreads();
-        return ok;
-    }
-    __device__ __forceinline__ void chain(int K, ipm::cgptr z, ipm::cgptr N, ipm::gptr out, bool reverse) {
-        if (first()) w0.chain(K, z, N, out, reverse);
-    }
-    template <int NR>
-    __device__ __forceinline__ void chain_n(int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR], bool reverse) {
-        if (first()) w0.template chain_n<NR>(K, z, N, o, reverse);
-    }
-};
-
-// Running totals over the solve_steps enqueued since the last scvx_batch_get_step_stats (one atomic per trajectory per
-// step): what a timed region actually executed -- conic solves, their interior-point iterations, how many were warm-started or
-// skipped, how many steps were rejected / failed.
-enum { ACC_TRAJ_STEPS = 0, ACC_SOLVES, ACC_IPM_ITERS, ACC_WARM, ACC_SKIPPED, ACC_REJECTED, ACC_FAILED, ACC_CONVERGED, ACC_N };
-
-// info[b] = {status, iters, merit, pobj}
-// DS: element type of the linearisation the discretisation kernel wrote (double; float behind scvx_batch_set_linearization_f32)
-template <class Ex, class DS = double, int NU = 3>
-__device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t work_stride, const double* x, const double* u,
-                                          const double* endpoint, const DS* deriv, const double* rk, const double* ic,
-                                          const int* active, double* work, double* sol, double* nu, double* info,
-                                          const int* step_status, double* ttr, double* acc) {
-    const int b = blockIdx.x;
-    if (b >= B) return;
-    if (active && !active[b]) return;
-    // Opt-in shortcut (scvx_solver_opts.reuse_inactive_tr): after a REJECTED step the subproblem is the same one with a
-    // halved radius (rocketland.jl:299-301 keeps about / dynam).  If the optimum just found lies strictly inside the new
-    // radius, the radius row is inactive with a zero multiplier and that optimum still satisfies every KKT condition of
-    // the new subproblem: the solve would return it again.  sol / nu / info are left as they are; iters = 0 marks it.
-    if (C.pad && step_status[b] == SCVX_ST_REJECTED && ttr[b] <= (1.0 - 1e-6) * rk[b]) {
-        if (threadIdx.x == 0) { info[4 * b + 1] = 0.0; atomicAdd(acc + ACC_SKIPPED, 1.0); }
-        return;
-    }
-    const int K = C.K;
-    Ex ex;
-    ipm::Solver<Ex, double, DS, NU> S(ex, C);
-    // kernel arguments are HBM pointers: hand them to the solver typed as such (see ipm::gptr)
-    // warm start: the last solve in this slab was for the same about / dynam (its step was rejected) and is still valid
-    const bool warm = C.warm && step_status[b] == SCVX_ST_REJECTED && ttr[b] < 1e300;
-    const ipm::Result r = S.solve((ipm::cgptr)(x + (size_t)b * (K + 1) * 14), (ipm::cgptr)(u + (size_t)b * (K + 1) * NU),
-                                  (ipm::cgptr)(endpoint + (size_t)b * K * 14), (typename ipm::gp<DS>::cptr)(deriv + (size_t)b * K * (14 * (14 + 2 * NU + 1))), rk[b],
-                                  (ipm::cgptr)(ic + (size_t)b * 6), (ipm::gptr)(work + (size_t)b * work_stride), warm);
-    const int nxu = S.L.nx + S.L.nu_;
-    const int nl = ex.nlanes();
-    double* so = sol + (size_t)b * (nxu + 1);
-    for (int i = threadIdx.x; i < nxu; i += nl) so[i] = S.V[i];
-    double* no = nu + (size_t)b * S.L.ny;
-    for (int i = threadIdx.x; i < S.L.ny; i += nl) no[i] = S.V[nxu + i];
-    if (threadIdx.x == 0) {
-        so[nxu] = S.V[S.L.iS];
-        info[4 * b + 0] = (double)r.status;
-        info[4 * b + 1] = (double)r.iters;
-        info[4 * b + 2] = r.merit;
-        info[4 * b + 3] = r.pobj;
-        ttr[b] = S.V[S.L.iTTR];   // the trust-region norm bound at the optimum (Jtr of build_model)
-        atomicAdd(acc + ACC_SOLVES, 1.0);
-        atomicAdd(acc + ACC_IPM_ITERS, (double)r.iters);
-        if (r.warmed) atomicAdd(acc + ACC_WARM, 1.0);
-#if defined(SCVX_IPM_PROF)
-        if (b == 0) for (int i = 0; i < 32; i++) work[i] = S.prof[i];  // diagnostic build: section cycles of trajectory 0
-#endif
-    }
-#if defined(SCVX_IPM_PROF)
-    if (b == 0 && threadIdx.x > 0 && (threadIdx.x & 63) == 0 && threadIdx.x < 256)
-        for (int i = 0; i < 32; i++) work[32 * (threadIdx.x >> 6) + i] = S.prof[i];  // ... and of its other wavefronts
-#endif
-}
-
-// one wavefront per trajectory (large batches: the chip is filled by trajectories)
-#ifndef SCVX_K4_OCC
-// Wavefronts per SIMD the single-wavefront solver is compiled for.  Measured (profiles/r02_k4_sections.md): 2 and 3 give
-// the same throughput at B = 8192 (143 vs 142 ms per solve of the batch: the kernel runs at the HBM streaming rate either
-// way), 2 is 4 % faster below 3,072 trajectories, and at 2 (<= 256 VGPRs) nothing spills -- at 3 (168 VGPRs) 147
-// registers did.  4 (128 VGPRs) is 17 % slower, 1 is 40 % slower at the full batch.
-#define SCVX_K4_OCC 2
-#endif
-template <class DS, int NU>
-__global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_kernel_t(ipm::Consts C, int B, size_t work_stride,
-                                                  const double* __restrict__ x, const double* __restrict__ u,
-                                                  const double* __restrict__ endpoint, const DS* __restrict__ deriv,
-                                                  const double* __restrict__ rk, const double* __restrict__ ic,
-                                                  const int* __restrict__ active, double* __restrict__ work,
-                                                  double* __restrict__ sol, double* __restrict__ nu,
-                                                  double* __restrict__ info, const int* __restrict__ step_status,
-                                                  double* __restrict__ ttr, double* __restrict__ acc) {
-    socp_body<WaveExT<NU>, DS, NU>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr, acc);
-}
 // the reference's model (control_dim = 3) keeps its two named kernels: profiles and tools refer to them
 __global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_kernel(ipm::Consts C, int B, size_t work_stride,
                                                   const double* __restrict__ x, const double* __restrict__ u,
@@ -460,23 +50,6 @@ __global__ __launch_bounds__(64, SCVX_K4_OCC) void socp_lin32_kernel(ipm::Consts
     socp_body<WaveEx, float>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr, acc);
 }
 
-// NW wavefronts per trajectory (batches that cannot fill the chip with one wavefront each)
-// Compiled for 2 wavefronts per SIMD like socp_kernel (248 VGPRs, no spills; unconstrained the compiler takes 274 = one
-// per SIMD, and a batch of more than 1,024 / NW trajectories runs in two rounds: B = 1,024 with NW = 2 took 14.5 ms, now 9.9).
-#ifndef SCVX_K4_BLOCK_OCC
-#define SCVX_K4_BLOCK_OCC 2
-#endif
-template <int NW, class DS = double, int NU = 3>
-__global__ __launch_bounds__(64 * NW, SCVX_K4_BLOCK_OCC) void socp_block_kernel(ipm::Consts C, int B, size_t work_stride,
-                                                  const double* __restrict__ x, const double* __restrict__ u,
-                                                  const double* __restrict__ endpoint, const DS* __restrict__ deriv,
-                                                  const double* __restrict__ rk, const double* __restrict__ ic,
-                                                  const int* __restrict__ active, double* __restrict__ work,
-                                                  double* __restrict__ sol, double* __restrict__ nu,
-                                                  double* __restrict__ info, const int* __restrict__ step_status,
-                                                  double* __restrict__ ttr, double* __restrict__ acc) {
-    socp_body<BlockEx<NW, NU>, DS, NU>(C, B, work_stride, x, u, endpoint, deriv, rk, ic, active, work, sol, nu, info, step_status, ttr, acc);
-}
 
 // cand = about + step (x, u in one contiguous [B][(K+1)*17+1] trajectory record, sigma last)
 __global__ void candidate_kernel(int B, int nrec, const double* __restrict__ traj, const double* __restrict__ sol,
@@ -690,8 +263,9 @@ int socp_waves(int B, int num_cus) {
     return B <= 2 * cus ? 4 : (B <= 4 * cus ? 2 : 1);
 }
 
-template <int NW, int NU = 3>
+template <int NW>
 void launch_socp_block(scvx_batch* b, const int* mask) {
+    constexpr int NU = 3;
     if (b->deriv_f)
         hipLaunchKernelGGL((scvx::socp_block_kernel<NW, float, NU>), dim3(b->B), dim3(64 * NW), 0, b->ctx->stream, b->C, b->B, b->work_stride,
                            b->x, b->u, b->endpoint, b->deriv_f, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr, b->acc);
@@ -712,15 +286,10 @@ int enqueue_socp(scvx_batch* b, const int* mask) {
     // scvx_solve's tail: once few trajectories are still live the solve is latency-bound again, and the executors with
     // several wavefronts per trajectory (dead blocks return at once) finish a step in half the time
     const int w = socp_waves(b->nlive_hint >= 0 && b->nlive_hint < b->B ? (b->nlive_hint > 0 ? b->nlive_hint : 1) : b->B, b->ctx->num_cus);
-    if (b->NU == 5) {   // fin extension: the same three executors, instantiated for control_dim = 5
-        if (w == 4) launch_socp_block<4, 5>(b, mask);
-        else if (w == 2) launch_socp_block<2, 5>(b, mask);
-        else if (b->deriv_f)
-            hipLaunchKernelGGL((scvx::socp_kernel_t<float, 5>), dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
-                               b->endpoint, b->deriv_f, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr, b->acc);
-        else
-            hipLaunchKernelGGL((scvx::socp_kernel_t<double, 5>), dim3(b->B), dim3(64), 0, b->ctx->stream, b->C, b->B, b->work_stride, b->x, b->u,
-                               b->endpoint, b->deriv, b->rk, b->ic, mask, b->work, b->sol, b->nu, b->info, b->status, b->ttr, b->acc);
+    if (b->NU == 5) {   // fin extension: the same three executors, instantiated for control_dim = 5 in scvx_socp_fin.hip
+        scvx::SocpLaunch a{b->C, b->B, b->work_stride, b->x, b->u, b->endpoint, b->deriv, b->deriv_f, b->rk, b->ic, mask,
+                           b->work, b->sol, b->nu, b->info, b->status, b->ttr, b->acc, b->ctx->stream};
+        scvx::launch_socp_fin(a, w);
     } else if (w == 4) launch_socp_block<4>(b, mask);
     else if (w == 2) launch_socp_block<2>(b, mask);
     else if (b->deriv_f)
