@@ -9,6 +9,8 @@
 //     linearize_kernel : Dynamics.linearize_dynamics on the new reference (K1)   (:318)
 // all on one stream, nothing returning to the host in between.
 //
+// The executors, the kernel body and the kernel templates of the conic solve are in scvx_socp.hpp; this file instantiates them for
+// the reference's model (control_dim = 3), scvx_socp_fin.hip for the fin extension (control_dim = 5).
 // socp_kernel runs ONE 64-LANE WAVEFRONT PER TRAJECTORY over the portable interior-point core
 // (scvx_ipm_core.hpp): lanes split the per-node cone work, the 14x14 tile arithmetic of the block-
 // tridiagonal Schur complement and the long dot products of the two big trust-region cones; reductions

@@ -177,9 +177,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, sizeof(R) == 4 ? 2 : 1) void 
 // ~440 instructions per stage) because SIMD lanes of a segment run in lock-step.  Here a block of 8 wavefronts
 // splits the roles:
 //   wave 0   (producer)  one LANE PER SEGMENT: integrates the 14 states of NS segments and publishes, for every RK
-//                        stage, the coefficient record a column needs (StageRec) into a double-buffered LDS slab;
-//   waves 1-7 (consumers) one lane per sensitivity column (15 per segment exo, 4 segments per wave; 21 x 3 aero):
-//                        read their segment's record (LDS broadcast), advance the column.
+//                        stage, the coefficient record a column needs (StageRec) into a double-buffered LDS slab --
+//                        group by group as it is computed, the force derivatives one column at a time
+//                        (stage_eval_publish, scvx_dyn.hpp: only the RHS stays live for the state update);
+//   waves 1-7 (consumers) one lane per sensitivity column (15 per segment exo, 4 segments per wave; 21 x 3 aero; 25 x 2 with
+//                        the fin extension): read their segment's record in three batches (LDS broadcast), advance the column.
 // One barrier per RK stage, the producer one stage ahead through a 2-slot ring (SG; or per substep, one substep ahead,
 // 8 slots).  The stage evaluation is executed once per 28 (21)
 // segments instead of once per 4 (3): ~1.8x fewer instructions per segment.  Output tiles leave through LDS as
