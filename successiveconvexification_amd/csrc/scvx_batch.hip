@@ -88,12 +88,15 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
                                                        int* __restrict__ iter, int* __restrict__ status,
                                                        const int* mask /* may be `active` or `live` itself */, int* active,
                                                        int* live, double* __restrict__ out, double* __restrict__ acc,
-                                                       int* __restrict__ nlive) {
+                                                       int* __restrict__ nlive, int* __restrict__ k1skip) {
     const int b = blockIdx.x;
     if (b >= B) return;
     // not stepped by this call (failed earlier, or converged inside scvx_solve): status[b] keeps saying why and
-    // out[b] keeps the (nu, dJ) of the last step this trajectory did take
-    if (!mask[b]) return;
+    // out[b] keeps the (nu, dJ) of the last step this trajectory did take; its iterate is unchanged: K1 skips it
+    if (!mask[b]) {
+        if (threadIdx.x == 0) k1skip[b] = SCVX_ST_REJECTED;
+        return;
+    }
     const int K = P.K, nrec = (K + 1) * (14 + P.NU) + 1;
     const double* c = cand + (size_t)b * nrec;
     const double* xp = xprop + (size_t)b * K * 14;
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(64) void tr_update_kernel(TrParams P, int B, const 
         }
         if (was_live && !live[b]) atomicSub(nlive, 1);   // device-side count of the trajectories scvx_solve still steps
         status[b] = st;
+        k1skip[b] = accept && st != SCVX_ST_SOLVER && st != SCVX_ST_NONFINITE && st != SCVX_ST_INFEASIBLE ? SCVX_ST_RUNNING : SCVX_ST_REJECTED;   // re-linearise only a new reference point (rocketland.jl:318; :301 returns before it)
         out[2 * b] = nun;
         out[2 * b + 1] = dJ;
         atomicAdd(acc + ACC_TRAJ_STEPS, 1.0);
@@ -203,6 +207,7 @@ struct scvx_batch {
     double *rk = nullptr, *cost = nullptr, *ic = nullptr, *info = nullptr, *out = nullptr, *work = nullptr;
     double *ttr = nullptr;   // trust-region norm bound at the last optimum (reuse_inactive_tr)
     double *acc = nullptr;   // scvx::ACC_N running totals (scvx_batch_get_step_stats)
+    int *k1skip = nullptr;   // per trajectory: >= SCVX_ST_REJECTED = the reference point did not change in the last step (K1 skips it)
     int *d_nlive = nullptr;  // device-side count of live trajectories (scvx_solve), mirrored asynchronously into pinned h_nlive[2]
     int *h_nlive = nullptr;
     hipEvent_t ev_nlive[2] = {nullptr, nullptr};
@@ -337,14 +342,14 @@ int enqueue_step(scvx_batch* b, const int* mask) {
     SCVX_HIP(ctx, scvx::launch_propagate(ctx, b->B, b->K, b->cx, b->cu, b->csigma, dt, b->xprop, st));
     if ((rc = mark(b))) return rc;
     hipLaunchKernelGGL(scvx::tr_update_kernel, dim3(b->B), dim3(64), 0, st, b->tr, b->B, b->cand, b->xprop, b->nu, b->info,
-                       b->traj, b->rk, b->cost, b->iter, b->status, mask, b->active, b->live, b->out, b->acc, b->d_nlive);
+                       b->traj, b->rk, b->cost, b->iter, b->status, mask, b->active, b->live, b->out, b->acc, b->d_nlive, b->k1skip);
     SCVX_HIP(ctx, hipGetLastError());
     if ((rc = mark(b))) return rc;
     rc = split_views(b, b->traj, b->x, b->u, b->sigma);
     if (rc) return rc;
     if ((rc = mark(b))) return rc;
     // rocketland.jl:318; a rejected step returns before it (:301, about / dynam kept): those trajectories are skipped
-    SCVX_HIP(ctx, relinearize(b, b->status));
+    SCVX_HIP(ctx, relinearize(b, b->k1skip));
     if ((rc = mark(b))) return rc;
     return SCVX_OK;
 }
@@ -414,6 +419,7 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     scvx::ipm::Layout L;
     L.init(K, C.vmax > 0.0, b->NU);
     b->work_stride = (L.work_doubles() + 7) & ~(size_t)7;
+    if (const char* v = std::getenv("SCVX_WORK_PAD"); v && *v) b->work_stride += (size_t)std::atoi(v) & ~(size_t)7;   // diagnostic: extra doubles between the slabs
     const size_t nB = (size_t)B;
     int rc = 0;
     rc |= dmalloc(ctx, &b->traj, nB * b->nrec);
@@ -438,6 +444,7 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     rc |= dmalloc(ctx, &b->ttr, nB);
     rc |= dmalloc(ctx, &b->acc, (size_t)scvx::ACC_N);
     rc |= dmalloc(ctx, &b->d_nlive, (size_t)1);
+    rc |= dmalloc(ctx, &b->k1skip, nB);
     if (!rc && (hipHostMalloc((void**)&b->h_nlive, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
                 hipEventCreateWithFlags(&b->ev_nlive[0], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&b->ev_nlive[1], hipEventDisableTiming) != hipSuccess)) rc = SCVX_ERR_HIP;
@@ -462,7 +469,7 @@ void scvx_batch_destroy(scvx_batch* b) {
     for (hipEvent_t e : b->ev_nlive) if (e) (void)hipEventDestroy(e);
     if (b->h_nlive) (void)hipHostFree(b->h_nlive);
     void* ptrs[] = {b->traj0, b->traj, b->cand, b->sol, b->x, b->u, b->sigma, b->cx, b->cu, b->csigma, b->endpoint, b->deriv, b->xprop,
-                    b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active, b->live, b->ttr, b->deriv_f, b->acc, b->d_nlive};
+                    b->nu, b->rk, b->cost, b->ic, b->info, b->out, b->work, b->iter, b->status, b->active, b->live, b->ttr, b->deriv_f, b->acc, b->d_nlive, b->k1skip};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete b;
