@@ -108,10 +108,12 @@ def test_fin_socp_matches_independent_oracle_on_every_executor(with_aero, K, aer
     try:
         for waves in ("1", "2", "4"):
             os.environ["SCVX_K4_WAVES"] = waves
-            b = ScvxBatch(c, 1).init(None)
+            # both solvers at the oracle's tolerance (1e-9): the optimum is flat, and at the device default (1e-8) the distance
+            # between two valid answers at K = 100 is 1e-5 .. 3e-5 in u depending on the path taken (seen with two starting points)
+            b = ScvxBatch(c, 1, tol=1e-9).init(None)
             xs, us, ss, nu = _check_fin_socp(po, ic, b, 100.0)
             st, its, merit, pobj = b.solver_stats()
-            assert st[0] == 0 and merit[0] < 1e-8
+            assert st[0] == 0 and merit[0] < 1e-9
             assert np.abs(xs[0] - xo).max() < 2e-5 and np.abs(us[0] - uo).max() < 2e-5, (waves, np.abs(xs[0] - xo).max(), np.abs(us[0] - uo).max())
             assert abs(ss[0] - (it0.sigma + sol.x[ix.dsig])) < 2e-5
             xb, ub = it0.x, it0.u
