@@ -456,7 +456,9 @@ def main():
                 "rejected_frac": tstats["rejected"] / max(tstats["traj_steps"], 1.0),
                 "failed_steps": int(tstats["failed"]), "converged_steps": int(tstats["converged"]),
                 "note": "totals over the timed solve_steps of rank 0's shard (device-side counters, scvx_batch_get_step_stats): the "
-                        "throughput depends on this mix -- a step whose solves are warm-started (after a rejection) costs ~1/3 of a cold one",
+                        "throughput depends on this mix -- a solve after a rejected step starts from the kept optimum of the same subproblem and, while that "
+                        "point lies inside the halved radius, its first residual evaluation (of the new problem) already meets the tolerance: 1 iteration, no factorisation; "
+                        "cold_start_only below is the figure with every solve started from scratch",
             },
             "roofline_socp": None if k4_ms <= 0 else {
                 "kernel": "scvx::socp_kernel (K4, the conic solve: 97 % of the step)", "bound": "hbm", "unit": "GB/s",

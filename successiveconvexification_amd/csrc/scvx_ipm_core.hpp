@@ -65,6 +65,13 @@
 #ifndef SCVX_INIT_SHIFT
 #define SCVX_INIT_SHIFT 0.25
 #endif
+// a solve after a rejected step restarts from the kept iterate while that iterate's trust-region norm is below this fraction of the new radius
+// (twin, bench mix, iterations per solve: 0.7 13.23, 0.8 13.16, 0.9 13.03, 1.0 12.74, 1.1 12.70, 1.2 12.77, 1.5 12.87, 2.0 14.36 with
+// failures, no condition 16.84 with failures: the kept iterate must still lie inside the new radius)
+// (those figures with the iterate kept at merit 1e-4).  Just below 1: the recomputed radius slack then stays above its floor (1e-3 rk).
+#ifndef SCVX_WARM_RADIUS
+#define SCVX_WARM_RADIUS 0.999
+#endif
 // fraction of the distance to the cone boundary taken by the combined step
 #ifndef SCVX_STEP_FRAC
 #define SCVX_STEP_FRAC 0.98
@@ -85,10 +92,15 @@
 // same subproblem data starts from it (only the radius row differs, and it is used only while that row stays inactive:
 // the old central path is then the new one).  Measured on 256 trajectories x 14 steps (tools/twin_stats.py --warm), IPM
 // iterations of a warm-started solve / mean over all solves: kept at 1e-2: 7.3 / 15.2, 1e-3: 6.0 / 14.7, 1e-4: 5.0 / 14.3,
-// 1e-5: 3.9 / 13.9 (cold: 19.0 / 19.7); every solve status 0 in all four.  1e-4 keeps a well-centred iterate and leaves the
-// warm solve five genuine iterations.
+// 1e-5: 3.9 / 13.9 (cold: 19.0 / 19.7); every solve status 0 in all four.  Rounds 2-3 shipped 1e-4 ("a well-centred iterate").
+// Late round 3, with the kept iterate required to lie inside the new radius (SCVX_WARM_RADIUS), later is better all the way to the
+// optimum itself -- mean iterations per solve on the bench mix / first failures on 100 random classes (tools/k4_fuzz.py):
+// 1e-4 12.74 / 1.19 %, 1e-5 12.26, 1e-6 11.83, 1e-7 11.44, 3e-8 11.25 / 1.03 %, the optimal iterate (merit < tol) 11.10 / 0.96 %.
+// Kept at the optimum, the next solve's first residual evaluation -- of the NEW problem, with the new radius row -- usually finds
+// the optimality conditions met and returns after that evaluation (status 0, 1 iteration, no factorisation); otherwise the iteration
+// carries on from there.  The value is a multiple of the solver tolerance.
 #ifndef SCVX_WARM_SAVE
-#define SCVX_WARM_SAVE 1e-4
+#define SCVX_WARM_SAVE 1.0
 #endif
 #ifndef SCVX_STREAM_U
 #define SCVX_STREAM_U 4   // elements in flight per lane in the streaming loops (Solver::stream)
@@ -2360,12 +2372,12 @@ struct Solver {
             if (bad) { res.status = 5; return res; }
         }
         cur_gate = INFINITY;
-        // ... and only while the new radius leaves the kept iterate well inside it (Jtr_w < 0.8 rk): then the radius row stays
-        // inactive and the old central path is (nearly) the new one -- 7 iterations instead of 19.  Once the radius starts to
-        // bind the kept iterate is far from the new path and a warm start costs MORE than a cold one (33 vs 21 measured);
+        // ... and only while the kept iterate lies inside the new radius (Jtr_w < SCVX_WARM_RADIUS rk): then the radius row is
+        // inactive or barely active and the old central path is (nearly) the new one -- 7 iterations instead of 19.  Once the radius
+        // binds in earnest the kept iterate is far from the new path and a warm start costs MORE than a cold one (33 vs 21 measured);
         // pulling the kept primal point inside the new radius (a convex combination with the reference point) and keeping
         // the duals breaks down within two iterations on 80 % of such solves: tried, not kept.
-        const bool warmed = warm && wh[0] == 1.0 && Vw[L.iTTR] < 0.8 * rk;
+        const bool warmed = warm && wh[0] == 1.0 && Vw[L.iTTR] < SCVX_WARM_RADIUS * rk;
         res.warmed = warmed ? 1 : 0;
         if (warmed) {
             // same subproblem, new radius: restart from the kept iterate; its radius slack is recomputed (and kept interior)
@@ -2468,7 +2480,7 @@ struct Solver {
                 best_in_V = true;
                 ex.sync();
             }
-            if (!kept && merit < SCVX_WARM_SAVE) {
+            if (!kept && merit < SCVX_WARM_SAVE * C.tol) {
                 copy(Vw, V, L.nv); copy(yw, y, L.ny); copy(Sw, S, L.nc); copy(Zw, Z, L.nc);
                 if (ex.lane() == 0) wh[0] = 1.0;
                 ex.sync();
