@@ -108,9 +108,16 @@ typedef struct scvx_solver_opts {
                        /* and that optimum is provably the new subproblem's optimum too.  The SCvx iterates are unchanged;   */
                        /* on the sample problems ~6 of the 14 solves of a solve_problem are such repeats.                    */
     int32_t warm_start;        /* 1 (default): the solve that follows a REJECTED step (same about / dynam, radius halved,  */
-                       /* rocketland.jl:299-301) starts from the iterate the previous solve passed at merit 1e-4, as long  */
-                       /* as the new radius stays inactive at it -- 5 interior-point iterations instead of 19; every       */
-                       /* solve still runs to `tol`.  0: every solve starts cold, like the reference's.                     */
+                       /* rocketland.jl:299-301) starts from the optimum the previous solve returned, as long as that point */
+                       /* lies inside the new radius: the residuals of the NEW subproblem are evaluated there and the solve */
+                       /* returns at once when they meet `tol` (1 iteration, no factorisation), else it iterates on from    */
+                       /* there; every solve still ends at `tol`.  0: every solve starts cold, like the reference's.        */
+    int32_t retries;           /* default 5, at most 7.  A solve that ends on its numerical floor above `tol` is run again from the   */
+                       /* cold start with another step rule (step fraction, centring exponent, starting shift, centring    */
+                       /* floor), at most this many times, before the trajectory is frozen as SCVX_ST_SOLVER: such failures */
+                       /* sit at the precision floor of the Newton system and move with the path taken.  0: one attempt.    */
+                       /* The iteration count reported for a solve is the sum over its attempts.                            */
+    int32_t reserved0;         /* must be 0 */
 } scvx_solver_opts;
 
 typedef struct scvx_ctx scvx_ctx;     /* owns device, stream, problem constants, aero tables */

@@ -1,6 +1,7 @@
 """ctypes front-end of oracle/scvx_port.cpp — the CPU twin of the device conic solver
 (oracle; rules in oracle/__init__.py).  Consts mirrors scvx::ipm::Consts of scvx_ipm_core.hpp."""
 import ctypes as C
+import os
 import numpy as np
 
 from . import port_lib
@@ -11,7 +12,7 @@ _dp = C.POINTER(C.c_double)
 
 class Consts(C.Structure):
     _fields_ = [("K", C.c_int), ("max_iter", C.c_int), ("refine", C.c_int), ("pad", C.c_int),
-                ("warm", C.c_int), ("pad2", C.c_int),
+                ("warm", C.c_int), ("retries", C.c_int),
                 ("tol", C.c_double), ("accept", C.c_double),
                 ("itan", C.c_double), ("sqcm", C.c_double), ("icos", C.c_double), ("Tmax", C.c_double),
                 ("Tmin", C.c_double), ("omMax", C.c_double), ("mdry", C.c_double), ("wNu", C.c_double),
@@ -20,8 +21,10 @@ class Consts(C.Structure):
                 ("wBi", C.c_double * 3), ("wBf", C.c_double * 3)]
 
 
-def consts(p: DescentProblem, tol=1e-8, max_iter=60, refine=6, accept=0.0) -> Consts:
+def consts(p: DescentProblem, tol=1e-8, max_iter=60, refine=6, accept=0.0, retries=None) -> Consts:
     c = Consts()
+    # the solver's ladder of step rules (scvx_solver_opts.retries, default 5); SCVX_PORT_RETRIES overrides the default (tools)
+    c.retries = int(os.environ.get("SCVX_PORT_RETRIES", "5")) if retries is None else int(retries)
     c.K, c.max_iter, c.refine, c.tol, c.accept = p.K, max_iter, refine, tol, max(accept, tol)
     c.itan = 1.0 / np.tan(np.radians(p.gammaGs))       # rocketland.jl:63
     c.sqcm = np.sqrt((1 - np.cos(np.radians(p.thetaMax))) / 2)  # :64
@@ -39,7 +42,7 @@ def _p(a):
 
 
 def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, max_iter=60, refine=6, nthreads=0, accept=0.0,
-         f32=False, work=None, warm=None, lin32=False):
+         f32=False, work=None, warm=None, lin32=False, retries=None):
     """Batched: xbar [B][K+1][14], ubar [B][K+1][nu], endpoint [B][K][14], deriv [B][K][14+2nu+1][14], rk [B]; nu = 3, or 5
     when p.fins (fin extension).  Returns dict(dx, du, ds, nu, status, iters, merit, pobj)."""
     xbar = np.ascontiguousarray(xbar, float)
@@ -52,7 +55,7 @@ def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, 
     if ic is None:
         ic = np.tile(np.concatenate([p.rIi, p.vIi]), (B, 1))
     ic = np.ascontiguousarray(ic, float)
-    c = consts(p, tol, max_iter, refine, accept)
+    c = consts(p, tol, max_iter, refine, accept, retries)
     NU = 5 if getattr(p, "fins", False) else 3
     assert ubar.shape[-1] == NU and deriv.shape[-2] == 14 + 2 * NU + 1, (ubar.shape, deriv.shape)
     sol = np.zeros((B, (K + 1) * (14 + NU) + 1))

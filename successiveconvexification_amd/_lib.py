@@ -38,7 +38,7 @@ class ScvxProblem(C.Structure):
 
 class ScvxSolverOpts(C.Structure):
     _fields_ = [("max_iter", C.c_int32), ("refine", C.c_int32), ("tol", C.c_double), ("accept_tol", C.c_double),
-                ("reuse_inactive_tr", C.c_int32), ("warm_start", C.c_int32)]
+                ("reuse_inactive_tr", C.c_int32), ("warm_start", C.c_int32), ("retries", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class ScvxThreedofOpts(C.Structure):

@@ -27,7 +27,7 @@ class ScvxBatch:
     """The batched ProblemIteration (master.jl:122-134) living in HBM."""
 
     def __init__(self, cache: IntegratorCache, B: int, tol: float = None, max_iter: int = None, refine: int = None,
-                 accept_tol: float = None, reuse_inactive_tr: bool = None, warm_start: bool = None):
+                 accept_tol: float = None, reuse_inactive_tr: bool = None, warm_start: bool = None, retries: int = None):
         self.cache = cache
         self.B = int(B)
         self.K = cache.problem.K
@@ -37,7 +37,7 @@ class ScvxBatch:
         h = C.c_void_p()
         _lib.check(cache.handle, self._L.scvx_batch_create(cache.handle, self.B, C.byref(h)), "scvx_batch_create")
         self.handle = h
-        if any(v is not None for v in (tol, max_iter, refine, accept_tol, reuse_inactive_tr, warm_start)):
+        if any(v is not None for v in (tol, max_iter, refine, accept_tol, reuse_inactive_tr, warm_start, retries)):
             o = _lib.ScvxSolverOpts()
             self._L.scvx_solver_default_opts(C.byref(o))
             if tol is not None:
@@ -53,6 +53,8 @@ class ScvxBatch:
                 o.reuse_inactive_tr = 1 if reuse_inactive_tr else 0
             if warm_start is not None:
                 o.warm_start = 1 if warm_start else 0
+            if retries is not None:
+                o.retries = int(retries)   # scvx_solver_opts.retries: the ladder of step rules behind a failed solve (0 = one attempt)
             _lib.check(cache.handle, self._L.scvx_batch_set_solver(h, C.byref(o)), "scvx_batch_set_solver")
 
     def _chk(self, rc, what):

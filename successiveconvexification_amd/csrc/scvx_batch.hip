@@ -376,6 +376,8 @@ int scvx_solver_default_opts(scvx_solver_opts* o) {
     o->accept_tol = 1e-8;   // = tol: anything but OPTIMAL is an error, as in the reference (rocketland.jl:273-276); widen to opt in to status 4
     o->reuse_inactive_tr = 0;
     o->warm_start = 1;
+    o->retries = 5;
+    o->reserved0 = 0;
     return SCVX_OK;
 }
 
@@ -402,7 +404,7 @@ int scvx_batch_create(scvx_ctx* ctx, int B, scvx_batch** out) {
     C.accept = b->opts.accept_tol;
     C.pad = b->opts.reuse_inactive_tr;
     C.warm = b->opts.warm_start;
-    C.pad2 = 0;
+    C.retries = b->opts.retries;
     C.itan = 1.0 / std::tan(p.gammaGs * d2r);                       // rocketland.jl:63
     C.sqcm = std::sqrt((1.0 - std::cos(p.thetaMax * d2r)) / 2.0);   // :64
     C.icos = 1.0 / std::cos(p.deltaMax * d2r);                      // :65
@@ -477,8 +479,8 @@ void scvx_batch_destroy(scvx_batch* b) {
 
 int scvx_batch_set_solver(scvx_batch* b, const scvx_solver_opts* o) {
     if (!b || !o) return SCVX_ERR_ARG;
-    if (o->max_iter < 1 || o->refine < 0 || !(o->tol > 0) || !(o->accept_tol >= o->tol))
-        return fail(b->ctx, SCVX_ERR_ARG, "bad solver options (max_iter >= 1, refine >= 0, 0 < tol <= accept_tol)");
+    if (o->max_iter < 1 || o->refine < 0 || !(o->tol > 0) || !(o->accept_tol >= o->tol) || o->retries < 0 || o->retries > 7)
+        return fail(b->ctx, SCVX_ERR_ARG, "bad solver options (max_iter >= 1, refine >= 0, 0 < tol <= accept_tol, 0 <= retries <= 7)");
     b->opts = *o;
     b->C.max_iter = o->max_iter;
     b->C.refine = o->refine;
@@ -486,6 +488,7 @@ int scvx_batch_set_solver(scvx_batch* b, const scvx_solver_opts* o) {
     b->C.accept = o->accept_tol;
     b->C.pad = o->reuse_inactive_tr ? 1 : 0;
     b->C.warm = o->warm_start ? 1 : 0;
+    b->C.retries = o->retries;
     return SCVX_OK;
 }
 

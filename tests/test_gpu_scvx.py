@@ -972,6 +972,56 @@ def test_fuzz_class_that_used_to_stall_matches_independent_oracle():
     b.close(); c.close()
 
 
+def test_retry_ladder_rescues_floor_failures_and_matches_oracle():
+    """scvx_solver_opts.retries (default 5): a conic solve that ends on its numerical floor above `tol` is run again from the cold
+    start under another step rule before its trajectory is frozen.  Class 39 of tools/k4_fuzz.py (K = 50, 55 % dry mass, glideslope
+    28 deg, dynamic-pressure cone on): on the second solve_step three of the 16 dispersed trajectories stall at merit 1.4e-8 ..
+    1.9e-8 with a single attempt (CPU twin; the set differs with the rounding, so the device's own single-attempt run says which).
+    With the ladder every solve is OPTIMAL, and the rescued trajectories agree with two steps of the independent oracle."""
+    import os
+    import sys
+    from dataclasses import replace
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import k4_fuzz
+    from oracle import model, scvx as oscvx
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    rng = np.random.default_rng(1)
+    base = model.base_prob_scaled()
+    for _ in range(40):
+        po = k4_fuzz.draw_class(rng, base)
+    assert po.K == 50 and po.enforce_dp
+    pp = replace(sp.base_prob_scaled, K=po.K, mdry=po.mdry, Tmin=po.Tmin, deltaMax=po.deltaMax, thetaMax=po.thetaMax,
+                 gammaGs=po.gammaGs, omMax=po.omMax, tf_guess=po.tf_guess, model_flags=sp.base_prob_scaled.model_flags | 1)
+    ic = model.disperse_ics(po, 16, 539, 0.3)
+    c = IntegratorCache(pp, npts=4)
+    runs = {}
+    for retries in (0, None):
+        b = ScvxBatch(c, 16, retries=retries).init(ic)
+        sts, its = [], []
+        for n in range(2):
+            st, nun, dj = b.solve_step()
+            sst, sit, merit, _ = b.solver_stats()
+            sts.append(st.copy()); its.append(sit.copy())
+        runs[retries] = (np.array(sts), np.array(its), b.trajectory())
+        b.close()
+    st0, it0, _ = runs[0]
+    st5, it5, (x5, u5, s5) = runs[None]
+    single_failed = np.nonzero((st0 == 3).any(axis=0))[0]
+    print("single attempt: frozen trajectories", single_failed.tolist(), "; with the ladder:", np.nonzero((st5 == 3).any(axis=0))[0].tolist(),
+          "; iterations of step 2 (ladder):", it5[1].tolist())
+    assert not (st5 >= 3).any(), st5                                   # nothing frozen, nothing non-finite
+    assert ((st0 >= 3).sum()) >= ((st5 >= 3).sum())
+    check = single_failed.tolist()[:2] if single_failed.size else [7, 13]
+    for tr in check:
+        it = oscvx.create_initial(po, 4, ic[tr, :3], ic[tr, 3:])
+        for n in range(2):
+            it, cnu, cdel = oscvx.solve_step(it)
+        assert np.abs(x5[tr] - it.x).max() < 5e-5 and np.abs(u5[tr] - it.u).max() < 5e-5, (tr, np.abs(x5[tr] - it.x).max())
+    c.close()
+
+
 def test_library_communicator_next_to_torch_nccl_group(tmp_path):
     """scvx_comm_create in a process that ALSO holds a live torch.distributed NCCL (= RCCL) group -- what
     bench.py does under torchrun with the default backend -- world of one on this box: the torch group all-reduces on the GPU first
