@@ -62,7 +62,9 @@ def k4_measured_traffic(B):
     upper bound: FETCH doubled — the kernel mixes narrow strided and wide coalesced reads)."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_B%d.json" % B))):
+    # *_pmc_mix_*: passes over the bench's own timed mix (per-launch mean over cold and warm steps, like avg_launch_ms); the
+    # single-cold-step passes (*_pmc_B*) are the fallback
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_B%d.json" % B))) + sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_mix_B%d.json" % B))):
         try:
             k = json.load(open(f))["kernels"]["scvx::socp_kernel"]
             n = k["launches_in_fetch_pass"]
