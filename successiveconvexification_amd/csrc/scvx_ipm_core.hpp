@@ -72,6 +72,17 @@
 #ifndef SCVX_WARM_RADIUS
 #define SCVX_WARM_RADIUS 0.999
 #endif
+// weight of the kept optimum in the starting point of a solve whose new radius cuts that optimum off (0 = plain cold start, the
+// default), and the fraction of the new radius it is pulled to.  OFF: 0.8 saves 4-7 % of the iterations (comment at its use), but a
+// run with it and a run with cold starts then end 1.6e-4 apart in x after 14 solve_steps (16 dispersed trajectories, device) where
+// they end 1e-6 apart without it -- the two take different paths to each flat optimum and the outer iteration carries the difference
+// along.  Closeness of repeated runs (and of the run to the oracle's) is worth more than those iterations.
+#ifndef SCVX_BLEND_WARM
+#define SCVX_BLEND_WARM 0.0
+#endif
+#ifndef SCVX_BLEND_RADIUS
+#define SCVX_BLEND_RADIUS 0.9
+#endif
 // fraction of the distance to the cone boundary taken by the combined step
 #ifndef SCVX_STEP_FRAC
 #define SCVX_STEP_FRAC 0.98
@@ -2411,8 +2422,10 @@ struct Solver {
         // inactive or barely active and the old central path is (nearly) the new one -- 7 iterations instead of 19.  Once the radius
         // binds in earnest the kept iterate is far from the new path and a warm start costs MORE than a cold one (33 vs 21 measured);
         // pulling the kept primal point inside the new radius (a convex combination with the reference point) and keeping
-        // the duals breaks down within two iterations on 80 % of such solves: tried, not kept.
+        // the duals breaks down within two iterations on 80 % of such solves.  What does work there is a BLEND of that pulled-in
+        // point with the cold starting point (below, SCVX_BLEND_WARM; measured, off by default).
         const bool warmed = warm && wh[0] == 1.0 && Vw[L.iTTR] < SCVX_WARM_RADIUS * rk;
+        const bool blend = warm && wh[0] == 1.0 && !warmed;   // same subproblem data, but the new radius cuts the kept optimum off
         res.warmed = warmed ? 1 : 0;
         if (warmed) {
             // same subproblem, new radius: restart from the kept iterate; its radius slack is recomputed (and kept interior)
@@ -2423,6 +2436,7 @@ struct Solver {
             }
             ex.sync();
         } else {
+        ex.sync();   // every wavefront has read wh[0] (warmed / blend above)
         if (ex.lane() == 0) wh[0] = 0.0;   // new subproblem data: whatever was kept belongs to another problem
         // ---- initial point (CVXOPT conelp style, W = I): two least-squares problems on one factorisation ----
         //   primal:  min ||s||  s.t. E w = e, s = a(w)        -> w, s     (the cost does not enter)
@@ -2472,6 +2486,29 @@ struct Solver {
             ex.sync();
         }
         SCVX_DBG("shifted: |S|^2 %.12e |Z|^2 %.12e\n", dot(S, S, L.nc), dot(Z, Z, L.nc));
+        if (blend && SCVX_BLEND_WARM > 0.0) {
+            // The solve after a rejected step whose halved radius cuts the kept optimum off: start between the cold point and that
+            // optimum pulled inside the new radius (scaled towards the reference point, which keeps it in every path cone when the
+            // reference point is), the multipliers likewise; the cold point's margins, scaled, keep the blend interior.  Twin, iterations
+            // per solve over the step mix, without -> with (weight 0.8; 0.5 ... 0.95 alike): exo 11.10 -> 10.71, aero 10.25 -> 9.76,
+            // K = 100 11.90 -> 11.04; first failures on random classes 0.96 % -> 1.00 % (single attempt).  The same blend for the solve
+            // after an ACCEPTED step (primal "stay here", kept multipliers) gained 2 % and is not in.
+            const double lm = SCVX_BLEND_WARM, th = SCVX_BLEND_RADIUS * rk / Vw[L.iTTR];
+            cone_map(V, tmpc, true);
+            for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) tmpc[i] = S[i] - tmpc[i];   // the cold point's margins
+            ex.sync();
+            for (int i = ex.lane(); i < L.nv; i += ex.nlanes()) {
+                bool fx = false;
+                if (i < 14) fx = fixed_x(0, i); else if (i >= 14 * K && i < L.nx) fx = fixed_x(K, i - 14 * K);
+                else if (i == L.nx + NU * K + 1 || i == L.nx + NU * K + 2) fx = true;
+                if (!fx) V[i] = lm * th * Vw[i] + (1.0 - lm) * V[i];
+            }
+            for (int i = ex.lane(); i < L.ny; i += ex.nlanes()) y[i] = lm * yw[i] + (1.0 - lm) * y[i];
+            ex.sync();
+            cone_map(V, S, true);
+            for (int i = ex.lane(); i < L.nc; i += ex.nlanes()) { S[i] += (1.0 - lm) * tmpc[i]; Z[i] = lm * Zw[i] + (1.0 - lm) * Z[i]; }
+            ex.sync();
+        }
         }   // cold start
 
         double best_merit = INFINITY; int best_it = 0;
