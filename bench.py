@@ -473,8 +473,9 @@ def main():
                 "traffic_source": k4t["source"] if k4t else None,
                 "bandwidth_used_frac_hi": (k4t["hi"] / (k4_ms * 1e-3) / HBM_PEAK) if k4t else None,
                 "note": "frac is ALGORITHMIC bytes (137 KB per trajectory per solve, SURVEY 8d) over time: the interior-point "
-                        "iterations stream a 614 KB per-trajectory state ~6 times each, ~20 iterations per solve, so the "
-                        "measured traffic is 300-500x the algorithmic bytes and the kernel runs at the HBM streaming rate",
+                        "iterations stream a 614 KB per-trajectory state ~6 times each (timed_region.ipm_iters_mean iterations per solve "
+                        "on average, ~17 for a cold one), so the measured traffic (PMC passes over this same step mix; FETCH_SIZE counts "
+                        "Infinity-Cache hits too) is 200-350x the algorithmic bytes and the kernel runs at the streaming rate of the memory system",
             },
             "solver_stats_last_step": {"ipm_iters_mean": float(np.mean(its)), "ipm_iters_max": int(np.max(its)),
                                        "optimal_frac": float(np.mean(st == 0)), "almost_optimal_frac": float(np.mean(st == 4)),
