@@ -159,3 +159,35 @@ def test_f32_linearisation_twin_converges_and_solves_the_rounded_problem():
         assert np.array_equal(r32[key], rr[key])          # same arithmetic on the same (widened) numbers
         assert np.abs(r32[key] - r64[key]).max() < 1e-4   # float rounding of D: 6e-8 relative
     assert np.abs(r32["pobj"] / r64["pobj"] - 1.0).max() < 1e-7
+
+
+def test_twin_retry_ladder_rescues_floor_failures():
+    """scvx_solver_opts.retries on the host twin (the device solver's core): class 39 of tools/k4_fuzz.py, second solve_step.  With one
+    attempt some of the 16 dispersed trajectories end on the numerical floor (status 2, merit 1e-8 .. 2e-8); with the default ladder
+    every solve is OPTIMAL, its iteration count is the sum over the attempts, and the result agrees with the single-attempt run on
+    the trajectories that never needed a second attempt (bit for bit: the first attempt is the same computation)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import k4_fuzz
+    from oracle import model, port
+    rng = np.random.default_rng(1)
+    base = model.base_prob_scaled()
+    for _ in range(40):
+        p = k4_fuzz.draw_class(rng, base)
+    ic = model.disperse_ics(p, 16, 539, 0.3)
+    # two steps of the loop, once per setting, through scvx_steps (which takes the ladder depth from the environment)
+    runs = {}
+    for r in ("0", "5"):
+        os.environ["SCVX_PORT_RETRIES"] = r
+        try:
+            runs[r] = port.scvx_steps(p, ic, 2, nsub=4, warm_start=True, accept=0.0)
+        finally:
+            os.environ.pop("SCVX_PORT_RETRIES", None)
+    s0, s5 = runs["0"]["status"][1], runs["5"]["status"][1]
+    assert (s0 != 0).any(), "this class no longer fails with a single attempt: pick another for the test"
+    assert (s5 == 0).all() and (runs["5"]["merit"][1] < 1e-8).all()
+    same = s0 == 0
+    assert np.array_equal(runs["0"]["iters"][1][same], runs["5"]["iters"][1][same])
+    assert (runs["5"]["iters"][1][~same] > runs["0"]["iters"][1][~same]).all()
+    assert np.array_equal(runs["0"]["x"][same], runs["5"]["x"][same])
