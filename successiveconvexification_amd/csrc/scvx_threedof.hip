@@ -108,7 +108,10 @@ struct WaveEx3 {
 };
 
 // sol [B][(K+1)*15+1]; info [B][6] = status, iters, pobj, gap, pres, dres
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void threedof_kernel(td::Tables T, int B, const double* __restrict__ ic, double* work,
+#ifndef SCVX_K0_WAVES
+#define SCVX_K0_WAVES 2   // wavefronts per SIMD the kernel is compiled for (and the launch is sized for): profiles/r03_k0_occupancy.md
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SCVX_K0_WAVES, SCVX_K0_WAVES))) void threedof_kernel(td::Tables T, int B, const double* __restrict__ ic, double* work,
                                                       size_t stride, double* sol, double* info, double* prof_out) {
     extern __shared__ double td_lds[];
     WaveEx3 ex{(td::lptr)td_lds};
@@ -228,7 +231,7 @@ int threedof_solve_dev(scvx_ctx* ctx, int B, const double* ic_dev, const scvx_th
     int rc = td_setup(ctx, o);
     if (rc) return rc;
     TdCache* c = ctx->td;
-    const int cap = (ctx->num_cus > 0 ? ctx->num_cus : 256) * 8;   // 2 wavefronts per SIMD
+    const int cap = (ctx->num_cus > 0 ? ctx->num_cus : 256) * 4 * SCVX_K0_WAVES;   // SCVX_K0_WAVES wavefronts per SIMD
     const int grid = B < cap ? B : cap;
     td::Layout L;
     L.init(c->P.K);
