@@ -975,6 +975,37 @@ def test_fuzz_class_that_used_to_stall_matches_independent_oracle():
     b.close(); c.close()
 
 
+def test_masked_trajectories_are_left_alone_and_cost_nothing():
+    """Masking (SURVEY 8e "masked/compacted"): a trajectory whose `active` flag is 0 is not stepped -- its iterate, scalars and
+    linearisation stay bit for bit what they were (K1 skips it too: its reference point did not move), and the trajectories that ARE
+    stepped get exactly what they get in a batch where everything is active."""
+    from oracle import model
+    po = model.base_prob_scaled()
+    B = 12
+    ic = model.disperse_ics(po, B, 20261004)
+    c, full = _setup(B, ic)
+    c2, part = _setup(B, ic)
+    full.solve_step(); part.solve_step()                      # one common step so that the masked ones hold a non-trivial state
+    st, act, live = part.flags()
+    mask = (np.arange(B) % 3 != 0).astype(np.int32)           # every third trajectory is left out
+    x0, u0, s0 = part.trajectory(); e0, d0 = part.linearization(); rk0, cost0, it0 = part.scalars()
+    part.set_flags(st, mask, mask)
+    for n in range(2):
+        sf, nuf, djf = full.solve_step()
+        sp_, nup, djp = part.solve_step()
+    x1, u1, s1 = part.trajectory(); e1, d1 = part.linearization(); rk1, cost1, it1 = part.scalars()
+    xf, uf, sff = full.trajectory(); ef, df = full.linearization(); rkf, costf, itf = full.scalars()
+    off, on = mask == 0, mask == 1
+    assert np.array_equal(x1[off], x0[off]) and np.array_equal(u1[off], u0[off]) and np.array_equal(s1[off], s0[off])
+    assert np.array_equal(e1[off], e0[off]) and np.array_equal(d1[off], d0[off])
+    assert np.array_equal(rk1[off], rk0[off]) and np.array_equal(it1[off], it0[off])
+    assert np.array_equal(x1[on], xf[on]) and np.array_equal(u1[on], uf[on]) and np.array_equal(s1[on], sff[on])
+    assert np.array_equal(e1[on], ef[on]) and np.array_equal(d1[on], df[on])
+    assert np.array_equal(rk1[on], rkf[on]) and np.array_equal(it1[on], itf[on])
+    assert np.array_equal(sp_[on], sf[on])
+    full.close(); part.close(); c.close(); c2.close()
+
+
 def test_retry_ladder_rescues_floor_failures_and_matches_oracle():
     """scvx_solver_opts.retries (default 5): a conic solve that ends on its numerical floor above `tol` is run again from the cold
     start under another step rule before its trajectory is frozen.  Class 39 of tools/k4_fuzz.py (K = 50, 55 % dry mass, glideslope
