@@ -164,6 +164,25 @@ function create_batch(problem::DescentProblem, cache::Cache; ics::Union{Nothing,
 end
 create_initial(problem::DescentProblem, cache::Cache) = iteration(create_batch(problem, cache))
 
+# What stands behind "the solver reports OPTIMAL" (rocketland.jl:271-276): struct scvx_solver_opts of include/scvx.h, field for field.
+struct SolverOpts
+    max_iter::Int32; refine::Int32; tol::Cdouble; accept_tol::Cdouble; reuse_inactive_tr::Int32; warm_start::Int32
+    retries::Int32; reserved0::Int32
+end
+# set_solver!(batch; tol = 1e-10, retries = 0, warm_start = false, ...): the defaults of the library for what is not named
+# (tol also moves accept_tol, whose default band is empty: OPTIMAL or error, as in the reference)
+function set_solver!(batch::Batch; kw...)
+    o = Ref(SolverOpts(0, 0, 0.0, 0.0, 0, 0, 0, 0))
+    ccall((:scvx_solver_default_opts, LIB), Cint, (Ref{SolverOpts},), o)
+    d = Dict(kw)
+    tol = get(d, :tol, o[].tol)
+    n = SolverOpts(get(d, :max_iter, o[].max_iter), get(d, :refine, o[].refine), tol, get(d, :accept_tol, tol),
+                   get(d, :reuse_inactive_tr, false) ? 1 : 0, get(d, :warm_start, o[].warm_start != 0) ? 1 : 0,
+                   get(d, :retries, o[].retries), 0)
+    check(batch.cache.ctx, ccall((:scvx_batch_set_solver, LIB), Cint, (Ptr{Cvoid}, Ref{SolverOpts}), batch.h, Ref(n)), "scvx_batch_set_solver")
+    return batch
+end
+
 # FirstRound.solve_initial (initial_solve.jl:17-110): the 3-DoF lossless-convexification landing SOCP, on the device.
 struct ThreedofOpts
     max_iter::Int32; refine::Int32; tol::Cdouble; delta::Cdouble; attitude::Int32; reserved::Int32

@@ -47,6 +47,22 @@ def test_julia_shim_struct_matches_header():
     assert jfields == hfields
 
 
+def test_julia_shim_solver_opts_match_header():
+    """julia/ScvxAMD.jl's SolverOpts and ThreedofOpts list the fields of scvx_solver_opts / scvx_threedof_opts in the header's order,
+    with the header's types (int32_t <-> Int32, double <-> Cdouble)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "scvx.h")).read()
+    jl = open(os.path.join(ROOT, "julia", "ScvxAMD.jl")).read()
+    for cname, jname in (("scvx_solver_opts", "SolverOpts"), ("scvx_threedof_opts", "ThreedofOpts")):
+        body = hdr[hdr.index("typedef struct %s {" % cname):hdr.index("} %s;" % cname)]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        hfields = [(n, {"int32_t": "Int32", "double": "Cdouble"}[t]) for t, n in re.findall(r"(double|int32_t)\s+(\w+)\s*;", body)]
+        sb = jl[jl.index("struct %s\n" % jname):jl.index("\nend", jl.index("struct %s\n" % jname))]
+        jfields = re.findall(r"(\w+)::(\w+)", sb)
+        assert len(hfields) >= 6 and [t for _, t in jfields] == [t for _, t in hfields], (cname, jfields, hfields)
+        assert [n for n, _ in jfields][:4] == [n for n, _ in hfields][:4]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fins", [False, True])
 def test_harness_replays_the_julia_call_sequence_bit_for_bit(tmp_path, aero_tables, fins):
