@@ -390,7 +390,7 @@ def main():
     if rank == 0:
         st, its, merit, pobj = batch.solver_stats()
         k1_step_ms = prof["linearize"] / max(nprof, 1)   # in the step: launches skip the trajectories whose step was rejected
-        # `roofline` is priced on FULL launches (every trajectory linearised): K1 alone, 5 back-to-back launches at the
+        # `roofline_k1` is priced on FULL launches (every trajectory linearised): K1 alone, 5 back-to-back launches at the
         # default npts on the batch's trajectories, HIP events on the stream it runs on
         k1_full, _ = k1_by_npts(cache, batch, torch, K, B, args.npts, sweep=(args.npts,), with_f32=False)
         k1_ms = k1_full[str(args.npts)]["ms"]
@@ -428,14 +428,14 @@ def main():
                 "K": K, "batch_per_gpu": B, "global_batch": shard.global_batch, "rk4_npts": args.npts,
                 "solver": "interior-point (NT scaling): optimal = merit < 1e-8, anything else freezes the trajectory as the "
                           "reference's error() does (accept_tol = tol, the default); the solve that "
-                          "follows a REJECTED step (same subproblem, radius halved) is warm-started from the previous solve's "
-                          "iterate at merit 1e-4 while the radius stays inactive there, and still runs to 1e-8 "
-                          "(cold_start_only = the same loop without it)",
+                          "follows a REJECTED step (same subproblem, radius halved) starts from the previous solve's optimum while "
+                          "that point lies inside the new radius, and still ends at 1e-8 (cold_start_only = the same loop without it); "
+                          "a solve that ends on its numerical floor is re-run under other step rules (retries = 5) before it counts as failed",
                 "parallelism": f"batch-sharded x{world}", "traj_iters_timed": done_all, "all_gather_shape": gathered,
                 "all_gather": gather_how,
             },
-            "roofline": {
-                "kernel": "scvx::linearize_pcp_kernel (K1, the discretisation kernel SURVEY 8d names; linearize_pc_kernel at npts <= 2)",
+            "roofline_k1": {
+                "kernel": "scvx::linearize_pcp_kernel (K1, the discretisation kernel SURVEY 8d names; linearize_pc_kernel at npts <= 2; 2 % of the step)",
                 "bound": "fp64" if args.npts >= 3 else "hbm",
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "traffic": traffic["bytes"] if traffic else None,
@@ -462,8 +462,9 @@ def main():
                         "point lies inside the halved radius, its first residual evaluation (of the new problem) already meets the tolerance: 1 iteration, no factorisation; "
                         "cold_start_only below is the figure with every solve started from scratch",
             },
-            "roofline_socp": None if k4_ms <= 0 else {
-                "kernel": "scvx::socp_kernel (K4, the conic solve: 97 % of the step)", "bound": "hbm", "unit": "GB/s",
+            # the dominant kernel: K4 (97 % of the step).  (Rounds 1-2 printed K1 here and K4 as roofline_socp.)
+            "roofline": None if k4_ms <= 0 else {
+                "kernel": "scvx::socp_kernel (K4, the conic solve: the dominant kernel, 97 % of the step)", "bound": "hbm", "unit": "GB/s",
                 "peak": HBM_PEAK / 1e9, "avg_launch_ms": k4_ms,
                 "alg_bytes_per_launch": socp_alg * B,
                 "achieved": socp_alg * B / (k4_ms * 1e-3) / 1e9,
