@@ -975,6 +975,44 @@ def test_fuzz_class_that_used_to_stall_matches_independent_oracle():
     b.close(); c.close()
 
 
+@pytest.mark.parametrize("cls", [3, 8, 21, 30, 62, 77, 90])
+def test_random_problem_classes_match_independent_oracle(cls):
+    """Off the sample problem: classes of tools/k4_fuzz.py (horizon 12 .. 64, mass ratio, throttle range, gimbal / tilt / glideslope /
+    rate limits, tf_guess, dynamic-pressure cone drawn at random) -- one solve_step of the first feasible dispersed trajectory on the
+    device against one solve_step of the independent oracle (oracle/scvx.py: explicit build_model rows + its own IPM), both at 1e-9."""
+    import os
+    import sys
+    from dataclasses import replace
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import k4_fuzz
+    from oracle import model, scvx as oscvx
+    from successiveconvexification_amd import sample_problems as sp
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    rng = np.random.default_rng(1)
+    base = model.base_prob_scaled()
+    for _ in range(cls + 1):
+        po = k4_fuzz.draw_class(rng, base)
+    pp = replace(sp.base_prob_scaled, K=po.K, mdry=po.mdry, Tmin=po.Tmin, deltaMax=po.deltaMax, thetaMax=po.thetaMax,
+                 gammaGs=po.gammaGs, omMax=po.omMax, tf_guess=po.tf_guess,
+                 model_flags=sp.base_prob_scaled.model_flags | (1 if po.enforce_dp else 0))
+    ic = model.disperse_ics(po, 4, 500 + cls, 0.3)
+    c = IntegratorCache(pp, npts=4)
+    b = ScvxBatch(c, 4, tol=1e-9).init(ic)
+    st, nun, dj = b.solve_step()
+    sst, its, merit, _ = b.solver_stats()
+    assert np.all((sst == 0) | (sst == 5)), sst                      # optimal, or an initial condition outside a path cone
+    tr = int(np.nonzero(sst == 0)[0][0])
+    x, u, s = b.trajectory()
+    rk, cost, it = b.scalars()
+    o0 = oscvx.create_initial(po, 4, ic[tr, :3], ic[tr, 3:])
+    o1, cnu, cdel = oscvx.solve_step(o0)
+    assert rk[tr] == o1.rk and abs(nun[tr] - cnu) < 1e-5 * max(1.0, cnu)
+    assert np.abs(x[tr] - o1.x).max() < 5e-5 and np.abs(u[tr] - o1.u).max() < 5e-5 and abs(s[tr] - o1.sigma) < 5e-5, \
+        (cls, np.abs(x[tr] - o1.x).max(), np.abs(u[tr] - o1.u).max())
+    b.close(); c.close()
+
+
 def test_masked_trajectories_are_left_alone_and_cost_nothing():
     """Masking (SURVEY 8e "masked/compacted"): a trajectory whose `active` flag is 0 is not stepped -- its iterate, scalars and
     linearisation stay bit for bit what they were (K1 skips it too: its reference point did not move), and the trajectories that ARE
