@@ -191,3 +191,26 @@ def test_twin_retry_ladder_rescues_floor_failures():
     assert np.array_equal(runs["0"]["iters"][1][same], runs["5"]["iters"][1][same])
     assert (runs["5"]["iters"][1][~same] > runs["0"]["iters"][1][~same]).all()
     assert np.array_equal(runs["0"]["x"][same], runs["5"]["x"][same])
+
+
+@pytest.mark.parametrize("cls", [8, 30, 77])
+def test_twin_on_random_problem_classes_matches_independent_oracle(cls):
+    """The device solver's core on the host (oracle/scvx_port.cpp) against the independent oracle off the sample problem: one
+    solve_step of classes of tools/k4_fuzz.py, both at 1e-9 (the GPU suite runs seven of them through the C ABI)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import k4_fuzz
+    from oracle import model, port, scvx as oscvx
+    rng = np.random.default_rng(1)
+    base = model.base_prob_scaled()
+    for _ in range(cls + 1):
+        p = k4_fuzz.draw_class(rng, base)
+    ic = model.disperse_ics(p, 4, 500 + cls, 0.3)
+    o = port.scvx_steps(p, ic, 1, nsub=4, tol=1e-9, accept=0.0)
+    st = o["status"][0]
+    assert np.all((st == 0) | (st == 5))
+    tr = int(np.nonzero(st == 0)[0][0])
+    o1, cnu, cdel = oscvx.solve_step(oscvx.create_initial(p, 4, ic[tr, :3], ic[tr, 3:]))
+    assert o["rk"][tr] == o1.rk
+    assert np.abs(o["x"][tr] - o1.x).max() < 5e-5 and np.abs(o["u"][tr] - o1.u).max() < 5e-5 and abs(o["sigma"][tr] - o1.sigma) < 5e-5
