@@ -58,8 +58,9 @@ def k1_measured_traffic(B):
 
 
 def k4_measured_traffic(B):
-    """HBM bytes per socp_kernel launch from the same committed PMC passes (lower bound: FETCH not doubled,
-    upper bound: FETCH doubled — the kernel mixes narrow strided and wide coalesced reads)."""
+    """HBM bytes per socp_kernel launch from the same committed PMC passes: hi = 2 x FETCH_SIZE + WRITE_SIZE, the calibrated figure
+    (profiles/r03_stream_ceiling.md: on this kernel's access pattern FETCH_SIZE reports 0.502 of the bytes read, WRITE_SIZE 1.005 of
+    the bytes written); lo = FETCH not doubled, kept for comparison with the rounds that carried the bracket."""
     import glob
     best = None
     # *_pmc_mix_*: passes over the bench's own timed mix (per-launch mean over cold and warm steps, like avg_launch_ms); the
@@ -475,8 +476,10 @@ def main():
                 "bandwidth_used_frac_hi": (k4t["hi"] / (k4_ms * 1e-3) / HBM_PEAK) if k4t else None,
                 "note": "frac is ALGORITHMIC bytes (137 KB per trajectory per solve, SURVEY 8d) over time: the interior-point "
                         "iterations stream a 614 KB per-trajectory state ~6 times each (timed_region.ipm_iters_mean iterations per solve "
-                        "on average, ~17 for a cold one), so the measured traffic (PMC passes over this same step mix; FETCH_SIZE counts "
-                        "Infinity-Cache hits too) is 200-350x the algorithmic bytes and the kernel runs at the streaming rate of the memory system",
+                        "on average, ~17 for a cold one), so the measured traffic (PMC passes over this same step mix; traffic = 2 x FETCH_SIZE + WRITE_SIZE, "
+                        "as calibrated on a kernel of known traffic with this access pattern: profiles/r03_stream_ceiling.md) is ~350x the algorithmic bytes "
+                        "and the kernel runs at the streaming rate of the memory system: bandwidth_used_frac_hi x 8 TB/s = 5.3 TB/s, where a "
+                        "2-reads-1-write stream of the same shape reaches 4.9",
             },
             "solver_stats_last_step": {"ipm_iters_mean": float(np.mean(its)), "ipm_iters_max": int(np.max(its)),
                                        "optimal_frac": float(np.mean(st == 0)), "almost_optimal_frac": float(np.mean(st == 4)),
