@@ -25,6 +25,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+// the same passes with 16 bytes per lane per load (each lane owns two adjacent elements): does the access width matter?
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void sweep2(double* work, size_t stride, int n, int nvec, int passes, double a) {
+    double* w = work + (size_t)blockIdx.x * stride;
+    const int lane = threadIdx.x;
+    const int n2 = n / 2;   // vectors are 8-byte aligned at odd offsets in general: the slab is laid out on even offsets here
+    for (int p = 0; p < passes; p++) {
+        double2* x = (double2*)(w + (size_t)((2 * p) % nvec) * (n + 1));
+        double2* y = (double2*)(w + (size_t)((2 * p + 1) % nvec) * (n + 1));
+        for (int i0 = lane; i0 < n2; i0 += 64 * 2) {
+            double2 xv[2], yv[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) { const int i = i0 + 64 * q; xv[q] = i < n2 ? x[i] : double2{0, 0}; yv[q] = i < n2 ? y[i] : double2{0, 0}; }
+#pragma unroll
+            for (int q = 0; q < 2; q++) { const int i = i0 + 64 * q; if (i < n2) y[i] = double2{a * xv[q].x + yv[q].x, a * xv[q].y + yv[q].y}; }
+        }
+        __syncthreads();
+    }
+}
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 8192, passes = argc > 2 ? atoi(argv[2]) : 400;
     const int n = 1571, nvec = 52;                       // 52 x 1,571 = 81,692 doubles of an 84,176-double slab
@@ -42,6 +61,15 @@ int main(int argc, char** argv) {
         float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
         const double bytes = (double)B * passes * n * 24.0;
         printf("B = %d, %d passes of %d doubles: %.2f ms, %.2f TB/s (2 reads + 1 write per element)\n", B, passes, n, ms, bytes / (ms * 1e-3) / 1e12);
+    }
+    for (int rep = 0; rep < 3; rep++) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(sweep2, dim3(B), dim3(64), 0, 0, work, stride, n, nvec, passes, 0.5);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        const double bytes = (double)B * passes * (n / 2 * 2) * 24.0;
+        printf("16 bytes per lane: B = %d, %d passes of %d doubles: %.2f ms, %.2f TB/s\n", B, passes, n / 2 * 2, ms, bytes / (ms * 1e-3) / 1e12);
     }
     (void)hipFree(work);
     return 0;
