@@ -215,6 +215,7 @@ struct scvx_batch {
     int *active = nullptr;   // 0 once a trajectory has failed (solver / non-finite): never stepped again
     int *live = nullptr;     // active and not yet converged: the trajectories scvx_solve still steps
     int device = 0;          // cached: scvx_batch_destroy must not touch a context that may already be gone
+    int nactive_host = -1;   // upper bound of the trajectories solve_step steps, as far as the host knows (set_flags counts them; -1 = all)
     int nlive_hint = -1;     // trajectories scvx_solve still steps (host view, a few steps old); -1 = all: picks the conic solver's executor
     bool initialised = false;
     bool profiling = false;
@@ -543,6 +544,7 @@ int scvx_batch_init(scvx_batch* b, const double* ic) {
     SCVX_HIP(ctx, relinearize(b, nullptr));
     SCVX_HIP(ctx, hipStreamSynchronize(st));  // host staging buffers go out of scope
     b->initialised = true;
+    b->nactive_host = -1;
     return SCVX_OK;
 }
 
@@ -590,13 +592,17 @@ int scvx_batch_reset(scvx_batch* b) {
     rc = split_views(b, b->traj, b->x, b->u, b->sigma);
     if (rc) return rc;
     SCVX_HIP(ctx, relinearize(b, nullptr));
+    b->nactive_host = -1;
     return SCVX_OK;
 }
 
 int scvx_solve_step_async(scvx_batch* b) {
     int rc = check_batch(b, true);
     if (rc) return rc;
-    return enqueue_step(b, b->active);
+    b->nlive_hint = b->nactive_host >= 0 && b->nactive_host < b->B ? b->nactive_host : -1;
+    rc = enqueue_step(b, b->active);
+    b->nlive_hint = -1;
+    return rc;
 }
 
 static int read_step_outputs(scvx_batch* b, int32_t* status, double* nu_norm, double* dJ) {
@@ -840,7 +846,12 @@ int scvx_batch_set_flags(scvx_batch* b, const int32_t* status, const int32_t* ac
     if (rc) return rc;
     scvx_ctx* ctx = b->ctx;
     if (status) SCVX_HIP(ctx, hipMemcpyAsync(b->status, status, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (active) SCVX_HIP(ctx, hipMemcpyAsync(b->active, active, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (active) {
+        SCVX_HIP(ctx, hipMemcpyAsync(b->active, active, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
+        int n = 0;
+        for (int t = 0; t < b->B; t++) n += active[t] != 0;
+        b->nactive_host = n;   // a mostly masked batch picks the conic solver's few-trajectories executors (as scvx_solve's tail does)
+    }
     if (live) SCVX_HIP(ctx, hipMemcpyAsync(b->live, live, (size_t)b->B * 4, hipMemcpyHostToDevice, ctx->stream));
     SCVX_HIP(ctx, hipMemsetAsync(b->ttr, 0x7f, (size_t)b->B * 8, ctx->stream));   // see scvx_batch_set_scalars
     SCVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
