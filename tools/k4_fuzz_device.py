@@ -1,6 +1,6 @@
 """Device fuzz of the conic solve's executors on RANDOM problem classes (the classes of tools/k4_fuzz.py): the four-wavefront
 executor (two-ended factorisation) against the one-wavefront executor, several solve_steps each -- solver statuses per step,
-iteration counts and the final trajectories.    python tools/k4_fuzz_device.py [--n 20] [--B 16] [--steps 6] [--seed 1]"""
+iteration counts and the final trajectories.    python tools/k4_fuzz_device.py [--n 20] [--B 16] [--steps 6] [--seed 1] [--fins] [--retries R]"""
 import argparse
 import os
 import sys
@@ -18,12 +18,14 @@ def main():
     ap.add_argument("--B", type=int, default=16)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--fins", action="store_true", help="every class with the fin extension (control_dim = 5, build-defined)")
+    ap.add_argument("--retries", type=int, default=None, help="scvx_solver_opts.retries (default: the library's, 5)")
     a = ap.parse_args()
     from successiveconvexification_amd import montecarlo as mc, sample_problems as sp
     from successiveconvexification_amd.batch import ScvxBatch
     from successiveconvexification_amd.dynamics import IntegratorCache
     rng = np.random.default_rng(a.seed)
-    base = sp.base_prob_scaled
+    base = sp.base_prob_fin_scaled() if a.fins else sp.base_prob_scaled
     print("| # | K | status per executor (all steps) | steps with different statuses | IPM its (1 / 4 wavefronts) | max final x difference (same-status trajectories) |")
     print("|---|---|---|---|---|---|")
     worst = 0.0
@@ -34,12 +36,14 @@ def main():
         p = replace(base, K=K, mdry=float(base.mwet * rng.uniform(0.4, 0.999)), Tmin=float(base.Tmax * rng.uniform(0.05, 0.6)),
                     deltaMax=float(rng.uniform(5.0, 30.0)), thetaMax=float(rng.uniform(30.0, 120.0)), gammaGs=float(rng.uniform(5.0, 45.0)),
                     omMax=float(rng.uniform(20.0, 120.0)), tf_guess=float(rng.uniform(0.5, 12.0)))
+        if a.fins:
+            p = replace(p, finmxf=float(rng.uniform(0.002, 0.02)))
         ic = mc.disperse_ics(p, 0, a.B, 500 + n, frac=0.3)
         res = {}
         for waves in ("1", "4"):
             os.environ["SCVX_K4_WAVES"] = waves
             c = IntegratorCache(p, npts=4)
-            b = ScvxBatch(c, a.B).init(ic)
+            b = ScvxBatch(c, a.B, retries=a.retries).init(ic)
             sts, its = [], []
             for _ in range(a.steps):
                 b.solve_step()
