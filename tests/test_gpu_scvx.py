@@ -705,6 +705,9 @@ def test_batch_api_argument_and_state_errors():
         b.init(np.zeros((3, 6)))             # ic must be [B][6]
     with pytest.raises(_lib.ScvxError):
         ScvxBatch(c, 2, tol=-1.0)            # bad solver options
+    with pytest.raises(_lib.ScvxError):
+        ScvxBatch(c, 2, retries=8)           # the ladder has seven further rules
+    ScvxBatch(c, 2, retries=0).close()       # one attempt only: the reference's literal behaviour
     b.init(None)
     st, nu, dj = b.solve_step()
     assert st.shape == (2,) and np.all(st == 1)
