@@ -22,7 +22,15 @@
  * only as commented-out code, so the model is DEFINED BY THIS BUILD from exactly those comments: control_dim = 5,
  * u[4:5] = coordinates of the fin force along fd1 = normalize((C(q) e2) x v) and fd2 = fd1 x v (dynamics.jl:60-63), the force
  * added to the aerodynamic force (:66) and its torque cross(rFB, ff) to the body torque (:69), and the cone
- * |u[4:5]| <= finmxf at every node (rocketland.jl:203-209).  Every array below then uses NU = 5:
+ * |u[4:5]| <= finmxf at every node (rocketland.jl:203-209).  Three choices the comments leave open, stated so that configs[4]
+ * numbers are not read as matching a reference model that does not exist:
+ *   (1) the commented expression at dynamics.jl:69 is `cross(info.rFB, ff) + bdy_trq`; only Jinv * (rFB x ff) is enabled here, the
+ *       aerodynamic body torque bdy_trq stays dropped exactly as in the live NU = 3 model (dynamics.jl:69,93);
+ *   (2) rFB is a body-frame arm and ff = u4 fd1 + u5 fd2 is built from inertial-frame vectors: the cross product mixes the two
+ *       frames as the comment does -- kept as written, not "fixed";
+ *   (3) the linearised thrust lower bound (rocketland.jl:199-201) uses |u[1:3]|, the thrust part of the control; the reference's
+ *       `norm(iterAbout[n].control)` would be the norm of all five components once the control had five.
+ * Every array below then uses NU = 5:
  *   u [B][K+1][5], inp[25], derivative 14x25 ([A | B- (5) | B+ (5) | Sigma]), trajectory record [(K+1)*19 + 1].
  * scvx_control_dim(ctx) returns NU.
  *

@@ -482,6 +482,9 @@ int scvx_batch_set_solver(scvx_batch* b, const scvx_solver_opts* o) {
     if (!b || !o) return SCVX_ERR_ARG;
     if (o->max_iter < 1 || o->refine < 0 || !(o->tol > 0) || !(o->accept_tol >= o->tol) || o->retries < 0 || o->retries > 7)
         return fail(b->ctx, SCVX_ERR_ARG, "bad solver options (max_iter >= 1, refine >= 0, 0 < tol <= accept_tol, 0 <= retries <= 7)");
+    // a caller built against the struct before `retries` / `reserved0` were added passes whatever follows its own fields here
+    if (o->reserved0 != 0)
+        return fail(b->ctx, SCVX_ERR_ARG, "scvx_solver_opts.reserved0 must be 0 (start from scvx_solver_opts_default; an older struct layout is not accepted)");
     b->opts = *o;
     b->C.max_iter = o->max_iter;
     b->C.refine = o->refine;

@@ -2371,7 +2371,11 @@ struct Solver {
         // sample problems no solve ever fails, so none is retried.  iters = the iterations of all attempts together.
         Result res;
         int iters_all = 0, first_warmed = 0;
+        // attempt_solve trades V and Vbest and may leave both names on one buffer (a failed attempt returns its best iterate through V):
+        // every attempt starts from the two buffers carve() handed out
+        const gptr V_first = V, Vbest_first = Vbest;
         for (int attempt = 0;; attempt++) {
+            V = V_first; Vbest = Vbest_first;
             //                          attempt:      0          1     2     3     4     5     6     7
             const double r_step[8] = {SCVX_STEP_FRAC,   0.9,  0.95, SCVX_STEP_FRAC, 0.8, 0.9, 0.85, 0.7};
             const double r_shift[8] = {SCVX_INIT_SHIFT, SCVX_INIT_SHIFT, SCVX_INIT_SHIFT, 1.0, SCVX_INIT_SHIFT, 5.0, 2.0, 0.5};

@@ -8,6 +8,8 @@ Three references, from tightest to loosest:
   * size-independent properties at the full batch (feasibility of what the solver returns, the linearised dynamics
     rows, the solver reaching its tolerance on every trajectory).
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -708,6 +710,10 @@ def test_batch_api_argument_and_state_errors():
     with pytest.raises(_lib.ScvxError):
         ScvxBatch(c, 2, retries=8)           # the ladder has seven further rules
     ScvxBatch(c, 2, retries=0).close()       # one attempt only: the reference's literal behaviour
+    o = _lib.ScvxSolverOpts()
+    c._L.scvx_solver_default_opts(ctypes.byref(o))
+    o.reserved0 = 3                          # what a caller built against the struct without `retries` / `reserved0` would pass
+    assert c._L.scvx_batch_set_solver(b.handle, ctypes.byref(o)) < 0
     b.init(None)
     st, nu, dj = b.solve_step()
     assert st.shape == (2,) and np.all(st == 1)
