@@ -83,3 +83,34 @@ def test_force_model_and_its_jacobian(aero):
     # exo problem: no force at all
     Fe, _ = od.aero_force(od.Params(model.base_prob_scaled()), [1, 0, 0, 0], [-0.2, 0.1, 0])
     assert np.all(Fe == 0)
+
+
+def test_interpolated_tables_against_the_reference_flight_log(aero):
+    """The ONLY reference-held number this path can be compared with: aero/lift_drag_test.csv (repacked as
+    tests/golden/lift_drag_flight_log.npz), 1,694 samples that aero/TestFlight.jl logged in flight -- AoA in degrees, Mach, and
+    the aerodynamic force divided by the air density, negated and projected on the velocity / lift directions (TestFlight.jl:66-90;
+    AeroValidate.jl:41-52 is the live form of the same comparison and recorded nothing).  The table holds forces in newtons at the
+    density of the sweep that made it (AeroTable.jl:40-84), which the reference does not record: only a RATIO can be compared.
+    Stated tolerance, and what it pins: over the 729 samples with Mach > 0.1 and AoA >= 160 deg (cos(AoA) as logged; the `inf`
+    row dropped), |table force| / |logged force / rho| has its median in [0.6, 1.4] and half of the samples within a factor 1.6 of
+    that median; the table's drag is <= 0 where the log's (negated) drag is >= 0.  This pins SURVEY 8a-5's table orientation
+    (cos(AoA) axis, Mach axis), the sign convention and the order of magnitude of what the spline returns -- LOOSELY, within the
+    scatter of a game flight log -- and nothing else on the path (not the SOCP, not the discretisation)."""
+    import os
+    from conftest import GOLDEN
+    p, par, d, l = aero
+    g = np.load(os.path.join(GOLDEN, "lift_drag_flight_log.npz"))
+    rows = np.stack([g[k] for k in ("aoa_deg", "mach", "drag", "lift")], axis=1)
+    assert rows.shape == (1694, 4) and np.isinf(rows[:, 1]).sum() == 1
+    rows = rows[np.isfinite(rows).all(1)]
+    sel = (rows[:, 1] > 0.1) & (rows[:, 0] >= 160.0)
+    assert sel.sum() == 729
+    cosa, mach = np.cos(np.radians(rows[sel, 0])), rows[sel, 1]
+    # table_eval returns the raw interpolant (newtons, as in lift_drag.csv); the problem's force_scalar enters in aero_force only
+    td = np.array([od.table_eval(par, 0, c, m)[0] for c, m in zip(cosa, mach)])
+    tl = np.array([od.table_eval(par, 1, c, m)[0] for c, m in zip(cosa, mach)])
+    ratio = np.hypot(td, tl) / np.hypot(rows[sel, 2], rows[sel, 3])
+    med = np.median(ratio)
+    assert 0.6 < med < 1.4, med
+    assert np.mean(np.abs(np.log(ratio / med)) < np.log(1.6)) > 0.5
+    assert np.all(td <= 0.0) and np.all(rows[sel, 2] >= 0.0)
