@@ -931,7 +931,7 @@ def test_two_rank_bench_on_one_gpu_matches_the_single_process_run(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, SCVX_DIST_BACKEND="gloo", SCVX_K4_WAVES="1", MASTER_ADDR="127.0.0.1")
-    common = ["--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-traj-check", "--no-k1-sweep"]
+    common = ["--steps", "2", "--warmup", "0", "--exact-steps", "--no-cpu-baseline", "--no-traj-check", "--no-k1-sweep"]
     f2, f1 = str(tmp_path / "two.npy"), str(tmp_path / "one.npy")
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--global-batch", "2048",
@@ -946,6 +946,37 @@ def test_two_rank_bench_on_one_gpu_matches_the_single_process_run(tmp_path):
     a, b = np.load(f2), np.load(f1)
     assert a.shape == b.shape == (2048, 51 * 17 + 1)
     assert np.array_equal(a, b)
+
+
+def test_bench_gpus_2_from_a_plain_shell_launches_its_own_ranks():
+    """`bench.py --gpus 2` with no WORLD_SIZE in the environment.  The parent starts the two rank processes itself
+    (it never touches the GPU), they rendezvous on 127.0.0.1 over gloo and share this box's one card; rank 0's ONE line comes back
+    through the parent: n_gpus 2, the headline = STRONG scaling of the global batch 8192 (BASELINE configs[3] as written: 4096 per
+    rank here), the weak figure (8192 per rank) beside it, whole solve_problem periods timed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SCVX_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-traj-check", "--no-k1-sweep"], env=env, capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["global_batch"] == 8192 and line["config"]["batch_per_gpu"] == 4096
+    assert line["steps"] == 14 and line["steps_requested"] == 3 and line["timed_region"]["indices_within_solve_problem"] == list(range(14))
+    assert line["config"]["traj_iters_timed"] == 14 * 8192 and line["config"]["all_gather_shape"] == [2, 4096, 51 * 17 + 1]
+    assert "2 ranks" in line["config"]["all_gather"]
+    w = line["weak_scaling"]
+    assert w["scaling"] == "weak" and w["batch_per_gpu"] == 8192 and w["global_batch"] == 16384 and w["value"] > 0
+    # a rank that fails makes the parent fail (here: an argument error inside the children)
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--global-batch", "8191", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-traj-check", "--no-k1-sweep"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert bad.returncode != 0
 
 
 def test_fuzz_class_that_used_to_stall_matches_independent_oracle():
