@@ -69,7 +69,9 @@ def socp(p: DescentProblem, xbar, ubar, endpoint, deriv, rk, ic=None, tol=1e-8, 
                                       wf.ctypes.data_as(C.POINTER(C.c_int32)))
     elif work is not None:   # persistent per-trajectory workspace + warm flags (the device's warm start after a rejected step)
         wf = np.ascontiguousarray(warm if warm is not None else np.zeros(B), np.int32)
-        port_lib().scvx_port_socp_ws(C.byref(c), C.c_int(B), _p(xbar), _p(ubar), _p(endpoint), _p(deriv), _p(rk), _p(ic), _p(sol), _p(nu),
+        # SCVX_PORT_FAC32 = 1 / 0 (tools): the factor of the Schur complement forced to float / double (default: the build's SCVX_FACTOR_T)
+        fac = os.environ.get("SCVX_PORT_FAC32")
+        (port_lib().scvx_port_socp_fac32 if fac == "1" else port_lib().scvx_port_socp_fac64 if fac == "0" else port_lib().scvx_port_socp_ws)(C.byref(c), C.c_int(B), _p(xbar), _p(ubar), _p(endpoint), _p(deriv), _p(rk), _p(ic), _p(sol), _p(nu),
                                      _p(info), C.c_int(nthreads), _p(work), wf.ctypes.data_as(C.POINTER(C.c_int32)))
     else:
       (port_lib().scvx_port_socp_f32 if f32 else (port_lib().scvx_port_socp_lin32 if lin32 else port_lib().scvx_port_socp))(C.byref(c), C.c_int(B), _p(xbar), _p(ubar), _p(endpoint), _p(deriv), _p(rk), _p(ic),

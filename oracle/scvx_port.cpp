@@ -75,16 +75,16 @@ struct HostEx {
         }
         return ok;
     }
-    template <int NR, class CP, class GP>
-    void chain_n(int K, CP const (&z)[NR], CP N, GP const (&o)[NR], bool reverse) {
+    template <int NR, class CP, class NP, class GP>
+    void chain_n(int K, CP const (&z)[NR], NP N, GP const (&o)[NR], bool reverse) {
         for (int q = 0; q < NR; q++) chain(K, z[q], N, o[q], reverse);
     }
     // out_k = z_k + N_k out_{k-1} (forward) or out_k = z_k + N_{k+1}' out_{k+1} (reverse); 14-vectors; N_k is the negated
     // coupling tile stored transposed (element (i, j) at 14 j + i), as Solver::build_kkt writes it.  T = storage type
     // (double, or float for the f32-storage twin): the running vector is carried in double, as in the device's MFMA
     // accumulators, and rounded once when it is stored.
-    template <class T>
-    void chain(int K, const T* z, const T* N, T* out, bool reverse) {
+    template <class T, class TN>
+    void chain(int K, const T* z, const TN* N, T* out, bool reverse) {
         double run[14] = {0};
         for (int step = 0; step < K; step++) {
             const int k = reverse ? K - 1 - step : step;
@@ -93,10 +93,10 @@ struct HostEx {
                 double a = z[14 * k + i];
                 if (step > 0) {
                     if (!reverse) {
-                        const T* col = N + (size_t)k * 196 + i;
+                        const TN* col = N + (size_t)k * 196 + i;
                         for (int j = 0; j < 14; j++) a += (double)col[14 * j] * run[j];
                     } else {
-                        const T* row = N + (size_t)(k + 1) * 196 + 14 * i;
+                        const TN* row = N + (size_t)(k + 1) * 196 + 14 * i;
                         for (int j = 0; j < 14; j++) a += (double)row[j] * run[j];
                     }
                 }
@@ -107,6 +107,10 @@ struct HostEx {
     }
 };
 }  // namespace
+
+#if defined(SCVX_COUNTERS)
+extern "C" { long long scvx_counters[8] = {0}; }
+#endif
 
 extern "C" {
 
@@ -130,7 +134,7 @@ size_t scvx_port_work_doubles_nu(int K, int with_dp, int nu) {
 // deriv [B][K][14+2NU+1][14], rk [B], ic [B][6].  Outputs: sol [B][(K+1)*(14+NU)+1] = dx, du, dsigma ; nu [B][K][14];
 // info [B][4] = status, iters, merit, pobj.  Stor = storage type of the linearisation and of the solver workspace.
 // NU = 3 (the reference's live model) or 5 (fin extension).
-template <class Stor, class DStor = Stor, int NU = 3>
+template <class Stor, class DStor = Stor, int NU = 3, class FStor = SCVX_FACTOR_T>
 static int port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
                      const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
                      int nthreads, Stor* work_all = nullptr, const int* warm = nullptr) {
@@ -148,7 +152,7 @@ static int port_socp(const scvx::ipm::Consts* C, int B, const double* xbar, cons
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < B; b++) {
             for (size_t i = 0; i < D.size(); i++) D[i] = (DStor)deriv[(size_t)b * K * DSZ + i];
-            scvx::ipm::Solver<HostEx, Stor, DStor, NU> S(ex, *C);
+            scvx::ipm::Solver<HostEx, Stor, DStor, NU, FStor> S(ex, *C);
             Stor* wk = work_all ? work_all + (size_t)b * nw : work.data();   // persistent per-trajectory slab, as on the device
             scvx::ipm::Result r = S.solve(xbar + (size_t)b * (K + 1) * 14, ubar + (size_t)b * (K + 1) * NU,
                                           endpoint + (size_t)b * K * 14, D.data(), rk[b], ic + (size_t)b * 6, wk,
@@ -183,6 +187,18 @@ int scvx_port_socp_lin32(const scvx::ipm::Consts* C, int B, const double* xbar, 
                          int nthreads) {
     return port_socp<double, float>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads);
 }
+// float FACTOR only (packed L^-1 and coupling tiles; everything else double): the preconditioner experiment of VERDICT r3 item 1c
+int scvx_port_socp_fac32(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
+                         const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
+                         int nthreads, double* work, const int* warm) {
+    return port_socp<double, double, 3, float>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads, work, warm);
+}
+// ... and with the factor in double (the form of rounds 1-3), for the A/B of profiles/r04_factor_f32.md
+int scvx_port_socp_fac64(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
+                         const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
+                         int nthreads, double* work, const int* warm) {
+    return port_socp<double, double, 3, double>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads, work, warm);
+}
 // fin extension (control_dim = 5), optional persistent workspace + warm flags (work == NULL: per-call scratch)
 int scvx_port_socp_fin(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
                        const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
@@ -193,7 +209,7 @@ int scvx_port_socp_fin(const scvx::ipm::Consts* C, int B, const double* xbar, co
 int scvx_port_socp_f32(const scvx::ipm::Consts* C, int B, const double* xbar, const double* ubar, const double* endpoint,
                        const double* deriv, const double* rk, const double* ic, double* sol, double* nu, double* info,
                        int nthreads) {
-    return port_socp<float>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads);
+    return port_socp<float, float, 3, float>(C, B, xbar, ubar, endpoint, deriv, rk, ic, sol, nu, info, nthreads);
 }
 }
 

@@ -113,6 +113,16 @@
 #ifndef SCVX_WARM_SAVE
 #define SCVX_WARM_SAVE 1.0
 #endif
+// Storage type of the block-tridiagonal FACTOR (Solver's FStor: packed L_k^-1 and the coupling tiles N_k, 301 numbers per segment,
+// read four times per interior-point iteration).  float (measured in round 4, profiles/r04_factor_f32.md): the
+// tiles are computed in double and rounded once when stored, every load widens, and the banded solves they serve sit under the
+// double-precision operator refinement of newton_solve.  NUMERICALLY FREE -- twin, 64 dispersed trajectories x 14 solve_steps: 11.17
+// iterations per solve either way, 1,842 vs 1,861 refinement corrections, every solve optimal; first failures over 60 random classes
+// 1.39 % vs 1.41 % -- and it moves 9.6 % fewer bytes per launch (PMC: 0.369 vs 0.408 TB), yet the kernel is 8 % SLOWER on the device
+// (83.5 vs 77.1 ms per launch of the bench mix): the conic solve's time is not set by its byte count alone.  Default: double.
+#ifndef SCVX_FACTOR_T
+#define SCVX_FACTOR_T double
+#endif
 #ifndef SCVX_STREAM_U
 #define SCVX_STREAM_U 4   // elements in flight per lane in the streaming loops (Solver::stream)
 #endif
@@ -138,6 +148,14 @@
 #define SCVX_DBG(...) fprintf(stderr, __VA_ARGS__)
 #else
 #define SCVX_DBG(...)
+#endif
+
+// optional host-side event counters (diagnostic twin builds only: -DSCVX_COUNTERS; tools/twin_stats.py --counters)
+#if defined(SCVX_COUNTERS) && !defined(__HIPCC__)
+extern "C" long long scvx_counters[8];   // 0 newton solves, 1 refinement checks (operator-form residual), 2 refinement correction solves, 3 factorisations
+#define SCVX_COUNT(i) do { _Pragma("omp atomic") scvx_counters[i]++; } while (0)
+#else
+#define SCVX_COUNT(i)
 #endif
 
 namespace scvx {
@@ -433,7 +451,10 @@ struct Result {
     int attempts; // step rules tried (1 unless the first ended on the numerical floor: Solver::solve)
 };
 
-template <class Ex, class Stor = double, class DStor = Stor, int NU = 3>
+// FStor: element type of the block-tridiagonal FACTOR (packed L_k^-1 and the coupling tiles N_k: 301 numbers per segment, read
+// four times per interior-point iteration).  float there makes every banded solve a preconditioner of accuracy ~6e-8 cond(S)
+// under the double-precision operator refinement of newton_solve (measured in profiles/r04_factor_f32.md).
+template <class Ex, class Stor = double, class DStor = Stor, int NU = 3, class FStor = SCVX_FACTOR_T>
 struct Solver {
     static_assert(NU == 3 || NU == 5, "control_dim 3 (the reference's live model) or 5 (fin extension)");
     static constexpr int NP = 14 + 2 * NU + 1;      // columns of a derivative tile: [A | B- | B+ | Sigma]
@@ -452,6 +473,8 @@ struct Solver {
     typedef typename gp<DStor>::cptr dcptr;   // the linearisation D as the discretisation kernel wrote it (double, or float
                                               // behind scvx_batch_set_linearization_f32: every load widens, arithmetic stays double)
     typedef typename gp<double>::cptr cdptr;  // the SCvx iterate: always double
+    typedef typename gp<FStor>::ptr fptr;     // the factor (Linv, Nf)
+    typedef typename gp<FStor>::cptr cfptr;
     Ex& ex;
     const Consts& C;
     Layout L;
@@ -465,7 +488,8 @@ struct Solver {
     gptr S, Z, lam, Wv, Wibz, tmpc, Wirz, sd;
     gptr Wbeta;
     gptr hx, hu;
-    gptr Linv, Nf, tchain;
+    fptr Linv, Nf;
+    gptr tchain;
     dptr At;   // A_k' copies, in the element type of D (a float D uses half of the slot)
     gptr ys, ytr, ynu;   // the three border multipliers  S y = Sg, E Hb^-1 Ptr, hnui Pnu
     gptr ptl, rtr;       // ptl = Hb^-1 Ptr (local, zero on nu),  rtr = E ptl
@@ -504,7 +528,7 @@ struct Solver {
         Wibz = w; w += nc; tmpc = w; w += nc; Wirz = w; w += nc; sd = w; w += nc;
         Wbeta = w; w += L.ncones;
         hx = w; w += (size_t)(K + 1) * HX_SZ; hu = w; w += (size_t)(K + 1) * HU_SZ;
-        Linv = w; w += (size_t)K * LINV_SZ; Nf = w; w += (size_t)K * 196; At = (dptr)w; w += (size_t)K * 196;
+        Linv = (fptr)w; w += (size_t)K * LINV_SZ; Nf = (fptr)w; w += (size_t)K * 196; At = (dptr)w; w += (size_t)K * 196;   // a float factor uses half of its slots
         tchain = w; w += ny;
         ys = w; w += ny; ytr = w; w += ny; ynu = w; w += ny; rtr = w; w += ny; ptl = w; w += nloc;
         tmpl = w; w += nloc; tmpl2 = w; w += nloc;
@@ -1261,7 +1285,7 @@ struct Solver {
     template <int N>
     SCVX_HD void solve_chains(const gptr (&t)[N], const gptr (&x)[N]) {
         const int K = L.K;
-        const cgptr Nf = this->Nf;
+        const cfptr Nf = this->Nf;
         cgptr tz[N], xz[N];
         for (int q = 0; q < N; q++) { tz[q] = t[q]; xz[q] = x[q]; }
         if constexpr (Ex::kTwisted) {
@@ -1272,8 +1296,8 @@ struct Solver {
                 ex.sync();
                 for (int e = ex.lane(); e < 14 * N; e += ex.nlanes()) {   // the middle node: both neighbours feed it
                     const int q = e / 14, i = e - 14 * q;
-                    cgptr Na = Nf + (size_t)m * 196 + i;            // N_m(i, j) at 14 j + i
-                    cgptr Nb = Nf + (size_t)(m + 1) * 196 + 14 * i;   // N'_m(i, j) at 14 i + j
+                    cfptr Na = Nf + (size_t)m * 196 + i;            // N_m(i, j) at 14 j + i
+                    cfptr Nb = Nf + (size_t)(m + 1) * 196 + 14 * i;   // N'_m(i, j) at 14 i + j
                     cgptr xa = x[q] + 14 * (m - 1); cgptr xb = x[q] + 14 * (m + 1);
                     double a = t[q][14 * m + i];
                     for (int j = 0; j < 14; j++) a += Na[14 * j] * xa[j] + Nb[j] * xb[j];
@@ -1294,11 +1318,11 @@ struct Solver {
     SCVX_HD_NI void S_solve(cgptr r, gptr x) {
         SCVX_T0();
         const int K = L.K;
-        const cgptr Linv = this->Linv;
+        const cfptr Linv = this->Linv;
         const gptr tchain = this->tchain;
         for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
             const int k = t / 14, i = t - 14 * k;
-            cgptr Li = Linv + (size_t)k * LINV_SZ + linv_row(i);
+            cfptr Li = Linv + (size_t)k * LINV_SZ + linv_row(i);
             cgptr rk_ = r + 14 * k;
             double a = 0;
 #if defined(__HIPCC__)
@@ -1319,7 +1343,7 @@ struct Solver {
         SCVX_TS(tp2_);
         for (int t = ex.lane(); t < 14 * K; t += ex.nlanes()) {
             const int k = t / 14, i = t - 14 * k;
-            cgptr Lk = Linv + (size_t)k * LINV_SZ;
+            cfptr Lk = Linv + (size_t)k * LINV_SZ;
             cgptr wk = tchain + 14 * k;
             double a = 0;
 #if defined(__HIPCC__)
@@ -1338,10 +1362,10 @@ struct Solver {
     template <int N>
     SCVX_HD_NI void S_solveN(const cgptr (&r)[N], const gptr (&x)[N], const gptr (&t)[N]) {
         const int K = L.K;
-        const cgptr Linv = this->Linv;
+        const cfptr Linv = this->Linv;
         for (int e = ex.lane(); e < 14 * K; e += ex.nlanes()) {
             const int k = e / 14, i = e - 14 * k;
-            cgptr Li = Linv + (size_t)k * LINV_SZ + linv_row(i);
+            cfptr Li = Linv + (size_t)k * LINV_SZ + linv_row(i);
             double a[N];
             for (int q = 0; q < N; q++) a[q] = 0;
             SCVX_UNROLL
@@ -1355,7 +1379,7 @@ struct Solver {
         solve_chains<N>(t, x);
         for (int e = ex.lane(); e < 14 * K; e += ex.nlanes()) {
             const int k = e / 14, i = e - 14 * k;
-            cgptr Lk = Linv + (size_t)k * LINV_SZ;
+            cfptr Lk = Linv + (size_t)k * LINV_SZ;
             double a[N];
             for (int q = 0; q < N; q++) a[q] = 0;
             SCVX_UNROLL
@@ -1399,7 +1423,7 @@ struct Solver {
     SCVX_HD_NI bool factor_pipelined() {
         const int K = L.K;
         const dcptr D_ = D; const cgptr hx_ = hx; const cgptr hu_ = hu;
-        const gptr Linv_ = Linv; const gptr Nf_ = Nf;
+        const fptr Linv_ = Linv; const fptr Nf_ = Nf;
         const double hnui_ = hnui;
         double* sc = ex.pipe_scratch();
         double* Sd = sc;                 // 2 x 196: ring; the chain factorises slot k in place (pivot tile)
@@ -1537,7 +1561,7 @@ struct Solver {
     SCVX_HD_NI bool factor_twisted() {
         const int K = L.K, m = K / 2, nb = K - 1 - m;   // nb nodes in the bottom half
         const dcptr D_ = D; const cgptr hx_ = hx; const cgptr hu_ = hu;
-        const gptr Linv_ = Linv; const gptr Nf_ = Nf;
+        const fptr Linv_ = Linv; const fptr Nf_ = Nf;
         const double hnui_ = hnui;
         const int w = ex.wave(), l = ex.wlane();
         const bool bot = w >= 2;
@@ -1773,6 +1797,7 @@ struct Solver {
     // solve adds no pass of its own over the factor and over D.
     SCVX_HD_NI bool build_kkt(bool with_pred = false) {
         const int K = L.K;
+        SCVX_COUNT(3);
         // big-cone scalars
         {
             const int dn = 14 * K + 1, dt = NXU * (K + 1) + 1;
@@ -1955,8 +1980,8 @@ struct Solver {
         const dcptr D_ = D;
         const cgptr hx_ = hx;
         const cgptr hu_ = hu;
-        const gptr Linv_ = Linv;
-        const gptr Nf_ = Nf;
+        const fptr Linv_ = Linv;
+        const fptr Nf_ = Nf;
         const double hnui_ = hnui;
         double* sc = ex.scratch();
         double* M = sc + 32;            // 196  pivot tile / So / scratch product
@@ -2246,6 +2271,7 @@ struct Solver {
             cone_map_t(tmpc, gx, rx);      // gx = -rx - J' W^-1 Wibz
             mask_fixed(gx);
         }
+        SCVX_COUNT(0);
         kkt_solve(gx, ry, dw, dy, -1.0, pred);   // equality right-hand side -ry
 #if defined(SCVX_IPM_DEBUG) && !defined(__HIPCC__)
         {
@@ -2264,6 +2290,7 @@ struct Solver {
         const int nref = (cur_gate < SCVX_REFINE_FROM && !(pred && !SCVX_REFINE_PRED)) ? C.refine : 0;
         double nr_prev = INFINITY;
         for (int it = 0; it < nref; it++) {
+            SCVX_COUNT(1);
             H_apply(dw, r1);
             const double sgy = Et_apply(dy, tmpl);
             ex.sync();
@@ -2304,6 +2331,7 @@ struct Solver {
                 stream(0, L.ny, [&](int i) { return D2{ry_[i], t2[i]}; }, [&](int i, const D2& v) { t2[i] = -v.a - v.b; });
             }
             ex.sync();
+            SCVX_COUNT(2);
             kkt_solve(r1, tmpy2, cw, cy);
             {
                 gptr dw_ = dw; cgptr cw_ = cw; gptr dy_ = dy; cgptr cy_ = cy;

@@ -174,15 +174,16 @@ struct WaveExT {
     // 4 runs of 14 consecutive doubles per instruction; reverse: the transposed element 14 row + g + 4c), and z rides in a fifth MFMA against a constant selector
     // (A[row][16 + g] = z_g[row], B[16 + g][n] = delta(g, n)), issued ahead of the dependent four.  Operands for step
     // s + R are requested while step s runs (R x 10 VGPRs in flight).
-    template <int NR>
-    __device__ __forceinline__ void chain_n(int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
+    template <int NR, class NP>
+    __device__ __forceinline__ void chain_n(int K, const ipm::cgptr (&z)[NR], NP N, const ipm::gptr (&o)[NR],
                                                bool reverse) {
         chain_range_n<NR>(K, z, N, o, reverse, reverse ? K - 1 : 0, K, true);
     }
     // The same recurrence over ns nodes starting at node k0 (the first one without a coupling term), for the two-ended
     // solve of BlockEx<4>: K is only the number of tiles (the reverse form reads the tile of node k + 1).
-    template <int NR>
-    __device__ __forceinline__ void chain_range_n(int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
+    // NP: pointer to the coupling tiles in the factor's storage type (double, or float: Solver's FStor); operands widen on load
+    template <int NR, class NP>
+    __device__ __forceinline__ void chain_range_n(int K, const ipm::cgptr (&z)[NR], NP N, const ipm::gptr (&o)[NR],
                                                      bool reverse, int k0, int ns, bool store_first) {
         static_assert(NR >= 1 && NR <= 4, "right-hand sides ride in k-slots 16..19");
         constexpr int R = SCVX_CHAIN_R;
@@ -212,17 +213,21 @@ struct WaveExT {
         const bool oin = n < NR;
         const bool oin3 = oin && g < 2;   // register 3 holds row g + 12
         const int dk = reverse ? -1 : 1;
-        double st[R][5];
-        auto issue = [&](int s, double (&f)[5]) {
+        // the tile operands stay in the factor's storage type until the step that consumes them: a conversion at the load would make
+        // every request wait for its own data and undo the R-deep prefetch
+        typedef decltype(+(*N)) NT;
+        NT st[R][4];
+        double sz[R];
+        auto issue = [&](int s, NT (&f)[4], double& fz) {
             const int k = k0 + dk * s;
-            ipm::cgptr base = N + (size_t)(reverse ? (k + 1 < K ? k + 1 : k) : k) * 196;   // reverse: the tile of node k + 1
+            const NP base = N + (size_t)(reverse ? (k + 1 < K ? k + 1 : k) : k) * 196;   // reverse: the tile of node k + 1
 #pragma unroll
             for (int c = 0; c < 4; c++) f[c] = base[offA[c]];
-            f[4] = zp[14 * k + offZ];
+            fz = zp[14 * k + offZ];
         };
 #pragma unroll
         for (int q = 0; q < R; q++)
-            if (q < ns) issue(q, st[q]);
+            if (q < ns) issue(q, st[q], sz[q]);
         v4f64 d = {0.0, 0.0, 0.0, 0.0};
         for (int s0 = 0; s0 < ns; s0 += R) {
 #pragma unroll
@@ -232,15 +237,15 @@ struct WaveExT {
                     // the first node has no coupling term (its tile is never written: mask, don't multiply)
                     const double m0 = s > 0 ? 1.0 : 0.0;
                     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(zin ? st[q][4] : 0.0, bsel, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(zin ? sz[q] : 0.0, bsel, acc, 0, 0, 0);
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
-                        const double a = (mA[c] * m0 != 0.0) ? st[q][c] : 0.0;
+                        const double a = (mA[c] * m0 != 0.0) ? (double)st[q][c] : 0.0;
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, d[c], acc, 0, 0, 0);
                     }
                     d = acc;
                     // operands of step s + R go into the registers this step has just consumed
-                    if (s + R < ns) issue(s + R, st[q]);
+                    if (s + R < ns) issue(s + R, st[q], sz[q]);
                     const int k = k0 + dk * s;
                     const bool st_ = store_first || s > 0;
                     if (oin && st_) {
@@ -253,7 +258,8 @@ struct WaveExT {
             }
         }
     }
-    __device__ __forceinline__ void chain(int K, ipm::cgptr z, ipm::cgptr N, ipm::gptr out, bool reverse) {
+    template <class NP>
+    __device__ __forceinline__ void chain(int K, ipm::cgptr z, NP N, ipm::gptr out, bool reverse) {
         const ipm::cgptr zs[1] = {z};
         const ipm::gptr os[1] = {out};
         chain_n<1>(K, zs, N, os, reverse);
@@ -279,8 +285,8 @@ struct BlockEx {
     // producer / consumer pairs, and the solve's recurrences run on wavefronts 0 and 2 side by side (Solver::factor_twisted)
     static constexpr bool kTwisted = NW == 4 && SCVX_K4_PIPELINE != 0 && SCVX_K4_TWISTED != 0;
     __device__ __forceinline__ double* pipe_scratch2() { return socp_pipe_lds2<NU_>(); }
-    template <int NR>
-    __device__ __forceinline__ void chain_range_n(int wv, int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR],
+    template <int NR, class NP>
+    __device__ __forceinline__ void chain_range_n(int wv, int K, const ipm::cgptr (&z)[NR], NP N, const ipm::gptr (&o)[NR],
                                                      bool reverse, int k0, int ns, bool store_first) {
         if (wave() == wv) w0.template chain_range_n<NR>(K, z, N, o, reverse, k0, ns, store_first);
     }
@@ -331,11 +337,12 @@ struct BlockEx {
         __syncthreads();
         return ok;
     }
-    __device__ __forceinline__ void chain(int K, ipm::cgptr z, ipm::cgptr N, ipm::gptr out, bool reverse) {
+    template <class NP>
+    __device__ __forceinline__ void chain(int K, ipm::cgptr z, NP N, ipm::gptr out, bool reverse) {
         if (first()) w0.chain(K, z, N, out, reverse);
     }
-    template <int NR>
-    __device__ __forceinline__ void chain_n(int K, const ipm::cgptr (&z)[NR], ipm::cgptr N, const ipm::gptr (&o)[NR], bool reverse) {
+    template <int NR, class NP>
+    __device__ __forceinline__ void chain_n(int K, const ipm::cgptr (&z)[NR], NP N, const ipm::gptr (&o)[NR], bool reverse) {
         if (first()) w0.template chain_n<NR>(K, z, N, o, reverse);
     }
 };
@@ -365,7 +372,7 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t wo
     }
     const int K = C.K;
     Ex ex;
-    ipm::Solver<Ex, double, DS, NU> S(ex, C);
+    ipm::Solver<Ex, double, DS, NU, SCVX_FACTOR_T> S(ex, C);
     // kernel arguments are HBM pointers: hand them to the solver typed as such (see ipm::gptr)
     // warm start: the last solve in this slab was for the same about / dynam (its step was rejected) and is still valid
     const bool warm = C.warm && step_status[b] == SCVX_ST_REJECTED && ttr[b] < 1e300;

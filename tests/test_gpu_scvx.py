@@ -257,8 +257,21 @@ def test_returned_iterate_is_feasible_full_batch():
     ic = bench.disperse_ics(po, 0, B, 20261004)
     c, b = _setup(B, ic, npts=10)
     _check_socp_properties(po, ic, b, 100.0)
-    # and after two accepted steps (the radius has grown to 100 * 3.2^2, the iterate is no longer the straight line)
-    b.solve_step(); b.solve_step()
+    # and after two accepted steps (the radius has grown to 100 * 3.2^2, the iterate is no longer the straight line): properties on
+    # all 8,192, and three sampled trajectories of this batch against the INDEPENDENT oracle (oracle/scvx.py: IPM on the exact
+    # build_model rows, rocketland.jl:226-321) after one and after two solve_steps -- as configs 3 and 5 have
+    from oracle import scvx as oscvx
+    sample = (0, 4097, 8191)
+    its = {tr: oscvx.create_initial(po, 10, ic[tr, :3], ic[tr, 3:]) for tr in sample}
+    for n in range(2):
+        st, nun, dj = b.solve_step()
+        xs, us, ss = b.trajectory()
+        rk, _, _ = b.scalars()
+        for tr in sample:
+            its[tr], cnu, cdel = oscvx.solve_step(its[tr])
+            assert rk[tr] == its[tr].rk, (n, tr)                         # same accept / reject decision and radius
+            assert np.abs(xs[tr] - its[tr].x).max() < 5e-5 and np.abs(us[tr] - its[tr].u).max() < 5e-5, (n, tr)
+            assert abs(ss[tr] - its[tr].sigma) < 5e-5 and abs(nun[tr] - cnu) < 1e-5, (n, tr)
     rk, _, _ = b.scalars()
     _check_socp_properties(po, ic, b, rk)
     b.close(); c.close()
