@@ -17,7 +17,7 @@
 
 namespace {
 struct HostEx {
-    double sc[2048];
+    double sc[2560];
     int lane() const { return 0; }
     int nlanes() const { return 1; }
     void sync() {}
@@ -33,9 +33,9 @@ struct HostEx {
     // C(14x14) = (acc ? C : 0) + alpha * A(14 x Kd) B(Kd x 14); element strides: C(i,j) = C[i*sci + j*scj],
     // A(i,k) = A[i*sai + k*sak], B(k,j) = B[k*sbk + j*sbj].  C must not alias A or B.
     void tile_gemm(double* Cm, int sci, int scj, const double* A, int sai, int sak, const double* B, int sbk, int sbj,
-                   int Kd, double alpha, bool acc) {
+                   int Kd, double alpha, bool acc, int nb = 14) {
         for (int i = 0; i < 14; i++)
-            for (int j = 0; j < 14; j++) {
+            for (int j = 0; j < nb; j++) {
                 double s = 0;
                 for (int k = 0; k < Kd; k++) s += A[i * sai + k * sak] * B[k * sbk + j * sbj];
                 double* c = Cm + i * sci + j * scj;

@@ -1229,7 +1229,7 @@ struct Solver {
     // One lane per output ROW: row j of the compact node inverse has at most three entries (hxi_apply's formulas), so
     // every lane loads three coefficients and three inputs that sit next to those of its neighbours.  (One lane per
     // node, as build_kkt assembles the blocks, reads 51 elements at a stride of 33 doubles: no two lanes share a line.)
-    SCVX_HD_NI void Hb_inv(cgptr g, gptr out) {
+    SCVX_HD_NI void Hb_inv(cgptr g, gptr out, bool with_nu = true) {
         SCVX_T0();
         const int K = L.K;
         const cgptr hx_ = hx; const cgptr hu_ = hu;
@@ -1257,7 +1257,7 @@ struct Solver {
                    },
                    [&](int t, const D6& w) { ou[t] = w.a * w.d + w.b * w.e + w.c * w.f; });
         }
-        {
+        if (with_nu) {
             cgptr gn = g + L.nx + L.nu_; gptr on = out + L.nx + L.nu_;
             const double hn = hnui;
             stream<8>(0, 14 * K, [&](int i) { return gn[i]; }, [&](int i, double v) { on[i] = hn * v; });
@@ -1377,6 +1377,31 @@ struct Solver {
         }
         ex.sync();
         solve_chains<N>(t, x);
+        for (int e = ex.lane(); e < 14 * K; e += ex.nlanes()) {
+            const int k = e / 14, i = e - 14 * k;
+            cfptr Lk = Linv + (size_t)k * LINV_SZ;
+            double a[N];
+            for (int q = 0; q < N; q++) a[q] = 0;
+            SCVX_UNROLL
+            for (int j = 0; j < 14; j++) {
+                const double l = j >= i ? Lk[linv_row(j) + (j >= i ? i : j)] : 0.0;
+                for (int q = 0; q < N; q++) a[q] += l * t[q][14 * k + j];
+            }
+            for (int q = 0; q < N; q++) x[q][e] = a[q];
+        }
+        ex.sync();
+    }
+    // The BACKWARD half of S_solveN for right-hand sides whose forward substitution has already been done (inside the factorisation
+    // loop, build_kkt): on entry x[q] holds t = L^-1 r, on exit x[q] holds the solution; t[q] is scratch.
+    template <int N>
+    SCVX_HD_NI void S_backN(const gptr (&x)[N], const gptr (&t)[N]) {
+        const int K = L.K;
+        const cfptr Linv = this->Linv;
+        const cfptr Nf = this->Nf;
+        cgptr xz[N];
+        for (int q = 0; q < N; q++) xz[q] = x[q];
+        ex.template chain_n<N>(K, xz, Nf, t, true);
+        ex.sync();
         for (int e = ex.lane(); e < 14 * K; e += ex.nlanes()) {
             const int k = e / 14, i = e - 14 * k;
             cfptr Lk = Linv + (size_t)k * LINV_SZ;
@@ -1992,6 +2017,18 @@ struct Solver {
         double* Bp = T + 14 * TS;           // 42   copy of Bp_k (column-major 14x3) kept across the D tile swap
         double* Hh = Bp + BPN;           // 84   hx_k (33) hu_k (9) | hx_{k+1} (33) hu_{k+1} (9)
         double* Hd = Hh + 2 * NODE_SZ;           // 196  dense Hxi of the node being multiplied
+        // FUSED BORDER (sequential loop only).  The three border systems and the predictor's banded system need, per segment,
+        //     r_k = (E Hb^-1 g)_k = [TA | TBm | TBp]_k [g_x,k; g_u,k; g_u,k+1] - Hxi_{k+1} g_x,k+1 + hnui g_nu,k   (g = Ptr, gx)
+        // -- products with tiles this loop has in LDS anyway -- and their forward substitution t_k = L_k^-1 r_k + N_k t_{k-1} needs
+        // L_k^-1 and N_k at the moment they are formed.  So the loop carries four right-hand sides along (columns: 0 Sg, 1 Ptr, 2 Pnu,
+        // 3 predictor) and leaves L^-1 r in ys / ytr / ynu / dy; what used to follow it -- a pass materialising Ptr, two Hb^-1 passes, a
+        // pass over D (E_apply2), a pass for the two plain columns, and the forward half of S_solveN (L^-1 and N streamed once
+        // more) -- is gone: per interior-point iteration ~0.45 of 3.5 MB and seven of ~50 dependent passes.
+        double* Gn = Hd + 196;                   // 2 x NXU x 4   node slices of the right-hand sides: [slot][row: x (14) | u (NU)][column]
+        double* Rk = Gn + 2 * NXU * 4;           // 14 x 4        r_k
+        double* Tt = Rk + 56;                    // 2 x 14 x 4    t_{k-1}, t_k (alternating)
+        double* Sg = Tt + 112;                   // 42            segment scalars: gx_nu,k (14) | ry_k (14) | Pnu_k (14)
+        constexpr bool kFusedBorder = !Ex::kPipelineFactor;
         bool ok = true;
         if constexpr (Ex::kPipelineFactor) {
             if constexpr (Ex::kTwisted) {
@@ -2012,20 +2049,47 @@ struct Solver {
             const int i = q / NU, c = q - NU * i;
             T[TS * i + 14 + c] = bhu(Dt, 14, i, c, Hh + NODE_SZ + HX_SZ);
         }
+        // node slices of the border right-hand sides: element e = NXU vec + row of node nd (vec 0: Ptr = v1 of the trust-region
+        // cone, column 1; vec 1: the predictor's gx, column 3); segment scalars: element e of segment sgk
+        const cgptr Wtr_ = Wv + L.o_tr + 1; const cgptr Wnu_ = Wv + L.o_nu + 1; const cgptr gx_ = gx; const cgptr ry_ = ry;
+        const int nx_ = L.nx, nxu_ = L.nx + L.nu_;
+        auto gnode_elem = [&](int nd, int e) -> double {
+            const int vec = e >= NXU ? 1 : 0, row = e - NXU * vec;
+            if (vec == 1 && !with_pred) return 0.0;
+            cgptr src = vec ? gx_ : Wtr_;
+            return row < 14 ? src[14 * nd + row] : src[nx_ + NU * nd + (row - 14)];
+        };
+        auto gseg_elem = [&](int sgk, int e) -> double {
+            if (e >= 28) return Wnu_[14 * sgk + (e - 28)];
+            if (!with_pred) return 0.0;
+            return e < 14 ? gx_[nxu_ + 14 * sgk + e] : ry_[14 * sgk + (e - 14)];
+        };
+        for (int e = ex.lane(); e < 2 * NXU * 4 + 56 + 112; e += ex.nlanes()) Gn[e] = 0.0;   // Gn, Rk, Tt (columns 0 and 2 of Gn stay zero)
+        ex.sync_lds();
+        for (int e = ex.lane(); e < 2 * NXU; e += ex.nlanes()) {
+            const int vec = e >= NXU ? 1 : 0, row = e - NXU * vec;
+            Gn[NXU * 4 + 4 * row + (vec ? 3 : 1)] = gnode_elem(0, e);
+        }
         ex.sync_lds();
         // the compact node inverses (42 doubles) are requested one segment ahead as well: lane e holds element e of node
         // k + 1 while segment k - 1 is processed (register-prefetching executors have at least 42 lanes)
         auto node_elem = [&](int node, int e) -> double {
             return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[HU_SZ * node + (e - HX_SZ)];
         };
-        double hn = 0.0;
+        double hn = 0.0, gn = 0.0, sgn = 0.0;
         if (Ex::kPrefetchRegs > 0 && ex.lane() < NODE_SZ) hn = node_elem(1, ex.lane());
+        if (Ex::kPrefetchRegs > 0 && ex.lane() < 2 * NXU) gn = gnode_elem(1, ex.lane());
+        if (Ex::kPrefetchRegs > 0 && ex.lane() < 42) sgn = gseg_elem(0, ex.lane());
+        const gptr xq_[4] = {ys, ytr, ynu, dy};
+        const gptr rtr_ = rtr;
         for (int k = 0; k < K; k++) {
             SCVX_TS(ta_);
             // prefetch the next segment's tile
             constexpr int NPRE = Ex::kPrefetchRegs > 0 ? (DSZ + Ex::kLanes - 1) / Ex::kLanes : 0;
-            double hn2 = 0.0;
+            double hn2 = 0.0, gn2 = 0.0, sgn2 = 0.0;
             if (NPRE > 0 && ex.lane() < NODE_SZ) hn2 = node_elem(k + 2 <= K ? k + 2 : K, ex.lane());
+            if (NPRE > 0 && ex.lane() < 2 * NXU) gn2 = gnode_elem(k + 2 <= K ? k + 2 : K, ex.lane());
+            if (NPRE > 0 && ex.lane() < 42) sgn2 = gseg_elem(k + 1 < K ? k + 1 : k, ex.lane());
             double pre[NPRE > 0 ? NPRE : 1];
             dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * DSZ;
             if (NPRE > 0) {
@@ -2039,6 +2103,15 @@ struct Solver {
                 Hh[NODE_SZ + e] = nk1;
             }
             hn = hn2;
+            // ... and the right-hand sides' slices: slot 0 <- slot 1 (node k), slot 1 <- node k + 1; the segment's scalars
+            for (int e = ex.lane(); e < 2 * NXU; e += ex.nlanes()) {
+                const int vec = e >= NXU ? 1 : 0, row = e - NXU * vec, at = 4 * row + (vec ? 3 : 1);
+                const double v1 = NPRE > 0 ? gn : gnode_elem(k + 1, e);
+                Gn[at] = Gn[NXU * 4 + at];
+                Gn[NXU * 4 + at] = v1;
+            }
+            for (int e = ex.lane(); e < 42; e += ex.nlanes()) Sg[e] = NPRE > 0 ? sgn : gseg_elem(k, e);
+            gn = gn2; sgn = sgn2;
             ex.sync_lds();
             for (int e = ex.lane(); e < 196 + BPN; e += ex.nlanes()) {
                 if (e < 196) {
@@ -2057,6 +2130,10 @@ struct Solver {
             // pivot tile: M += [TA|TBm|TBp] [A|Bm|Bp]'  -  Wb_{k-1} Wb_{k-1}'
             ex.tile_gemm(M, 14, 1, T, TS, 1, Dt, 14, 1, TW, 1.0, true);
             if (k > 0) ex.tile_gemm(M, 14, 1, Wp, 14, 1, Wp, 1, 14, 14, -1.0, true);
+            // r_k (columns 1 and 3): [TA | TBm]_k [g_x,k; g_u,k] + TBp_k g_u,k+1 - Hxi_{k+1} g_x,k+1
+            ex.tile_gemm(Rk, 4, 1, T, TS, 1, Gn, 4, 1, 14 + NU, 1.0, false, 4);
+            ex.tile_gemm(Rk, 4, 1, T + 14 + NU, TS, 1, Gn + NXU * 4 + 14 * 4, 4, 1, NU, 1.0, true, 4);
+            ex.tile_gemm(Rk, 4, 1, Hd, 14, 1, Gn + NXU * 4, 4, 1, 14, -1.0, true, 4);
             ex.sync_lds();
             SCVX_TE(tb_, 5);
             SCVX_TS(tc_);
@@ -2069,10 +2146,27 @@ struct Solver {
                 const int i = q <= p ? p : 13 - p, j = q <= p ? q : q - (p + 1);
                 Linv_[(size_t)k * LINV_SZ + e] = Li[14 * i + j];
             }
+            // the plain parts of r_k: column 0 = Sg_k (the sigma column of D_k), column 2 = hnui Pnu_k, column 3 += hnui gx_nu,k + ry_k
+            for (int i = ex.lane(); i < 14; i += ex.nlanes()) {
+                Rk[4 * i] = Dt[14 * CS + i];
+                Rk[4 * i + 2] = hnui_ * Sg[28 + i];
+                Rk[4 * i + 3] += hnui_ * Sg[i] + Sg[14 + i];
+                rtr_[14 * k + i] = Rk[4 * i + 1];   // rtr = E Hb^-1 Ptr itself is kept: the border coefficients and every solve use it
+            }
             if (k > 0) {  // Nf[k] = -Linv_k Wb_{k-1}, stored transposed (the layout the executor's chain consumes)
                 ex.tile_gemm(M, 1, 14, Li, 14, 1, Wp, 14, 1, 14, -1.0, false);
                 ex.sync_lds();
                 for (int e = ex.lane(); e < 196; e += ex.nlanes()) Nf_[(size_t)k * 196 + e] = M[e];
+            } else ex.sync_lds();
+            {   // forward substitution of the four right-hand sides: t_k = L_k^-1 r_k + N_k t_{k-1}
+                double* Tc = Tt + 56 * (k & 1); const double* Tp = Tt + 56 * ((k + 1) & 1);
+                ex.tile_gemm(Tc, 4, 1, Li, 14, 1, Rk, 4, 1, 14, 1.0, false, 4);
+                if (k > 0) ex.tile_gemm(Tc, 4, 1, M, 1, 14, Tp, 4, 1, 14, 1.0, true, 4);
+                ex.sync_lds();
+                for (int e = ex.lane(); e < 56; e += ex.nlanes()) {
+                    const int q = e / 14, i = e - 14 * q;
+                    if (q < 3 || with_pred) xq_[q][14 * k + i] = Tc[4 * i + q];
+                }
             }
             SCVX_TE(td_, 13);
             SCVX_TS(te_);
@@ -2117,7 +2211,20 @@ struct Solver {
         // Only the multipliers y are kept.  The local parts l = Hb^-1 (g - E'y) of the border solutions are never
         // formed: every border coefficient is an inner product in y-space (below), and a solve applies its border
         // correction to dy and to the right-hand side BEFORE its single final  Hb^-1 (g - E'dy)  (kkt_solve).
-        {
+        if constexpr (kFusedBorder) {
+            // the forward substitutions were carried by the loop: Hb^-1 Ptr on (dx, du) for the two inner products that use it, then
+            // the backward halves
+            Hb_inv(Wv + L.o_tr + 1, ptl, false);
+            if (with_pred) {
+                const gptr xx[4] = {ys, ytr, ynu, dy};
+                const gptr tt4[4] = {tchain, cy, tq0, tq1};
+                S_backN<4>(xx, tt4);
+            } else {
+                const gptr xx[3] = {ys, ytr, ynu};
+                const gptr tt3[3] = {tchain, cy, tq0};
+                S_backN<3>(xx, tt3);
+            }
+        } else {
             const int nxu = L.nx + L.nu_;
             const gptr g_tr = r1;     // nloc: Ptr on (dx,du), 0 on nu   (r1: refinement scratch, idle here)
             {

@@ -16,14 +16,18 @@ namespace scvx {
 // only).  A pointer carried in the executor object is reloaded from memory in each non-inlined routine, loses its
 // address space, and every LDS access becomes a flat_load/flat_store that also waits on the global loads and
 // stores in flight (vmcnt) — which serialises the tile arithmetic behind the HBM traffic it is meant to overlap.
-__shared__ __attribute__((aligned(16))) double g_socp_lds[1552];
+__shared__ __attribute__((aligned(16))) double g_socp_lds[1904];   // + the fused border's tiles (Solver::build_kkt: Gn, Rk, Tt, Sg)
 // ... and of the fin instantiation (control_dim = 5: 14 x 25 tiles, 24-column [TA | TBm | TBp]); separate symbols so that the
 // kernels of the reference's model keep their LDS footprint
-__shared__ __attribute__((aligned(16))) double g_socp_lds5[1704];
+__shared__ __attribute__((aligned(16))) double g_socp_lds5[2064];
 #define SCVX_PIPE_LDS5 (2 * 392 + 588 + 392 + 196 + 350 + 364 + 70 + 2 * 46 + 3 * 196 + 8)
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds5[SCVX_PIPE_LDS5];
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds25[SCVX_PIPE_LDS5];
 template <int NU> __device__ __forceinline__ double* socp_lds() { if constexpr (NU == 5) return g_socp_lds5; else return g_socp_lds; }
+// The multi-wavefront kernels factorise through the pipeline's own tiles (g_socp_pipe_lds*) and need only the 32-double header of the
+// scratch (reduction partials, flags): a symbol of their own, so that they do not carry the single-wavefront kernel's tile space
+// (with it the two-wavefront block would not fit four times into a CU's 160 KB)
+__shared__ __attribute__((aligned(16))) double g_socp_blk_hdr[32];
 // tiles of the two-wavefront factorisation pipeline (multi-wavefront kernels only: a kernel that never references the
 // symbol does not get the allocation)
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 3 * 196 + 8];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
@@ -83,20 +87,21 @@ struct WaveExT {
     // Fragment maps (cdna guide §3, f64 form): A: lane l holds A[l&15][l>>4], B: lane l holds B[l>>4][l&15],
     // C/D: register r of lane l is C[(l>>4) + 4r][l&15].  Rows/columns 14,15 and k >= Kd are fed zeros.
     typedef double v4f64 __attribute__((ext_vector_type(4)));
+    // nb: number of columns of B / C that exist (right-hand-side blocks of the fused border: 4); the others are fed zeros and not stored
     __device__ __forceinline__ void tile_gemm(double* Cm, int sci, int scj, const double* A, int sai, int sak,
-                                              const double* B, int sbk, int sbj, int Kd, double alpha, bool acc) {
+                                              const double* B, int sbk, int sbj, int Kd, double alpha, bool acc, int nb = 14) {
         const int l = lane();
         const int rc = l & 15, kq = l >> 4;
         v4f64 c = {0.0, 0.0, 0.0, 0.0};
-        const bool in = rc < 14;
+        const bool in = rc < 14, inb = rc < nb;
         for (int k0 = 0; k0 < Kd; k0 += 4) {
             const int k = k0 + kq;
             const bool kin = in && (k < Kd);
             const double a = kin ? A[rc * sai + k * sak] : 0.0;
-            const double b = kin ? B[k * sbk + rc * sbj] : 0.0;
+            const double b = (inb && k < Kd) ? B[k * sbk + rc * sbj] : 0.0;
             c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
         }
-        if (in) {
+        if (inb) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = kq + 4 * r;
@@ -303,14 +308,15 @@ struct BlockEx {
     __device__ __forceinline__ int nlanes() const { return 64 * NW; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
     __device__ __forceinline__ void sync_lds() { __syncthreads(); }
-    __device__ __forceinline__ double* scratch() { return socp_lds<NU_>(); }
+    __device__ __forceinline__ double* hdr() { if constexpr (kPipelineFactor) return g_socp_blk_hdr; else return socp_lds<NU_>(); }
+    __device__ __forceinline__ double* scratch() { return hdr(); }   // the tiles behind the header exist only without the pipeline (sequential build_kkt)
     __device__ __forceinline__ bool first() const { return threadIdx.x < 64; }
     // slots 0..NW-1 of the scratch header hold the per-wavefront partials, slot 16 a flag
     template <class OP>
     __device__ __forceinline__ double reduce(double x, OP op) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) x = op(x, __shfl_xor(x, o, 64));
-        double* red = socp_lds<NU_>();
+        double* red = hdr();
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
         __syncthreads();
         double r = red[0];
@@ -323,11 +329,11 @@ struct BlockEx {
     __device__ __forceinline__ double min(double x) { return reduce(x, [](double a, double b) { return fmin(a, b); }); }
     __device__ __forceinline__ bool all(bool b) { return __syncthreads_and(b ? 1 : 0) != 0; }
     __device__ __forceinline__ void tile_gemm(double* Cm, int sci, int scj, const double* A, int sai, int sak, const double* B,
-                                              int sbk, int sbj, int Kd, double alpha, bool acc) {
-        if (first()) w0.tile_gemm(Cm, sci, scj, A, sai, sak, B, sbk, sbj, Kd, alpha, acc);
+                                              int sbk, int sbj, int Kd, double alpha, bool acc, int nb = 14) {
+        if (first()) w0.tile_gemm(Cm, sci, scj, A, sai, sak, B, sbk, sbj, Kd, alpha, acc, nb);
     }
     __device__ __forceinline__ bool chol_inv14(const double* M, double* Li) {
-        double* flag = socp_lds<NU_>() + 16;
+        double* flag = hdr() + 16;
         if (first()) {
             const bool ok = w0.chol_inv14(M, Li);
             if (threadIdx.x == 0) *flag = ok ? 1.0 : 0.0;
