@@ -42,6 +42,24 @@ struct HostEx {
                 *c = (acc ? *c : 0.0) + alpha * s;
             }
     }
+    // sums of products on one accumulator (the device keeps it in MFMA registers): see WaveExT::acc_mac
+    struct Acc { double c[14][14]; };
+    void acc_zero(Acc& a) { for (int i = 0; i < 14; i++) for (int j = 0; j < 14; j++) a.c[i][j] = 0.0; }
+    void acc_mac(Acc& a, const double* A, int sai, int sak, const double* B, int sbk, int sbj, int Kd, double alpha, int nb = 14) {
+        for (int i = 0; i < 14; i++)
+            for (int j = 0; j < nb; j++) {
+                double s = a.c[i][j];
+                for (int k = 0; k < Kd; k++) s += (alpha * A[i * sai + k * sak]) * B[k * sbk + j * sbj];
+                a.c[i][j] = s;
+            }
+    }
+    void acc_store(const Acc& a, double* Cm, int sci, int scj, bool add, int nb = 14) {
+        for (int i = 0; i < 14; i++)
+            for (int j = 0; j < nb; j++) {
+                double* c = Cm + i * sci + j * scj;
+                *c = (add ? *c : 0.0) + a.c[i][j];
+            }
+    }
     // L^-1 (row-major, lower) of the Cholesky factor of the SPD tile M
     bool chol_inv14(double* M, double* Li) {
         const bool ok = chol14(M);

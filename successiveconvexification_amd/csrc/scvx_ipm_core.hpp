@@ -2128,12 +2128,18 @@ struct Solver {
             SCVX_TE(ta_, 2);
             SCVX_TS(tb_);
             // pivot tile: M += [TA|TBm|TBp] [A|Bm|Bp]'  -  Wb_{k-1} Wb_{k-1}'
-            ex.tile_gemm(M, 14, 1, T, TS, 1, Dt, 14, 1, TW, 1.0, true);
-            if (k > 0) ex.tile_gemm(M, 14, 1, Wp, 14, 1, Wp, 1, 14, 14, -1.0, true);
-            // r_k (columns 1 and 3): [TA | TBm]_k [g_x,k; g_u,k] + TBp_k g_u,k+1 - Hxi_{k+1} g_x,k+1
-            ex.tile_gemm(Rk, 4, 1, T, TS, 1, Gn, 4, 1, 14 + NU, 1.0, false, 4);
-            ex.tile_gemm(Rk, 4, 1, T + 14 + NU, TS, 1, Gn + NXU * 4 + 14 * 4, 4, 1, NU, 1.0, true, 4);
-            ex.tile_gemm(Rk, 4, 1, Hd, 14, 1, Gn + NXU * 4, 4, 1, 14, -1.0, true, 4);
+            {   // two independent accumulators, no LDS round trip between the terms of either sum
+                typename Ex::Acc cm, cr;
+                ex.acc_zero(cm); ex.acc_zero(cr);
+                ex.acc_mac(cm, T, TS, 1, Dt, 14, 1, TW, 1.0);
+                // r_k (columns 1 and 3): [TA | TBm]_k [g_x,k; g_u,k] + TBp_k g_u,k+1 - Hxi_{k+1} g_x,k+1
+                ex.acc_mac(cr, T, TS, 1, Gn, 4, 1, 14 + NU, 1.0, 4);
+                if (k > 0) ex.acc_mac(cm, Wp, 14, 1, Wp, 1, 14, 14, -1.0);
+                ex.acc_mac(cr, T + 14 + NU, TS, 1, Gn + NXU * 4 + 14 * 4, 4, 1, NU, 1.0, 4);
+                ex.acc_mac(cr, Hd, 14, 1, Gn + NXU * 4, 4, 1, 14, -1.0, 4);
+                ex.acc_store(cm, M, 14, 1, true);
+                ex.acc_store(cr, Rk, 4, 1, false, 4);
+            }
             ex.sync_lds();
             SCVX_TE(tb_, 5);
             SCVX_TS(tc_);
@@ -2160,8 +2166,11 @@ struct Solver {
             } else ex.sync_lds();
             {   // forward substitution of the four right-hand sides: t_k = L_k^-1 r_k + N_k t_{k-1}
                 double* Tc = Tt + 56 * (k & 1); const double* Tp = Tt + 56 * ((k + 1) & 1);
-                ex.tile_gemm(Tc, 4, 1, Li, 14, 1, Rk, 4, 1, 14, 1.0, false, 4);
-                if (k > 0) ex.tile_gemm(Tc, 4, 1, M, 1, 14, Tp, 4, 1, 14, 1.0, true, 4);
+                typename Ex::Acc ct;
+                ex.acc_zero(ct);
+                ex.acc_mac(ct, Li, 14, 1, Rk, 4, 1, 14, 1.0, 4);
+                if (k > 0) ex.acc_mac(ct, M, 1, 14, Tp, 4, 1, 14, 1.0, 4);
+                ex.acc_store(ct, Tc, 4, 1, false, 4);
                 ex.sync_lds();
                 for (int e = ex.lane(); e < 56; e += ex.nlanes()) {
                     const int q = e / 14, i = e - 14 * q;
