@@ -25,6 +25,8 @@ while glob.glob("gpurun_out/%s_%d_FETCH_SIZE.log" % (tag, n)):
         if meta:
             # the pass holds 16 launches (2 warm-up + 14 counted by the device-side counters); warm-up = 2 cold-ish steps: scale by launches
             e["traffic_per_launch"] = (2 * fe + wr) / 16.0
+            if "warmup_ipm_iters" in meta:
+                e["bytes_per_ipm_iteration"] = (2 * fe + wr) / (meta["ipm_iters"] + meta["warmup_ipm_iters"])
     out[str(n)] = e
     print(n, json.dumps(e))
     n += 1
