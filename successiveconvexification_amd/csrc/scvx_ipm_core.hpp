@@ -1444,8 +1444,13 @@ struct Solver {
     // CONSUMES them one segment behind; one workgroup barrier per segment.  Same arithmetic, same results.
     //   producer k:  TBp_k;  Sd_k = Hxi_{k+1} + hnui I + [TA|TBm|TBp]_k D_k';  TA_{k+1}, TBm_{k+1};  So_k = -TA_{k+1} + TBm_{k+1} Bp_k'
     //   consumer k:  M = Sd_k - Wb_{k-1} Wb_{k-1}';  L^-1 = chol_inv(M);  store L^-1;  Nf_k = -L^-1 Wb_{k-1};  Wb_k = So_k L^-T
+    // Since round 4 the pipeline also carries the border (as the sequential loop of build_kkt does, see there): the assembly wavefront
+    // forms r_k = (E Hb^-1 g)_k for the four right-hand sides from the tiles it holds, and the CHAIN wavefront -- which used to wait
+    // two thirds of every step at the hand-over barrier -- stores L_k^-1, forms and stores N_k, and runs the forward substitution
+    // t_k = L_k^-1 r_k + N_k t_{k-1}; the separate post stage is gone.  (Measured at B = 1,024, two wavefronts per trajectory:
+    // the assembly wavefront was the bottleneck with 7.5 k cycles per step of which 4.3 k post stage; profiles/r04_k4_sections_small.txt.)
     template <class E2 = Ex>
-    SCVX_HD_NI bool factor_pipelined() {
+    SCVX_HD_NI bool factor_pipelined(bool with_pred) {
         const int K = L.K;
         const dcptr D_ = D; const cgptr hx_ = hx; const cgptr hu_ = hu;
         const fptr Linv_ = Linv; const fptr Nf_ = Nf;
@@ -1461,12 +1466,37 @@ struct Solver {
         double* Bp = T + 14 * TS;            // producer: Bp_k kept across the tile swap
         double* Hh = Bp + BPN;            // producer: node inverses k | k+1
         double* Hd = Hh + 2 * NODE_SZ;   // producer: dense Hxi_{k+1}
+        double* Gn = Hd + 196;           // producer: 2 x NXU x 4 node slices of the border right-hand sides (columns 1 = Ptr, 3 = gx)
+        double* Rr = Gn + 2 * NXU * 4;   // 3 x 56: r_k ring (producer writes k, the chain reads k one step later)
+        double* Tt = Rr + 168;           // chain: 2 x 56  t_{k-1}, t_k
+        double* Sg = Tt + 112;           // producer: 42 segment scalars gx_nu,k | ry_k | Pnu_k
         const int w = ex.wave(), l = ex.wlane();
         bool ok = true;
         auto node_elem = [&](int node, int e) -> double {
             return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[HU_SZ * node + (e - HX_SZ)];
         };
+        const cgptr Wtr_ = Wv + L.o_tr + 1; const cgptr Wnu_ = Wv + L.o_nu + 1; const cgptr gx_ = gx; const cgptr ry_ = ry;
+        const int nx_ = L.nx, nxu_ = L.nx + L.nu_;
+        auto gnode_elem = [&](int nd, int e) -> double {   // element e = NXU vec + row of node nd (vec 0: Ptr, 1: gx)
+            const int vec = e >= NXU ? 1 : 0, row = e - NXU * vec;
+            if (vec == 1 && !with_pred) return 0.0;
+            cgptr src = vec ? gx_ : Wtr_;
+            return row < 14 ? src[14 * nd + row] : src[nx_ + NU * nd + (row - 14)];
+        };
+        auto gseg_elem = [&](int sgk, int e) -> double {
+            if (e >= 28) return Wnu_[14 * sgk + (e - 28)];
+            if (!with_pred) return 0.0;
+            return e < 14 ? gx_[nxu_ + 14 * sgk + e] : ry_[14 * sgk + (e - 14)];
+        };
+        const gptr xq_[4] = {ys, ytr, ynu, dy};
+        const gptr rtr_ = rtr;
         if (w == 1) {   // producer prologue: D_0, node 0 -> TA_0, TBm_0
+            for (int e = l; e < 2 * NXU * 4; e += 64) Gn[e] = 0.0;   // columns 0 and 2 stay zero
+            ex.w_sync_lds();
+            for (int e = l; e < 2 * NXU; e += 64) {
+                const int vec = e >= NXU ? 1 : 0, row = e - NXU * vec;
+                Gn[NXU * 4 + 4 * row + (vec ? 3 : 1)] = gnode_elem(0, e);
+            }
             for (int e = l; e < DSZ; e += 64) Dt[e] = D_[e];
             for (int e = l; e < NODE_SZ; e += 64) Hh[NODE_SZ + e] = node_elem(0, e);
             ex.w_sync_lds();
@@ -1479,9 +1509,10 @@ struct Solver {
             }
             ex.w_sync_lds();
         }
-        const int PW = ex.nlanes() > 128 ? 2 : 1;   // wavefront of the post stage: an idle one if the block has more than two
         double hnext = (w == 1 && l < NODE_SZ) ? node_elem(1, l) : 0.0;   // the assembly wavefront keeps the next node's inverses one step ahead
-        for (int t = 0; t <= K + 1; t++) {
+        double gnext = (w == 1 && l < 2 * NXU) ? gnode_elem(1, l) : 0.0;  // ... and the right-hand sides' slices and segment scalars
+        double sgnext = (w == 1 && l < 42) ? gseg_elem(0, l) : 0.0;
+        for (int t = 0; t <= K; t++) {
             if (w == 1 && t < K) {
                 const int k = t;
                 SCVX_TS(tp0_);
@@ -1492,9 +1523,20 @@ struct Solver {
                 SCVX_UNROLL
                 for (int q = 0; q < NPW; q++) { const int e = l + 64 * q; pre[q] = e < DSZ ? Dn[e] : 0.0; }
                 for (int e = l; e < NODE_SZ; e += 64) { Hh[e] = Hh[NODE_SZ + e]; }
+                if (l < 2 * NXU) {   // slot 0 <- slot 1 (node k)
+                    const int vec = l >= NXU ? 1 : 0, row = l - NXU * vec, at = 4 * row + (vec ? 3 : 1);
+                    Gn[at] = Gn[NXU * 4 + at];
+                }
+                if (l < 42) Sg[l] = sgnext;
                 ex.w_sync_lds();
                 if (l < NODE_SZ) Hh[NODE_SZ + l] = hnext;                          // node k + 1, requested a step ago
                 hnext = l < NODE_SZ ? node_elem(k + 2 <= K ? k + 2 : K, l) : 0.0;   // node k + 2 for the next step
+                if (l < 2 * NXU) {
+                    const int vec = l >= NXU ? 1 : 0, row = l - NXU * vec;
+                    Gn[NXU * 4 + 4 * row + (vec ? 3 : 1)] = gnext;
+                }
+                gnext = l < 2 * NXU ? gnode_elem(k + 2 <= K ? k + 2 : K, l) : 0.0;
+                sgnext = l < 42 ? gseg_elem(k + 1 < K ? k + 1 : k, l) : 0.0;
                 ex.w_sync_lds();
                 for (int e = l; e < 196 + BPN; e += 64) {
                     if (e < 196) {
@@ -1510,7 +1552,26 @@ struct Solver {
                 ex.w_sync_lds();
                 SCVX_TE(tp0_, 24);
                 SCVX_TS(tp1_);
-                ex.w_tile_gemm(Sdk, 14, 1, T, TS, 1, Dt, 14, 1, TW, 1.0, true);
+                {
+                    double* Rk = Rr + 56 * (k % 3);
+                    typename E2::WAcc cm, cr;
+                    ex.w_acc_zero(cm); ex.w_acc_zero(cr);
+                    ex.w_acc_mac(cm, T, TS, 1, Dt, 14, 1, TW, 1.0);
+                    // r_k (columns 1 and 3): [TA | TBm]_k [g_x,k; g_u,k] + TBp_k g_u,k+1 - Hxi_{k+1} g_x,k+1
+                    ex.w_acc_mac(cr, T, TS, 1, Gn, 4, 1, 14 + NU, 1.0, 4);
+                    ex.w_acc_mac(cr, T + 14 + NU, TS, 1, Gn + NXU * 4 + 14 * 4, 4, 1, NU, 1.0, 4);
+                    ex.w_acc_mac(cr, Hd, 14, 1, Gn + NXU * 4, 4, 1, 14, -1.0, 4);
+                    ex.w_acc_store(cm, Sdk, 14, 1, true);
+                    ex.w_acc_store(cr, Rk, 4, 1, false, 4);
+                    ex.w_sync_lds();
+                    // the plain parts: column 0 = Sg_k, column 2 = hnui Pnu_k, column 3 += hnui gx_nu,k + ry_k; rtr_k is kept as well
+                    if (l < 14) {
+                        Rk[4 * l] = Dt[14 * CS + l];
+                        Rk[4 * l + 2] = hnui_ * Sg[28 + l];
+                        Rk[4 * l + 3] += hnui_ * Sg[l] + Sg[14 + l];
+                        rtr_[14 * k + l] = Rk[4 * l + 1];
+                    }
+                }
                 SCVX_TE(tp1_, 25);
                 SCVX_TS(tp2_);
                 if (k + 1 < K) {
@@ -1549,22 +1610,32 @@ struct Solver {
                 SCVX_TS(tc3_);
                 if (k + 1 < K) { ex.w_tile_gemm(Wp + 196 * (k % 3), 14, 1, Sok, 14, 1, Lik, 1, 14, 14, 1.0, false); ex.w_sync_lds(); }
                 SCVX_TE(tc3_, 27);
-            }
-            if (w == PW && t >= 2) {
-                // ---- post stage, one step behind the chain: L^-1 (packed) and Nf_j = -L_j^-1 Wb_{j-1} to HBM ----
-                const int j = t - 2;
+                // ---- what used to be the post stage, now in the chain wavefront's idle time: L^-1 (packed) and N_k = -L_k^-1 Wb_{k-1} to
+                // HBM, then the forward substitution of the four right-hand sides, t_k = L_k^-1 r_k + N_k t_{k-1} ----
                 SCVX_TS(tc2_);
-                const double* Lij = Li + 196 * (j & 1);
                 for (int e = l; e < LINV_SZ; e += 64) {
                     const int p = e / 15, q = e - 15 * p;
                     const int i = q <= p ? p : 13 - p, jj = q <= p ? q : q - (p + 1);
-                    Linv_[(size_t)j * LINV_SZ + e] = Lij[14 * i + jj];
+                    Linv_[(size_t)k * LINV_SZ + e] = Lik[14 * i + jj];
                 }
-                if (j > 0) {
-                    ex.w_tile_gemm(Mq, 1, 14, Lij, 14, 1, Wp + 196 * ((j + 2) % 3), 14, 1, 14, -1.0, false);
+                if (k > 0) {
+                    ex.w_tile_gemm(Mq, 1, 14, Lik, 14, 1, Wpm, 14, 1, 14, -1.0, false);
                     ex.w_sync_lds();
-                    for (int e = l; e < 196; e += 64) Nf_[(size_t)j * 196 + e] = Mq[e];
+                    for (int e = l; e < 196; e += 64) Nf_[(size_t)k * 196 + e] = Mq[e];
+                }
+                {
+                    const double* Rk = Rr + 56 * (k % 3);
+                    double* Tc = Tt + 56 * (k & 1); const double* Tp = Tt + 56 * ((k + 1) & 1);
+                    typename E2::WAcc ct;
+                    ex.w_acc_zero(ct);
+                    ex.w_acc_mac(ct, Lik, 14, 1, Rk, 4, 1, 14, 1.0, 4);
+                    if (k > 0) ex.w_acc_mac(ct, Mq, 1, 14, Tp, 4, 1, 14, 1.0, 4);
+                    ex.w_acc_store(ct, Tc, 4, 1, false, 4);
                     ex.w_sync_lds();
+                    if (l < 56) {
+                        const int q = l / 14, i = l - 14 * q;
+                        if (q < 3 || with_pred) xq_[q][14 * k + i] = Tc[4 * i + q];
+                    }
                 }
                 SCVX_TE(tc2_, 26);
             }
@@ -2028,13 +2099,14 @@ struct Solver {
         double* Rk = Gn + 2 * NXU * 4;           // 14 x 4        r_k
         double* Tt = Rk + 56;                    // 2 x 14 x 4    t_{k-1}, t_k (alternating)
         double* Sg = Tt + 112;                   // 42            segment scalars: gx_nu,k (14) | ry_k (14) | Pnu_k (14)
-        constexpr bool kFusedBorder = !Ex::kPipelineFactor;
+        // (the two-ended factorisation of the four-wavefront blocks keeps the separate border: its forward substitution runs from both ends)
+        const bool kFusedBorder = !(Ex::kTwisted && twisted());
         bool ok = true;
         if constexpr (Ex::kPipelineFactor) {
             if constexpr (Ex::kTwisted) {
-                ok = twisted() ? factor_twisted() : factor_pipelined();
+                ok = twisted() ? factor_twisted() : factor_pipelined(with_pred);
             } else
-            ok = factor_pipelined();   // two wavefronts: Schur-block assembly one segment ahead of the Cholesky chain
+            ok = factor_pipelined(with_pred);   // two wavefronts: Schur-block assembly one segment ahead of the Cholesky chain
         } else {
         // All 14x14xK products below go through ex.tile_gemm: FP64 MFMA (v_mfma_f64_16x16x4) on the device — one A and
         // one B element per lane per instruction instead of 2 LDS reads per multiply-add — plain loops on the host.
@@ -2220,7 +2292,7 @@ struct Solver {
         // Only the multipliers y are kept.  The local parts l = Hb^-1 (g - E'y) of the border solutions are never
         // formed: every border coefficient is an inner product in y-space (below), and a solve applies its border
         // correction to dy and to the right-hand side BEFORE its single final  Hb^-1 (g - E'dy)  (kkt_solve).
-        if constexpr (kFusedBorder) {
+        if (kFusedBorder) {
             // the forward substitutions were carried by the loop: Hb^-1 Ptr on (dx, du) for the two inner products that use it, then
             // the backward halves
             Hb_inv(Wv + L.o_tr + 1, ptl, false);

@@ -23,7 +23,7 @@ __shared__ __attribute__((aligned(16))) double g_socp_lds[1904];   // + the fuse
 // ... and of the fin instantiation (control_dim = 5: 14 x 25 tiles, 24-column [TA | TBm | TBp]); separate symbols so that the
 // kernels of the reference's model keep their LDS footprint
 __shared__ __attribute__((aligned(16))) double g_socp_lds5[2064];
-#define SCVX_PIPE_LDS5 (2 * 392 + 588 + 392 + 196 + 350 + 364 + 70 + 2 * 46 + 3 * 196 + 8)
+#define SCVX_PIPE_LDS5 (2 * 392 + 588 + 392 + 196 + 350 + 364 + 70 + 2 * 46 + 3 * 196 + 8 + 96)
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds5[SCVX_PIPE_LDS5];
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds25[SCVX_PIPE_LDS5];
 template <int NU> __device__ __forceinline__ double* socp_lds() { if constexpr (NU == 5) return g_socp_lds5; else return g_socp_lds; }
@@ -33,7 +33,7 @@ template <int NU> __device__ __forceinline__ double* socp_lds() { if constexpr (
 __shared__ __attribute__((aligned(16))) double g_socp_blk_hdr[32];
 // tiles of the two-wavefront factorisation pipeline (multi-wavefront kernels only: a kernel that never references the
 // symbol does not get the allocation)
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 3 * 196 + 8];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 3 * 196 + 8 + 96];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
 #ifndef SCVX_K4_PIPELINE
 #define SCVX_K4_PIPELINE 1
 #endif
@@ -338,6 +338,12 @@ struct BlockEx {
         w0.tile_gemm(Cm, sci, scj, A, sai, sak, B, sbk, sbj, Kd, alpha, acc);
     }
     __device__ __forceinline__ bool w_chol_inv14(const double* M, double* Li) { return w0.chol_inv14(M, Li); }
+    // wave-level accumulator products (the calling wavefront, whichever it is: the stages of the factorisation pipeline)
+    typedef typename WaveExT<NU_>::Acc WAcc;
+    __device__ __forceinline__ void w_acc_zero(WAcc& c) { w0.acc_zero(c); }
+    __device__ __forceinline__ void w_acc_mac(WAcc& c, const double* A, int sai, int sak, const double* B, int sbk, int sbj, int Kd,
+                                              double alpha, int nb = 14) { w0.acc_mac(c, A, sai, sak, B, sbk, sbj, Kd, alpha, nb); }
+    __device__ __forceinline__ void w_acc_store(const WAcc& c, double* Cm, int sci, int scj, bool add, int nb = 14) { w0.acc_store(c, Cm, sci, scj, add, nb); }
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int nlanes() const { return 64 * NW; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
