@@ -634,7 +634,11 @@ def main():
                     s2, i2, m2, _ = b2.solver_stats()
                     out["optimal_frac"] = float(np.mean(s2 == 0))
                     out["merit_max"] = float(np.max(m2))
-                    out["traj_linf_vs_f64_run"] = float(np.abs(b2.trajectory_record() - rec64).max()) if rec64 is not None else None
+                    if rec64 is not None:
+                        # per trajectory: after a whole solve_problem a few trajectories take a different accept / reject decision at a
+                        # borderline ratio test and end elsewhere (the max); the median / 99th percentile say how close the rest stay
+                        dd = np.abs(b2.trajectory_record() - rec64).max(axis=1)
+                        out["traj_linf_vs_f64_run"] = {"median": float(np.median(dd)), "p99": float(np.quantile(dd, 0.99)), "max": float(dd.max())}
                 b2.close()
                 return out
             line["f32_linearization"] = dict(variant(lin32=True), dtype="f64 arithmetic, f32 derivative tiles",
