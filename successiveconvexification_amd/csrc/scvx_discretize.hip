@@ -586,6 +586,225 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
 #endif
 }
 
+// The persistent pipeline with the producer's stage split over TWO wavefronts (aero / fin models; scvx_dyn.hpp: stage_state_publish /
+// stage_cols_publish).  Roles: wave 0 = P0 (state path, one lane per segment), wave 1 = P1 (derivative part of the record, one stage
+// behind P0, one lane per segment), waves 2.. = consumers (one lane per sensitivity column, one stage behind P1).  One barrier per tick;
+// stage n of a group lives in ring slot n % 3 (P0 writes it at tick n, P1 completes it at tick n + 1, the consumers read it at tick n + 2),
+// the hand-over record in slot n % 2.  Six consumer wavefronts instead of seven: 18 (aero) / 12 (fins) segments per group.
+#ifndef SCVX_K1_SPLIT
+#define SCVX_K1_SPLIT 1
+#endif
+template <bool AERO, typename R, typename O = R, bool FIN = false>
+__global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp2_kernel(
+    DynP<R> p, long nseg, int K, const R* __restrict__ x, const R* __restrict__ u,
+    const R* __restrict__ sigma, R dt, int nsub, R* __restrict__ endpoint,
+    O* __restrict__ deriv, const int* __restrict__ skip) {
+    static_assert(AERO || FIN, "the exo producer is not the bottleneck");
+    constexpr int LPS = K1Map<AERO, FIN>::LPS, SPW = K1Map<AERO, FIN>::SPW;
+    constexpr int NU = K1Map<AERO, FIN>::NU, NP = K1Map<AERO, FIN>::NP, DSZ = K1Map<AERO, FIN>::DSZ, HV = K1Map<AERO, FIN>::HV;
+    typedef typename Vec2<R>::type VEC2;
+    typedef typename Vec2<O>::type OVEC2;
+    constexpr int NC = PC_WAVES - 2;
+    constexpr int NS = NC * SPW;               // segments per group
+    constexpr int NR = StageRec<AERO, FIN>::N, NH = HandRec<FIN>::N;
+    constexpr int RING_D = 3 * NR * NS, HAND_D = 2 * NH * NS, TILE_D = NC * SPW * DSZ;
+    __shared__ __attribute__((aligned(16))) R lds[RING_D + HAND_D + TILE_D];
+    R* const hand = lds + RING_D;
+    R* const tiles = hand + HAND_D;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+#if defined(SCVX_K1_PROF)
+    double k1wait_ = 0.0;
+    const unsigned long long k1t0_ = __builtin_amdgcn_s_memtime();
+#endif
+    const R h = dt / R(nsub);
+    const R inv_n = R(1.0) / R(nsub);
+    const int T = 4 * nsub;                    // stages per segment
+    const long ngrp = (nseg + NS - 1) / NS;
+    auto advance = [&](long g) {
+        while (g < ngrp && block_unchanged(skip, g * NS, NS, nseg, K)) g += gridDim.x;
+        return g;
+    };
+    long grp = advance(blockIdx.x);
+
+    if (wave == 0) {
+        // ---------------- P0: the state path, lane = segment ----------------
+        const bool live = lane < NS;
+        const int l = live ? lane : 0;
+        R nx[14], nu6[2 * NU], nsig = R(0.0);
+        auto fetch = [&](long g) {
+            long seg = g * NS + l;
+            if (seg >= nseg) seg = nseg - 1;
+            const long b = seg / K;
+            const int k = (int)(seg - b * K);
+            const R* xk = x + ((size_t)b * (K + 1) + k) * 14;
+            const R* uk = u + ((size_t)b * (K + 1) + k) * NU;
+#pragma unroll
+            for (int i = 0; i < 14; i++) nx[i] = xk[i];
+#pragma unroll
+            for (int i = 0; i < 2 * NU; i++) nu6[i] = uk[i];
+            nsig = sigma[b];
+        };
+        if (grp < ngrp) fetch(grp);
+        while (grp < ngrp) {
+            const long nxt = advance(grp + gridDim.x);
+            const long seg = grp * NS + l;
+            const bool valid = live && seg < nseg;
+            const R sig = nsig;
+            R xs[14], xa[14], xt[14];
+#pragma unroll
+            for (int i = 0; i < 14; i++) { xs[i] = nx[i]; xa[i] = xs[i]; xt[i] = xs[i]; }
+            R ukv[NU], upv[NU];
+#pragma unroll
+            for (int j = 0; j < NU; j++) { ukv[j] = nu6[j]; upv[j] = nu6[NU + j]; }
+            int slot = 0, hs = 0;
+            for (int s = 0; s < nsub; s++) {
+#pragma unroll
+                for (int stg = 0; stg < 4; stg++) {
+                    const R lkp = (R(s) + (stg == 0 ? R(0.0) : (stg == 3 ? R(1.0) : R(0.5)))) * inv_n;
+                    const R lkm = R(1.0) - lkp;
+                    R uu[NU];
+#pragma unroll
+                    for (int j = 0; j < NU; j++) uu[j] = fma(ukv[j], lkm, upv[j] * lkp);
+                    struct { R g[14]; } st;
+                    stage_state_publish<AERO, FIN>(p, xt, uu, st.g, lds + slot * NR * NS + l, NS, live, hand + hs * NH * NS + l, NS);
+                    const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
+                    const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
+#pragma unroll
+                    for (int i = 0; i < 14; i++) {
+                        const R dx = sig * st.g[i];
+                        xa[i] = fma(wacc, dx, xa[i]);
+                        xt[i] = (stg < 3) ? fma(wnext, dx, xs[i]) : xa[i];
+                    }
+                    slot = slot == 2 ? 0 : slot + 1;
+                    hs ^= 1;
+                    K1_BAR();   // tick: stage 4 s + stg is handed to P1
+                }
+#pragma unroll
+                for (int i = 0; i < 14; i++) xs[i] = xa[i];
+            }
+            K1_BAR();   // P1's last stage
+            K1_BAR();   // the consumers' last stage
+            if (nxt < ngrp) fetch(nxt);
+            if (valid) {
+                R* ep = endpoint + (size_t)seg * 14;
+#pragma unroll
+                for (int i = 0; i < 14; i++) ep[i] = xs[i];
+            }
+            K1_BAR();  // matches the consumers' tile barrier
+            grp = nxt;
+        }
+#if defined(SCVX_K1_PROF)
+        if (blockIdx.x == 0 && lane == 0) { g_k1prof[2 * wave] = k1wait_; g_k1prof[2 * wave + 1] = (double)(__builtin_amdgcn_s_memtime() - k1t0_); }
+#endif
+        return;
+    }
+    if (wave == 1) {
+        // ---------------- P1: the derivative part of the records, one stage behind P0 ----------------
+        const bool live = lane < NS;
+        const int l = live ? lane : 0;
+        while (grp < ngrp) {
+            const long nxt = advance(grp + gridDim.x);
+            int slot = 0, hs = 0;
+            K1_BAR();   // stage 0 has been handed over
+            for (int n = 0; n < T; n++) {
+                stage_cols_publish<AERO, FIN>(p, hand + hs * NH * NS + l, NS, lds + slot * NR * NS + l, NS, live);
+                slot = slot == 2 ? 0 : slot + 1;
+                hs ^= 1;
+                K1_BAR();
+            }
+            K1_BAR();   // the consumers' last stage
+            K1_BAR();   // tile barrier
+            grp = nxt;
+        }
+#if defined(SCVX_K1_PROF)
+        if (blockIdx.x == 0 && lane == 0) { g_k1prof[2 * wave] = k1wait_; g_k1prof[2 * wave + 1] = (double)(__builtin_amdgcn_s_memtime() - k1t0_); }
+#endif
+        return;
+    }
+
+    // ---------------- consumers: lane = (segment, column), two stages behind P0 ----------------
+    const int cw = wave - 2;
+    const int sl = lane / LPS;
+    const int slot_c = lane - sl * LPS;
+    const int col = slot_c;
+    const bool lane_live = sl < SPW;
+    const int ls = cw * SPW + (lane_live ? sl : 0);   // local segment index in the group
+    const bool is_uk = (col >= 14) && (col < 14 + NU);
+    const bool is_up = (col >= 14 + NU) && (col < 14 + 2 * NU);
+    const int comp = is_uk ? col - 14 : (is_up ? col - 14 - NU : -1);
+    const R gsel = (col == NP - 1) ? R(1.0) : R(0.0);
+    R ec[NU];
+#pragma unroll
+    for (int j = 0; j < NU; j++) ec[j] = (comp == j) ? R(1.0) : R(0.0);
+    auto sigma_of = [&](long g) {
+        long seg = g * NS + ls;
+        if (seg >= nseg) seg = nseg - 1;
+        return sigma[seg / K];
+    };
+    R nsig = grp < ngrp ? sigma_of(grp) : R(0.0);
+    while (grp < ngrp) {
+        const long nxt = advance(grp + gridDim.x);
+        const long seg_base = grp * NS;
+        const R sig = nsig;
+        R c[14], ca[14], ct[14];
+#pragma unroll
+        for (int i = 0; i < 14; i++) { c[i] = (col == i) ? R(1.0) : R(0.0); ca[i] = c[i]; ct[i] = c[i]; }
+        K1_BAR();  // P0's first stage
+        K1_BAR();  // ... completed by P1
+        int slot = 0;
+        for (int s = 0; s < nsub; s++) {
+#pragma unroll
+            for (int stg = 0; stg < 4; stg++) {
+                const R lkp = (R(s) + (stg == 0 ? R(0.0) : (stg == 3 ? R(1.0) : R(0.5)))) * inv_n;
+                const R lkm = R(1.0) - lkp;
+                const R wk = is_uk ? lkm : (is_up ? lkp : R(0.0));
+                R wc[NU];
+#pragma unroll
+                for (int j = 0; j < NU; j++) wc[j] = ec[j] * wk;
+                R dc[14];
+                column_deriv_rec_any<AERO, FIN>(p, lds + slot * NR * NS + ls, NS, ct, wc, gsel, sig, dc);
+                const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
+                const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
+#pragma unroll
+                for (int i = 0; i < 14; i++) {
+                    ca[i] = fma(wacc, dc[i], ca[i]);
+                    ct[i] = (stg < 3) ? fma(wnext, dc[i], c[i]) : ca[i];
+                }
+                slot = slot == 2 ? 0 : slot + 1;
+                K1_BAR();
+            }
+#pragma unroll
+            for (int i = 0; i < 14; i++) c[i] = ca[i];
+        }
+        if (nxt < ngrp) nsig = sigma_of(nxt);
+        // ---- epilogue: columns into this wavefront's LDS tile -> coalesced 16-byte stores ----
+        R* t = tiles + cw * SPW * DSZ;
+        if (lane_live) {
+#pragma unroll
+            for (int i = 0; i < 14; i++) t[sl * DSZ + col * 14 + i] = c[i];
+        }
+        K1_BAR();
+        const long seg0 = seg_base + (long)cw * SPW;
+        if (seg0 < nseg) {
+            const long rem = nseg - seg0;
+            const int nvalid = rem < SPW ? (int)rem : SPW;
+            const int n2 = nvalid * HV;
+            OVEC2* out = reinterpret_cast<OVEC2*>(deriv + (size_t)seg0 * DSZ);
+            const VEC2* src = reinterpret_cast<const VEC2*>(t);
+#pragma unroll
+            for (int r = 0; r < (SPW * HV + 63) / 64; r++) {
+                const int e = lane + 64 * r;
+                if (e < n2) { const VEC2 v = src[e]; OVEC2 o; o.x = O(v.x); o.y = O(v.y); out[e] = o; }
+            }
+        }
+        grp = nxt;
+    }
+#if defined(SCVX_K1_PROF)
+    if (blockIdx.x == 0 && lane == 0) { g_k1prof[2 * wave] = k1wait_; g_k1prof[2 * wave + 1] = (double)(__builtin_amdgcn_s_memtime() - k1t0_); }
+#endif
+}
+
 template <bool AERO, typename R, bool FIN = false>
 __global__ __launch_bounds__(256) void propagate_kernel(DynP<R> p, long nseg, int K, const R* __restrict__ x,
                                                         const R* __restrict__ u,
@@ -666,7 +885,9 @@ hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, con
     const bool fin = ctx->dyn.fin != 0;
     if constexpr (std::is_same<R, O>::value)
         if (ctx->k1_variant == 0 && !fin) return launch_linearize_simple<R>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st, skip);
-    const int ns = (PC_WAVES - 1) * (fin ? K1Map<true, true>::SPW : (ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW));
+    // aero / fin models from 3 substeps up: the producer's stage split over two wavefronts (linearize_pcp2_kernel), six consumer wavefronts
+    const bool split = SCVX_K1_SPLIT != 0 && (fin || ctx->dyn.aero) && ctx->k1_sg != 0 && (ctx->k1_persist < 0 ? ctx->nsub >= 3 : ctx->k1_persist != 0);
+    const int ns = (PC_WAVES - (split ? 2 : 1)) * (fin ? K1Map<true, true>::SPW : (ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW));
     // stage-granular pipeline by default (faster at every npts measured: 0.70 -> 0.60 ms at npts 1, 3.05 -> 2.96 ms
     // at npts 10, B = 8192, fp64); SCVX_K1_SG=0 selects the substep-granular form
     const bool sg = ctx->k1_sg != 0;
@@ -678,7 +899,12 @@ hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, con
     const unsigned grid = (unsigned)(!persist || ngrp < cap ? ngrp : cap);
     const dim3 g(grid), blk(64 * PC_WAVES);
     const DynP<R> dp(ctx->dyn);
-    if (fin) {   // control_dim = 5: the stage-granular pipeline (persistent from 3 substeps up), exo or aero
+    if (split) {
+        if (fin) {
+            if (ctx->dyn.aero) hipLaunchKernelGGL((linearize_pcp2_kernel<true, R, O, true>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+            else hipLaunchKernelGGL((linearize_pcp2_kernel<false, R, O, true>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+        } else hipLaunchKernelGGL((linearize_pcp2_kernel<true, R, O, false>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+    } else if (fin) {   // control_dim = 5: the stage-granular pipeline (persistent from 3 substeps up), exo or aero
         if (persist) {
             if (ctx->dyn.aero) hipLaunchKernelGGL((linearize_pcp_kernel<true, R, O, true>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
             else hipLaunchKernelGGL((linearize_pcp_kernel<false, R, O, true>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);

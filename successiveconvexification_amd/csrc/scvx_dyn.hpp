@@ -736,6 +736,194 @@ __device__ __forceinline__ void stage_eval_publish(const DynP<R>& p, const R* x,
     }
 }
 
+// ---- the producer's stage split over TWO wavefronts (aero / fin models: linearize_pcp2_kernel) ----
+// With aerodynamics the producer is the block's bottleneck (its consumers wait 65-80 % of the kernel at the stage barriers,
+// profiles/r04_k1_split.md): one stage is the spline tables, the force, seven force-derivative columns and the rate Jacobian, a
+// serial chain on one wavefront.  Only the first half of that feeds the state recurrence.  So wavefront P0 runs the STATE path --
+// rotation matrix, tables, force, right-hand side -- publishes the part of the record it owns and hands (q, v, w, u, 1/m and the
+// prepared aerodynamic / fin quantities: HandRec) to wavefront P1, which one stage later produces the DERIVATIVE part of the
+// same record: the seven columns of d(C u + F)/d(q, v) / m, the fin torque columns and the rate Jacobian.  Same arithmetic as
+// stage_eval_publish, statement for statement.
+template <bool FIN> struct HandRec {
+    // q 0..3 | v 4..6 | w 7..9 | u 10..14 | invm 15 | flags 16 | ivn vn2 c iln drag lift 17..22 | fs_td1 fs_td2 fs_tl1 fs_tl2 23..26 |
+    // bv 27..29 | l 30..32 | fin: fd1 33..35 | b2 36..38 | inn 39
+    static constexpr int N = FIN ? 40 : 33;
+};
+template <bool AERO, bool FIN, typename R>
+__device__ __forceinline__ void stage_state_publish(const DynP<R>& p, const R* x, const R* u, R* g, R* rec, int stride, bool live,
+                                                    R* hand, int hstride) {
+    constexpr int oC = 14, oInvm = 23, oAm = 24, oQ = 48, oW = 52, oKu = 55;
+    constexpr int oF1 = 67, oF2 = 70, oG1 = 94, oG2 = 97;
+    const R* v = x + 4;
+    const R* q = x + 7;
+    const R* w = x + 11;
+    auto PUT = [&](int i, R val) { if (live) rec[i * stride] = val; };
+    auto HPUT = [&](int i, R val) { if (live) hand[i * hstride] = val; };
+    R C[9];
+    dcm(q, C);
+#pragma unroll
+    for (int i = 0; i < 9; i++) PUT(oC + i, C[i]);
+    const R invm = R(1.0) / x[0];
+    PUT(oInvm, invm);
+    const R q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const R u1 = u[0], u2 = u[1], u3 = u[2];
+    R F[3] = {R(0.0), R(0.0), R(0.0)}, ff[3] = {R(0.0), R(0.0), R(0.0)};
+    AeroPrep<R> A;
+    FinPrep<R> Fp;
+    int flags = 0;
+    if (AERO) {
+        aero_prep(p, v, C, A);
+#pragma unroll
+        for (int i = 0; i < 3; i++) F[i] = A.F[i];
+        flags |= (A.on ? 1 : 0) | (A.clamped ? 2 : 0) | (A.has_lift ? 4 : 0);
+        HPUT(17, A.ivn); HPUT(18, A.vn2); HPUT(19, A.c); HPUT(20, A.iln); HPUT(21, A.drag); HPUT(22, A.lift);
+        HPUT(23, A.fs_td1); HPUT(24, A.fs_td2); HPUT(25, A.fs_tl1); HPUT(26, A.fs_tl2);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { HPUT(27 + i, A.bv[i]); HPUT(30 + i, A.l[i]); }
+    }
+    if (FIN) {
+        fin_prep(v, C, Fp);
+        flags |= Fp.ok ? 8 : 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            ff[i] = u[3] * Fp.fd1[i] + u[4] * Fp.fd2[i];
+            F[i] += ff[i];
+            PUT(oF1 + i, Fp.fd1[i]);
+            PUT(oF2 + i, Fp.fd2[i]);
+            PUT(oG1 + i, p.JrF[3 * i] * Fp.fd1[0] + p.JrF[3 * i + 1] * Fp.fd1[1] + p.JrF[3 * i + 2] * Fp.fd1[2]);
+            PUT(oG2 + i, p.JrF[3 * i] * Fp.fd2[0] + p.JrF[3 * i + 1] * Fp.fd2[1] + p.JrF[3 * i + 2] * Fp.fd2[2]);
+            HPUT(33 + i, Fp.fd1[i]); HPUT(36 + i, Fp.b2[i]);
+        }
+        HPUT(39, Fp.inn);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) HPUT(i, q[i]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { HPUT(4 + i, v[i]); HPUT(7 + i, w[i]); }
+#pragma unroll
+    for (int i = 0; i < (FIN ? 5 : 3); i++) HPUT(10 + i, u[i]);
+    HPUT(15, invm);
+    HPUT(16, (R)flags);
+    g[0] = -p.alpha * sqrt(u1 * u1 + u2 * u2 + u3 * u3);
+    g[1] = v[0]; g[2] = v[1]; g[3] = v[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const R acc = (C[3 * i] * u1 + C[3 * i + 1] * u2 + C[3 * i + 2] * u3 + F[i]) * invm;
+        g[4 + i] = acc;
+        PUT(oAm + i, -acc * invm);
+    }
+    g[4] -= p.g0;
+    g[7] = R(0.5) * (-w[0] * q1 - w[1] * q2 - w[2] * q3);
+    g[8] = R(0.5) * (w[0] * q0 + w[2] * q2 - w[1] * q3);
+    g[9] = R(0.5) * (w[1] * q0 - w[2] * q1 + w[0] * q3);
+    g[10] = R(0.5) * (w[2] * q0 + w[1] * q1 - w[0] * q2);
+    {
+        R Jw[3], t[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) Jw[i] = p.J[3 * i] * w[0] + p.J[3 * i + 1] * w[1] + p.J[3 * i + 2] * w[2];
+        t[0] = (p.rTB[1] * u3 - p.rTB[2] * u2) - (w[1] * Jw[2] - w[2] * Jw[1]);
+        t[1] = (p.rTB[2] * u1 - p.rTB[0] * u3) - (w[2] * Jw[0] - w[0] * Jw[2]);
+        t[2] = (p.rTB[0] * u2 - p.rTB[1] * u1) - (w[0] * Jw[1] - w[1] * Jw[0]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            g[11 + i] = p.Jinv[3 * i] * t[0] + p.Jinv[3 * i + 1] * t[1] + p.Jinv[3 * i + 2] * t[2];
+            if (FIN) g[11 + i] += p.JrF[3 * i] * ff[0] + p.JrF[3 * i + 1] * ff[1] + p.JrF[3 * i + 2] * ff[2];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) PUT(i, g[i]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) PUT(oQ + i, q[i]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) PUT(oW + i, w[i]);
+    {
+        const R un = sqrt(u1 * u1 + u2 * u2 + u3 * u3);
+        const R k = un > R(0.0) ? -p.alpha / un : R(0.0);
+        PUT(oKu, k * u1); PUT(oKu + 1, k * u2); PUT(oKu + 2, k * u3);
+    }
+}
+template <bool AERO, bool FIN, typename R>
+__device__ __forceinline__ void stage_cols_publish(const DynP<R>& p, const R* hand, int hstride, R* rec, int stride, bool live) {
+    constexpr int oDq = 27, oMw = 39, oDv = 58, oWq = 73, oWv = 85;
+    auto PUT = [&](int i, R val) { if (live) rec[i * stride] = val; };
+    auto H = [&](int i) { return hand[i * hstride]; };
+    R q[4], v[3], w[3], u[5] = {R(0.0), R(0.0), R(0.0), R(0.0), R(0.0)};
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = H(i);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { v[i] = H(4 + i); w[i] = H(7 + i); }
+#pragma unroll
+    for (int i = 0; i < (FIN ? 5 : 3); i++) u[i] = H(10 + i);
+    const R invm = H(15);
+    const int flags = (int)H(16);
+    const R q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const R u1 = u[0], u2 = u[1], u3 = u[2];
+    AeroPrep<R> A;
+    FinPrep<R> Fp;
+    if (AERO) {
+        A.on = (flags & 1) != 0; A.clamped = (flags & 2) != 0; A.has_lift = (flags & 4) != 0;
+        A.ivn = H(17); A.vn2 = H(18); A.c = H(19); A.iln = H(20); A.drag = H(21); A.lift = H(22);
+        A.fs_td1 = H(23); A.fs_td2 = H(24); A.fs_tl1 = H(25); A.fs_tl2 = H(26);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { A.bv[i] = H(27 + i); A.l[i] = H(30 + i); A.F[i] = R(0.0); }
+        A.isos = R(1.0) / p.sos;
+    }
+    if (FIN) {
+        Fp.ok = (flags & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { Fp.fd1[i] = H(33 + i); Fp.b2[i] = H(36 + i); Fp.fd2[i] = R(0.0); }
+        Fp.inn = H(39);
+    }
+    auto column = [&](auto Jt) {
+        constexpr int J = decltype(Jt)::value;
+        R d[3] = {R(0.0), R(0.0), R(0.0)};
+        if (AERO) aero_col<J>(q, v, A, d);
+        if (FIN) {
+            R df[3];
+            fin_col<J>(q, v, Fp, u[3], u[4], df);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                d[i] += df[i];
+                PUT((J < 4 ? oWq + 4 * i + J : oWv + 3 * i + (J - 4)), p.JrF[3 * i] * df[0] + p.JrF[3 * i + 1] * df[1] + p.JrF[3 * i + 2] * df[2]);
+            }
+        }
+        if (J < 4) {
+            R D[3];   // column J of d(C u)/dq
+            if (J == 0) { D[0] = R(2.0) * (-q3 * u2 + q2 * u3); D[1] = R(2.0) * (q3 * u1 - q1 * u3); D[2] = R(2.0) * (-q2 * u1 + q1 * u2); }
+            if (J == 1) { D[0] = R(2.0) * (q2 * u2 + q3 * u3); D[1] = R(2.0) * (q2 * u1 - R(2.0) * q1 * u2 - q0 * u3); D[2] = R(2.0) * (q3 * u1 + q0 * u2 - R(2.0) * q1 * u3); }
+            if (J == 2) { D[0] = R(2.0) * (-R(2.0) * q2 * u1 + q1 * u2 + q0 * u3); D[1] = R(2.0) * (q1 * u1 + q3 * u3); D[2] = R(2.0) * (-q0 * u1 + q3 * u2 - R(2.0) * q2 * u3); }
+            if (J == 3) { D[0] = R(2.0) * (-R(2.0) * q3 * u1 - q0 * u2 + q1 * u3); D[1] = R(2.0) * (q0 * u1 - R(2.0) * q3 * u2 + q2 * u3); D[2] = R(2.0) * (q1 * u1 + q2 * u2); }
+#pragma unroll
+            for (int i = 0; i < 3; i++) PUT(oDq + 4 * i + J, (D[i] + d[i]) * invm);
+        } else if (AERO || FIN) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) PUT(oDv + 3 * i + (J - 4), d[i] * invm);
+        }
+    };
+    column(std::integral_constant<int, 0>()); column(std::integral_constant<int, 1>());
+    column(std::integral_constant<int, 2>()); column(std::integral_constant<int, 3>());
+    column(std::integral_constant<int, 4>()); column(std::integral_constant<int, 5>()); column(std::integral_constant<int, 6>());
+    {   // T = [w]x J - [Jw]x ; Mw = -Jinv T
+        R Jw[3], T[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++) Jw[i] = p.J[3 * i] * w[0] + p.J[3 * i + 1] * w[1] + p.J[3 * i + 2] * w[2];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            T[0 + j] = -w[2] * p.J[3 + j] + w[1] * p.J[6 + j];
+            T[3 + j] = w[2] * p.J[0 + j] - w[0] * p.J[6 + j];
+            T[6 + j] = -w[1] * p.J[0 + j] + w[0] * p.J[3 + j];
+        }
+        T[1] += Jw[2]; T[2] -= Jw[1];
+        T[3] -= Jw[2]; T[5] += Jw[0];
+        T[6] += Jw[1]; T[7] -= Jw[0];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                PUT(oMw + 3 * i + j, -(p.Jinv[3 * i] * T[j] + p.Jinv[3 * i + 1] * T[3 + j] + p.Jinv[3 * i + 2] * T[6 + j]));
+    }
+}
+
 // d/dt of one sensitivity column from a published stage record, read in THREE BATCHES (mass / position / velocity rows | attitude
 // and rate rows | the RHS itself): at most ~45 of the record's 58 / 67 / 100 values are live at once next to the column's own 42
 // (c, its RK accumulator and stage value).  Reading the whole record in one batch (round 2's column_deriv_rec) keeps one LDS round

@@ -19,13 +19,20 @@ from successiveconvexification_amd.dynamics import IntegratorCache
 from conftest import random_segments
 from oracle import model
 
-npts = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+aero = "--aero" in sys.argv
+npts = int(args[0]) if args else 10
 B, K = 8192, 50
 x, u, s = random_segments(model.base_prob_scaled(), B, K, 20261006)
 xd, ud, sd = (torch.tensor(a, device="cuda") for a in (x, u, s))
 e = torch.empty((B, K, 14), dtype=torch.float64, device="cuda")
 d = torch.empty((B, K, 21, 14), dtype=torch.float64, device="cuda")
-c = IntegratorCache(sp.base_prob_scaled, npts=npts)
+if aero:
+    from successiveconvexification_amd.defns import AtmosphericData
+    z = np.load(os.path.join(ROOT, "tests", "golden", "lift_drag_tables.npz"))
+    c = IntegratorCache(sp.base_prob_aero_scaled(AtmosphericData(z["drag"], z["lift"], z["torque"])), npts=npts)
+else:
+    c = IntegratorCache(sp.base_prob_scaled, npts=npts)
 L = c._L
 for _ in range(3):
     assert L.scvx_linearize_f64(c.handle, B, K, C.c_void_p(xd.data_ptr()), C.c_void_p(ud.data_ptr()), C.c_void_p(sd.data_ptr()), C.c_double(1 / 51),
@@ -34,7 +41,7 @@ c.synchronize()
 out = np.zeros(32)
 L.scvx_debug_k1_prof.argtypes = [C.POINTER(C.c_double)]
 assert L.scvx_debug_k1_prof(out.ctypes.data_as(C.POINTER(C.c_double))) == 0
-print("npts = %d, block 0 of the persistent kernel (57 groups of 28 segments)" % npts)
+print("npts = %d, %s, block 0 of the persistent kernel" % (npts, "aero" if aero else "exo"))
 print("| wavefront | role | in barriers | total (s_memtime ticks) |")
 print("|---|---|---|---|")
 for w in range(8):
