@@ -125,7 +125,7 @@ typedef struct scvx_solver_opts {
                        /* floor), at most this many times, before the trajectory is frozen as SCVX_ST_SOLVER: such failures */
                        /* sit at the precision floor of the Newton system and move with the path taken.  0: one attempt.    */
                        /* The iteration count reported for a solve is the sum over its attempts.                            */
-    int32_t reserved0;         /* must be 0 */
+    int32_t reserved0;         /* must be 0: scvx_batch_set_solver returns SCVX_ERR_ARG otherwise (a struct from before `retries` ends here) */
 } scvx_solver_opts;
 
 typedef struct scvx_ctx scvx_ctx;     /* owns device, stream, problem constants, aero tables */
