@@ -21,16 +21,25 @@ from oracle import model
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 aero = "--aero" in sys.argv
+fins = "--fins" in sys.argv
 npts = int(args[0]) if args else 10
 B, K = 8192, 50
 x, u, s = random_segments(model.base_prob_scaled(), B, K, 20261006)
 xd, ud, sd = (torch.tensor(a, device="cuda") for a in (x, u, s))
 e = torch.empty((B, K, 14), dtype=torch.float64, device="cuda")
 d = torch.empty((B, K, 21, 14), dtype=torch.float64, device="cuda")
+tabs = None
 if aero:
     from successiveconvexification_amd.defns import AtmosphericData
     z = np.load(os.path.join(ROOT, "tests", "golden", "lift_drag_tables.npz"))
-    c = IntegratorCache(sp.base_prob_aero_scaled(AtmosphericData(z["drag"], z["lift"], z["torque"])), npts=npts)
+    tabs = AtmosphericData(z["drag"], z["lift"], z["torque"])
+if fins:
+    c = IntegratorCache(sp.base_prob_fin_scaled(tabs) if tabs is not None else sp.base_prob_fin_scaled(), npts=npts)
+    fin = 0.01 * np.random.default_rng(7).uniform(-0.7, 0.7, (B, K + 1, 2))
+    ud = torch.tensor(np.concatenate([u, fin], -1), device="cuda")
+    d = torch.empty((B, K, 25, 14), dtype=torch.float64, device="cuda")
+elif aero:
+    c = IntegratorCache(sp.base_prob_aero_scaled(tabs), npts=npts)
 else:
     c = IntegratorCache(sp.base_prob_scaled, npts=npts)
 L = c._L
@@ -41,7 +50,7 @@ c.synchronize()
 out = np.zeros(32)
 L.scvx_debug_k1_prof.argtypes = [C.POINTER(C.c_double)]
 assert L.scvx_debug_k1_prof(out.ctypes.data_as(C.POINTER(C.c_double))) == 0
-print("npts = %d, %s, block 0 of the persistent kernel" % (npts, "aero" if aero else "exo"))
+print("npts = %d, %s%s, block 0 of the persistent kernel" % (npts, "aero" if aero else "exo", " + fins" if fins else ""))
 print("| wavefront | role | in barriers | total (s_memtime ticks) |")
 print("|---|---|---|---|")
 for w in range(8):
