@@ -594,6 +594,14 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
 #ifndef SCVX_K1_SPLIT
 #define SCVX_K1_SPLIT 1
 #endif
+// Segment batches per consumer lane.  With the stage split the consumers still wait half of every tick; with NB = 2 each consumer lane
+// carries one sensitivity column of TWO segments (two sets of c / accumulator / stage value), the producers' lanes cover twice the
+// segments at no cost in time (a lane per segment, and the roles are latency-bound), and a tick serves 36 (aero) / 24 (fins) segments.
+// (Without aerodynamics -- exo + fins -- the split block is already balanced, consumers included: one batch.)
+#ifndef SCVX_K1_NB
+#define SCVX_K1_NB 2
+#endif
+template <bool AERO> struct K1Split { static constexpr int NB = AERO ? SCVX_K1_NB : 1; };
 template <bool AERO, typename R, typename O = R, bool FIN = false>
 __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp2_kernel(
     DynP<R> p, long nseg, int K, const R* __restrict__ x, const R* __restrict__ u,
@@ -605,7 +613,8 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp2_kernel(
     typedef typename Vec2<R>::type VEC2;
     typedef typename Vec2<O>::type OVEC2;
     constexpr int NC = PC_WAVES - 2;
-    constexpr int NS = NC * SPW;               // segments per group
+    constexpr int NB = K1Split<AERO>::NB;
+    constexpr int NS = NC * SPW * NB;          // segments per group
     constexpr int NR = StageRec<AERO, FIN>::N, NH = HandRec<FIN>::N;
     constexpr int RING_D = 3 * NR * NS, HAND_D = 2 * NH * NS, TILE_D = NC * SPW * DSZ;
     __shared__ __attribute__((aligned(16))) R lds[RING_D + HAND_D + TILE_D];
@@ -691,7 +700,8 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp2_kernel(
 #pragma unroll
                 for (int i = 0; i < 14; i++) ep[i] = xs[i];
             }
-            K1_BAR();  // matches the consumers' tile barrier
+#pragma unroll
+            for (int bb = 0; bb < NB; bb++) K1_BAR();  // matches the consumers' tile barriers
             grp = nxt;
         }
 #if defined(SCVX_K1_PROF)
@@ -714,7 +724,8 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp2_kernel(
                 K1_BAR();
             }
             K1_BAR();   // the consumers' last stage
-            K1_BAR();   // tile barrier
+#pragma unroll
+            for (int bb = 0; bb < NB; bb++) K1_BAR();   // tile barriers
             grp = nxt;
         }
 #if defined(SCVX_K1_PROF)
@@ -729,7 +740,9 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp2_kernel(
     const int slot_c = lane - sl * LPS;
     const int col = slot_c;
     const bool lane_live = sl < SPW;
-    const int ls = cw * SPW + (lane_live ? sl : 0);   // local segment index in the group
+    int ls[NB];                                        // local segment index in the group, per batch
+#pragma unroll
+    for (int bb = 0; bb < NB; bb++) ls[bb] = (bb * NC + cw) * SPW + (lane_live ? sl : 0);
     const bool is_uk = (col >= 14) && (col < 14 + NU);
     const bool is_up = (col >= 14 + NU) && (col < 14 + 2 * NU);
     const int comp = is_uk ? col - 14 : (is_up ? col - 14 - NU : -1);
@@ -737,19 +750,25 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp2_kernel(
     R ec[NU];
 #pragma unroll
     for (int j = 0; j < NU; j++) ec[j] = (comp == j) ? R(1.0) : R(0.0);
-    auto sigma_of = [&](long g) {
-        long seg = g * NS + ls;
+    auto sigma_of = [&](long g, int bb) {
+        long seg = g * NS + ls[bb];
         if (seg >= nseg) seg = nseg - 1;
         return sigma[seg / K];
     };
-    R nsig = grp < ngrp ? sigma_of(grp) : R(0.0);
+    R nsig[NB];
+#pragma unroll
+    for (int bb = 0; bb < NB; bb++) nsig[bb] = grp < ngrp ? sigma_of(grp, bb) : R(0.0);
     while (grp < ngrp) {
         const long nxt = advance(grp + gridDim.x);
         const long seg_base = grp * NS;
-        const R sig = nsig;
-        R c[14], ca[14], ct[14];
+        R sig[NB];
+        R c[NB][14], ca[NB][14], ct[NB][14];
 #pragma unroll
-        for (int i = 0; i < 14; i++) { c[i] = (col == i) ? R(1.0) : R(0.0); ca[i] = c[i]; ct[i] = c[i]; }
+        for (int bb = 0; bb < NB; bb++) {
+            sig[bb] = nsig[bb];
+#pragma unroll
+            for (int i = 0; i < 14; i++) { c[bb][i] = (col == i) ? R(1.0) : R(0.0); ca[bb][i] = c[bb][i]; ct[bb][i] = c[bb][i]; }
+        }
         K1_BAR();  // P0's first stage
         K1_BAR();  // ... completed by P1
         int slot = 0;
@@ -762,40 +781,49 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp2_kernel(
                 R wc[NU];
 #pragma unroll
                 for (int j = 0; j < NU; j++) wc[j] = ec[j] * wk;
-                R dc[14];
-                column_deriv_rec_any<AERO, FIN>(p, lds + slot * NR * NS + ls, NS, ct, wc, gsel, sig, dc);
                 const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
                 const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
 #pragma unroll
-                for (int i = 0; i < 14; i++) {
-                    ca[i] = fma(wacc, dc[i], ca[i]);
-                    ct[i] = (stg < 3) ? fma(wnext, dc[i], c[i]) : ca[i];
+                for (int bb = 0; bb < NB; bb++) {
+                    R dc[14];
+                    column_deriv_rec_any<AERO, FIN>(p, lds + slot * NR * NS + ls[bb], NS, ct[bb], wc, gsel, sig[bb], dc);
+#pragma unroll
+                    for (int i = 0; i < 14; i++) {
+                        ca[bb][i] = fma(wacc, dc[i], ca[bb][i]);
+                        ct[bb][i] = (stg < 3) ? fma(wnext, dc[i], c[bb][i]) : ca[bb][i];
+                    }
                 }
                 slot = slot == 2 ? 0 : slot + 1;
                 K1_BAR();
             }
 #pragma unroll
-            for (int i = 0; i < 14; i++) c[i] = ca[i];
+            for (int bb = 0; bb < NB; bb++)
+#pragma unroll
+                for (int i = 0; i < 14; i++) c[bb][i] = ca[bb][i];
         }
-        if (nxt < ngrp) nsig = sigma_of(nxt);
-        // ---- epilogue: columns into this wavefront's LDS tile -> coalesced 16-byte stores ----
+#pragma unroll
+        for (int bb = 0; bb < NB; bb++) if (nxt < ngrp) nsig[bb] = sigma_of(nxt, bb);
+        // ---- epilogue, batch by batch through this wavefront's LDS tile: columns in -> coalesced 16-byte stores out ----
         R* t = tiles + cw * SPW * DSZ;
-        if (lane_live) {
 #pragma unroll
-            for (int i = 0; i < 14; i++) t[sl * DSZ + col * 14 + i] = c[i];
-        }
-        K1_BAR();
-        const long seg0 = seg_base + (long)cw * SPW;
-        if (seg0 < nseg) {
-            const long rem = nseg - seg0;
-            const int nvalid = rem < SPW ? (int)rem : SPW;
-            const int n2 = nvalid * HV;
-            OVEC2* out = reinterpret_cast<OVEC2*>(deriv + (size_t)seg0 * DSZ);
-            const VEC2* src = reinterpret_cast<const VEC2*>(t);
+        for (int bb = 0; bb < NB; bb++) {
+            if (lane_live) {
 #pragma unroll
-            for (int r = 0; r < (SPW * HV + 63) / 64; r++) {
-                const int e = lane + 64 * r;
-                if (e < n2) { const VEC2 v = src[e]; OVEC2 o; o.x = O(v.x); o.y = O(v.y); out[e] = o; }
+                for (int i = 0; i < 14; i++) t[sl * DSZ + col * 14 + i] = c[bb][i];
+            }
+            K1_BAR();
+            const long seg0 = seg_base + (long)(bb * NC + cw) * SPW;
+            if (seg0 < nseg) {
+                const long rem = nseg - seg0;
+                const int nvalid = rem < SPW ? (int)rem : SPW;
+                const int n2 = nvalid * HV;
+                OVEC2* out = reinterpret_cast<OVEC2*>(deriv + (size_t)seg0 * DSZ);
+                const VEC2* src = reinterpret_cast<const VEC2*>(t);
+#pragma unroll
+                for (int r = 0; r < (SPW * HV + 63) / 64; r++) {
+                    const int e = lane + 64 * r;
+                    if (e < n2) { const VEC2 v = src[e]; OVEC2 o; o.x = O(v.x); o.y = O(v.y); out[e] = o; }
+                }
             }
         }
         grp = nxt;
@@ -887,7 +915,8 @@ hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, con
         if (ctx->k1_variant == 0 && !fin) return launch_linearize_simple<R>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st, skip);
     // aero / fin models from 3 substeps up: the producer's stage split over two wavefronts (linearize_pcp2_kernel), six consumer wavefronts
     const bool split = SCVX_K1_SPLIT != 0 && (fin || ctx->dyn.aero) && ctx->k1_sg != 0 && (ctx->k1_persist < 0 ? ctx->nsub >= 3 : ctx->k1_persist != 0);
-    const int ns = (PC_WAVES - (split ? 2 : 1)) * (fin ? K1Map<true, true>::SPW : (ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW));
+    const int ns = (PC_WAVES - (split ? 2 : 1)) * (split ? (ctx->dyn.aero ? K1Split<true>::NB : K1Split<false>::NB) : 1)
+                   * (fin ? K1Map<true, true>::SPW : (ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW));
     // stage-granular pipeline by default (faster at every npts measured: 0.70 -> 0.60 ms at npts 1, 3.05 -> 2.96 ms
     // at npts 10, B = 8192, fp64); SCVX_K1_SG=0 selects the substep-granular form
     const bool sg = ctx->k1_sg != 0;
