@@ -18,6 +18,9 @@ import numpy as np
 NX, NU = 14, 3
 
 
+CAPTURE = None   # set to a list to record (Sd, So) of every factorisation (oracle/bcr_proto.py)
+
+
 def soc_nt(s, z):
     """Nesterov-Todd scaling of one second-order cone: returns (v, beta) with W = beta (2 v v' - J)."""
     sj = np.sqrt(s[0] * s[0] - s[1:] @ s[1:])
@@ -287,6 +290,8 @@ def solve(p, xbar, ubar, endpoint, deriv, rk, tol=1e-8, max_iter=60, verbose=Fal
                      + hnui * np.eye(NX))
             if k + 1 < K:
                 So[k] = -A_[k + 1] @ Hxi[k + 1] + Bm[k + 1] @ Hui[k + 1] @ Bp[k].T
+        if CAPTURE is not None:      # oracle/bcr_proto.py: the block-tridiagonal Schur complements of a real solve, iteration by iteration
+            CAPTURE.append((Sd.copy(), So.copy()))
         # block Cholesky
         L = np.zeros_like(Sd)
         Wb = np.zeros_like(So)
