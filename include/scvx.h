@@ -128,6 +128,17 @@ typedef struct scvx_solver_opts {
     int32_t reserved0;         /* must be 0: scvx_batch_set_solver returns SCVX_ERR_ARG otherwise (a struct from before `retries` ends here) */
 } scvx_solver_opts;
 
+/* ---- ABI guard ----------------------------------------------------------------------------- */
+/* scvx_problem, scvx_solver_opts and scvx_threedof_opts carry no size member: a binding written against another revision of
+ * this header would hand over a struct of another layout and nothing would fail.  SCVX_ABI_VERSION is raised with every change
+ * of a struct layout or of a signature below; scvx_abi_version() returns the value the LIBRARY was compiled with and
+ * scvx_abi_struct_sizes() the sizeof of the three structs as the library sees them, in that order.  A binding compares both
+ * with its own image before its first call (Python: _lib.lib(); Julia: ScvxAMD.check_abi(); C: tests/abi_harness.c).
+ * Neither function touches the device. */
+#define SCVX_ABI_VERSION 4
+int scvx_abi_version(void);
+int scvx_abi_struct_sizes(int32_t out[3]);
+
 typedef struct scvx_ctx scvx_ctx;     /* owns device, stream, problem constants, aero tables */
 typedef struct scvx_batch scvx_batch; /* owns the batched iterate (ProblemIteration x B)     */
 

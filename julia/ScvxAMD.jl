@@ -48,6 +48,17 @@ function CProblem(p::DescentProblem; model_flags::Integer=0, finmxf::Real=0.01) 
              Int32(p.K), Int32(p.imax), Int32(aero ? 1 : 0), Int32(model_flags))
 end
 
+# the ABI guard of include/scvx.h (SCVX_ABI_VERSION; sizeof of scvx_problem / scvx_solver_opts / scvx_threedof_opts as the library sees them)
+const ABI_VERSION = 4
+function check_abi()
+    v = Int(ccall((:scvx_abi_version, LIB), Cint, ()))
+    sz = zeros(Int32, 3)
+    ccall((:scvx_abi_struct_sizes, LIB), Cint, (Ptr{Int32},), sz)
+    mine = Int32[sizeof(CProblem), sizeof(SolverOpts), sizeof(ThreedofOpts)]
+    (v == ABI_VERSION && sz == mine) || error("libscvx_hip.so: ABI version $v / struct sizes $sz, this binding expects $ABI_VERSION / $mine")
+    nothing
+end
+
 check(ctx, rc, what) = rc == 0 || error("$what failed ($rc): " * unsafe_string(ccall((:scvx_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx)))
 
 # ---- IntegratorCache (dynamics.jl:258): owner of the device context -------------------------------------------------
@@ -75,6 +86,7 @@ end
 # Jacobians are compiled into the library); `tables` = (drag, lift, trq) raw grids for an AtmosphericData problem.
 function Cache(prob::DescentProblem, info=nothing, lin_mod=nothing; device::Int=0, npts::Int=10, tables=nothing,
                model_flags::Integer=0, finmxf::Real=0.01)
+    check_abi()   # before the first struct crosses the boundary
     ref = Ref{Ptr{Cvoid}}(C_NULL)
     cp = Ref(CProblem(prob; model_flags=model_flags, finmxf=finmxf))
     rc = ccall((:scvx_ctx_create, LIB), Cint, (Ref{CProblem}, Cint, Ref{Ptr{Cvoid}}), cp, device, ref)

@@ -46,9 +46,13 @@ class ScvxThreedofOpts(C.Structure):
                 ("attitude", C.c_int32), ("reserved", C.c_int32)]
 
 
+ABI_VERSION = 4   # SCVX_ABI_VERSION of the include/scvx.h these structs and signatures were written against
+
 _vp = C.c_void_p
 # name -> (restype, argtypes); must list every symbol include/scvx.h declares (tests check this)
 SIGNATURES = {
+    "scvx_abi_version": (C.c_int, []),
+    "scvx_abi_struct_sizes": (C.c_int, [_ip]),
     "scvx_ctx_create": (C.c_int, [C.POINTER(ScvxProblem), C.c_int, C.POINTER(_vp)]),
     "scvx_ctx_destroy": (None, [_vp]),
     "scvx_last_error": (C.c_char_p, [_vp]),
@@ -161,6 +165,13 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)  # AttributeError if the library lacks an ABI symbol
         fn.restype = res
         fn.argtypes = args
+    # the ABI guard of include/scvx.h: a library built from another revision of the header is refused before the first call
+    sizes = (C.c_int32 * 3)()
+    L.scvx_abi_struct_sizes(sizes)
+    mine = (C.sizeof(ScvxProblem), C.sizeof(ScvxSolverOpts), C.sizeof(ScvxThreedofOpts))
+    if L.scvx_abi_version() != ABI_VERSION or tuple(sizes) != mine:
+        raise ScvxError(f"{LIB_PATH}: ABI version {L.scvx_abi_version()} / struct sizes {tuple(sizes)}, this binding expects "
+                        f"{ABI_VERSION} / {mine}: rebuild the library from this tree's include/scvx.h")
     _LIB = L
     return L
 

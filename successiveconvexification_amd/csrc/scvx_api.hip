@@ -157,6 +157,14 @@ void scvx_ctx_destroy(scvx_ctx* ctx) {
     delete ctx;
 }
 
+int scvx_abi_version(void) { return SCVX_ABI_VERSION; }
+
+int scvx_abi_struct_sizes(int32_t out[3]) {
+    if (!out) return SCVX_ERR_ARG;
+    out[0] = (int32_t)sizeof(scvx_problem); out[1] = (int32_t)sizeof(scvx_solver_opts); out[2] = (int32_t)sizeof(scvx_threedof_opts);
+    return SCVX_OK;
+}
+
 const char* scvx_last_error(const scvx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int scvx_control_dim(const scvx_ctx* ctx) { return ctx && (ctx->prob.model_flags & SCVX_MODEL_FINS) ? 5 : 3; }

@@ -65,6 +65,13 @@ int main(int argc, char **argv) {
     FILE *fo = fopen(argv[2], "wb");
     if (!fo) { perror(argv[2]); return 1; }
 
+    /* check_abi(): the library was compiled from the header this program was compiled with */
+    int32_t asz[3];
+    if (scvx_abi_version() != SCVX_ABI_VERSION || scvx_abi_struct_sizes(asz) != 0 || asz[0] != (int32_t)sizeof(scvx_problem) ||
+        asz[1] != (int32_t)sizeof(scvx_solver_opts) || asz[2] != (int32_t)sizeof(scvx_threedof_opts)) {
+        fprintf(stderr, "ABI mismatch: library %d, header %d\n", scvx_abi_version(), SCVX_ABI_VERSION);
+        return 2;
+    }
     /* Cache(prob, info, lin_mod; tables=...) */
     scvx_ctx *ctx = NULL;
     if (scvx_ctx_create(&p, 0, &ctx) != 0) { fprintf(stderr, "scvx_ctx_create failed\n"); return 2; }

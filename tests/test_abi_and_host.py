@@ -41,6 +41,26 @@ def test_struct_layouts_match_the_header(tmp_path):
     assert (ctypes.sizeof(P), P.K.offset, P.wNu.offset, ctypes.sizeof(_lib.ScvxSolverOpts)) == (a, b, cc, d)
 
 
+def test_abi_guard_reports_the_header_and_refuses_another_revision(monkeypatch):
+    """scvx_abi_version / scvx_abi_struct_sizes (no device call): the library's values are the header's and the binding's; a binding
+    written for another revision (version or a struct size) is refused at load, before any struct crosses the boundary."""
+    from successiveconvexification_amd import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "scvx.h")).read()
+    assert int(re.search(r"#define SCVX_ABI_VERSION (\d+)", hdr).group(1)) == L.scvx_abi_version() == _lib.ABI_VERSION
+    sz = (ctypes.c_int32 * 3)()
+    assert L.scvx_abi_struct_sizes(sz) == 0
+    assert tuple(sz) == (ctypes.sizeof(_lib.ScvxProblem), ctypes.sizeof(_lib.ScvxSolverOpts), ctypes.sizeof(_lib.ScvxThreedofOpts))
+    assert L.scvx_abi_struct_sizes(None) == -1   # SCVX_ERR_ARG
+    # the Julia shim carries the same number
+    jl = open(os.path.join(ROOT, "julia", "ScvxAMD.jl")).read()
+    assert int(re.search(r"const ABI_VERSION = (\d+)", jl).group(1)) == _lib.ABI_VERSION
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.ScvxError, match="ABI version"):
+        _lib.lib()
+
+
 def test_missing_extension_fails_loudly(monkeypatch):
     from successiveconvexification_amd import _lib
     monkeypatch.setattr(_lib, "_LIB", None)
