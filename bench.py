@@ -480,10 +480,17 @@ def main():
             out = torch.empty((world, B, n // B), dtype=torch.float64, device="cuda")
             torch.cuda.synchronize()
             rc = cache._L.scvx_allgather_trajectories(batch.handle, C.c_void_p(out.data_ptr()))
-            if rc != 0:
-                raise SystemExit("scvx_allgather_trajectories failed: %s" % cache._L.scvx_last_error(cache.handle))
-            cache.synchronize()
-        else:
+            if rc == 0:
+                cache.synchronize()
+            # every rank learns whether the collective was enqueued everywhere: a rank that failed must not leave the others
+            # without the line -- all of them then repeat the gather through torch.distributed and the line says so
+            rcs = [None] * world
+            dist.all_gather_object(rcs, int(rc))
+            if any(r != 0 for r in rcs):
+                native = False
+                gather_how = (f"torch.distributed {backend} all_gather, {world} ranks (scvx_allgather_trajectories failed on rank(s) "
+                              f"{[i for i, r in enumerate(rcs) if r != 0]}: {cache._L.scvx_last_error(cache.handle).decode(errors='replace') if rc != 0 else 'ok here'})")
+        if not native:
             if dist.get_backend() != "nccl":
                 mine, dev = mine.cpu(), "cpu"
             out = mc.gather_records(mine, dist)
