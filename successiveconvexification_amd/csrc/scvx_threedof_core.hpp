@@ -67,9 +67,11 @@ namespace td {
 // against both counters -- each LDS step of the factorisation then also waits for the L stores in flight.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TD_LOCAL __attribute__((address_space(3)))
+#define TD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // nothing is scheduled across this point
 #define TD_UNROLL8 _Pragma("unroll 8")   // per-cone loops: the long cone (N + 2 rows) is walked by one lane, keep 8 loads in flight
 #else
 #define TD_LOCAL
+#define TD_SCHED_FENCE()
 #define TD_UNROLL8
 #endif
 typedef SCVX_GLOBAL double* gptr;
@@ -673,31 +675,46 @@ struct Solver {
             const int jend = j0 + ST < nb ? j0 + ST : nb;
             for (int j = j0; j < jend; j++) {
                 const TD_LOCAL double* col = wn + (j % NSLOT) * BS;
+                // every LDS read of the step is requested before anything waits for one (the pivot, its scale, the operands of the
+                // trailing update, this lane's entry of the column: one LDS round trip; in the compiler's own order the pivot's
+                // division -- nine dependent instructions -- sat between the requests).  Worth 2.5 % of a solve at B = 1 and 1 % at
+                // B = 8,192 (profiles/r04_k0_column_step.md): the step is bound by the ~135 instructions a single wavefront issues
+                // for it, not by LDS latency.
                 double dj = col[0];
-                const bool var = is_var(N, j);
-                // dynamic regularisation: the pivot keeps the sign quasi-definiteness gives it, and does not fall below
-                // the rounding level of the entry it started from (an active cone's block is rank one to working
-                // precision in the last iterations); the refinement passes absorb the perturbation
-                const double fl = 1e-15 * dor[j % NSLOT] + 1e-13;
-                if (!(fabs(dj) < 1e300)) ok = false;   // NaN or overflow: the caller retries with more regularisation
-                if (var ? !(dj > fl) : !(dj < -fl)) dj = var ? fl : -fl;
-                const double idj = 1.0 / dj;
-                // all reads of the trailing update, then all writes: one LDS round trip per step (a lane without a
-                // q-th entry updates the spare double behind the pivot scales)
-                double tv[PP];
+                const double dsc = dor[j % NSLOT];
+                double ca[PP], cb[PP], cw[PP];
                 int ti[PP];
                 SCVX_UNROLL
                 for (int q = 0; q < PP; q++) {
                     const int ab = pab[q], a = ab >> 8, b = ab & 255;
                     ti[q] = ab ? ((j + b) % NSLOT) * BS + (a - b) : spare;
-                    tv[q] = wn[ti[q]] - col[a] * col[b] * idj;
+                    ca[q] = col[a]; cb[q] = col[b]; cw[q] = wn[ti[q]];
                 }
+                constexpr int PD = (BS + Ex::kLanes - 1) / Ex::kLanes;   // column entries per lane (1 on a wavefront)
+                double cd[PD];
                 SCVX_UNROLL
-                for (int q = 0; q < PP; q++) wn[ti[q]] = tv[q];
-                for (int d = lane; d < BS; d += nl) {
-                    const double lv = col[d] * idj;
-                    lb[(size_t)j * BS + d] = d == 0 ? idj : lv;
-                    if (d >= 1 && j + d < nb) ut[(size_t)(j + d) * BS + d] = lv;
+                for (int q = 0; q < PD; q++) { const int d = lane + q * nl; cd[q] = d < BS ? col[d] : 0.0; }
+                TD_SCHED_FENCE();
+                const bool var = is_var(N, j);
+                // dynamic regularisation: the pivot keeps the sign quasi-definiteness gives it, and does not fall below
+                // the rounding level of the entry it started from (an active cone's block is rank one to working
+                // precision in the last iterations); the refinement passes absorb the perturbation
+                const double fl = 1e-15 * dsc + 1e-13;
+                if (!(fabs(dj) < 1e300)) ok = false;   // NaN or overflow: the caller retries with more regularisation
+                if (var ? !(dj > fl) : !(dj < -fl)) dj = var ? fl : -fl;
+                const double idj = 1.0 / dj;
+                // all reads of the trailing update, then all writes (a lane without a q-th entry updates the spare double
+                // behind the pivot scales)
+                SCVX_UNROLL
+                for (int q = 0; q < PP; q++) wn[ti[q]] = cw[q] - ca[q] * cb[q] * idj;
+                SCVX_UNROLL
+                for (int q = 0; q < PD; q++) {
+                    const int d = lane + q * nl;
+                    if (d < BS) {
+                        const double lv = cd[q] * idj;
+                        lb[(size_t)j * BS + d] = d == 0 ? idj : lv;
+                        if (d >= 1 && j + d < nb) ut[(size_t)(j + d) * BS + d] = lv;
+                    }
                 }
                 ex.sync_lds();
             }
