@@ -2,6 +2,7 @@
 // units that instantiate them -- scvx_batch.hip (control_dim = 3, the reference's model) and scvx_socp_fin.hip (control_dim = 5, the
 // fin extension) -- so that the two sets of instantiations compile side by side.
 #pragma once
+#include <new>
 #include "scvx_internal.hpp"
 #include "scvx_ipm_core.hpp"
 
@@ -410,7 +411,7 @@ enum { ACC_TRAJ_STEPS = 0, ACC_SOLVES, ACC_IPM_ITERS, ACC_WARM, ACC_SKIPPED, ACC
 // info[b] = {status, iters, merit, pobj}
 // DS: element type of the linearisation the discretisation kernel wrote (double; float behind scvx_batch_set_linearization_f32)
 template <class Ex, class DS = double, int NU = 3>
-__device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t work_stride, const double* x, const double* u,
+__device__ __forceinline__ void socp_body(const ipm::Consts& Cin, int B, size_t work_stride, const double* x, const double* u,
                                           const double* endpoint, const DS* deriv, const double* rk, const double* ic,
                                           const int* active, double* work, double* sol, double* nu, double* info,
                                           const int* step_status, double* ttr, double* acc) {
@@ -421,13 +422,28 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& C, int B, size_t wo
     // halved radius (rocketland.jl:299-301 keeps about / dynam).  If the optimum just found lies strictly inside the new
     // radius, the radius row is inactive with a zero multiplier and that optimum still satisfies every KKT condition of
     // the new subproblem: the solve would return it again.  sol / nu / info are left as they are; iters = 0 marks it.
-    if (C.pad && step_status[b] == SCVX_ST_REJECTED && ttr[b] <= (1.0 - 1e-6) * rk[b]) {
+    if (Cin.pad && step_status[b] == SCVX_ST_REJECTED && ttr[b] <= (1.0 - 1e-6) * rk[b]) {
         if (threadIdx.x == 0) { info[4 * b + 1] = 0.0; atomicAdd(acc + ACC_SKIPPED, 1.0); }
         return;
     }
-    const int K = C.K;
-    Ex ex;
-    ipm::Solver<Ex, double, DS, NU, SCVX_FACTOR_T> S(ex, C);
+    const int K = Cin.K;
+    // The solver object (some 60 pointers into the slab, the layout, the scalars of the current factorisation), the executor and
+    // the constants live in LDS, one copy per wavefront.  As an automatic object it sat in private memory -- 1.4 KB per LANE,
+    // 64 identical copies per wavefront, 0.2 GB for the trajectories in flight -- and every non-inlined routine of the solver
+    // opens with loads of the members it needs: some 750 of them per interior-point iteration, each a 256 / 512-byte row of that
+    // private memory that has long left L2 when the routine comes round again.  Every lane writes the same values.
+    typedef ipm::Solver<Ex, double, DS, NU, SCVX_FACTOR_T> SolverT;
+    struct Frame {
+        ipm::Consts C; Ex ex; SolverT S;
+        __device__ Frame(const ipm::Consts& c) : C(c), ex(), S(ex, C) {}
+    };
+    constexpr int NWV = Ex::kLanes / 64;
+    constexpr int FSZ = (int)((sizeof(Frame) + 15) & ~(size_t)15);
+    __shared__ __attribute__((aligned(16))) unsigned char frame_mem[NWV * FSZ];
+    Frame* const F = new (frame_mem + (threadIdx.x >> 6) * FSZ) Frame(Cin);
+    const ipm::Consts& C = F->C;
+    Ex& ex = F->ex;
+    SolverT& S = F->S;
     // kernel arguments are HBM pointers: hand them to the solver typed as such (see ipm::gptr)
     // warm start: the last solve in this slab was for the same about / dynam (its step was rejected) and is still valid
     const bool warm = C.warm && step_status[b] == SCVX_ST_REJECTED && ttr[b] < 1e300;

@@ -62,47 +62,65 @@ struct WaveEx3 {
     // v_readlane and every lane within the bandwidth does one FMA -- no LDS round trip inside the chunk (the vector
     // visits LDS once per chunk).  The L entries of the NEXT chunk are in flight while this one computes.
     static constexpr int CH = 16;   // CH + BW <= 64
+    // The chunk's L entries as they lie in memory, no masking: entry of step t for lane l is m[(J +- t) * BS + (l - t)] -- one base
+    // address, constant stride.  L is zero-padded by LPAD on both sides (chunk starts are clamped to [-1, nb]), columns past the
+    // matrix hold zeros (the window is fed zeros there) and the never-written corner of the row copy (row r, d > r) is zeroed
+    // once per solve, so the only entries that must not be used are the ones outside the band, d = l - t not in [1, BW]: a
+    // predicate of (lane, step) alone, which the compiler keeps in scalar registers across the whole sweep (run_chunk).
     template <bool FWD>
     __device__ __forceinline__ void load_chunk(double (&c)[CH], td::cgptr m, int J, int nb) const {
         const int l = (int)threadIdx.x;
-        // entry of step t: m[(J +- t) * BS + (l - t)] -- one base address, constant stride
-        td::cgptr base = m + ((long)J * td::BS + l);
+        const int Jc = FWD ? (J < nb ? J : nb) : (J > -1 ? J : -1);
+        td::cgptr base = m + ((long)Jc * td::BS + l);
 #pragma unroll
-        for (int t = 0; t < CH; t++) {
-            const int j = FWD ? J + t : J - t, d = l - t;
-            const bool in = j >= 0 && j < nb && d >= 1 && d <= td::BW && (FWD ? j + d < nb : j - d >= 0);
-            const double v = base[FWD ? t * (td::BS - 1) : -t * (td::BS + 1)];   // unconditional: L is zero-padded by LPAD
-            c[t] = in ? v : 0.0;
-        }
+        for (int t = 0; t < CH; t++) c[t] = base[FWD ? t * (td::BS - 1) : -t * (td::BS + 1)];
     }
     template <bool FWD>
     __device__ __forceinline__ void run_chunk(const double (&c)[CH], td::lptr xs, int J, int nb) {
+        if (FWD ? J >= nb : J < 0) return;   // wave-uniform: a prefetched chunk past the end
         const int l = (int)threadIdx.x;
         const int idx = FWD ? J + l : J - l;
         const bool in = idx >= 0 && idx < nb;
         double xw = in ? xs[idx] : 0.0;
 #pragma unroll
-        for (int t = 0; t < CH; t++) xw = fma(-c[t], bcast(xw, t), xw);
+        for (int t = 0; t < CH; t++) {
+            const double b = bcast(xw, t);
+            if ((unsigned)(l - t - 1) < (unsigned)td::BW) xw = fma(-c[t], b, xw);   // 1 <= l - t <= BW: inside the band
+        }
         if (in) xs[idx] = xw;
         sync_lds();
     }
+    // Four chunks in flight: under load an L entry comes from HBM (a slab per wavefront in flight, 0.5 GB in all), a chunk computes
+    // in ~0.2 us and a request takes ten times that -- with one chunk of look-ahead the sweeps ran at memory latency.
     __device__ __forceinline__ void band_sweeps(td::lptr xs, td::cgptr lb, td::cgptr ut, int nb) {
-        double ca[CH], cb[CH];
-        load_chunk<true>(ca, lb, 0, nb);
-        for (int J = 0; J < nb; J += 2 * CH) {
-            load_chunk<true>(cb, lb, J + CH, nb);
-            run_chunk<true>(ca, xs, J, nb);
-            load_chunk<true>(ca, lb, J + 2 * CH, nb);
-            run_chunk<true>(cb, xs, J + CH, nb);
+        double c0[CH], c1[CH], c2[CH], c3[CH];
+        load_chunk<true>(c0, lb, 0, nb);
+        load_chunk<true>(c1, lb, CH, nb);
+        load_chunk<true>(c2, lb, 2 * CH, nb);
+        for (int J = 0; J < nb; J += 4 * CH) {
+            load_chunk<true>(c3, lb, J + 3 * CH, nb);
+            run_chunk<true>(c0, xs, J, nb);
+            load_chunk<true>(c0, lb, J + 4 * CH, nb);
+            run_chunk<true>(c1, xs, J + CH, nb);
+            load_chunk<true>(c1, lb, J + 5 * CH, nb);
+            run_chunk<true>(c2, xs, J + 2 * CH, nb);
+            load_chunk<true>(c2, lb, J + 6 * CH, nb);
+            run_chunk<true>(c3, xs, J + 3 * CH, nb);
         }
         for (int j = (int)threadIdx.x; j < nb; j += 64) xs[j] *= lb[(size_t)j * td::BS];
         sync_lds();
-        load_chunk<false>(ca, ut, nb - 1, nb);
-        for (int J = nb - 1; J >= 0; J -= 2 * CH) {
-            load_chunk<false>(cb, ut, J - CH, nb);
-            run_chunk<false>(ca, xs, J, nb);
-            load_chunk<false>(ca, ut, J - 2 * CH, nb);
-            run_chunk<false>(cb, xs, J - CH, nb);
+        load_chunk<false>(c0, ut, nb - 1, nb);
+        load_chunk<false>(c1, ut, nb - 1 - CH, nb);
+        load_chunk<false>(c2, ut, nb - 1 - 2 * CH, nb);
+        for (int J = nb - 1; J >= 0; J -= 4 * CH) {
+            load_chunk<false>(c3, ut, J - 3 * CH, nb);
+            run_chunk<false>(c0, xs, J, nb);
+            load_chunk<false>(c0, ut, J - 4 * CH, nb);
+            run_chunk<false>(c1, xs, J - CH, nb);
+            load_chunk<false>(c1, ut, J - 5 * CH, nb);
+            run_chunk<false>(c2, xs, J - 2 * CH, nb);
+            load_chunk<false>(c2, ut, J - 6 * CH, nb);
+            run_chunk<false>(c3, xs, J - 3 * CH, nb);
         }
     }
 };

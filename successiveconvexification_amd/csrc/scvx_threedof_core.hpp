@@ -997,6 +997,9 @@ struct Solver {
             (w + L.lb)[-1 - k] = 0.0; (w + L.lb)[(size_t)nb * BS + k] = 0.0;
             (w + L.ut)[-1 - k] = 0.0; (w + L.ut)[(size_t)nb * BS + k] = 0.0;
         });
+        // the corner of the row copy that no factorisation writes (row r, d > r: L[r][r - d] does not exist): the register sweeps
+        // read it unmasked
+        each(BS * BS, [&](int k) { const int r = k / BS, d = k - BS * r; if (d > r && r < nb) (w + L.ut)[(size_t)r * BS + d] = 0.0; });
         ex.sync();
         // ---- initial point: W = I,  [0 A' G'; A 0 0; G 0 -I][x; y; z] = [-c; b; h],  s = -z, shifted into the cone ----
         scale(true);
