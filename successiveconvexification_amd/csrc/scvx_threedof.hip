@@ -129,13 +129,20 @@ struct WaveEx3 {
 #ifndef SCVX_K0_WAVES
 #define SCVX_K0_WAVES 2   // wavefronts per SIMD the kernel is compiled for (and the launch is sized for): profiles/r03_k0_occupancy.md
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SCVX_K0_WAVES, SCVX_K0_WAVES))) void threedof_kernel(td::Tables T, int B, const double* __restrict__ ic, double* work,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SCVX_K0_WAVES, SCVX_K0_WAVES))) void threedof_kernel(td::Tables Tin, int B, const double* __restrict__ ic, double* work,
                                                       size_t stride, double* sol, double* info, double* prof_out) {
     extern __shared__ double td_lds[];
-    WaveEx3 ex{(td::lptr)td_lds};
-    const int no = td::out_doubles(T.N);
+    // tables, executor and solver object in LDS, one copy for the wavefront: as automatic objects they sat in private memory (one
+    // copy per LANE) and every non-inlined routine opened with loads of that memory (profiles/r04_k4_lds_frame.md, the same change in K4)
+    struct Frame {
+        td::Tables T; WaveEx3 ex; td::Solver<WaveEx3> S;
+        __device__ Frame(const td::Tables& t, td::lptr lds, double* w) : T(t), ex{lds}, S(ex, T, w) {}
+    };
+    __shared__ __attribute__((aligned(16))) unsigned char frame_mem[(sizeof(Frame) + 15) & ~(size_t)15];
+    const int no = td::out_doubles(Tin.N);
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        td::Solver<WaveEx3> S(ex, T, work + (size_t)blockIdx.x * stride);
+        Frame* const F = new (frame_mem) Frame(Tin, (td::lptr)td_lds, work + (size_t)blockIdx.x * stride);
+        td::Solver<WaveEx3>& S = F->S;
         const td::Result r = S.solve(ic + (size_t)b * 6, sol + (size_t)b * no);
         if (threadIdx.x == 0) {
             double* o = info + (size_t)b * 6;
