@@ -138,6 +138,14 @@
 #else
 #define SCVX_UNROLL
 #endif
+// The device executors keep the solver object and the constants in LDS (socp_body's frame): told so, the compiler addresses the members
+// with ds_read / ds_write instead of flat instructions (which also count against vmcnt: a member read inside a streaming loop then
+// waits for every global load in flight).  First statement of every non-inlined routine.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SCVX_NO_LDS_FRAME)
+#define SCVX_THIS_LDS() do { __builtin_assume(__builtin_amdgcn_is_shared((const void*)this)); __builtin_assume(__builtin_amdgcn_is_shared((const void*)&C)); } while (0)
+#else
+#define SCVX_THIS_LDS() do { } while (0)
+#endif
 #define SCVX_T0() SCVX_TS(t0_)
 #define SCVX_T1(slot) SCVX_TE(t0_, slot)
 #if defined(SCVX_IPM_DEBUG) && !defined(__HIPCC__)
@@ -607,6 +615,7 @@ struct Solver {
     // out[k][i] = sum_j D_k[i][j] [dx_k; du_k; du_{k+1}; s]_j + nu_k[i] - dx_{k+1}[i]   (with_s: include the s column)
     //             + sa * add[k][i]  (add may be null);  returns |out|^2
     SCVX_HD_NI double E_apply(cgptr v, gptr out, bool with_s, cgptr add = nullptr, double sa = 1.0) {
+        SCVX_THIS_LDS();
         SCVX_T0();
         const int K = L.K;
         const double s = with_s ? v[L.iS] : 0.0;
@@ -635,6 +644,7 @@ struct Solver {
     // the same lane)
     // pc / pn (mode 1 only): base - pc Ptr - pn Pnu - E_loc' y, the right-hand side of a solve's final Hb^-1 (kkt_solve)
     SCVX_HD_NI double Et_apply(cgptr yy, gptr g, cgptr base = nullptr, int mode = 0, double pc = 0.0, double pn = 0.0) {
+        SCVX_THIS_LDS();
         SCVX_T0();
         const int K = L.K;
         const bool corr = pc != 0.0 || pn != 0.0;
@@ -687,6 +697,7 @@ struct Solver {
     // ---- cone maps: a(w), J dw, J' z ----
     // out = a(v) if affine else J v
     SCVX_HD_NI void cone_map(cgptr v, gptr out, bool affine) {
+        SCVX_THIS_LDS();
         SCVX_T0();
         const int K = L.K;
         const double af = affine ? 1.0 : 0.0;
@@ -736,6 +747,7 @@ struct Solver {
     }
     // g = J' z (var-shaped, all nv entries written), or g = -sub - J' z when sub is given (the Newton right-hand side)
     SCVX_HD_NI void cone_map_t(cgptr z, gptr g, cgptr sub = nullptr) {
+        SCVX_THIS_LDS();
         SCVX_T0();
         const int K = L.K;
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
@@ -852,6 +864,7 @@ struct Solver {
     }
     // out = W in  /  W^-1 in   (cone vectors; in may alias out)
     SCVX_HD_NI void W_all(cgptr in, gptr out, bool inverse) {
+        SCVX_THIS_LDS();
         SCVX_T0();
         all_small([&](auto Dt_, int off, int c) {
             constexpr int d = decltype(Dt_)::value;
@@ -957,6 +970,7 @@ struct Solver {
 
     // ---- sweep 1: scaling, residual, predictor right-hand side ----
     SCVX_HD_NI void scale_pass(double& gap_out, double& nrz2_out) {
+        SCVX_THIS_LDS();
         SCVX_T0();
         double gap = 0, nrz2 = 0;
         const cgptr S_ = S; const cgptr Z_ = Z; const cgptr V_ = V;
@@ -1040,6 +1054,7 @@ struct Solver {
     // it) and, for the big cones, <v, W dz>_1 in bigvz[].
     template <bool PRED>
     SCVX_HD_NI double dir_pass() {
+        SCVX_THIS_LDS();
         SCVX_T0();
         double amax = INFINITY;
         const cgptr dw_ = dw; const cgptr Wv_ = Wv; const cgptr lam_ = lam; const cgptr Wirz_ = Wirz; const cgptr Wibz_ = Wibz;
@@ -1119,6 +1134,7 @@ struct Solver {
     // With a = W^-1 ds_aff (in sd) and b = W dz_aff = -lam - a:   t = lam \ (-lam o lam - a o b + sigmu e),
     // Wibz = -Wirz - t,  tmpc = W^-1 Wibz.
     SCVX_HD_NI void corr_rhs_pass(double sigmu) {
+        SCVX_THIS_LDS();
         SCVX_T0();
         const cgptr Wv_ = Wv; const cgptr lam_ = lam; const cgptr Wirz_ = Wirz; const cgptr sd_ = sd; const cgptr Wbeta_ = Wbeta;
         const gptr Wibz_ = Wibz; const gptr tmpc_ = tmpc;
@@ -1183,6 +1199,7 @@ struct Solver {
 
     // ---- sweep 5: S += alpha (J dw - rz) with rz = S - a(V) recomputed from the old V,  Z += alpha W^-1 (W dz) ----
     SCVX_HD_NI void update_pass(double alpha) {
+        SCVX_THIS_LDS();
         SCVX_T0();
         const gptr S_ = S; const gptr Z_ = Z; const cgptr V_ = V; const cgptr dw_ = dw; const cgptr Wv_ = Wv; const cgptr sd_ = sd;
         const cgptr Wbeta_ = Wbeta;
@@ -1230,6 +1247,7 @@ struct Solver {
     // every lane loads three coefficients and three inputs that sit next to those of its neighbours.  (One lane per
     // node, as build_kkt assembles the blocks, reads 51 elements at a stride of 33 doubles: no two lanes share a line.)
     SCVX_HD_NI void Hb_inv(cgptr g, gptr out, bool with_nu = true) {
+        SCVX_THIS_LDS();
         SCVX_T0();
         const int K = L.K;
         const cgptr hx_ = hx; const cgptr hu_ = hu;
@@ -1316,6 +1334,7 @@ struct Solver {
         ex.sync();
     }
     SCVX_HD_NI void S_solve(cgptr r, gptr x) {
+        SCVX_THIS_LDS();
         SCVX_T0();
         const int K = L.K;
         const cfptr Linv = this->Linv;
@@ -1361,6 +1380,7 @@ struct Solver {
     // r, x, t: N arrays of [K][14] each (t: scratch); nothing may alias.
     template <int N>
     SCVX_HD_NI void S_solveN(const cgptr (&r)[N], const gptr (&x)[N], const gptr (&t)[N]) {
+        SCVX_THIS_LDS();
         const int K = L.K;
         const cfptr Linv = this->Linv;
         for (int e = ex.lane(); e < 14 * K; e += ex.nlanes()) {
@@ -1395,6 +1415,7 @@ struct Solver {
     // loop, build_kkt): on entry x[q] holds t = L^-1 r, on exit x[q] holds the solution; t[q] is scratch.
     template <int N>
     SCVX_HD_NI void S_backN(const gptr (&x)[N], const gptr (&t)[N]) {
+        SCVX_THIS_LDS();
         const int K = L.K;
         const cfptr Linv = this->Linv;
         const cfptr Nf = this->Nf;
@@ -1418,6 +1439,7 @@ struct Solver {
     }
     // out0 = E v0, out1 = E v1 + add1 (both without the s column) with one pass over D
     SCVX_HD_NI void E_apply2(cgptr v0, cgptr v1, gptr out0, gptr out1, cgptr add1) {
+        SCVX_THIS_LDS();
         SCVX_T0();
         const int K = L.K;
         for (int r = ex.lane(); r < 14 * K; r += ex.nlanes()) {
@@ -1451,6 +1473,7 @@ struct Solver {
     // the assembly wavefront was the bottleneck with 7.5 k cycles per step of which 4.3 k post stage; profiles/r04_k4_sections_small.txt.)
     template <class E2 = Ex>
     SCVX_HD_NI bool factor_pipelined(bool with_pred) {
+        SCVX_THIS_LDS();
         const int K = L.K;
         const dcptr D_ = D; const cgptr hx_ = hx; const cgptr hu_ = hu;
         const fptr Linv_ = Linv; const fptr Nf_ = Nf;
@@ -1655,6 +1678,7 @@ struct Solver {
     // N'_{j-1} = -L_{j-1}^-1 Wb'_j UNtransposed, slot j <= m the usual N_j = -L_j^-1 Wb_{j-1} transposed.
     template <class E2 = Ex>
     SCVX_HD_NI bool factor_twisted() {
+        SCVX_THIS_LDS();
         const int K = L.K, m = K / 2, nb = K - 1 - m;   // nb nodes in the bottom half
         const dcptr D_ = D; const cgptr hx_ = hx; const cgptr hu_ = hu;
         const fptr Linv_ = Linv; const fptr Nf_ = Nf;
@@ -1892,6 +1916,7 @@ struct Solver {
     // [Hb E'; E 0][dw; dy] = [gx; -ry] is produced alongside the three border systems (dw, dy), so the predictor's
     // solve adds no pass of its own over the factor and over D.
     SCVX_HD_NI bool build_kkt(bool with_pred = false) {
+        SCVX_THIS_LDS();
         const int K = L.K;
         SCVX_COUNT(3);
         // big-cone scalars
@@ -2366,6 +2391,7 @@ struct Solver {
     // full reduced KKT: [H E'; E 0][dwv; dyv] = [g; ryv]  (g var-shaped incl. 4 globals)
     // have_band: (dwv, dyv) already hold the banded solution for (g, rsign ryv) (build_kkt(with_pred))
     SCVX_HD_NI void kkt_solve(cgptr g, cgptr ryv, gptr dwv, gptr dyv, double rsign = 1.0, bool have_band = false) {
+        SCVX_THIS_LDS();
         // banded multiplier: S dy = E Hb^-1 g - rsign ryv   (have_band: build_kkt(true) left it in dyv)
         if (!have_band) {
             Hb_inv(g, tmpl);
@@ -2444,6 +2470,7 @@ struct Solver {
 
     // H dwv (var-shaped, incl. globals) in operator form: J' W^-1 W^-1 J dwv
     SCVX_HD_NI void H_apply(cgptr dwv, gptr out) {
+        SCVX_THIS_LDS();
         cone_map(dwv, tmpc, false);
         ex.sync();
         W_all(tmpc, tmpc, true);
@@ -2455,6 +2482,7 @@ struct Solver {
     // Newton step for the cone right-hand side held in tmpc = W^-1 Wibz (scale_pass / corr_rhs_pass): results in dw, dy
     // pred: gx and the banded part of the solve were prepared before / inside build_kkt(true)
     SCVX_HD_NI void newton_solve(bool pred) {
+        SCVX_THIS_LDS();
         if (!pred) {
             cone_map_t(tmpc, gx, rx);      // gx = -rx - J' W^-1 Wibz
             mask_fixed(gx);
@@ -2536,6 +2564,7 @@ struct Solver {
     // 5e4 that takes five iterations to work off.  Twin, 14-step bench mix: 14.21 -> 13.16 iterations per solve; first failures over
     // 100 random classes 1.16 % -> 1.10 %: tools/k4_fuzz.py, profiles/r03_k4_init_shift.md.)
     SCVX_HD_NI void shift_into_cone(gptr X) {
+        SCVX_THIS_LDS();
         all_small([&](auto Dt_, int off, int) {
             constexpr int dm = decltype(Dt_)::value;
             double n = 0;
@@ -2612,6 +2641,7 @@ struct Solver {
     }
 
     SCVX_HD_NI Result attempt_solve(cdptr ic, bool warm) {
+        SCVX_THIS_LDS();
         const int K = L.K;
         zero(V, L.nv); zero(y, L.ny);
         if (ex.lane() == 0) {
