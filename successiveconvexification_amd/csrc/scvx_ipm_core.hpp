@@ -2390,8 +2390,7 @@ struct Solver {
 
     // full reduced KKT: [H E'; E 0][dwv; dyv] = [g; ryv]  (g var-shaped incl. 4 globals)
     // have_band: (dwv, dyv) already hold the banded solution for (g, rsign ryv) (build_kkt(with_pred))
-    SCVX_HD_NI void kkt_solve(cgptr g, cgptr ryv, gptr dwv, gptr dyv, double rsign = 1.0, bool have_band = false) {
-        SCVX_THIS_LDS();
+    SCVX_HD void kkt_solve(cgptr g, cgptr ryv, gptr dwv, gptr dyv, double rsign = 1.0, bool have_band = false) {
         // banded multiplier: S dy = E Hb^-1 g - rsign ryv   (have_band: build_kkt(true) left it in dyv)
         if (!have_band) {
             Hb_inv(g, tmpl);
@@ -2481,8 +2480,7 @@ struct Solver {
 
     // Newton step for the cone right-hand side held in tmpc = W^-1 Wibz (scale_pass / corr_rhs_pass): results in dw, dy
     // pred: gx and the banded part of the solve were prepared before / inside build_kkt(true)
-    SCVX_HD_NI void newton_solve(bool pred) {
-        SCVX_THIS_LDS();
+    SCVX_HD void newton_solve(bool pred) {
         if (!pred) {
             cone_map_t(tmpc, gx, rx);      // gx = -rx - J' W^-1 Wibz
             mask_fixed(gx);
