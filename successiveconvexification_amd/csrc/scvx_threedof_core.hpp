@@ -976,12 +976,70 @@ struct Solver {
         });
     }
 
+    // (the passes of solve()'s loop are routines of their own, like every pass: inlined into the kernel body their loop-invariant
+    // addresses were hoisted out of the iteration loop and spilled)
+    SCVX_HD_NI void residuals(double& pobj, double& dobj, double& nx, double& ny, double& gap, double& nz) {
+        gptr u = w + L.u, s = w + L.s, z = w + L.z, ru = w + L.ru, rz = w + L.rz;
+        const int nb = T.nb, m = T.m, N = T.N;
+        pobj = 0; dobj = 0; nx = 0; ny = 0;
+        struct Two { double r, o, w; };
+        each2<4>(nb + 1, [&](int p) {
+            const bool var = p == nb || is_var(N, p);
+            const double qp = var ? tt.q[p] : bq(p);
+            const double a = A_row(u, p);
+            Two t;
+            t.r = var ? qp + a - Et_at(z, p) : a - qp;
+            t.o = qp * u[p];
+            t.w = 0.0;
+            return t;
+        }, [&](int p, Two t) {
+            ru[p] = t.r;
+            if (p == nb || is_var(N, p)) { nx += t.r * t.r; pobj += t.o; }
+            else { ny += t.r * t.r; dobj -= t.o; }
+        });
+        gap = 0; nz = 0;
+        each2<4>(m, [&](int r) {
+            Two t;
+            t.w = s[r];
+            t.r = t.w - (E_row(u, r) + tt.e_h[r]);
+            t.o = z[r];
+            return t;
+        }, [&](int r, Two t) {
+            rz[r] = t.r; nz += t.r * t.r; gap += t.w * t.o; dobj -= tt.e_h[r] * t.o;
+        });
+        pobj = ex.sum(pobj); dobj = ex.sum(dobj); nx = ex.sum(nx); ny = ex.sum(ny); nz = ex.sum(nz); gap = ex.sum(gap);
+        ex.sync();
+    }
+    SCVX_HD_NI void pred_rhs() {
+        cgptr ru = w + L.ru, rz = w + L.rz, s = w + L.s;
+        gptr bu = w + L.bu, bz = w + L.bz;
+        const int nb = T.nb, m = T.m;
+        each2<4>(nb + 1, [&](int p) { return -ru[p]; }, [&](int p, double v) { bu[p] = v; });
+        each2<4>(m, [&](int r) { return -rz[r] + s[r]; }, [&](int r, double v) { bz[r] = v; });
+        ex.sync();
+    }
+    SCVX_HD_NI void corr_bu() {
+        cgptr ru = w + L.ru;
+        gptr bu = w + L.bu;
+        each2<4>(T.nb + 1, [&](int p) { return -ru[p]; }, [&](int p, double v) { bu[p] = v; });
+        ex.sync();
+    }
+    SCVX_HD_NI void take_step(double alpha) {
+        gptr u = w + L.u, s = w + L.s, z = w + L.z;
+        cgptr du = w + L.du, dz = w + L.dz, ds = w + L.ds;
+        const int nb = T.nb, m = T.m;
+        each2<4>(nb + 1, [&](int p) { return u[p] + alpha * du[p]; }, [&](int p, double v) { u[p] = v; });
+        each2<4>(m, [&](int r) { return z[r] + alpha * dz[r]; }, [&](int r, double v) { z[r] = v; });
+        each2<4>(m, [&](int r) { return s[r] + alpha * ds[r]; }, [&](int r, double v) { s[r] = v; });
+        ex.sync();
+    }
+
     SCVX_HD Result solve(const double* ic_, double* out_) {
         cgptr ic = (cgptr)ic_;
         gptr out = (gptr)out_;
         icv = ic;
         gptr u = w + L.u, s = w + L.s, z = w + L.z;
-        gptr ru = w + L.ru, rz = w + L.rz, du = w + L.du, dz = w + L.dz, ds = w + L.ds;
+        gptr du = w + L.du, dz = w + L.dz;
         gptr bu = w + L.bu, bz = w + L.bz;
         const int nb = T.nb, m = T.m, N = T.N;
         TD_TS(tt_);
@@ -1022,34 +1080,8 @@ struct Solver {
             R.iters = it;
             TD_TS(t8_);
             // residuals: ru = [c + A'y - E'z at variables; A x - b at equalities], rz = s - e(x)
-            double pobj = 0, dobj = 0, nx = 0, ny = 0;
-            struct Two { double r, o, w; };
-            each2<4>(nb + 1, [&](int p) {
-                const bool var = p == nb || is_var(N, p);
-                const double qp = var ? tt.q[p] : bq(p);
-                const double a = A_row(u, p);
-                Two t;
-                t.r = var ? qp + a - Et_at(z, p) : a - qp;
-                t.o = qp * u[p];
-                t.w = 0.0;
-                return t;
-            }, [&](int p, Two t) {
-                ru[p] = t.r;
-                if (p == nb || is_var(N, p)) { nx += t.r * t.r; pobj += t.o; }
-                else { ny += t.r * t.r; dobj -= t.o; }
-            });
-            double gap = 0, nz = 0;
-            each2<4>(m, [&](int r) {
-                Two t;
-                t.w = s[r];
-                t.r = t.w - (E_row(u, r) + tt.e_h[r]);
-                t.o = z[r];
-                return t;
-            }, [&](int r, Two t) {
-                rz[r] = t.r; nz += t.r * t.r; gap += t.w * t.o; dobj -= tt.e_h[r] * t.o;
-            });
-            pobj = ex.sum(pobj); dobj = ex.sum(dobj); nx = ex.sum(nx); ny = ex.sum(ny); nz = ex.sum(nz); gap = ex.sum(gap);
-            ex.sync();
+            double pobj, dobj, nx, ny, gap, nz;
+            residuals(pobj, dobj, nx, ny, gap, nz);
             const double pres = fmax(sqrt(ny) / nrm_b, sqrt(nz) / T.nrm_h), dres = sqrt(nx) / T.nrm_c;
             const double relgap = gap / fmax(1.0, fmax(fabs(pobj), fabs(dobj)));
             R.pobj = pobj; R.gap = gap; R.pres = pres; R.dres = dres;
@@ -1084,17 +1116,14 @@ struct Solver {
             const double mu = gap / degree;
 
             // predictor: ds_rhs = -lam o lam, so W (lam \ ds_rhs) = -W lam = -s:  bz = -rz + s
-            each2<4>(nb + 1, [&](int p) { return -ru[p]; }, [&](int p, double v) { bu[p] = v; });
-            each2<4>(m, [&](int r) { return -rz[r] + s[r]; }, [&](int r, double v) { bz[r] = v; });
-            ex.sync();
+            pred_rhs();
             kkt_solve(bu, bz, du, dz, TD_PRED_REFINE);
             TD_TS(t9_);
             double alpha = fmin(1.0, step_pass(du, dz));
             const double sigma = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
             // combined: ds_rhs = -lam o lam - (W^-1 ds_a) o (W dz_a) + sigma mu e;  bz = -rz - W (lam \ ds_rhs)
             corr_rhs(sigma * mu);
-            each2<4>(nb + 1, [&](int p) { return -ru[p]; }, [&](int p, double v) { bu[p] = v; });
-            ex.sync();
+            corr_bu();
             TD_TE(t9_, 9);
             kkt_solve(bu, bz, du, dz, (retried || fmax(pres, relgap) < TD_REFINE_FROM) ? (T.refine > 1 ? T.refine : 1) + (retried ? 1 : 0) : 0);
             TD_TS(t10_);
@@ -1102,10 +1131,7 @@ struct Solver {
             // the numerical floor: an iterate that is a certified near-optimum (the band the oracle's solver, oracle/ipm.py,
             // and Mosek / ECOS at their default tolerances report as OPTIMAL) is accepted when the KKT system breaks down
             if (!(alpha >= 1e-8)) { R.status = near ? TD_OPTIMAL : (almost ? TD_ALMOST : (alpha == alpha ? TD_STALLED : TD_NONFINITE)); break; }
-            each2<4>(nb + 1, [&](int p) { return u[p] + alpha * du[p]; }, [&](int p, double v) { u[p] = v; });
-            each2<4>(m, [&](int r) { return z[r] + alpha * dz[r]; }, [&](int r, double v) { z[r] = v; });
-            each2<4>(m, [&](int r) { return s[r] + alpha * ds[r]; }, [&](int r, double v) { s[r] = v; });
-            ex.sync();
+            take_step(alpha);
             TD_TE(t10_, 10);
         }
         // the variables, node by node, then nkaR
