@@ -1,4 +1,4 @@
-for L in variants/libscvx_k0base.so successiveconvexification_amd/libscvx_hip.so; do echo "== $L"; timeout -k 10 300 python -c "
+for L in variants/libscvx_k0base.so successiveconvexification_amd/libscvx_hip.so $EXTRA; do echo "== $L"; timeout -k 10 300 python -c "
 import sys, os, runpy
 sys.path.insert(0, '.')
 from successiveconvexification_amd import _lib
