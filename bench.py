@@ -160,11 +160,18 @@ def cpu_baseline(npts, seed, steps, reps=5):
                       f"device path (scvx_ipm_core.hpp incl. its warm start after rejected steps + RK4 npts={npts}); the Julia reference itself cannot run here"}
 
 
-def traj_linf_vs_oracle(cache_cls, batch_cls, prob, npts, tol=None):
+def oracle_full_run_fixture(tol):
+    """the oracle's recorded solve_problem at solver tolerance `tol` (1e-9, the oracle's default, is the unsuffixed file)"""
+    return os.path.join(ROOT, "tests", "golden", "oracle_scvx_full.npz" if abs(tol - 1e-9) < 1e-24 else "oracle_scvx_full_tol%g.npz" % tol)
+
+
+def traj_linf_vs_oracle(cache_cls, batch_cls, prob, npts, tol=None, same_tol=False):
     """Second half of the headline metric ("traj L-inf vs ref"): a complete Rocketland.solve_problem of the sample
     problem (B = 1, imax-1 = 14 solve_steps) on the device against the oracle's recorded run, a committed fixture
-    (tests/golden/oracle_scvx_full.npz — data; generated by tests/golden/make_oracle_full_run.py).  Outside the timed region."""
-    f = os.path.join(ROOT, "tests", "golden", "oracle_scvx_full.npz" if tol is None else "oracle_scvx_full_tol%g.npz" % tol)
+    (tests/golden/oracle_scvx_full*.npz — data; generated by tests/golden/make_oracle_full_run.py).  Outside the timed region.
+    tol = None: the device at its default (1e-8) against the oracle at ITS default (1e-9) -- rounds 1-4's figure.
+    same_tol (or any explicit tol): device and oracle at the same tolerance."""
+    f = oracle_full_run_fixture(1e-9) if tol is None else oracle_full_run_fixture(tol)
     if not os.path.exists(f) or npts != 10:
         return None
     g = np.load(f)
@@ -269,16 +276,30 @@ def k1_error_by_npts(cache_cls, prob, sweep=(1, 2, 4, 10)):
 
 
 def k4_traffic_model(tstats, launches):
-    """HBM bytes per socp_kernel launch MODELLED for this run: bytes per interior-point iteration and per solve as calibrated by PMC
-    passes (profiles/r04_k4_traffic_model.json: 2 x FETCH_SIZE + WRITE_SIZE over launches with known iteration counts) times THIS run's
-    own device-side counters.  None when no calibration is on file."""
-    f = os.path.join(ROOT, "profiles", "r04_k4_traffic_model.json")
-    if not os.path.exists(f) or launches <= 0:
+    """HBM bytes per socp_kernel launch MODELLED for this run: bytes per interior-point iteration as calibrated by PMC passes
+    (profiles/r*_k4_traffic_model.json, the newest round on file: 2 x FETCH_SIZE + WRITE_SIZE over launches with known iteration
+    counts, written by tools/final_profiles.sh together with the hash of the library sources it measured) times THIS run's own
+    device-side counters.  `calibration_matches_running_library` is False when the sources have changed since the calibration --
+    the modelled traffic is then a stale figure and says so.  None when no calibration is on file."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k4_traffic_model.json")))
+    if not files or launches <= 0:
         return None
+    f = files[-1]
     m = json.load(open(f))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import lib_hash
+        running = lib_hash.lib_source_hash()
+    except Exception:
+        running = None
     total = m["bytes_per_ipm_iteration"] * tstats["ipm_iters"] + m.get("bytes_per_solve", 0.0) * tstats["solves"]
+    cal = m.get("lib_source_hash")
     return {"bytes_per_launch": total / launches, "bytes_per_ipm_iteration": m["bytes_per_ipm_iteration"],
-            "bytes_per_solve": m.get("bytes_per_solve", 0.0), "source": "profiles/r04_k4_traffic_model.json: " + m.get("source", "")}
+            "bytes_per_solve": m.get("bytes_per_solve", 0.0), "calibrated_on_lib_source_hash": cal, "calibrated_on_git_head": m.get("git_head"),
+            "running_lib_source_hash": running,
+            "calibration_matches_running_library": (cal == running) if (cal and running) else False,
+            "source": "profiles/%s: %s" % (os.path.basename(f), m.get("source", ""))}
 
 
 SOCP_ALG_BYTES = 137 * 1024  # SURVEY.md 8d: K4 reads the linearisation and the iterate, writes the solution (per trajectory)
@@ -539,6 +560,11 @@ def main():
             "steps_requested": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / steps,
+            # what `value` counts, made first-class: a solve_step that is REJECTED (rocketland.jl:299-301) keeps the
+            # reference point, so the trajectories ADVANCE at accepted_steps_per_s; a whole Rocketland.solve_problem (imax - 1 solve_steps
+            # from create_initial) completes at solve_problems_per_s.  Rank 0's shard x world (every shard draws from the same law).
+            "accepted_steps_per_s": world * (tstats["traj_steps"] - tstats["rejected"] - tstats["failed"]) / elapsed,
+            "solve_problems_per_s": (done_all / period) / elapsed if not args.no_reset else None,
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,

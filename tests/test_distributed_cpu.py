@@ -71,6 +71,50 @@ def test_two_rank_shard_and_gather(scaling, batch):
     assert why is not None and ("unique_id" in why or "scvx_comm_create" in why or "RCCL not loadable" in why)  # no GPU here: the bootstrap reports it, on every rank
 
 
+def _worker8(rank, world, port, q):
+    """the driver's N = 8 strong-scaling shape on CPU: global 8192 -> 1024 per rank, records of the real size"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from successiveconvexification_amd import montecarlo as mc, sample_problems as sp
+    p = sp.base_prob_scaled
+    nrec = (p.K + 1) * 17 + 1
+    shard = mc.Shard(p, 8192, 20261004, rank, world, "strong")
+    rec = np.zeros((shard.B, nrec))
+    rec[:, 0] = np.arange(shard.lo, shard.hi)
+    rec[:, 1:7] = shard.ic
+    rec[:, -1] = rank
+    out = mc.gather_records(torch.tensor(rec), dist)
+    t, n = mc.reduce_clock(0.5 + 0.01 * rank, shard.B * 14, dist)
+    if rank == 0:
+        q.put((tuple(out.shape), out[:, :, 0].numpy().copy(), out[:, 0, -1].numpy().copy(), out[:, :, 1:7].numpy().copy(), t, n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_strong_shard_and_gather_shape_of_the_driver_run():
+    """VERDICT r4 item 6, the part that can run without eight processes on one card (the GPU box's process guard allows six):
+    eight gloo ranks on CPU run the bench's own sharding / gather / clock code at the driver's N = 8 shape -- global batch 8192,
+    1024 trajectories per rank, records of (K+1)*17+1 = 868 values -- and the gathered array is (8, 1024, 868) in global order with
+    exactly the initial conditions one 8192 batch would draw."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    shape, idx, ranks, ics, t, n = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert shape == (8, 1024, 868)
+    assert np.array_equal(idx.reshape(-1), np.arange(8192)) and np.array_equal(ranks, np.arange(8))
+    from successiveconvexification_amd import montecarlo as mc, sample_problems as sp
+    assert np.array_equal(ics.reshape(8192, 6), mc.disperse_ics(sp.base_prob_scaled, 0, 8192, 20261004))
+    assert abs(t - 0.57) < 1e-12 and n == 8192 * 14
+
+
 def test_strong_scaling_needs_divisible_batch():
     from successiveconvexification_amd import montecarlo as mc, sample_problems as sp
     with pytest.raises(ValueError):
