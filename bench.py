@@ -285,14 +285,15 @@ def k4_traffic_model(tstats, launches):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k4_traffic_model.json")))
     if not files or launches <= 0:
         return None
-    f = files[-1]
-    m = json.load(open(f))
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         import lib_hash
         running = lib_hash.lib_source_hash()
     except Exception:
         running = None
+    # the calibration taken on THIS library if there is one, else the last one on file (flagged as not matching)
+    f = next((g for g in reversed(files) if json.load(open(g)).get("lib_source_hash") == running), files[-1])
+    m = json.load(open(f))
     total = m["bytes_per_ipm_iteration"] * tstats["ipm_iters"] + m.get("bytes_per_solve", 0.0) * tstats["solves"]
     cal = m.get("lib_source_hash")
     return {"bytes_per_launch": total / launches, "bytes_per_ipm_iteration": m["bytes_per_ipm_iteration"],

@@ -129,6 +129,11 @@
 #ifndef SCVX_REFINE_FROM
 #define SCVX_REFINE_FROM 1e-4
 #endif
+// the corrector's refinement check folded into the solve and the direction pass (Solver::newton_corr, round 5); 0 = the separate
+// H_apply / E'dy passes of rounds 2-4 (newton_solve)
+#ifndef SCVX_REFINE_FUSED
+#define SCVX_REFINE_FUSED 1
+#endif
 // refinement of a Newton solve stops once its first-row residual is below this fraction of the dual tolerance
 #ifndef SCVX_REFINE_STOP
 #define SCVX_REFINE_STOP 0.1
@@ -513,6 +518,7 @@ struct Solver {
     bool p_sigma_cube = false;
     double p_mu_floor = 0.25;   // SCVX_MU_FLOOR (defined where it is used, in attempt_solve)
     double bigvz[2];  // <v, W dz>_1 of the two big cones (corr_dir_pass -> update_pass)
+    double bigvx2[2]; // v0 wij_0 - <v, wij>_1 of the two big cones, wij = W^-1 J dw (dir_pass<false, true> -> cone_map_t(hbig))
 #if defined(SCVX_IPM_PROF)
     double prof[32];   // in-kernel section timers (diagnostic builds)
 #endif
@@ -643,7 +649,9 @@ struct Solver {
     // mode 1: g = base - E_loc' y;  mode 2: g = E_loc' y - base  (base may be g itself: each entry is read and written by
     // the same lane)
     // pc / pn (mode 1 only): base - pc Ptr - pn Pnu - E_loc' y, the right-hand side of a solve's final Hb^-1 (kkt_solve)
-    SCVX_HD_NI double Et_apply(cgptr yy, gptr g, cgptr base = nullptr, int mode = 0, double pc = 0.0, double pn = 0.0) {
+    // eout (optional): the raw products E_loc' y on the (dx, du) rows as well (the refinement's operator-form check reuses them instead
+    // of a second pass over D: newton_corr)
+    SCVX_HD_NI double Et_apply(cgptr yy, gptr g, cgptr base = nullptr, int mode = 0, double pc = 0.0, double pn = 0.0, gptr eout = nullptr) {
         SCVX_THIS_LDS();
         SCVX_T0();
         const int K = L.K;
@@ -659,6 +667,7 @@ struct Solver {
                 for (int i = 0; i < 14; i++) a += col[14 * i] * yk[i];
             }
             if (k > 0) a -= yy[14 * (k - 1) + j];
+            if (eout) eout[t] = a;
             if (mode) a = mode == 1 ? b0 - a : a - b0;
             g[t] = a;
         }
@@ -676,6 +685,7 @@ struct Solver {
                 cgptr yk = yy + 14 * (k - 1);
                 for (int i = 0; i < 14; i++) a += col[i] * yk[i];
             }
+            if (eout) eout[L.nx + t] = a;
             if (mode) a = mode == 1 ? b0 - a : a - b0;
             g[L.nx + t] = a;
         }
@@ -746,13 +756,20 @@ struct Solver {
         SCVX_T1(21);
     }
     // g = J' z (var-shaped, all nv entries written), or g = -sub - J' z when sub is given (the Newton right-hand side)
-    SCVX_HD_NI void cone_map_t(cgptr z, gptr g, cgptr sub = nullptr) {
+    // hbig: the bodies of the two big cones in z hold wij = W^-1 (J dw) (dir_pass<false, true>); their second scaling
+    // W^-1 wij = (-2 vx2 v_i + wij_i) / beta is applied here, on the fly (the heads in z are final)
+    SCVX_HD_NI void cone_map_t(cgptr z, gptr g, cgptr sub = nullptr, bool hbig = false) {
         SCVX_THIS_LDS();
         SCVX_T0();
         const int K = L.K;
+        const double ht_c = hbig ? -2.0 * bigvx2[1] : 0.0, ht_s = hbig ? 1.0 / Wbeta[L.c_tr] : 1.0;
+        const double hn_c = hbig ? -2.0 * bigvx2[0] : 0.0, hn_s = hbig ? 1.0 / Wbeta[L.c_nu] : 1.0;
+        cgptr vtr = Wv + L.o_tr + 1;
         for (int k = ex.lane(); k <= K; k += ex.nlanes()) {
             double gl[NXU];   // the node's rows are assembled in registers and stored once
             cgptr trx = z + L.o_tr + 1 + 14 * k;
+            if (hbig) { for (int j = 0; j < 14; j++) gl[j] = (ht_c * vtr[14 * k + j] + trx[j]) * ht_s; }
+            else
             for (int j = 0; j < 14; j++) gl[j] = trx[j];
             if (k >= 1) gl[0] += z[L.o_mass + (k - 1)];
             if (k < K) {
@@ -771,11 +788,13 @@ struct Solver {
             cgptr tb = z + L.o_tb + 4 * k;
             cgptr tc = z + L.o_tc + 4 * k;
             const double zl = z[L.o_lb + k];
-            for (int c = 0; c < 3; c++) gl[14 + c] = tru[c] + tb[1 + c] + tc[1 + c] + zl * uhat[3 * k + c];
+            double tu[NU];
+            for (int c = 0; c < NU; c++) tu[c] = hbig ? (ht_c * vtr[L.nx + NU * k + c] + tru[c]) * ht_s : (double)tru[c];
+            for (int c = 0; c < 3; c++) gl[14 + c] = tu[c] + tb[1 + c] + tc[1 + c] + zl * uhat[3 * k + c];
             gl[14] += tc[0] * C.icos;
             if constexpr (NU == 5) {
                 cgptr f = z + L.o_fin + 3 * k;
-                gl[17] = tru[3] + f[1]; gl[18] = tru[4] + f[2];
+                gl[17] = tu[3] + f[1]; gl[18] = tu[4] + f[2];
             }
             gptr gx_ = g + 14 * k; gptr gu = g + L.nx + NU * k;
             if (sub) {
@@ -794,6 +813,9 @@ struct Solver {
             if (sub) {
                 cgptr sn = sub + L.nx + L.nu_;
                 stream(0, 14 * K, [&](int i) { return D2{zn[i], sn[i]}; }, [&](int i, const D2& x) { gn[i] = -x.b - x.a; });
+            } else if (hbig) {
+                cgptr vn = Wv + L.o_nu + 1;
+                stream(0, 14 * K, [&](int i) { return D2{zn[i], vn[i]}; }, [&](int i, const D2& x) { gn[i] = (hn_c * x.b + x.a) * hn_s; });
             } else {
                 stream<8>(0, 14 * K, [&](int i) { return zn[i]; }, [&](int i, double x) { gn[i] = x; });
             }
@@ -1052,13 +1074,17 @@ struct Solver {
     // wij = W^-1 J dw,  W^-1 ds = wij - Wirz,  W dz = -(wij + Wibz)   (predictor: Wibz = lam - Wirz, so W dz = -lam - W^-1 ds).
     // PRED: stores sd = W^-1 ds (the corrector's right-hand side needs it).  Otherwise stores sd = W dz (update_pass needs
     // it) and, for the big cones, <v, W dz>_1 in bigvz[].
-    template <bool PRED>
+    // CHECK (corrector only): also leaves u = W^-1 wij in tmpc for the refinement's operator-form residual H dw = J' W^-1 (W^-1 J dw)
+    // -- the first scaling is computed here anyway.  Small cones and the heads of the big cones: final; bodies of the big cones: wij
+    // itself, with bigvx2[] = v0 wij_0 - <v, wij>_1 (summed from the computed wij) for cone_map_t(hbig) to finish.
+    template <bool PRED, bool CHECK = false>
     SCVX_HD_NI double dir_pass() {
+        static_assert(!(PRED && CHECK), "the operator-form check belongs to the corrector");
         SCVX_THIS_LDS();
         SCVX_T0();
         double amax = INFINITY;
         const cgptr dw_ = dw; const cgptr Wv_ = Wv; const cgptr lam_ = lam; const cgptr Wirz_ = Wirz; const cgptr Wibz_ = Wibz;
-        const cgptr Wbeta_ = Wbeta; const gptr sd_ = sd;
+        const cgptr Wbeta_ = Wbeta; const gptr sd_ = sd; const gptr tc_ = tmpc;
         for_small([&](auto G_, auto Dt_, int off, int c, int q) {
             constexpr int GRP = decltype(G_)::value, D = decltype(Dt_)::value;
             double ds[D], l[D], wr[D], a[D], b[D];
@@ -1067,6 +1093,7 @@ struct Solver {
             for (int i = 0; i < D; i++) { l[i] = lam_[off + i]; wr[i] = Wirz_[off + i]; }
             if constexpr (D == 1) {
                 const double wij = ds[0] / beta;
+                if (CHECK) tc_[off] = wij / beta;
                 a[0] = wij - wr[0];
                 b[0] = PRED ? -l[0] - a[0] : -(wij + Wibz_[off]);
                 const double sa = a[0] < 0.0 ? -l[0] / a[0] : INFINITY, sb = b[0] < 0.0 ? -l[0] / b[0] : INFINITY;
@@ -1076,6 +1103,11 @@ struct Solver {
                 double v[D], wij[D];
                 for (int i = 0; i < D; i++) v[i] = Wv_[off + i];
                 soc_W_small(v, beta, D, ds, wij, true);
+                if (CHECK) {
+                    double uu[D];
+                    soc_W_small(v, beta, D, wij, uu, true);
+                    for (int i = 0; i < D; i++) tc_[off + i] = uu[i];
+                }
                 for (int i = 0; i < D; i++) { a[i] = wij[i] - wr[i]; b[i] = PRED ? -l[i] - a[i] : -(wij[i] + Wibz_[off + i]); }
                 double ll = 0, la = 0, aa = 0, lb = 0, bb = 0;
                 for (int i = 1; i < D; i++) { ll += l[i] * l[i]; la += l[i] * a[i]; aa += a[i] * a[i]; lb += l[i] * b[i]; bb += b[i] * b[i]; }
@@ -1100,7 +1132,8 @@ struct Solver {
             const double wij0 = (2.0 * vx * v0 - d0) * ibeta;
             const double a0 = wij0 - wr[0];
             const double b0 = PRED ? -l0 - a0 : -(wij0 + wb[0]);
-            double ll = 0, la = 0, aa = 0, lb = 0, bb = 0, vb = 0;
+            double ll = 0, la = 0, aa = 0, lb = 0, bb = 0, vb = 0, vw = 0;
+            const gptr to = tc_ + bc.off;
             if (PRED) {
                 stream(1, bc.dim, [&](int i) { return D4{v[i], db[i], wr[i], l[i]}; },
                        [&](int i, const D4& w) {
@@ -1114,11 +1147,17 @@ struct Solver {
                            const double wij = (-2.0 * vx * w.a + w.b) * ibeta;
                            const double ai = wij - w.c, bi = -(wij + w.e);
                            so[i] = bi;
+                           if (CHECK) { to[i] = wij; vw += w.a * wij; }
                            ll += w.d * w.d; la += w.d * ai; aa += ai * ai; lb += w.d * bi; bb += bi * bi; vb += w.a * bi;
                        });
             }
             ll = ex.sum(ll); la = ex.sum(la); aa = ex.sum(aa); lb = ex.sum(lb); bb = ex.sum(bb);
             if (!PRED) bigvz[q] = ex.sum(vb);
+            if (CHECK) {
+                const double vx2 = v0 * wij0 - ex.sum(vw);
+                bigvx2[q] = vx2;
+                if (ex.lane() == 0) to[0] = (2.0 * vx2 * v0 - wij0) * ibeta;
+            }
             if (ex.lane() == 0) so[0] = PRED ? a0 : b0;
             const double sa = soc_maxstep_parts(l0, a0, l0 * l0 - ll, l0 * a0 - la, a0 * a0 - aa);
             const double sb = soc_maxstep_parts(l0, b0, l0 * l0 - ll, l0 * b0 - lb, b0 * b0 - bb);
@@ -2390,7 +2429,9 @@ struct Solver {
 
     // full reduced KKT: [H E'; E 0][dwv; dyv] = [g; ryv]  (g var-shaped incl. 4 globals)
     // have_band: (dwv, dyv) already hold the banded solution for (g, rsign ryv) (build_kkt(with_pred))
-    SCVX_HD void kkt_solve(cgptr g, cgptr ryv, gptr dwv, gptr dyv, double rsign = 1.0, bool have_band = false) {
+    // eout / sgout (optional): E_loc' dyv on the (dx, du) rows and Sg . dyv, by-products of the final E' product (newton_corr)
+    SCVX_HD void kkt_solve(cgptr g, cgptr ryv, gptr dwv, gptr dyv, double rsign = 1.0, bool have_band = false, gptr eout = nullptr,
+                           double* sgout = nullptr) {
         // banded multiplier: S dy = E Hb^-1 g - rsign ryv   (have_band: build_kkt(true) left it in dyv)
         if (!have_band) {
             Hb_inv(g, tmpl);
@@ -2461,7 +2502,10 @@ struct Solver {
         }
         ex.sync();
         // ... and the local step in one go:  dw = Hb^-1 (g - Ptr ctr - Pnu cnu - E'dy)
-        (void)Et_apply(dyv, tmpl2, g, 1, ctr, cnu);
+        {
+            const double sg_ = Et_apply(dyv, tmpl2, g, 1, ctr, cnu, eout);
+            if (sgout) *sgout = sg_;
+        }
         Hb_inv(tmpl2, dwv);
         if (ex.lane() == 0) { dwv[L.iS] = s_; dwv[L.iTS] = ts_; dwv[L.iTNU] = tnu_; dwv[L.iTTR] = ttr_; }
         ex.sync();
@@ -2554,6 +2598,72 @@ struct Solver {
             }
             ex.sync();
         }
+    }
+
+    // The corrector's Newton step + its scaled direction + the step length, with the refinement's residual check folded in (round 5).
+    // newton_solve's check costs a pass over D (E'dy), three cone-vector passes (J dw, W^-1 twice) and J' -- 0.43 MB, in every
+    // iteration of the endgame.  Here: E'dy is a by-product of the solve's own final E' product (kkt_solve's eout), and W^-1 J dw is what
+    // dir_pass computes anyway (CHECK: it also leaves W^-1 of it in tmpc).  The check is then one J' gather and one combination:
+    // 0.12 MB.  Same operator form (J' W^-1 W^-1 J dw), same stopping rules; a correction (rare: ~2 per solve) re-runs the direction pass.
+    // Returns the largest step to the cone boundary (dir_pass<false>).
+    SCVX_HD double newton_corr() {
+        cone_map_t(tmpc, gx, rx);      // gx = -rx - J' W^-1 Wibz
+        mask_fixed(gx);
+        SCVX_COUNT(0);
+        const int nref = cur_gate < SCVX_REFINE_FROM ? C.refine : 0;
+        if (nref == 0) {
+            kkt_solve(gx, ry, dw, dy, -1.0, false);
+            return dir_pass<false>();
+        }
+        const gptr et = tmpv;          // E_loc' dy on the (dx, du) rows; on the nu rows it is dy itself
+        double sgy = 0.0;
+        kkt_solve(gx, ry, dw, dy, -1.0, false, et, &sgy);
+        const int nxu = L.nx + L.nu_;
+        double nr_prev = INFINITY, amax = INFINITY;
+        for (int it = 0;; it++) {
+            if (it >= nref) { amax = dir_pass<false>(); break; }
+            amax = dir_pass<false, true>();
+            SCVX_COUNT(1);
+            cone_map_t(tmpc, r1, nullptr, true);     // r1 = H dw (operator form)
+            {
+                gptr r1_ = r1; cgptr g_ = gx; cgptr et_ = et; cgptr dy_ = dy;
+                stream(0, nxu, [&](int i) { return D3{g_[i], r1_[i], et_[i]}; }, [&](int i, const D3& v) { r1_[i] = v.a - v.b - v.c; });
+                stream(nxu, L.nloc, [&](int i) { return D3{g_[i], r1_[i], dy_[i - nxu]}; }, [&](int i, const D3& v) { r1_[i] = v.a - v.b - v.c; });
+            }
+            ex.sync();
+            if (ex.lane() == 0) {
+                r1[L.iS] = gx[L.iS] - r1[L.iS] - sgy;
+                r1[L.iTNU] = gx[L.iTNU] - r1[L.iTNU];
+                r1[L.iTTR] = gx[L.iTTR] - r1[L.iTTR];
+                r1[L.iTS] = gx[L.iTS] - r1[L.iTS];
+            }
+            ex.sync();
+            mask_fixed(r1);
+            const double nr1 = sqrt(sumsq(r1, L.nv));
+            SCVX_DBG("      refine %d: |r1| %.3e\n", it, nr1);
+            if (nr1 <= SCVX_REFINE_STOP * C.tol * (C.wNu > 1.0 ? C.wNu : 1.0)) break;
+            if (it > 0 && !(nr1 < 0.5 * nr_prev)) break;   // the corrections have stopped contracting: precision floor
+            nr_prev = nr1;
+            E_apply(dw, tmpy2, true);
+            ex.sync();
+            {
+                gptr t2 = tmpy2; cgptr ry_ = ry;
+                stream(0, L.ny, [&](int i) { return D2{ry_[i], t2[i]}; }, [&](int i, const D2& v) { t2[i] = -v.a - v.b; });
+            }
+            ex.sync();
+            SCVX_COUNT(2);
+            double sgc = 0.0;
+            kkt_solve(r1, tmpy2, cw, cy, 1.0, false, tmpl, &sgc);   // tmpl: kkt_solve's own scratch, free again when its last E' product runs
+            sgy += sgc;
+            {
+                gptr dw_ = dw; cgptr cw_ = cw; gptr dy_ = dy; cgptr cy_ = cy; gptr et_ = et; cgptr ec = tmpl;
+                stream(0, L.nv, [&](int i) { return D2{dw_[i], cw_[i]}; }, [&](int i, const D2& v) { dw_[i] = v.a + v.b; });
+                stream(0, L.ny, [&](int i) { return D2{dy_[i], cy_[i]}; }, [&](int i, const D2& v) { dy_[i] = v.a + v.b; });
+                stream(0, nxu, [&](int i) { return D2{et_[i], ec[i]}; }, [&](int i, const D2& v) { et_[i] = v.a + v.b; });
+            }
+            ex.sync();
+        }
+        return amax;
     }
 
     // Every cone whose point is not at least SCVX_INIT_SHIFT inside gets its own multiple of e added, just enough to be that far
@@ -2844,8 +2954,12 @@ struct Solver {
 #endif
             }
             corr_rhs_pass(smu);
+#if SCVX_REFINE_FUSED
+            { SCVX_TS(tN_); alpha = p_step_frac * newton_corr(); SCVX_TE(tN_, 10); }
+#else
             { SCVX_TS(tN_); newton_solve(false); SCVX_TE(tN_, 10); }
             alpha = p_step_frac * dir_pass<false>();
+#endif
             if (alpha > 1.0) alpha = 1.0;
             SCVX_DBG("    cmb alpha %.6e |dw|^2 %.6e\n", alpha, dot(dw, dw, L.nv));
             if (!(alpha == alpha)) { res.status = stop_status(3); break; }
