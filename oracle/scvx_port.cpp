@@ -30,6 +30,7 @@ struct HostEx {
     static constexpr int kLanes = 1;
     static constexpr bool kPipelineFactor = false;
     static constexpr bool kTwisted = false;
+    static constexpr bool kFusedResidual = true;
     // C(14x14) = (acc ? C : 0) + alpha * A(14 x Kd) B(Kd x 14); element strides: C(i,j) = C[i*sci + j*scj],
     // A(i,k) = A[i*sai + k*sak], B(k,j) = B[k*sbk + j*sbj].  C must not alias A or B.
     void tile_gemm(double* Cm, int sci, int scj, const double* A, int sai, int sak, const double* B, int sbk, int sbj,

@@ -134,6 +134,15 @@
 #ifndef SCVX_REFINE_FUSED
 #define SCVX_REFINE_FUSED 1
 #endif
+// E'y and E V formed inside the factorisation loop instead of by two passes over D of their own (build_kkt(res), round 5); 0 = the separate
+// passes.  MEASURED AND OFF (profiles/r05_k4_inloop_residuals.md): it removes 5.3 % of the kernel's HBM traffic (PMC: 3.35 -> 3.17 MB per
+// interior-point iteration) and makes the kernel 9.5 % SLOWER (64.75 -> 70.9 ms per launch of the bench mix): the two small matrix-vector
+// products, their node slices and stores add ~8 k cycles to each of the 50 dependent steps of the loop (in-kernel timers: loop 19.2 M ->
+// 25.8 M cycles per solve), and a wavefront's time in that loop is NOT hidden behind the other wavefronts' streaming -- the loop's latency
+// and the streamed bytes add up.  Kept as a switch because it is the measurement that says so.
+#ifndef SCVX_FUSED_RES
+#define SCVX_FUSED_RES 0
+#endif
 // refinement of a Newton solve stops once its first-row residual is below this fraction of the dual tolerance
 #ifndef SCVX_REFINE_STOP
 #define SCVX_REFINE_STOP 0.1
@@ -518,6 +527,7 @@ struct Solver {
     bool p_sigma_cube = false;
     double p_mu_floor = 0.25;   // SCVX_MU_FLOOR (defined where it is used, in attempt_solve)
     double bigvz[2];  // <v, W dz>_1 of the two big cones (corr_dir_pass -> update_pass)
+    double res_nrx2, res_nry2, res_sgy;   // build_kkt(res): |rx|^2 over the local rows, |ry|^2, Sg . y
     double bigvx2[2]; // v0 wij_0 - <v, wij>_1 of the two big cones, wij = W^-1 J dw (dir_pass<false, true> -> cone_map_t(hbig))
 #if defined(SCVX_IPM_PROF)
     double prof[32];   // in-kernel section timers (diagnostic builds)
@@ -758,7 +768,8 @@ struct Solver {
     // g = J' z (var-shaped, all nv entries written), or g = -sub - J' z when sub is given (the Newton right-hand side)
     // hbig: the bodies of the two big cones in z hold wij = W^-1 (J dw) (dir_pass<false, true>); their second scaling
     // W^-1 wij = (-2 vx2 v_i + wij_i) / beta is applied here, on the fly (the heads in z are final)
-    SCVX_HD_NI void cone_map_t(cgptr z, gptr g, cgptr sub = nullptr, bool hbig = false) {
+    // neg (without sub): g = -J' z
+    SCVX_HD_NI void cone_map_t(cgptr z, gptr g, cgptr sub = nullptr, bool hbig = false, bool neg = false) {
         SCVX_THIS_LDS();
         SCVX_T0();
         const int K = L.K;
@@ -804,8 +815,9 @@ struct Solver {
                 for (int j = 0; j < 14; j++) gx_[j] = -sb[j] - gl[j];
                 for (int c = 0; c < NU; c++) gu[c] = -sb[14 + c] - gl[14 + c];
             } else {
-                for (int j = 0; j < 14; j++) gx_[j] = gl[j];
-                for (int c = 0; c < NU; c++) gu[c] = gl[14 + c];
+                const double sg = neg ? -1.0 : 1.0;
+                for (int j = 0; j < 14; j++) gx_[j] = sg * gl[j];
+                for (int c = 0; c < NU; c++) gu[c] = sg * gl[14 + c];
             }
         }
         {
@@ -817,15 +829,17 @@ struct Solver {
                 cgptr vn = Wv + L.o_nu + 1;
                 stream(0, 14 * K, [&](int i) { return D2{zn[i], vn[i]}; }, [&](int i, const D2& x) { gn[i] = (hn_c * x.b + x.a) * hn_s; });
             } else {
-                stream<8>(0, 14 * K, [&](int i) { return zn[i]; }, [&](int i, double x) { gn[i] = x; });
+                const double sg = neg ? -1.0 : 1.0;
+                stream<8>(0, 14 * K, [&](int i) { return zn[i]; }, [&](int i, double x) { gn[i] = sg * x; });
             }
         }
         if (ex.lane() == 0) {
+            const double sg = neg ? -1.0 : 1.0;
             const double g0 = z[L.o_nu], g1 = z[L.o_tr] - z[L.o_rk], g2 = z[L.o_sg], g3 = z[L.o_sg + 1];
-            g[L.iTNU] = sub ? -sub[L.iTNU] - g0 : g0;
-            g[L.iTTR] = sub ? -sub[L.iTTR] - g1 : g1;
-            g[L.iTS] = sub ? -sub[L.iTS] - g2 : g2;
-            g[L.iS] = sub ? -sub[L.iS] - g3 : g3;
+            g[L.iTNU] = sub ? -sub[L.iTNU] - g0 : sg * g0;
+            g[L.iTTR] = sub ? -sub[L.iTTR] - g1 : sg * g1;
+            g[L.iTS] = sub ? -sub[L.iTS] - g2 : sg * g2;
+            g[L.iS] = sub ? -sub[L.iS] - g3 : sg * g3;
         }
         ex.sync();
         SCVX_T1(21);
@@ -1954,7 +1968,9 @@ struct Solver {
     // with_pred: gx holds the (masked) predictor right-hand side and ry the equality residual; their banded solution
     // [Hb E'; E 0][dw; dy] = [gx; -ry] is produced alongside the three border systems (dw, dy), so the predictor's
     // solve adds no pass of its own over the factor and over D.
-    SCVX_HD_NI bool build_kkt(bool with_pred = false) {
+    // res (sequential loop only, needs with_pred): rx / gx hold their D-independent parts on entry; the loop completes them with E'y,
+    // forms ry = E V + dk and leaves |rx_local|^2, |ry|^2, Sg . y in res_nrx2 / res_nry2 / res_sgy (see the loop)
+    SCVX_HD_NI bool build_kkt(bool with_pred = false, bool res = false) {
         SCVX_THIS_LDS();
         const int K = L.K;
         SCVX_COUNT(3);
@@ -2162,7 +2178,11 @@ struct Solver {
         double* Gn = Hd + 196;                   // 2 x NXU x 4   node slices of the right-hand sides: [slot][row: x (14) | u (NU)][column]
         double* Rk = Gn + 2 * NXU * 4;           // 14 x 4        r_k
         double* Tt = Rk + 56;                    // 2 x 14 x 4    t_{k-1}, t_k (alternating)
-        double* Sg = Tt + 112;                   // 42            segment scalars: gx_nu,k (14) | ry_k (14) | Pnu_k (14)
+        double* Sg = Tt + 112;                   // 84            segment scalars: gx_nu,k | ry_k | Pnu_k | res: nu_k | dk_k | rx_nu,k (14 each)
+        double* Sk = Sg + 84;                    // 14            Sg_k, the sigma column of D_k (kept across the tile swap)
+        double* Vn = Sk + 14;                    // 2 x NXU       res: node slices of V, slots k | k+1
+        double* Pn = Vn + 2 * NXU;               // 2 x NXU       res: node slices of the D-independent part of rx
+        double* Yv = Pn + 2 * NXU;               // 2 x 14        res: y_k | y_{k+1}
         // (the two-ended factorisation of the four-wavefront blocks keeps the separate border: its forward substitution runs from both ends)
         const bool kFusedBorder = !(Ex::kTwisted && twisted());
         bool ok = true;
@@ -2174,6 +2194,17 @@ struct Solver {
         } else {
         // All 14x14xK products below go through ex.tile_gemm: FP64 MFMA (v_mfma_f64_16x16x4) on the device — one A and
         // one B element per lane per instruction instead of 2 LDS reads per multiply-add — plain loops on the host.
+        //
+        // RESIDUALS IN THE LOOP (round 5, `res`).  An iteration used to read the linearisation D once for E V (equality residual), once
+        // (plus the A_k' copies) for E'y (dual residual) and once more here.  With `res` the loop, which stages every D_k tile in LDS
+        // anyway, forms both products itself:
+        //     ry_k = (E V + dk)_k                                   while D_k is staged,
+        //     (E'y) at node k+1 = [A | B-]_{k+1}' y_{k+1} + B+_k' y_k - y_k      right after D_{k+1} has been swapped in,
+        // completes  rx = (c - J'Z) + E'y  and  gx = q - E'y  node by node from the D-independent parts the cone passes left in rx / gx
+        // (rx = c - J'Z, gx = -(c - J'Z) - J' W^-1 (lam - W^-1 rz)), writes rx, gx, ry back and accumulates |rx|^2, |ry|^2 and Sg . y.
+        // Because g of node k+1 is only known after the swap, r_k is formed in two parts -- [TA | TBm]_k g_k early, TBp_k g_u,k+1 -
+        // Hxi_{k+1} g_x,k+1 late -- and the forward substitution t_k = L_k^-1 r_k + N_k t_{k-1} closes the step (its N_k t_{k-1} part
+        // waits in the accumulator registers while the swap overwrites the tile N_k sits in).
         // prologue: D_0, hx_0/hu_0 -> LDS; TA_0, TBm_0
         for (int e = ex.lane(); e < DSZ; e += ex.nlanes()) Dt[e] = D_[e];
         for (int e = ex.lane(); e < NODE_SZ; e += ex.nlanes()) Hh[NODE_SZ + e] = e < HX_SZ ? hx_[e] : hu_[e - HX_SZ];
@@ -2187,24 +2218,55 @@ struct Solver {
         }
         // node slices of the border right-hand sides: element e = NXU vec + row of node nd (vec 0: Ptr = v1 of the trust-region
         // cone, column 1; vec 1: the predictor's gx, column 3); segment scalars: element e of segment sgk
-        const cgptr Wtr_ = Wv + L.o_tr + 1; const cgptr Wnu_ = Wv + L.o_nu + 1; const cgptr gx_ = gx; const cgptr ry_ = ry;
+        const cgptr Wtr_ = Wv + L.o_tr + 1; const cgptr Wnu_ = Wv + L.o_nu + 1; const gptr gx_ = gx; const gptr ry_ = ry;
+        const gptr rx_ = rx; const cgptr V_ = V; const cgptr y_ = y; const cgptr dk_ = dk;
         const int nx_ = L.nx, nxu_ = L.nx + L.nu_;
         auto gnode_elem = [&](int nd, int e) -> double {
             const int vec = e >= NXU ? 1 : 0, row = e - NXU * vec;
             if (vec == 1 && !with_pred) return 0.0;
-            cgptr src = vec ? gx_ : Wtr_;
+            cgptr src = vec ? (cgptr)gx_ : Wtr_;
             return row < 14 ? src[14 * nd + row] : src[nx_ + NU * nd + (row - 14)];
         };
+        // res: element e = NXU vec + row of node nd (vec 0: V, vec 1: the D-independent part of rx)
+        auto vnode_elem = [&](int nd, int e) -> double {
+            const int vec = e >= NXU ? 1 : 0, row = e - NXU * vec;
+            cgptr src = vec ? (cgptr)rx_ : V_;
+            return row < 14 ? src[14 * nd + row] : src[nx_ + NU * nd + (row - 14)];
+        };
+        // segment scalars: [0,14) gx_nu,k | [14,28) ry_k (read only without res) | [28,42) Pnu_k | res: [42,56) nu_k | [56,70) dk_k | [70,84) rx_nu,k
         auto gseg_elem = [&](int sgk, int e) -> double {
+            if (e >= 70) return rx_[nxu_ + 14 * sgk + (e - 70)];
+            if (e >= 56) return dk_[14 * sgk + (e - 56)];
+            if (e >= 42) return V_[nxu_ + 14 * sgk + (e - 42)];
             if (e >= 28) return Wnu_[14 * sgk + (e - 28)];
             if (!with_pred) return 0.0;
-            return e < 14 ? gx_[nxu_ + 14 * sgk + e] : ry_[14 * sgk + (e - 14)];
+            return e < 14 ? gx_[nxu_ + 14 * sgk + e] : (res ? 0.0 : (double)ry_[14 * sgk + (e - 14)]);
         };
+        const int NSG = res ? 84 : 42;
         for (int e = ex.lane(); e < 2 * NXU * 4 + 56 + 112; e += ex.nlanes()) Gn[e] = 0.0;   // Gn, Rk, Tt (columns 0 and 2 of Gn stay zero)
         ex.sync_lds();
         for (int e = ex.lane(); e < 2 * NXU; e += ex.nlanes()) {
             const int vec = e >= NXU ? 1 : 0, row = e - NXU * vec;
             Gn[NXU * 4 + 4 * row + (vec ? 3 : 1)] = gnode_elem(0, e);
+            if (res) (vec ? Pn : Vn)[NXU + row] = vnode_elem(0, e);
+        }
+        double nrx2 = 0.0, nry2 = 0.0, sgacc = 0.0;   // lane-local partial sums of |rx|^2, |ry|^2, Sg . y
+        const double s_var = res ? (double)V_[L.iS] : 0.0;
+        if (res) {
+            for (int e = ex.lane(); e < 14; e += ex.nlanes()) Yv[14 + e] = y_[e];
+            ex.sync_lds();
+            // node 0: (E'y)_x,0 = A_0' y_0, (E'y)_u,0 = B-_0' y_0; fixed rows (rocketland.jl:109-113) are zero in rx and gx
+            for (int row = ex.lane(); row < NXU; row += ex.nlanes()) {
+                double ev = 0.0;
+                for (int i = 0; i < 14; i++) ev += Dt[14 * row + i] * Yv[14 + i];
+                const bool fx = row < 14 && fixed_x(0, row);
+                const double rxv = fx ? 0.0 : Pn[NXU + row] + ev;
+                const double gxv = fx ? 0.0 : Gn[NXU * 4 + 4 * row + 3] - ev;
+                Gn[NXU * 4 + 4 * row + 3] = gxv;
+                const int at = row < 14 ? row : nx_ + (row - 14);
+                rx_[at] = rxv; gx_[at] = gxv;
+                nrx2 += rxv * rxv;
+            }
         }
         ex.sync_lds();
         // the compact node inverses (42 doubles) are requested one segment ahead as well: lane e holds element e of node
@@ -2212,20 +2274,30 @@ struct Solver {
         auto node_elem = [&](int node, int e) -> double {
             return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[HU_SZ * node + (e - HX_SZ)];
         };
-        double hn = 0.0, gn = 0.0, sgn = 0.0;
+        double hn = 0.0, gn = 0.0, sgn = 0.0, sgnb = 0.0, vpn = 0.0, yn = 0.0;
         if (Ex::kPrefetchRegs > 0 && ex.lane() < NODE_SZ) hn = node_elem(1, ex.lane());
         if (Ex::kPrefetchRegs > 0 && ex.lane() < 2 * NXU) gn = gnode_elem(1, ex.lane());
         if (Ex::kPrefetchRegs > 0 && ex.lane() < 42) sgn = gseg_elem(0, ex.lane());
+        if (Ex::kPrefetchRegs > 0 && res) {
+            if (ex.lane() < 42) sgnb = gseg_elem(0, 42 + ex.lane());
+            if (ex.lane() < 2 * NXU) vpn = vnode_elem(1, ex.lane());
+            if (ex.lane() < 14) yn = y_[(K > 1 ? 14 : 0) + ex.lane()];
+        }
         const gptr xq_[4] = {ys, ytr, ynu, dy};
         const gptr rtr_ = rtr;
         for (int k = 0; k < K; k++) {
             SCVX_TS(ta_);
             // prefetch the next segment's tile
             constexpr int NPRE = Ex::kPrefetchRegs > 0 ? (DSZ + Ex::kLanes - 1) / Ex::kLanes : 0;
-            double hn2 = 0.0, gn2 = 0.0, sgn2 = 0.0;
+            double hn2 = 0.0, gn2 = 0.0, sgn2 = 0.0, sgnb2 = 0.0, vpn2 = 0.0, yn2 = 0.0;
             if (NPRE > 0 && ex.lane() < NODE_SZ) hn2 = node_elem(k + 2 <= K ? k + 2 : K, ex.lane());
             if (NPRE > 0 && ex.lane() < 2 * NXU) gn2 = gnode_elem(k + 2 <= K ? k + 2 : K, ex.lane());
             if (NPRE > 0 && ex.lane() < 42) sgn2 = gseg_elem(k + 1 < K ? k + 1 : k, ex.lane());
+            if (NPRE > 0 && res) {
+                if (ex.lane() < 42) sgnb2 = gseg_elem(k + 1 < K ? k + 1 : k, 42 + ex.lane());
+                if (ex.lane() < 2 * NXU) vpn2 = vnode_elem(k + 2 <= K ? k + 2 : K, ex.lane());
+                if (ex.lane() < 14) yn2 = y_[14 * (k + 2 < K ? k + 2 : K - 1) + ex.lane()];
+            }
             double pre[NPRE > 0 ? NPRE : 1];
             dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * DSZ;
             if (NPRE > 0) {
@@ -2245,10 +2317,27 @@ struct Solver {
                 const double v1 = NPRE > 0 ? gn : gnode_elem(k + 1, e);
                 Gn[at] = Gn[NXU * 4 + at];
                 Gn[NXU * 4 + at] = v1;
+                if (res) {
+                    double* dst = vec ? Pn : Vn;
+                    const double w1 = NPRE > 0 ? vpn : vnode_elem(k + 1, e);
+                    dst[row] = dst[NXU + row];
+                    dst[NXU + row] = w1;
+                }
             }
-            for (int e = ex.lane(); e < 42; e += ex.nlanes()) Sg[e] = NPRE > 0 ? sgn : gseg_elem(k, e);
-            gn = gn2; sgn = sgn2;
+            for (int e = ex.lane(); e < 42; e += ex.nlanes()) {
+                Sg[e] = NPRE > 0 ? sgn : gseg_elem(k, e);
+                if (res) Sg[42 + e] = NPRE > 0 ? sgnb : gseg_elem(k, 42 + e);
+            }
+            if (res)
+                for (int e = ex.lane(); e < 14; e += ex.nlanes()) {
+                    Yv[e] = Yv[14 + e];
+                    Yv[14 + e] = NPRE > 0 ? yn : (double)y_[14 * (k + 1 < K ? k + 1 : K - 1) + e];
+                }
+            for (int e = ex.lane(); e < 14; e += ex.nlanes()) Sk[e] = Dt[14 * CS + e];   // Sg_k: the tile is swapped before r_k is closed
+            gn = gn2; sgn = sgn2; sgnb = sgnb2; vpn = vpn2; yn = yn2;
             ex.sync_lds();
+            SCVX_TE(ta_, 2);
+            SCVX_TS(ta2_);
             for (int e = ex.lane(); e < 196 + BPN; e += ex.nlanes()) {
                 if (e < 196) {
                     const int i = e / 14, j = e - 14 * i;
@@ -2260,19 +2349,38 @@ struct Solver {
                     T[TS * i + 14 + NU + c] = bhu(Dt, 14 + NU, i, c, Hh + NODE_SZ + HX_SZ);
                 }
             }
+            if (res) {
+                // the nu rows of segment k ((E'y)_nu,k = y_k), the equality residual ry_k, and Sg_k . y_k
+                for (int i = ex.lane(); i < 14; i += ex.nlanes()) {
+                    const double yk = Yv[i];
+                    const double rxv = Sg[70 + i] + yk, gxv = Sg[i] - yk;
+                    Sg[i] = gxv;
+                    rx_[nxu_ + 14 * k + i] = rxv; gx_[nxu_ + 14 * k + i] = gxv;
+                    nrx2 += rxv * rxv;
+                    double a = 0.0;
+                    for (int j = 0; j < 14; j++) a += Dt[14 * j + i] * Vn[j];
+                    for (int j = 0; j < NU; j++) a += Dt[14 * (14 + j) + i] * Vn[14 + j];
+                    for (int j = 0; j < NU; j++) a += Dt[14 * (14 + NU + j) + i] * Vn[NXU + 14 + j];
+                    a += Dt[14 * CS + i] * s_var;
+                    a += Sg[42 + i] - Vn[NXU + i];
+                    a += Sg[56 + i];
+                    Sg[14 + i] = a;
+                    ry_[14 * k + i] = a;
+                    nry2 += a * a;
+                    sgacc += Dt[14 * CS + i] * yk;
+                }
+            }
             ex.sync_lds();
-            SCVX_TE(ta_, 2);
+            SCVX_TE(ta2_, 24);
             SCVX_TS(tb_);
             // pivot tile: M += [TA|TBm|TBp] [A|Bm|Bp]'  -  Wb_{k-1} Wb_{k-1}'
             {   // two independent accumulators, no LDS round trip between the terms of either sum
                 typename Ex::Acc cm, cr;
                 ex.acc_zero(cm); ex.acc_zero(cr);
                 ex.acc_mac(cm, T, TS, 1, Dt, 14, 1, TW, 1.0);
-                // r_k (columns 1 and 3): [TA | TBm]_k [g_x,k; g_u,k] + TBp_k g_u,k+1 - Hxi_{k+1} g_x,k+1
+                // r_k, early part (columns 1 and 3): [TA | TBm]_k [g_x,k; g_u,k]
                 ex.acc_mac(cr, T, TS, 1, Gn, 4, 1, 14 + NU, 1.0, 4);
                 if (k > 0) ex.acc_mac(cm, Wp, 14, 1, Wp, 1, 14, 14, -1.0);
-                ex.acc_mac(cr, T + 14 + NU, TS, 1, Gn + NXU * 4 + 14 * 4, 4, 1, NU, 1.0, 4);
-                ex.acc_mac(cr, Hd, 14, 1, Gn + NXU * 4, 4, 1, 14, -1.0, 4);
                 ex.acc_store(cm, M, 14, 1, true);
                 ex.acc_store(cr, Rk, 4, 1, false, 4);
             }
@@ -2288,32 +2396,19 @@ struct Solver {
                 const int i = q <= p ? p : 13 - p, j = q <= p ? q : q - (p + 1);
                 Linv_[(size_t)k * LINV_SZ + e] = Li[14 * i + j];
             }
-            // the plain parts of r_k: column 0 = Sg_k (the sigma column of D_k), column 2 = hnui Pnu_k, column 3 += hnui gx_nu,k + ry_k
-            for (int i = ex.lane(); i < 14; i += ex.nlanes()) {
-                Rk[4 * i] = Dt[14 * CS + i];
-                Rk[4 * i + 2] = hnui_ * Sg[28 + i];
-                Rk[4 * i + 3] += hnui_ * Sg[i] + Sg[14 + i];
-                rtr_[14 * k + i] = Rk[4 * i + 1];   // rtr = E Hb^-1 Ptr itself is kept: the border coefficients and every solve use it
-            }
+            SCVX_TE(td_, 13);
+            SCVX_TS(td2_);
+            typename Ex::Acc ct;   // t_k = L_k^-1 r_k + N_k t_{k-1}: the second term now, the first when r_k is complete
+            ex.acc_zero(ct);
+            double* Tc = Tt + 56 * (k & 1); const double* Tp = Tt + 56 * ((k + 1) & 1);
             if (k > 0) {  // Nf[k] = -Linv_k Wb_{k-1}, stored transposed (the layout the executor's chain consumes)
                 ex.tile_gemm(M, 1, 14, Li, 14, 1, Wp, 14, 1, 14, -1.0, false);
                 ex.sync_lds();
                 for (int e = ex.lane(); e < 196; e += ex.nlanes()) Nf_[(size_t)k * 196 + e] = M[e];
-            } else ex.sync_lds();
-            {   // forward substitution of the four right-hand sides: t_k = L_k^-1 r_k + N_k t_{k-1}
-                double* Tc = Tt + 56 * (k & 1); const double* Tp = Tt + 56 * ((k + 1) & 1);
-                typename Ex::Acc ct;
-                ex.acc_zero(ct);
-                ex.acc_mac(ct, Li, 14, 1, Rk, 4, 1, 14, 1.0, 4);
-                if (k > 0) ex.acc_mac(ct, M, 1, 14, Tp, 4, 1, 14, 1.0, 4);
-                ex.acc_store(ct, Tc, 4, 1, false, 4);
-                ex.sync_lds();
-                for (int e = ex.lane(); e < 56; e += ex.nlanes()) {
-                    const int q = e / 14, i = e - 14 * q;
-                    if (q < 3 || with_pred) xq_[q][14 * k + i] = Tc[4 * i + q];
-                }
+                ex.acc_mac(ct, M, 1, 14, Tp, 4, 1, 14, 1.0, 4);
+                ex.sync_lds();   // M is overwritten below
             }
-            SCVX_TE(td_, 13);
+            SCVX_TE(td2_, 25);
             SCVX_TS(te_);
             if (k + 1 < K) {
                 // keep Bp_k, swap in D_{k+1}
@@ -2326,6 +2421,8 @@ struct Solver {
                     for (int e = ex.lane(); e < DSZ; e += ex.nlanes()) Dt[e] = Dn[e];
                 }
                 ex.sync_lds();
+                SCVX_TE(te_, 26);
+                SCVX_TS(te2_);
                 // TA_{k+1} = A_{k+1} Hxi_{k+1}, TBm_{k+1}
                 ex.tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
                 for (int q = ex.lane(); q < BPN; q += ex.nlanes()) {
@@ -2333,17 +2430,72 @@ struct Solver {
                     T[TS * i + 14 + c] = bhu(Dt, 14, i, c, Hh + NODE_SZ + HX_SZ);
                 }
                 ex.sync_lds();
+                SCVX_TE(te2_, 27);
+                SCVX_TS(te3_);
                 // So[k] = -TA_{k+1} + TBm_{k+1} Bp_k'
                 for (int e = ex.lane(); e < 196; e += ex.nlanes()) {
                     const int i = e / 14, j = e - 14 * i;
                     M[e] = so_elem(T, Bp, i, j);
                 }
                 ex.sync_lds();
+                SCVX_TE(te3_, 28);
+                SCVX_TS(te4_);
                 ex.tile_gemm(Wp, 14, 1, M, 14, 1, Li, 1, 14, 14, 1.0, false);      // Wb_k = So Linv'
+                SCVX_TE(te4_, 29);
+            }
+            SCVX_TS(te5_);
+            if (res) {
+                // node k + 1: (E'y)_x = A_{k+1}' y_{k+1} - y_k, (E'y)_u = B-_{k+1}' y_{k+1} + B+_k' y_k (at the last node only the y_k terms,
+                // B+_{K-1} still staged in the tile); rx = (c - J'Z) + E'y, gx = q - E'y, fixed rows zero (rocketland.jl:109-115)
+                const bool lastn = k + 1 == K;
+                for (int row = ex.lane(); row < NXU; row += ex.nlanes()) {
+                    double ev = 0.0;
+                    if (!lastn) {
+                        for (int i = 0; i < 14; i++) ev += Dt[14 * row + i] * Yv[14 + i];
+                        if (row < 14) ev -= Yv[row];
+                        else for (int i = 0; i < 14; i++) ev += Bp[14 * (row - 14) + i] * Yv[i];
+                    } else {
+                        if (row < 14) ev = -Yv[row];
+                        else for (int i = 0; i < 14; i++) ev += Dt[14 * (NU + row) + i] * Yv[i];   // column 14 + NU + (row - 14)
+                    }
+                    const bool fx = lastn && (row < 14 ? fixed_x(K, row) : fixed_u(K, row - 14));
+                    const double rxv = fx ? 0.0 : Pn[NXU + row] + ev;
+                    const double gxv = fx ? 0.0 : Gn[NXU * 4 + 4 * row + 3] - ev;
+                    Gn[NXU * 4 + 4 * row + 3] = gxv;
+                    const int at = row < 14 ? 14 * (k + 1) + row : nx_ + NU * (k + 1) + (row - 14);
+                    rx_[at] = rxv; gx_[at] = gxv;
+                    nrx2 += rxv * rxv;
+                }
             }
             ex.sync_lds();
-            SCVX_TE(te_, 14);
+            {   // r_k, late part: TBp_k g_u,k+1 - Hxi_{k+1} g_x,k+1; then the plain parts and the forward substitution
+                typename Ex::Acc cr;
+                ex.acc_zero(cr);
+                ex.acc_mac(cr, T + 14 + NU, TS, 1, Gn + NXU * 4 + 14 * 4, 4, 1, NU, 1.0, 4);
+                ex.acc_mac(cr, Hd, 14, 1, Gn + NXU * 4, 4, 1, 14, -1.0, 4);
+                ex.acc_store(cr, Rk, 4, 1, true, 4);
+            }
+            ex.sync_lds();
+            // the plain parts of r_k: column 0 = Sg_k (the sigma column of D_k), column 2 = hnui Pnu_k, column 3 += hnui gx_nu,k + ry_k
+            for (int i = ex.lane(); i < 14; i += ex.nlanes()) {
+                Rk[4 * i] = Sk[i];
+                Rk[4 * i + 2] = hnui_ * Sg[28 + i];
+                Rk[4 * i + 3] += hnui_ * Sg[i] + Sg[14 + i];
+                rtr_[14 * k + i] = Rk[4 * i + 1];   // rtr = E Hb^-1 Ptr itself is kept: the border coefficients and every solve use it
+            }
+            ex.sync_lds();
+            SCVX_TE(te5_, 30);
+            SCVX_TS(te6_);
+            ex.acc_mac(ct, Li, 14, 1, Rk, 4, 1, 14, 1.0, 4);
+            ex.acc_store(ct, Tc, 4, 1, false, 4);
+            ex.sync_lds();
+            for (int e = ex.lane(); e < 56; e += ex.nlanes()) {
+                const int q = e / 14, i = e - 14 * q;
+                if (q < 3 || with_pred) xq_[q][14 * k + i] = Tc[4 * i + q];
+            }
+            SCVX_TE(te6_, 31);
         }
+        if (res) { res_nrx2 = ex.sum(nrx2); res_nry2 = ex.sum(nry2); res_sgy = ex.sum(sgacc); }
         }   // sequential factorisation
         ex.sync();   // the factors written above are read back (by other lanes) in the border solves
         SCVX_TE(tC_, 6);
@@ -2882,20 +3034,45 @@ struct Solver {
             scale_pass(gap, nrz2);
             // dual and equality residuals
             SCVX_TS(tR_);
-            cone_map_t(Z, rx);
-            const double sgy = Et_apply(y, rx, rx, 2);     // rx = E'y - J'Z on the local part
-            if (ex.lane() == 0) {
-                rx[14 * K] += -1.0;
-                rx[L.iS] = -rx[L.iS] + sgy;
-                rx[L.iTNU] = C.wNu - rx[L.iTNU];
-                rx[L.iTTR] = 0.5 - rx[L.iTTR];
-                rx[L.iTS] = 1.0 - rx[L.iTS];
+            // fused (round 5): the two products with the linearisation, E'y and E V, are formed by the factorisation loop, which stages
+            // every D_k tile anyway (build_kkt(res)); the stopping tests then follow the factorisation, and the last iteration of a solve
+            // factorises once for nothing (1 of ~18).  The first look at a restart from a kept optimum (usually its only one) takes the
+            // separate passes: it needs no factorisation at all.
+            const bool fused = SCVX_FUSED_RES != 0 && Ex::kFusedResidual && !(warmed && it == 1);
+            double nrx, nry;
+            bool kkt_ok = true;
+            if (!fused) {
+                cone_map_t(Z, rx);
+                const double sgy = Et_apply(y, rx, rx, 2);     // rx = E'y - J'Z on the local part
+                if (ex.lane() == 0) {
+                    rx[14 * K] += -1.0;
+                    rx[L.iS] = -rx[L.iS] + sgy;
+                    rx[L.iTNU] = C.wNu - rx[L.iTNU];
+                    rx[L.iTTR] = 0.5 - rx[L.iTTR];
+                    rx[L.iTS] = 1.0 - rx[L.iTS];
+                }
+                ex.sync();
+                mask_fixed(rx);
+                const double nry2 = E_apply(V, ry, true, dk, 1.0);   // ry = E V + dk
+                nrx = sqrt(sumsq(rx, L.nv)); nry = sqrt(nry2);
+            } else {
+                cone_map_t(Z, rx, nullptr, false, true);             // rx = -J'Z ...
+                if (ex.lane() == 0) {                                // ... + c (the s row still lacks Sg . y)
+                    rx[14 * K] += -1.0;
+                    rx[L.iTNU] = C.wNu + rx[L.iTNU];
+                    rx[L.iTTR] = 0.5 + rx[L.iTTR];
+                    rx[L.iTS] = 1.0 + rx[L.iTS];
+                }
+                ex.sync();
+                cone_map_t(tmpc, gx, rx);                            // gx = -(c - J'Z) - J' W^-1 (lam - W^-1 rz)
+                kkt_ok = build_kkt(true, true);                      // + / - E'y, ry, the norms; and the factorisation
+                if (ex.lane() == 0) { rx[L.iS] += res_sgy; gx[L.iS] -= res_sgy; }
+                ex.sync();
+                const double g0 = rx[L.iS], g1 = rx[L.iTNU], g2 = rx[L.iTTR], g3 = rx[L.iTS];
+                nrx = sqrt(res_nrx2 + (g0 * g0 + g1 * g1 + g2 * g2 + g3 * g3)); nry = sqrt(res_nry2);
             }
-            ex.sync();
-            mask_fixed(rx);
-            const double nry2 = E_apply(V, ry, true, dk, 1.0);   // ry = E V + dk
             const double pobj = -V[14 * K] + C.wNu * V[L.iTNU] + 0.5 * V[L.iTTR] + V[L.iTS];
-            const double nrx = sqrt(sumsq(rx, L.nv)), nry = sqrt(nry2), nrz = sqrt(nrz2);
+            const double nrz = sqrt(nrz2);
             const double pres = nry > nrz ? nry : nrz;
             const double dres = nrx / (C.wNu > 1.0 ? C.wNu : 1.0);
             const double relgap = gap / (fabs(pobj) > 1.0 ? fabs(pobj) : 1.0);
@@ -2922,9 +3099,12 @@ struct Solver {
             if (best_merit < C.accept && merit > SCVX_BLOWUP_STOP * best_merit) { res.status = stop_status(2); break; }
             if (it - best_it >= SCVX_STALL_ITERS && best_merit < 1e-5) { res.status = stop_status(2); break; }
             if (it == C.max_iter) { res.status = stop_status(1); break; }
-            cone_map_t(tmpc, gx, rx);      // predictor right-hand side gx = -rx - J' W^-1 (lam - W^-1 rz), solved with the border
-            mask_fixed(gx);
-            if (!build_kkt(true)) { SCVX_DBG("    factorisation failed\n"); res.status = stop_status(2); break; }
+            if (!fused) {
+                cone_map_t(tmpc, gx, rx);      // predictor right-hand side gx = -rx - J' W^-1 (lam - W^-1 rz), solved with the border
+                mask_fixed(gx);
+                kkt_ok = build_kkt(true);
+            }
+            if (!kkt_ok) { SCVX_DBG("    factorisation failed\n"); res.status = stop_status(2); break; }
             const double mu = gap / degree;
             { SCVX_TS(tN_); newton_solve(true); SCVX_TE(tN_, 10); }   // predictor: affine right-hand side -lam o lam
             double alpha = dir_pass<true>();

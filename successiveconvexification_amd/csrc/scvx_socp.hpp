@@ -20,10 +20,10 @@ namespace scvx {
 // only).  A pointer carried in the executor object is reloaded from memory in each non-inlined routine, loses its
 // address space, and every LDS access becomes a flat_load/flat_store that also waits on the global loads and
 // stores in flight (vmcnt) — which serialises the tile arithmetic behind the HBM traffic it is meant to overlap.
-__shared__ __attribute__((aligned(16))) double g_socp_lds[1904];   // + the fused border's tiles (Solver::build_kkt: Gn, Rk, Tt, Sg)
+__shared__ __attribute__((aligned(16))) double g_socp_lds[2112];   // + the fused border's tiles (Solver::build_kkt: Gn, Rk, Tt, Sg)
 // ... and of the fin instantiation (control_dim = 5: 14 x 25 tiles, 24-column [TA | TBm | TBp]); separate symbols so that the
 // kernels of the reference's model keep their LDS footprint
-__shared__ __attribute__((aligned(16))) double g_socp_lds5[2064];
+__shared__ __attribute__((aligned(16))) double g_socp_lds5[2272];
 #define SCVX_PIPE_LDS5 (2 * 392 + 588 + 392 + 196 + 350 + 364 + 70 + 2 * 46 + 3 * 196 + 8 + 96)
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds5[SCVX_PIPE_LDS5];
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds25[SCVX_PIPE_LDS5];
@@ -85,6 +85,7 @@ struct WaveExT {
     static constexpr int kPrefetchRegs = 1;  // > 0: the next D tile is held in registers (ceil(tile / 64) per lane) while segment k is processed
     static constexpr bool kTwisted = false;
     static constexpr bool kPipelineFactor = false;
+    static constexpr bool kFusedResidual = true;   // Solver::build_kkt(res): E'y and E V inside the sequential factorisation loop
 
     // C(14x14) = (acc ? C : 0) + alpha * A(14 x Kd) B(Kd x 14) on the FP64 matrix pipe: ceil(Kd/4) x
     // v_mfma_f64_16x16x4_f64, tiles in LDS with arbitrary element strides (so transposes are free).
@@ -92,18 +93,39 @@ struct WaveExT {
     // C/D: register r of lane l is C[(l>>4) + 4r][l&15].  Rows/columns 14,15 and k >= Kd are fed zeros.
     typedef double v4f64 __attribute__((ext_vector_type(4)));
     // nb: number of columns of B / C that exist (right-hand-side blocks of the fused border: 4); the others are fed zeros and not stored
+    // Operand fetch of a product with Kd <= 4 KS k-slots: EVERY lane reads from a valid (clamped) LDS address and the value is masked
+    // afterwards -- a predicated read compiles to a branch around each ds_read, which puts every read in a basic block of its own and
+    // makes the wavefront wait out the LDS latency once per MFMA (round 5: ~850 -> ~350 cycles per 14x14x14 product; the factorisation
+    // loop runs nine such products per segment).  All reads of a product are issued before its first MFMA.
+    static constexpr int KS = 6;   // k-slots of 4: Kd <= 24 (the widest operand is [TA | TBm | TBp], 24 columns with the fin extension)
+    __device__ __forceinline__ void fetch_ab(const double* A, int sai, int sak, const double* B, int sbk, int sbj, int Kd, int nb,
+                                             double (&a)[KS], double (&b)[KS]) {
+        const int l = lane();
+        const int rc = l & 15, kq = l >> 4;
+        const int ra = rc < 14 ? rc : 0, rb = rc < nb ? rc : 0;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            if (4 * s < Kd) {
+                const int k = 4 * s + kq, kc = k < Kd ? k : 0;
+                a[s] = A[ra * sai + kc * sak];
+                b[s] = B[kc * sbk + rb * sbj];
+            }
+        }
+    }
     __device__ __forceinline__ void tile_gemm(double* Cm, int sci, int scj, const double* A, int sai, int sak,
                                               const double* B, int sbk, int sbj, int Kd, double alpha, bool acc, int nb = 14) {
         const int l = lane();
         const int rc = l & 15, kq = l >> 4;
         v4f64 c = {0.0, 0.0, 0.0, 0.0};
         const bool in = rc < 14, inb = rc < nb;
-        for (int k0 = 0; k0 < Kd; k0 += 4) {
-            const int k = k0 + kq;
-            const bool kin = in && (k < Kd);
-            const double a = kin ? A[rc * sai + k * sak] : 0.0;
-            const double b = (inb && k < Kd) ? B[k * sbk + rc * sbj] : 0.0;
-            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+        double a[KS], b[KS];
+        fetch_ab(A, sai, sak, B, sbk, sbj, Kd, nb, a, b);
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            if (4 * s < Kd) {
+                const bool kin = 4 * s + kq < Kd;
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64((in && kin) ? a[s] : 0.0, (inb && kin) ? b[s] : 0.0, c, 0, 0, 0);
+            }
         }
         if (inb) {
 #pragma unroll
@@ -126,11 +148,14 @@ struct WaveExT {
         const int l = lane();
         const int rc = l & 15, kq = l >> 4;
         const bool in = rc < 14, inb = rc < nb;
-        for (int k0 = 0; k0 < Kd; k0 += 4) {
-            const int k = k0 + kq;
-            const double a = (in && k < Kd) ? alpha * A[rc * sai + k * sak] : 0.0;
-            const double b = (inb && k < Kd) ? B[k * sbk + rc * sbj] : 0.0;
-            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+        double a[KS], b[KS];
+        fetch_ab(A, sai, sak, B, sbk, sbj, Kd, nb, a, b);
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            if (4 * s < Kd) {
+                const bool kin = 4 * s + kq < Kd;
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64((in && kin) ? alpha * a[s] : 0.0, (inb && kin) ? b[s] : 0.0, c, 0, 0, 0);
+            }
         }
     }
     __device__ __forceinline__ void acc_store(const Acc& c, double* Cm, int sci, int scj, bool add, int nb = 14) {
@@ -319,6 +344,7 @@ struct BlockEx {
     WaveExT<NU_> w0;
     static constexpr int kLanes = 64 * NW;
     static constexpr int kPrefetchRegs = 1;
+    static constexpr bool kFusedResidual = false;  // the multi-wavefront factorisation pipelines keep the separate residual passes
     // the factorisation loop as a producer / consumer pair of wavefronts (Solver::factor_pipelined)
     static constexpr bool kPipelineFactor = SCVX_K4_PIPELINE != 0;
     // two-ended (twisted) factorisation and solve: the chain is eliminated from both ends towards the middle block by two
@@ -426,6 +452,15 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& Cin, int B, size_t 
         if (threadIdx.x == 0) { info[4 * b + 1] = 0.0; atomicAdd(acc + ACC_SKIPPED, 1.0); }
         return;
     }
+#if defined(SCVX_K4_STAGGER_US)
+    // experiment (profiles/r05_k4_stagger.md): the 2,048 wavefronts of a launch's first round start together and run the same phases at the
+    // same time; a start delay spread over one interior-point iteration de-correlates them
+    if (blockIdx.x < 2048) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)(((blockIdx.x * 2654435761u) >> 16) % 16u) * (unsigned long long)(SCVX_K4_STAGGER_US * 100 / 16);
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     const int K = Cin.K;
     // The solver object (some 60 pointers into the slab, the layout, the scalars of the current factorisation), the executor and
     // the constants live in LDS, one copy per wavefront.  As an automatic object it sat in private memory -- 1.4 KB per LANE,
