@@ -61,6 +61,10 @@ struct HostEx {
                 *c = (add ? *c : 0.0) + a.c[i][j];
             }
     }
+    void acc_store_init(const Acc& a, double* Cm, const double* H, double diag) {
+        for (int i = 0; i < 14; i++)
+            for (int j = 0; j < 14; j++) Cm[14 * i + j] = (H[14 * i + j] + (i == j ? diag : 0.0)) + a.c[i][j];
+    }
     // L^-1 (row-major, lower) of the Cholesky factor of the SPD tile M
     bool chol_inv14(double* M, double* Li) {
         const bool ok = chol14(M);

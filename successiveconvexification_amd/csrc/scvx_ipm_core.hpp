@@ -462,6 +462,19 @@ SCVX_HD void hxi_apply(PH h, const double* x, double* y) {
     y[10] = h[HX_Q34 + 2] * x[9] + h[HX_Q34 + 3] * x[10];
     for (int i = 0; i < 3; i++) y[11 + i] = h[HX_W + 3 * i] * x[11] + h[HX_W + 3 * i + 1] * x[12] + h[HX_W + 3 * i + 2] * x[13];
 }
+// Dense position (14 i + j) of entry l of the compact node inverse in the 14x14 tile Hxi; l = HX_SZ is the second copy of the
+// (q0, q1) diagonal value HX_Q at (8, 8).  The other 162 entries of the tile are structural zeros: the factorisation loops zero the
+// tile once and scatter these 34 per segment (round 5; hxi_entry per element -- six data-dependent branches for each of 196
+// elements -- was 2.9 k of the loop's 24 k cycles per segment).
+SCVX_HD int hx_dense_pos(int l) {
+    if (l >= HX_SZ) return 8 * 15;
+    if (l >= HX_W) { const int q = l - HX_W; return 14 * (11 + q / 3) + 11 + q % 3; }
+    if (l >= HX_Q34) { const int q = l - HX_Q34; return 14 * (9 + q / 2) + 9 + q % 2; }
+    if (l == HX_Q) return 7 * 15;
+    if (l >= HX_V) { const int q = l - HX_V; return 14 * (4 + q / 3) + 4 + q % 3; }
+    if (l >= HX_R) { const int q = l - HX_R; return 14 * (1 + q / 3) + 1 + q % 3; }
+    return 0;
+}
 // ------------------------------------------------------------------------------------------------
 // the solver
 // ------------------------------------------------------------------------------------------------
@@ -1585,6 +1598,7 @@ struct Solver {
             }
             ex.w_sync_lds();
         }
+        const int hpos_lane = hx_dense_pos(l <= HX_SZ ? l : 0);
         double hnext = (w == 1 && l < NODE_SZ) ? node_elem(1, l) : 0.0;   // the assembly wavefront keeps the next node's inverses one step ahead
         double gnext = (w == 1 && l < 2 * NXU) ? gnode_elem(1, l) : 0.0;  // ... and the right-hand sides' slices and segment scalars
         double sgnext = (w == 1 && l < 42) ? gseg_elem(0, l) : 0.0;
@@ -1614,16 +1628,10 @@ struct Solver {
                 gnext = l < 2 * NXU ? gnode_elem(k + 2 <= K ? k + 2 : K, l) : 0.0;
                 sgnext = l < 42 ? gseg_elem(k + 1 < K ? k + 1 : k, l) : 0.0;
                 ex.w_sync_lds();
-                for (int e = l; e < 196 + BPN; e += 64) {
-                    if (e < 196) {
-                        const int i = e / 14, j = e - 14 * i;
-                        const double h = hxi_entry(Hh + NODE_SZ, i, j);
-                        Hd[e] = h;
-                        Sdk[e] = h + (i == j ? hnui_ : 0.0);
-                    } else {
-                        const int q = e - 196, i = q / NU, c = q - NU * i;
-                        T[TS * i + 14 + NU + c] = bhu(Dt, 14 + NU, i, c, Hh + NODE_SZ + HX_SZ);
-                    }
+                if (l <= HX_SZ) Hd[hpos_lane] = Hh[NODE_SZ + (l < HX_SZ ? l : HX_Q)];   // the 34 non-zeros of the dense Hxi_{k+1}
+                for (int q = l; q < BPN; q += 64) {
+                    const int i = q / NU, c = q - NU * i;
+                    T[TS * i + 14 + NU + c] = bhu(Dt, 14 + NU, i, c, Hh + NODE_SZ + HX_SZ);
                 }
                 ex.w_sync_lds();
                 SCVX_TE(tp0_, 24);
@@ -1637,7 +1645,7 @@ struct Solver {
                     ex.w_acc_mac(cr, T, TS, 1, Gn, 4, 1, 14 + NU, 1.0, 4);
                     ex.w_acc_mac(cr, T + 14 + NU, TS, 1, Gn + NXU * 4 + 14 * 4, 4, 1, NU, 1.0, 4);
                     ex.w_acc_mac(cr, Hd, 14, 1, Gn + NXU * 4, 4, 1, 14, -1.0, 4);
-                    ex.w_acc_store(cm, Sdk, 14, 1, true);
+                    ex.w_acc_store_init(cm, Sdk, Hd, hnui_);   // Sd_k = Hxi_{k+1} + hnui I + the products
                     ex.w_acc_store(cr, Rk, 4, 1, false, 4);
                     ex.w_sync_lds();
                     // the plain parts: column 0 = Sg_k, column 2 = hnui Pnu_k, column 3 += hnui gx_nu,k + ry_k; rtr_k is kept as well
@@ -2285,6 +2293,7 @@ struct Solver {
         }
         const gptr xq_[4] = {ys, ytr, ynu, dy};
         const gptr rtr_ = rtr;
+        const int hpos_lane = hx_dense_pos(ex.lane() <= HX_SZ ? ex.lane() : 0);
         for (int k = 0; k < K; k++) {
             SCVX_TS(ta_);
             // prefetch the next segment's tile
@@ -2338,16 +2347,12 @@ struct Solver {
             ex.sync_lds();
             SCVX_TE(ta_, 2);
             SCVX_TS(ta2_);
-            for (int e = ex.lane(); e < 196 + BPN; e += ex.nlanes()) {
-                if (e < 196) {
-                    const int i = e / 14, j = e - 14 * i;
-                    const double h = hxi_entry(Hh + NODE_SZ, i, j);
-                    Hd[e] = h;
-                    M[e] = h + (i == j ? hnui_ : 0.0);   // pivot tile starts from Hxi_{k+1} + hnui I
-                } else {  // TBp_k = Bp_k Hui_{k+1}
-                    const int q = e - 196, i = q / NU, c = q - NU * i;
-                    T[TS * i + 14 + NU + c] = bhu(Dt, 14 + NU, i, c, Hh + NODE_SZ + HX_SZ);
-                }
+            // dense Hxi_{k+1}: its 34 structural non-zeros (the rest of the tile stays zero); the pivot tile starts from it (acc_store_init)
+            for (int e = ex.lane(); e <= HX_SZ; e += ex.nlanes())
+                Hd[Ex::kLanes >= 64 ? hpos_lane : hx_dense_pos(e)] = Hh[NODE_SZ + (e < HX_SZ ? e : HX_Q)];
+            for (int q = ex.lane(); q < BPN; q += ex.nlanes()) {   // TBp_k = Bp_k Hui_{k+1}
+                const int i = q / NU, c = q - NU * i;
+                T[TS * i + 14 + NU + c] = bhu(Dt, 14 + NU, i, c, Hh + NODE_SZ + HX_SZ);
             }
             if (res) {
                 // the nu rows of segment k ((E'y)_nu,k = y_k), the equality residual ry_k, and Sg_k . y_k
@@ -2381,7 +2386,7 @@ struct Solver {
                 // r_k, early part (columns 1 and 3): [TA | TBm]_k [g_x,k; g_u,k]
                 ex.acc_mac(cr, T, TS, 1, Gn, 4, 1, 14 + NU, 1.0, 4);
                 if (k > 0) ex.acc_mac(cm, Wp, 14, 1, Wp, 1, 14, 14, -1.0);
-                ex.acc_store(cm, M, 14, 1, true);
+                ex.acc_store_init(cm, M, Hd, hnui_);   // M = Hxi_{k+1} + hnui I + the products
                 ex.acc_store(cr, Rk, 4, 1, false, 4);
             }
             ex.sync_lds();

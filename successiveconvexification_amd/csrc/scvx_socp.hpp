@@ -173,6 +173,18 @@ struct WaveExT {
         }
     }
 
+    // M = H + diag I + c (14x14, row-major tiles): the pivot tile of the factorisation loop starts from the dense node inverse
+    __device__ __forceinline__ void acc_store_init(const Acc& c, double* Cm, const double* H, double diag) {
+        const int l = lane();
+        const int rc = l & 15, kq = l >> 4;
+        if (rc < 14) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = kq + 4 * r;
+                if (row < 14) Cm[row * 14 + rc] = (H[row * 14 + rc] + (row == rc ? diag : 0.0)) + c[r];
+            }
+        }
+    }
     // Li = L^-1 (row-major, lower) where L L' = M, for the 14x14 SPD pivot tile in LDS.  Lane i keeps row i of
     // M/L in VGPRs; pivots, column entries and the rows needed by the inversion travel by readlane:
     // 105 broadcasts for the factorisation, 105 for the inverse, no barrier inside.
@@ -371,6 +383,8 @@ struct BlockEx {
     __device__ __forceinline__ void w_acc_mac(WAcc& c, const double* A, int sai, int sak, const double* B, int sbk, int sbj, int Kd,
                                               double alpha, int nb = 14) { w0.acc_mac(c, A, sai, sak, B, sbk, sbj, Kd, alpha, nb); }
     __device__ __forceinline__ void w_acc_store(const WAcc& c, double* Cm, int sci, int scj, bool add, int nb = 14) { w0.acc_store(c, Cm, sci, scj, add, nb); }
+    __device__ __forceinline__ void w_acc_store_init(const WAcc& c, double* Cm, const double* H, double diag) { w0.acc_store_init(c, Cm, H, diag); }
+    __device__ __forceinline__ void acc_store_init(const WAcc& c, double* Cm, const double* H, double diag) { if (first()) w0.acc_store_init(c, Cm, H, diag); }
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int nlanes() const { return 64 * NW; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
