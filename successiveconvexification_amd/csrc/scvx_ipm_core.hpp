@@ -541,6 +541,15 @@ struct Solver {
     double p_mu_floor = 0.25;   // SCVX_MU_FLOOR (defined where it is used, in attempt_solve)
     double bigvz[2];  // <v, W dz>_1 of the two big cones (corr_dir_pass -> update_pass)
     double res_nrx2, res_nry2, res_sgy;   // build_kkt(res): |rx|^2 over the local rows, |ry|^2, Sg . y
+    // BORDER IN t-SPACE (round 5).  With S = L L' every border coefficient <r_a, S^-1 r_b> is the inner product <t_a, t_b> of the
+    // FORWARD-substituted right-hand sides t = L^-1 r, which the factorisation loop has at hand: it accumulates their 4 x 4 Gram matrix
+    // (columns: Sg | rtr | hnui Pnu | the predictor's right-hand side) on one MFMA accumulator.  The three border systems are never
+    // back-substituted: ys / ytr / ynu keep t_s, t_tr, t_nu, a solve forward-substitutes its own right-hand side, takes three inner
+    // products with them, solves the 3 x 3 border, combines IN t-SPACE and back-substitutes once.  Per iteration: one backward
+    // sweep over the factor with 4 right-hand sides, the border-coefficient pass and two y-space passes per solve are gone.
+    bool tsp;           // this factorisation's border is kept in t-space (every form but the two-ended factorisation)
+    double gram[16];    // <t_a, t_b>, a, b in {s, tr, nu, pred}
+    double gn_pred;     // <Pnu, gx_nu> of the predictor's right-hand side
     double bigvx2[2]; // v0 wij_0 - <v, wij>_1 of the two big cones, wij = W^-1 J dw (dir_pass<false, true> -> cone_map_t(hbig))
 #if defined(SCVX_IPM_PROF)
     double prof[32];   // in-kernel section timers (diagnostic builds)
@@ -1442,6 +1451,35 @@ struct Solver {
         SCVX_T1(0);
     }
 
+    // forward half of S_solve: t = L^-1 r (tchain is scratch; r and t distinct buffers)
+    SCVX_HD_NI void S_fwd(cgptr r, gptr t) {
+        SCVX_THIS_LDS();
+        SCVX_T0();
+        const int K = L.K;
+        const cfptr Linv = this->Linv;
+        const gptr tchain = this->tchain;
+        for (int e = ex.lane(); e < 14 * K; e += ex.nlanes()) {
+            const int k = e / 14, i = e - 14 * k;
+            cfptr Li = Linv + (size_t)k * LINV_SZ + linv_row(i);
+            cgptr rk_ = r + 14 * k;
+            double a = 0;
+            SCVX_UNROLL
+            for (int j = 0; j < 14; j++) a += (j <= i ? Li[j <= i ? j : i] : 0.0) * rk_[j];   // fixed trip count: the loads batch
+            tchain[e] = a;
+        }
+        ex.sync();
+        SCVX_TE(t0_, 16);
+        SCVX_TS(tc1_);
+        {
+            const cgptr tz[1] = {tchain};
+            const gptr xs[1] = {t};
+            ex.template chain_n<1>(K, tz, this->Nf, xs, false);
+        }
+        ex.sync();
+        SCVX_TE(tc1_, 17);
+        SCVX_T1(0);
+    }
+
     // N right-hand sides (N <= 4) through the block-tridiagonal solve with ONE pass over Linv / Nf per sweep.
     // r, x, t: N arrays of [K][14] each (t: scratch); nothing may alias.
     template <int N>
@@ -1599,6 +1637,9 @@ struct Solver {
             ex.w_sync_lds();
         }
         const int hpos_lane = hx_dense_pos(l <= HX_SZ ? l : 0);
+        typename E2::WAcc cg;   // chain wavefront: Gram matrix of the forward-substituted right-hand sides (Solver::gram)
+        ex.w_acc_zero(cg);
+        double gnacc = 0.0;     // assembly wavefront: <Pnu, gx_nu>
         double hnext = (w == 1 && l < NODE_SZ) ? node_elem(1, l) : 0.0;   // the assembly wavefront keeps the next node's inverses one step ahead
         double gnext = (w == 1 && l < 2 * NXU) ? gnode_elem(1, l) : 0.0;  // ... and the right-hand sides' slices and segment scalars
         double sgnext = (w == 1 && l < 42) ? gseg_elem(0, l) : 0.0;
@@ -1654,6 +1695,7 @@ struct Solver {
                         Rk[4 * l + 2] = hnui_ * Sg[28 + l];
                         Rk[4 * l + 3] += hnui_ * Sg[l] + Sg[14 + l];
                         rtr_[14 * k + l] = Rk[4 * l + 1];
+                        gnacc += Sg[28 + l] * Sg[l];
                     }
                 }
                 SCVX_TE(tp1_, 25);
@@ -1716,6 +1758,7 @@ struct Solver {
                     if (k > 0) ex.w_acc_mac(ct, Mq, 1, 14, Tp, 4, 1, 14, 1.0, 4);
                     ex.w_acc_store(ct, Tc, 4, 1, false, 4);
                     ex.w_sync_lds();
+                    ex.w_acc_mac(cg, Tc, 1, 4, Tc, 4, 1, 14, 1.0, 4);   // Gram matrix of the forward-substituted right-hand sides
                     if (l < 56) {
                         const int q = l / 14, i = l - 14 * q;
                         if (q < 3 || with_pred) xq_[q][14 * k + i] = Tc[4 * i + q];
@@ -1727,6 +1770,10 @@ struct Solver {
             ex.sync();   // hand-over: producer's slot k is complete, consumer has finished with slot k - 1
             SCVX_TE(tb_, 28);
         }
+        if (w == 0) ex.w_acc_store(cg, Rr, 4, 1, false, 4);
+        ex.sync();
+        for (int q = 0; q < 16; q++) gram[q] = Rr[q];
+        gn_pred = ex.sum(gnacc);
         return ex.all(ok);
     }
 
@@ -2294,6 +2341,9 @@ struct Solver {
         const gptr xq_[4] = {ys, ytr, ynu, dy};
         const gptr rtr_ = rtr;
         const int hpos_lane = hx_dense_pos(ex.lane() <= HX_SZ ? ex.lane() : 0);
+        typename Ex::Acc cg;   // Gram matrix of the forward-substituted right-hand sides (rows / columns 0..3), summed over the segments
+        ex.acc_zero(cg);
+        double gnacc = 0.0;    // <Pnu, gx_nu>, lane-local
         for (int k = 0; k < K; k++) {
             SCVX_TS(ta_);
             // prefetch the next segment's tile
@@ -2486,7 +2536,7 @@ struct Solver {
                 Rk[4 * i] = Sk[i];
                 Rk[4 * i + 2] = hnui_ * Sg[28 + i];
                 Rk[4 * i + 3] += hnui_ * Sg[i] + Sg[14 + i];
-                rtr_[14 * k + i] = Rk[4 * i + 1];   // rtr = E Hb^-1 Ptr itself is kept: the border coefficients and every solve use it
+                gnacc += Sg[28 + i] * Sg[i];
             }
             ex.sync_lds();
             SCVX_TE(te5_, 30);
@@ -2494,6 +2544,7 @@ struct Solver {
             ex.acc_mac(ct, Li, 14, 1, Rk, 4, 1, 14, 1.0, 4);
             ex.acc_store(ct, Tc, 4, 1, false, 4);
             ex.sync_lds();
+            ex.acc_mac(cg, Tc, 1, 4, Tc, 4, 1, 14, 1.0, 4);   // rows 0..3: t_a . t_b of this segment (the other rows: never read)
             for (int e = ex.lane(); e < 56; e += ex.nlanes()) {
                 const int q = e / 14, i = e - 14 * q;
                 if (q < 3 || with_pred) xq_[q][14 * k + i] = Tc[4 * i + q];
@@ -2501,6 +2552,11 @@ struct Solver {
             SCVX_TE(te6_, 31);
         }
         if (res) { res_nrx2 = ex.sum(nrx2); res_nry2 = ex.sum(nry2); res_sgy = ex.sum(sgacc); }
+        ex.sync_lds();
+        ex.acc_store(cg, Rk, 4, 1, false, 4);
+        ex.sync_lds();
+        for (int q = 0; q < 16; q++) gram[q] = Rk[q];
+        gn_pred = ex.sum(gnacc);
         }   // sequential factorisation
         ex.sync();   // the factors written above are read back (by other lanes) in the border solves
         SCVX_TE(tC_, 6);
@@ -2513,19 +2569,17 @@ struct Solver {
         // Only the multipliers y are kept.  The local parts l = Hb^-1 (g - E'y) of the border solutions are never
         // formed: every border coefficient is an inner product in y-space (below), and a solve applies its border
         // correction to dy and to the right-hand side BEFORE its single final  Hb^-1 (g - E'dy)  (kkt_solve).
+        tsp = kFusedBorder;
         if (kFusedBorder) {
-            // the forward substitutions were carried by the loop: Hb^-1 Ptr on (dx, du) for the two inner products that use it, then
-            // the backward halves
+            // the forward substitutions AND their Gram matrix were carried by the loop: ys / ytr / ynu (and dy, with_pred) stay in t-space;
+            // what is left is Hb^-1 Ptr on (dx, du) for the two inner products that use it
             Hb_inv(Wv + L.o_tr + 1, ptl, false);
-            if (with_pred) {
-                const gptr xx[4] = {ys, ytr, ynu, dy};
-                const gptr tt4[4] = {tchain, cy, tq0, tq1};
-                S_backN<4>(xx, tt4);
-            } else {
-                const gptr xx[3] = {ys, ytr, ynu};
-                const gptr tt3[3] = {tchain, cy, tq0};
-                S_backN<3>(xx, tt3);
-            }
+            const double ptp = dot(Wv + L.o_tr + 1, ptl, L.nx + L.nu_);
+            css = gram[0]; cst = -gram[1]; csn = -gram[2];
+            cts = -gram[1]; ctt = -ptp + gram[5]; ctn = gram[6];
+            cns = -gram[2]; cnt_ = gram[6]; pny = gram[10] / hnui_;
+            SCVX_TE(tB_, 7);
+            return ex.all(ok);
         } else {
             const int nxu = L.nx + L.nu_;
             const gptr g_tr = r1;     // nloc: Ptr on (dx,du), 0 on nu   (r1: refinement scratch, idle here)
@@ -2589,24 +2643,44 @@ struct Solver {
     // eout / sgout (optional): E_loc' dyv on the (dx, du) rows and Sg . dyv, by-products of the final E' product (newton_corr)
     SCVX_HD void kkt_solve(cgptr g, cgptr ryv, gptr dwv, gptr dyv, double rsign = 1.0, bool have_band = false, gptr eout = nullptr,
                            double* sgout = nullptr) {
-        // banded multiplier: S dy = E Hb^-1 g - rsign ryv   (have_band: build_kkt(true) left it in dyv)
+        // banded multiplier: S dy = E Hb^-1 g - rsign ryv   (have_band: build_kkt(true) left it in dyv -- forward-substituted only, tsp)
+        // inner products of the banded LOCAL solution dl = Hb^-1 (g - E'dy) with Sg / Ptr / Pnu, without forming dl:
+        //   <Ptr, dl> = <ptl, g> - <rtr, dy>,   <Pnu, dl_nu> = hnui (<Pnu, g_nu> - <Pnu, dy>)
+        double c0s, c0t, c0n;
+        if (tsp) {
+            // t-space: dyv holds t_g = L^-1 (E Hb^-1 g - rsign ryv);  <Sg, dy> = <t_s, t_g>, <rtr, dy> = <t_tr, t_g>, hnui <Pnu, dy> = <t_nu, t_g>
+            double a0, a1, a2, gn;
+            if (have_band) { a0 = gram[3]; a1 = gram[7]; a2 = gram[11]; gn = gn_pred; }
+            else {
+                Hb_inv(g, tmpl);
+                (void)E_apply(tmpl, tmpy, false, ryv, -rsign);
+                S_fwd(tmpy, dyv);
+                double q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                cgptr b0 = ys; cgptr b1 = ytr; cgptr b2 = ynu; cgptr wn = Wv + L.o_nu + 1; cgptr gnu = g + L.nx + L.nu_;
+                stream(0, L.ny, [&](int i) { return D6{dyv[i], b0[i], b1[i], b2[i], wn[i], gnu[i]}; },
+                       [&](int, const D6& v) { q0 += v.a * v.b; q1 += v.a * v.c; q2 += v.a * v.d; q3 += v.e * v.f; });
+                a0 = ex.sum(q0); a1 = ex.sum(q1); a2 = ex.sum(q2); gn = ex.sum(q3);
+            }
+            c0s = a0;
+            c0t = dot(ptl, g, L.nx + L.nu_) - a1;
+            c0n = hnui * gn - a2;
+        } else {
         if (!have_band) {
             Hb_inv(g, tmpl);
             (void)E_apply(tmpl, tmpy, false, ryv, -rsign);
             S_solve(tmpy, dyv);
         }
-        // inner products of the banded LOCAL solution dl = Hb^-1 (g - E'dy) with Sg / Ptr / Pnu, without forming dl:
-        //   <Ptr, dl> = <ptl, g> - <rtr, dy>,   <Pnu, dl_nu> = hnui (<Pnu, g_nu> - <Pnu, dy>)
         double a = 0, bt = 0, bn = 0, gn = 0;
         {
             const dcptr D_ = D; cgptr rt = rtr; cgptr wn = Wv + L.o_nu + 1; cgptr gnu = g + L.nx + L.nu_;
             stream(0, L.ny, [&](int r) { const int k = r / 14, i = r - 14 * k; return D5{D_[(size_t)k * DSZ + 14 * CS + i], dyv[r], rt[r], wn[r], gnu[r]}; },
                    [&](int, const D5& v) { a += v.a * v.b; bt += v.c * v.b; bn += v.d * v.b; gn += v.d * v.e; });
         }
-        const double c0s = ex.sum(a);
+        c0s = ex.sum(a);
         bt = ex.sum(bt); bn = ex.sum(bn); gn = ex.sum(gn);
-        const double c0t = dot(ptl, g, L.nx + L.nu_) - bt;
-        const double c0n = hnui * (gn - bn);
+        c0t = dot(ptl, g, L.nx + L.nu_) - bt;
+        c0n = hnui * (gn - bn);
+        }
         // ---- border: three unknowns (s, ctr, cnu), the heads of the cones eliminated in closed form ----
         // With W^-2 = [[h00, h01 v1'], [h01 v1, b2 I + h11 v1 v1']] a cone whose head t appears in no other row gives
         //     h00 t + h01 pi = g_t,   c = h01 t + h11 pi = kappa + sigma pi,   pi = <v1, l>,
@@ -2652,12 +2726,17 @@ struct Solver {
         const double tnu_ = (g[L.iTNU] - h01n * pi_n) / h00n;
         const double ts_ = g[L.iTS] / h00s - q_sg[3] * s_;
         ex.sync();
-        {   // the border correction in y-space ...
+        {   // the border correction (in y-space, or -- tsp -- in t-space: the same combination of the forward-substituted vectors) ...
             cgptr b0 = ys; cgptr b1 = ytr; cgptr b2 = ynu;
             stream(0, L.ny, [&](int i) { return D4{dyv[i], b0[i], b1[i], b2[i]}; },
                    [&](int i, const D4& v) { dyv[i] = v.a + v.b * s_ - v.c * ctr - v.d * cnu; });
         }
         ex.sync();
+        if (tsp) {   // ... followed by the one back substitution of the solve
+            const gptr xx[1] = {dyv};
+            const gptr tt[1] = {tchain};
+            S_backN<1>(xx, tt);
+        }
         // ... and the local step in one go:  dw = Hb^-1 (g - Ptr ctr - Pnu cnu - E'dy)
         {
             const double sg_ = Et_apply(dyv, tmpl2, g, 1, ctr, cnu, eout);
