@@ -540,6 +540,8 @@ struct Solver {
     bool p_sigma_cube = false;
     double p_mu_floor = 0.25;   // SCVX_MU_FLOOR (defined where it is used, in attempt_solve)
     double bigvz[2];  // <v, W dz>_1 of the two big cones (corr_dir_pass -> update_pass)
+    double bigq[2][6]; // body sums of the two big cones from the predictor's direction pass: <l,l>, <l,a>, <a,a>, <v,l>, <v,wr>, <v,a>
+                       // (a = W^-1 ds_aff): every reduction corr_rhs_pass needs is a combination of these (no reduction sweep of its own)
     double res_nrx2, res_nry2, res_sgy;   // build_kkt(res): |rx|^2 over the local rows, |ry|^2, Sg . y
     // BORDER IN t-SPACE (round 5).  With S = L L' every border coefficient <r_a, S^-1 r_b> is the inner product <t_a, t_b> of the
     // FORWARD-substituted right-hand sides t = L^-1 r, which the factorisation loop has at hand: it accumulates their 4 x 4 Gram matrix
@@ -1170,12 +1172,14 @@ struct Solver {
             const double b0 = PRED ? -l0 - a0 : -(wij0 + wb[0]);
             double ll = 0, la = 0, aa = 0, lb = 0, bb = 0, vb = 0, vw = 0;
             const gptr to = tc_ + bc.off;
+            double pvl = 0, pvw = 0, pva = 0;
             if (PRED) {
                 stream(1, bc.dim, [&](int i) { return D4{v[i], db[i], wr[i], l[i]}; },
                        [&](int i, const D4& w) {
                            const double ai = (-2.0 * vx * w.a + w.b) * ibeta - w.c, bi = -w.d - ai;
                            so[i] = ai;
                            ll += w.d * w.d; la += w.d * ai; aa += ai * ai; lb += w.d * bi; bb += bi * bi;
+                           pvl += w.a * w.d; pvw += w.a * w.c; pva += w.a * ai;
                        });
             } else {
                 stream(1, bc.dim, [&](int i) { return D5{v[i], db[i], wr[i], l[i], wb[i]}; },
@@ -1188,6 +1192,10 @@ struct Solver {
                        });
             }
             ll = ex.sum(ll); la = ex.sum(la); aa = ex.sum(aa); lb = ex.sum(lb); bb = ex.sum(bb);
+            if (PRED) {
+                bigq[q][0] = ll; bigq[q][1] = la; bigq[q][2] = aa;
+                bigq[q][3] = ex.sum(pvl); bigq[q][4] = ex.sum(pvw); bigq[q][5] = ex.sum(pva);
+            }
             if (!PRED) bigvz[q] = ex.sum(vb);
             if (CHECK) {
                 const double vx2 = v0 * wij0 - ex.sum(vw);
@@ -1245,14 +1253,11 @@ struct Solver {
             const gptr wbo = Wibz_ + bc.off; const gptr to = tmpc_ + bc.off;
             const double l0 = l[0], a0 = a[0], b0 = -l0 - a0, v0 = v[0], wr0 = wr[0];
             const double beta = Wbeta_[bc.cidx], ibeta = 1.0 / beta;
-            // one reduction sweep: the heads are known, so rhs_i = -2 l0 l_i - (a0 b_i + b0 a_i) is available per element
-            double ll = 0, ab = 0, lr = 0, vr = 0, vl = 0, vw = 0;
-            stream(1, bc.dim, [&](int i) { return D4{l[i], a[i], v[i], wr[i]}; },
-                   [&](int, const D4& w) {
-                       const double bi = -w.a - w.b, ri = -2.0 * l0 * w.a - (a0 * bi + b0 * w.b);
-                       ll += w.a * w.a; ab += w.b * bi; lr += w.a * ri; vr += w.c * ri; vl += w.c * w.a; vw += w.c * w.d;
-                   });
-            ll = ex.sum(ll); ab = ex.sum(ab); lr = ex.sum(lr); vr = ex.sum(vr); vl = ex.sum(vl); vw = ex.sum(vw);
+            // no reduction sweep: rhs_i = -2 l0 l_i - (a0 b_i + b0 a_i) = c1 l_i + c2 a_i (b_i = -l_i - a_i), so every sum over the body is a
+            // combination of the six the predictor's direction pass took on its way (bigq)
+            const double c1 = -2.0 * l0 + a0, c2 = a0 - b0;
+            const double ll = bigq[q][0], la = bigq[q][1], aa = bigq[q][2], vl = bigq[q][3], vw = bigq[q][4], va = bigq[q][5];
+            const double ab = -la - aa, lr = c1 * ll + c2 * la, vr = c1 * vl + c2 * va;
             const double rhs0 = -(ll + l0 * l0) + (-(ab + a0 * b0) + sigmu);
             const double x0 = (l0 * rhs0 - lr) / (l0 * l0 - ll);
             const double il0 = 1.0 / l0;
@@ -1273,7 +1278,9 @@ struct Solver {
     }
 
     // ---- sweep 5: S += alpha (J dw - rz) with rz = S - a(V) recomputed from the old V,  Z += alpha W^-1 (W dz) ----
-    SCVX_HD_NI void update_pass(double alpha) {
+    // ... and V += alpha dw on the way: the bodies of the two big cones ARE the local part of V (Vn: where the new iterate goes -- V
+    // itself, or the other buffer while V holds the best iterate so far)
+    SCVX_HD_NI void update_pass(double alpha, gptr Vn) {
         SCVX_THIS_LDS();
         SCVX_T0();
         const gptr S_ = S; const gptr Z_ = Z; const cgptr V_ = V; const cgptr dw_ = dw; const cgptr Wv_ = Wv; const cgptr sd_ = sd;
@@ -1303,16 +1310,20 @@ struct Solver {
             const double vx = v0 * b0 - bigvz[q];
             const double s0 = s[0], z0 = z[0], a0 = V_[bc.head], d0 = dw_[bc.head];
             ex.sync();   // every lane holds the heads before lane 0 overwrites them
+            const gptr vnb = Vn + bc.body - 1;
             stream(1, bc.dim, [&](int i) { return D6{s[i], z[i], v[i], b[i], ab[i], db[i]}; },
                    [&](int i, const D6& w) {
                        s[i] = w.a + alpha * (w.f - (w.a - w.e));
                        z[i] = w.b + alpha * ((-2.0 * vx * w.c + w.d) * ibeta);
+                       vnb[i] = w.e + alpha * w.f;
                    });
             if (ex.lane() == 0) {
                 s[0] = s0 + alpha * (d0 - (s0 - a0));
                 z[0] = z0 + alpha * ((2.0 * vx * v0 - b0) * ibeta);
             }
         }
+        ex.sync();
+        for (int i = L.nloc + ex.lane(); i < L.nv; i += ex.nlanes()) Vn[i] = V_[i] + alpha * dw_[i];   // the four global variables
         ex.sync();
         SCVX_T1(23);
     }
@@ -3228,10 +3239,9 @@ struct Solver {
             SCVX_DBG("    cmb alpha %.6e |dw|^2 %.6e\n", alpha, dot(dw, dw, L.nv));
             if (!(alpha == alpha)) { res.status = stop_status(3); break; }
             if (alpha < 1e-9) { res.status = stop_status(2); break; }
-            update_pass(alpha);   // S, Z (reads the old V)
             {
-                cgptr V_ = V; const gptr Vn = best_in_V ? Vbest : V; cgptr dw_ = dw; gptr y_ = y; cgptr dy_ = dy;
-                stream(0, L.nv, [&](int i) { return D2{V_[i], dw_[i]}; }, [&](int i, const D2& v) { Vn[i] = v.a + alpha * v.b; });
+                const gptr Vn = best_in_V ? Vbest : V; gptr y_ = y; cgptr dy_ = dy;
+                update_pass(alpha, Vn);   // S, Z (from the old V) and the new V
                 if (best_in_V) { Vbest = V; V = Vn; best_in_V = false; }   // Vbest now holds the best iterate, V the new one
                 stream(0, L.ny, [&](int i) { return D2{y_[i], dy_[i]}; }, [&](int i, const D2& v) { y_[i] = v.a + alpha * v.b; });
             }
