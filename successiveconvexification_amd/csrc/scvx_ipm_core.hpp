@@ -1817,6 +1817,7 @@ struct Solver {
         double* Hd = Hh + 2 * NODE_SZ;   // producer: dense Hxi (bottom: two of them, by step parity)
         double* Mp = Hd + 392;           // producer: N tile of the node the chain finished one step ago
         bool ok = true;
+        const int hpos_lane = hx_dense_pos(l <= HX_SZ ? l : 0);
         auto node_elem = [&](int node, int e) -> double {
             return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[HU_SZ * node + (e - HX_SZ)];
         };
@@ -1862,7 +1863,7 @@ struct Solver {
             for (int e = l; e < NODE_SZ; e += 64) { Hh[e] = node_elem(K - 1, e); Hh[NODE_SZ + e] = node_elem(K, e); }
             for (int q = l; q < BPN; q += 64) Bp[q] = D_[(size_t)(K - 2) * DSZ + 14 * (14 + NU) + q];
             ex.w_sync_lds();
-            for (int e = l; e < 196; e += 64) Hd[196 + e] = hxi_entry(Hh + NODE_SZ, e / 14, e % 14);   // parity 1 = "step -1"
+            for (int e = l; e < 196; e += 64) { Hd[196 + e] = hxi_entry(Hh + NODE_SZ, e / 14, e % 14); Hd[e] = 0.0; }   // parity 1 = "step -1"; parity 0: the structural zeros
             ex.w_sync_lds();
         }
         const int nsteps = (m > nb ? m : nb) + 1;
@@ -1882,19 +1883,18 @@ struct Solver {
                 if (l < NODE_SZ) Hh[NODE_SZ + l] = hnext;                          // node k + 1, requested a step ago
                 hnext = l < NODE_SZ ? node_elem(k + 2 <= K ? k + 2 : K, l) : 0.0;   // node k + 2 for the next step
                 ex.w_sync_lds();
-                for (int e = l; e < 196 + BPN; e += 64) {
-                    if (e < 196) {
-                        const int i = e / 14, j = e - 14 * i;
-                        const double h = hxi_entry(Hh + NODE_SZ, i, j);
-                        Hd[e] = h;
-                        Sdk[e] = h + (i == j ? hnui_ : 0.0);
-                    } else {
-                        const int q = e - 196, i = q / NU, c = q - NU * i;
-                        T[TS * i + 14 + NU + c] = bhu(Dt, 14 + NU, i, c, Hh + NODE_SZ + HX_SZ);
-                    }
+                if (l <= HX_SZ) Hd[hpos_lane] = Hh[NODE_SZ + (l < HX_SZ ? l : HX_Q)];   // the 34 non-zeros of the dense Hxi_{k+1}
+                for (int q = l; q < BPN; q += 64) {
+                    const int i = q / NU, c = q - NU * i;
+                    T[TS * i + 14 + NU + c] = bhu(Dt, 14 + NU, i, c, Hh + NODE_SZ + HX_SZ);
                 }
                 ex.w_sync_lds();
-                ex.w_tile_gemm(Sdk, 14, 1, T, TS, 1, Dt, 14, 1, TW, 1.0, true);
+                {
+                    typename E2::WAcc cm;
+                    ex.w_acc_zero(cm);
+                    ex.w_acc_mac(cm, T, TS, 1, Dt, 14, 1, TW, 1.0);
+                    ex.w_acc_store_init(cm, Sdk, Hd, hnui_);   // Sd_k = Hxi_{k+1} + hnui I + [TA | TBm | TBp]_k D_k'
+                }
                 if (k < m) {
                     for (int q = l; q < BPN; q += 64) Bp[q] = Dt[14 * (14 + NU) + q];
                     ex.w_sync_lds();
@@ -1948,11 +1948,7 @@ struct Solver {
                 double bpn[(BPN + 63) / 64];
                 SCVX_UNROLL
                 for (int q = 0; q < (BPN + 63) / 64; q++) { const int e = l + 64 * q; bpn[q] = e < BPN ? (double)D_[(size_t)kb2 * DSZ + 14 * (14 + NU) + e] : 0.0; }
-                for (int e = l; e < 196; e += 64) {
-                    const int i = e / 14, j = e - 14 * i;
-                    Hd0[e] = hxi_entry(Hh, i, j);
-                    Sdk[e] = Hd1[e] + (i == j ? hnui_ : 0.0);
-                }
+                if (l <= HX_SZ) Hd0[hpos_lane] = Hh[l < HX_SZ ? l : HX_Q];   // dense Hxi_k: its 34 non-zeros (both parities were zeroed once)
                 ex.w_sync_lds();
                 ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd0, 14, 1, 14, 1.0, false);     // TA_k = A_k Hxi_k
                 for (int q = l; q < 2 * BPN; q += 64) {
@@ -1963,7 +1959,12 @@ struct Solver {
                     T[TS * i + c0 + c] = bhu(Dt, c0, i, c, h);
                 }
                 ex.w_sync_lds();
-                ex.w_tile_gemm(Sdk, 14, 1, T, TS, 1, Dt, 14, 1, TW, 1.0, true);
+                {
+                    typename E2::WAcc cm;
+                    ex.w_acc_zero(cm);
+                    ex.w_acc_mac(cm, T, TS, 1, Dt, 14, 1, TW, 1.0);
+                    ex.w_acc_store_init(cm, Sdk, Hd1, hnui_);   // Sd_k = Hxi_{k+1} + hnui I + [TA | TBm | TBp]_k D_k'
+                }
                 for (int e = l; e < 196; e += 64) {
                     const int i = e / 14, j = e - 14 * i;
                     Sok[e] = so_elem(T, Bp, i, j);   // So_{k-1}
