@@ -94,10 +94,12 @@ def test_conic_kernels_keep_the_solver_object_out_of_private_memory(tmp_path):
     assert len(conic) >= 12, sorted(kernels)     # 2 + 4 (control_dim 3) and 2 + 4 (fins)
     for n, k in conic.items():
         assert int(k["vgpr_spill_count"]) == 0, (n, k)
-        assert int(k["private_segment_fixed_size"]) <= 1024, (n, k)     # 496 (one wavefront) ... 868 (four, fins)
+        assert int(k["private_segment_fixed_size"]) <= 1280, (n, k)     # 832 (one wavefront) ... 1192 (four, fins): register saves around calls
         assert int(k["group_segment_fixed_size"]) <= 64 * 1024, (n, k)
     one = [k for n, k in conic.items() if "socp_kernelE" in n][0]
-    assert int(one["private_segment_fixed_size"]) <= 640 and int(one["group_segment_fixed_size"]) <= 160 * 1024 // 9, one
+    # round 5: 496 -> 832 B (the solve and its refinement check are one routine now: more values live across the non-inlined passes;
+    # ~200 scratch accesses per interior-point iteration, 3 % of its traffic); LDS: eight single-wavefront blocks per CU (two per SIMD)
+    assert int(one["private_segment_fixed_size"]) <= 896 and int(one["group_segment_fixed_size"]) <= 160 * 1024 // 8, one
     k0 = [k for n, k in kernels.items() if "threedof_kernelE" in n][0]
     assert int(k0["private_segment_fixed_size"]) <= 1200, k0
 

@@ -992,13 +992,13 @@ def test_bench_gpus_2_from_a_plain_shell_launches_its_own_ranks():
     assert bad.returncode != 0
 
 
-def test_six_rank_rehearsal_of_the_drivers_n8_shape_on_one_gpu(tmp_path):
+def test_five_rank_rehearsal_of_the_drivers_n8_shape_on_one_gpu(tmp_path):
     """the first real 8-GPU run must not be the first many-rank run.  The GPU box's process guard allows at most
-    SIX processes on its card, so the rehearsal is six ranks (the eight-rank sharding / gather / clock logic runs on CPU over gloo:
-    tests/test_distributed_cpu.py::test_eight_rank_strong_shard_and_gather_shape_of_the_driver_run): `bench.py --gpus 6
-    --global-batch 6144` from a plain shell -- 1,024 trajectories per rank, exactly the per-rank shard (and therefore the
-    two-wavefront executor) of the driver's N = 8 run of the 8,192 batch -- over gloo, the six processes sharing the card.  The
-    gathered records must equal, bit for bit, a single-process run of the same 6,144 trajectories with that executor pinned."""
+    SIX processes on its card and this test process is one of them, so the rehearsal is FIVE ranks (the eight-rank sharding / gather /
+    clock logic runs on CPU over gloo: tests/test_distributed_cpu.py::test_eight_rank_strong_shard_and_gather_shape_of_the_driver_run):
+    `bench.py --gpus 5 --global-batch 5120` from a plain shell -- 1,024 trajectories per rank, exactly the per-rank shard (and
+    therefore the two-wavefront executor) of the driver's N = 8 run of the 8,192 batch -- over gloo, the five processes sharing the
+    card.  The gathered records must equal, bit for bit, a single-process run of the same 5,120 trajectories with that executor pinned."""
     import json
     import os
     import subprocess
@@ -1007,24 +1007,24 @@ def test_six_rank_rehearsal_of_the_drivers_n8_shape_on_one_gpu(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["SCVX_DIST_BACKEND"] = "gloo"
     common = ["--steps", "2", "--warmup", "0", "--exact-steps", "--no-cpu-baseline", "--no-traj-check", "--no-k1-sweep"]
-    f6, f1 = str(tmp_path / "six.npy"), str(tmp_path / "one.npy")
-    r6 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "6", "--global-batch", "6144", "--dump-gathered", f6] + common,
+    f5, f1 = str(tmp_path / "five.npy"), str(tmp_path / "one.npy")
+    r5 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "5", "--global-batch", "5120", "--dump-gathered", f5] + common,
                         env=env, capture_output=True, text=True, timeout=1500, cwd=root)
-    assert r6.returncode == 0, r6.stderr[-3000:]
-    lines = [l for l in r6.stdout.splitlines() if l.startswith("{")]
+    assert r5.returncode == 0, r5.stderr[-3000:]
+    lines = [l for l in r5.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 6 and line["scaling"] == "strong" and line["config"]["batch_per_gpu"] == 1024
-    assert line["config"]["all_gather_shape"] == [6, 1024, 51 * 17 + 1] and line["config"]["traj_iters_timed"] == 2 * 6144
-    assert "6 ranks" in line["config"]["all_gather"]
-    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--batch", "6144", "--dump-gathered", f1] + common,
+    assert line["n_gpus"] == 5 and line["scaling"] == "strong" and line["config"]["batch_per_gpu"] == 1024
+    assert line["config"]["all_gather_shape"] == [5, 1024, 51 * 17 + 1] and line["config"]["traj_iters_timed"] == 2 * 5120
+    assert "5 ranks" in line["config"]["all_gather"]
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--batch", "5120", "--dump-gathered", f1] + common,
                         env=dict(env, SCVX_DIST_BACKEND="nccl", SCVX_K4_WAVES="2"), capture_output=True, text=True, timeout=900, cwd=root)
     assert r1.returncode == 0, r1.stderr[-3000:]
-    a, b = np.load(f6), np.load(f1)
-    assert a.shape == b.shape == (6144, 51 * 17 + 1)
+    a, b = np.load(f5), np.load(f1)
+    assert a.shape == b.shape == (5120, 51 * 17 + 1)
     assert np.array_equal(a, b)
     # a rank that dies takes the job down with a non-zero exit code (an argument error inside the children)
-    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "6", "--global-batch", "6143", "--steps", "1", "--warmup", "0",
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "5", "--global-batch", "5119", "--steps", "1", "--warmup", "0",
                           "--no-cpu-baseline", "--no-traj-check", "--no-k1-sweep"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert bad.returncode != 0
 
