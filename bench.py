@@ -587,6 +587,14 @@ def main():
                           "follows a REJECTED step (same subproblem, radius halved) starts from the previous solve's optimum while "
                           "that point lies inside the new radius, and still ends at 1e-8 (cold_start_only = the same loop without it); "
                           "a solve that ends on its numerical floor is re-run under other step rules (retries = 5) before it counts as failed",
+                "parity_contract": {
+                    "solver_tol": args.tol if args.tol > 0 else 1e-8, "traj_linf_tol": 1e-4,
+                    "statement": "`value` is measured at solver tolerance 1e-8 (every conic solve to max(pres, dres, relgap) < 1e-8: the "
+                                 "tolerance class of the reference's own solver defaults, rocketland.jl:58-59) and its parity figure, "
+                                 "traj_linf_vs_oracle, is taken at the SAME setting on both sides: a complete solve_problem stays within 1e-4 "
+                                 "of the oracle's run (measured 3.6e-5 in x; the subproblem optima are flat).  SURVEY 8c's proposed 1e-5 is met "
+                                 "from tol 3e-10 down: value_at_traj_linf_1e-5 carries that throughput with its own parity figure "
+                                 "(profiles/r05_tol_sweep.md has the sweep).  The oracle itself is unpinned (no reference-held vectors exist)"},
                 "parallelism": f"batch-sharded x{world}, {scaling} scaling", "traj_iters_timed": done_all, "all_gather_shape": gathered,
                 "all_gather": gather_how,
             },
@@ -650,7 +658,9 @@ def main():
         if world == 1 and not args.no_k1_sweep and not args.aero:
             line["k1_error_vs_dop853_by_npts"] = k1_error_by_npts(IntegratorCache, p)
         if world == 1 and not args.no_traj_check and not args.aero:
-            line["traj_linf_vs_oracle"] = traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts)
+            # device and oracle at the SAME solver tolerance (the headline's: 1e-8 unless --tol); rounds 1-4 compared the device at 1e-8
+            # with the oracle at its own default 1e-9
+            line["traj_linf_vs_oracle"] = traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts, tol=(args.tol if args.tol > 0 else 1e-8))
         if world == 1 and not args.no_traj_check:
             # NOT the headline: the same loop (a) with every solve started cold, as the reference's solver does, and (b) with
             # scvx_solver_opts.reuse_inactive_tr (a conic solve whose optimum is provably unchanged after a rejected step is
@@ -681,11 +691,14 @@ def main():
                                              "workspace, norms and pivots in double (BASELINE configs[3-4] 'fp32', SURVEY H7); "
                                              "same loop, same seed as `value`")
             if not args.aero and args.tol <= 0:
-                # SURVEY 8c asks for converged-trajectory L-inf <= 1e-5: met with both solvers at 1e-10 (the optimum of each subproblem is
-                # flat: at the default 1e-8 two valid answers sit a few 1e-5 apart).  The throughput AT that tolerance, with its parity figure:
-                line["at_tol_1e-10"] = dict(variant(tol=1e-10), traj_linf_vs_oracle=traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts, tol=1e-10),
-                                            note="the same timed region with scvx_solver_opts.tol = 1e-10 (every solve to merit < 1e-10), and the full "
-                                                 "solve_problem parity against the oracle run at the same tolerance (tests/golden/oracle_scvx_full_tol1e-10.npz)")
+                # SURVEY 8c proposed a converged-trajectory L-inf <= 1e-5.  The optimum of each subproblem is flat: with both solvers at the
+                # same tolerance the full-run distance is 3.3e-5 ... 3.8e-5 from 1e-8 down to 1e-9 and drops below 1e-5 from 3e-10 on
+                # (profiles/r05_tol_sweep.md).  The throughput AT the loosest tolerance that meets 1e-5, with its own parity figure:
+                line["value_at_traj_linf_1e-5"] = dict(variant(tol=3e-10), solver_tol=3e-10,
+                                                       traj_linf_vs_oracle=traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts, tol=3e-10),
+                                                       note="the same timed region with scvx_solver_opts.tol = 3e-10 on the device AND in the oracle "
+                                                            "(tests/golden/oracle_scvx_full_tol3e-10.npz): the fastest setting of profiles/r05_tol_sweep.md "
+                                                            "whose complete solve_problem stays within 1e-5 of the oracle's")
             line["cold_start_only"] = dict(variant(warm_start=False), note="warm_start = 0: every conic solve starts from the "
                                            "CVXOPT-style cold point, also the re-solve after a rejected step")
             line["with_reuse_inactive_tr"] = dict(variant(reuse_inactive_tr=True), note="opt-in shortcut, off in the headline: after a "
