@@ -9,6 +9,12 @@
 #ifndef SCVX_LDS_FENCE_SCOPE
 #define SCVX_LDS_FENCE_SCOPE "wavefront"   // orders the LDS traffic of ONE wavefront (its own tiles): no s_waitcnt needed, the LDS queue of a wavefront is in order.  Cross-wavefront hand-overs go through __syncthreads (BlockEx::sync).  70.9 -> 70.6 ms per launch against "workgroup"
 #endif
+// WaveExT::chol_inv14 with the inverse riding on the factorisation's column steps (1) instead of following it (0).  MEASURED AND OFF
+// (round 5): same results, but chol_inv14 itself 4.2 M -> 5.0 M cycles per solve and the whole factorisation loop 15.8 M -> 20.3 M (28 live
+// row registers per lane instead of 14 push the loop's other values out): B = 8192 59.5 -> 63.7 ms per launch, B = 1024 10.15 -> 10.6.
+#ifndef SCVX_CHOL_FUSED_INV
+#define SCVX_CHOL_FUSED_INV 0
+#endif
 #ifndef SCVX_CHAIN_R
 #define SCVX_CHAIN_R 8   // steps of the block recurrence whose operands are in flight (10 VGPRs each)
 #endif
@@ -200,6 +206,44 @@ struct WaveExT {
         for (int j = 0; j < 14; j++) dmax = fmax(dmax, M[15 * j]);   // same address in every lane: LDS broadcast reads
         const double floor_ = fmax(1e-13 * dmax, 1e-300);
         bool ok = dmax > 0.0;
+#if SCVX_CHOL_FUSED_INV
+        // ONE sweep (round 5): lane i also carries row i of X = L^-1 (started as e_i) and every column step j of the factorisation
+        // applies its forward-substitution update  X_i -= L[i][j] X_j  (X_j = row j, final at step j, times 1 / L[j][j]) next to the
+        // trailing update of M.  Same products in the same order as the two-phase form (factorise, then invert column by column),
+        // but the 105 inverse updates no longer wait for the factorisation to end: they fill the issue slots under the pivot chains.
+        double x[14];
+#pragma unroll
+        for (int c = 0; c < 14; c++) x[c] = (c == i) ? 1.0 : 0.0;
+        double myip = 0.0;
+#pragma unroll
+        for (int j = 0; j < 14; j++) {
+            const double d0 = bcast(m[j], j);
+            ok = ok && (d0 == d0);
+            const double d = fmax(d0, floor_);
+            double ip = __builtin_amdgcn_rsq(d);
+            const double hd = 0.5 * d;
+            ip = fma(ip, fma(-hd * ip, ip, 0.5), ip);
+            ip = fma(ip, fma(-hd * ip, ip, 0.5), ip);
+            if (i == j) myip = ip;
+            m[j] = (i == j) ? d * ip : m[j] * ip;       // L[i][j]; rows above j hold junk in column j, never read
+            const double l0 = (i > j) ? m[j] : 0.0;     // rows <= j of X are final: they take no update
+#pragma unroll
+            for (int c = 0; c <= j; c++) {
+                const double xjc = bcast(x[c], j) * ip;   // X[j][c]
+                x[c] = fma(-l0, xjc, x[c]);
+            }
+#pragma unroll
+            for (int c = j + 1; c < 14; c++) {
+                const double lcj = bcast(m[j], c);
+                m[c] = fma(-m[j], lcj, m[c]);   // rows i < c update junk (their upper triangle is never read): no select
+            }
+        }
+        if (i < 14) {
+#pragma unroll
+            for (int c = 0; c < 14; c++) Li[14 * i + c] = (c <= i) ? x[c] * myip : 0.0;
+        }
+        return ok;
+#else
         double ipv[14];   // 1 / L[j][j], identical in every lane: the inverse below multiplies instead of dividing
 #pragma unroll
         for (int j = 0; j < 14; j++) {
@@ -237,6 +281,7 @@ struct WaveExT {
             for (int a = 0; a < 14; a++) Li[14 * a + i] = x[a];
         }
         return ok;
+#endif
     }
 
     // out_k = z_k + N_k out_{k-1} (forward) / out_k = z_k + N_{k+1}' out_{k+1} (reverse) for NR right-hand sides at
