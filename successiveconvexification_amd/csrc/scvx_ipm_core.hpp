@@ -1598,15 +1598,15 @@ struct Solver {
         double* So = Sd + 392;           // 2 x 196
         double* Wp = So + 392;           // 3 x 196: Wb ring (chain writes k, reads k-1; the post stage reads k-2)
         double* Li = Wp + 588;           // 2 x 196: Linv ring (chain writes k; the post stage reads k-1)
-        double* Mq = Li + 392;           // post stage: Nf product
-        double* Dt = Mq + 196;           // producer: D_k tile
+        double* Mq = Li + 392;           // 2 x 196: N_k ring (chain writes k; the assembly wavefront's forward substitution reads k one step later)
+        double* Dt = Mq + 392;           // producer: D_k tile
         double* T = Dt + DSZ;            // producer: [TA | TBm | TBp], row stride 22
         double* Bp = T + 14 * TS;            // producer: Bp_k kept across the tile swap
         double* Hh = Bp + BPN;            // producer: node inverses k | k+1
         double* Hd = Hh + 2 * NODE_SZ;   // producer: dense Hxi_{k+1}
         double* Gn = Hd + 196;           // producer: 2 x NXU x 4 node slices of the border right-hand sides (columns 1 = Ptr, 3 = gx)
         double* Rr = Gn + 2 * NXU * 4;   // 3 x 56: r_k ring (producer writes k, the chain reads k one step later)
-        double* Tt = Rr + 168;           // chain: 2 x 56  t_{k-1}, t_k
+        double* Tt = Rr + 168;           // forward substitution (assembly wavefront): 2 x 56  t_{k-1}, t_k
         double* Sg = Tt + 112;           // producer: 42 segment scalars gx_nu,k | ry_k | Pnu_k
         const int w = ex.wave(), l = ex.wlane();
         bool ok = true;
@@ -1654,6 +1654,27 @@ struct Solver {
         double hnext = (w == 1 && l < NODE_SZ) ? node_elem(1, l) : 0.0;   // the assembly wavefront keeps the next node's inverses one step ahead
         double gnext = (w == 1 && l < 2 * NXU) ? gnode_elem(1, l) : 0.0;  // ... and the right-hand sides' slices and segment scalars
         double sgnext = (w == 1 && l < 42) ? gseg_elem(0, l) : 0.0;
+        // Round 5: the forward substitution t_k = L_k^-1 r_k + N_k t_{k-1} of the four border right-hand sides (with their Gram matrix)
+        // is the ASSEMBLY wavefront's again, one barrier behind the chain: with the tile products unpredicated and the dense node inverse
+        // scattered, the assembly stage shrank to 7.2 k cycles per segment while the chain wavefront (pivot update, Cholesky + inverse,
+        // coupling tile, L^-1 / N_k stores AND this substitution) took 11.4 k and the assembly waited 4.2 k of every step.
+        auto fwd_subst = [&](int kp) {
+            const double* Rk = Rr + 56 * (kp % 3);
+            const double* Lik = Li + 196 * (kp & 1);
+            const double* Mqk = Mq + 196 * (kp & 1);
+            double* Tc = Tt + 56 * (kp & 1); const double* Tp = Tt + 56 * ((kp + 1) & 1);
+            typename E2::WAcc ct;
+            ex.w_acc_zero(ct);
+            ex.w_acc_mac(ct, Lik, 14, 1, Rk, 4, 1, 14, 1.0, 4);
+            if (kp > 0) ex.w_acc_mac(ct, Mqk, 1, 14, Tp, 4, 1, 14, 1.0, 4);
+            ex.w_acc_store(ct, Tc, 4, 1, false, 4);
+            ex.w_sync_lds();
+            ex.w_acc_mac(cg, Tc, 1, 4, Tc, 4, 1, 14, 1.0, 4);   // Gram matrix of the forward-substituted right-hand sides
+            if (l < 56) {
+                const int q = l / 14, i = l - 14 * q;
+                if (q < 3 || with_pred) xq_[q][14 * kp + i] = Tc[4 * i + q];
+            }
+        };
         for (int t = 0; t <= K; t++) {
             if (w == 1 && t < K) {
                 const int k = t;
@@ -1756,32 +1777,23 @@ struct Solver {
                     Linv_[(size_t)k * LINV_SZ + e] = Lik[14 * i + jj];
                 }
                 if (k > 0) {
-                    ex.w_tile_gemm(Mq, 1, 14, Lik, 14, 1, Wpm, 14, 1, 14, -1.0, false);
+                    double* Mqk = Mq + 196 * (k & 1);
+                    ex.w_tile_gemm(Mqk, 1, 14, Lik, 14, 1, Wpm, 14, 1, 14, -1.0, false);
                     ex.w_sync_lds();
-                    for (int e = l; e < 196; e += 64) Nf_[(size_t)k * 196 + e] = Mq[e];
-                }
-                {
-                    const double* Rk = Rr + 56 * (k % 3);
-                    double* Tc = Tt + 56 * (k & 1); const double* Tp = Tt + 56 * ((k + 1) & 1);
-                    typename E2::WAcc ct;
-                    ex.w_acc_zero(ct);
-                    ex.w_acc_mac(ct, Lik, 14, 1, Rk, 4, 1, 14, 1.0, 4);
-                    if (k > 0) ex.w_acc_mac(ct, Mq, 1, 14, Tp, 4, 1, 14, 1.0, 4);
-                    ex.w_acc_store(ct, Tc, 4, 1, false, 4);
-                    ex.w_sync_lds();
-                    ex.w_acc_mac(cg, Tc, 1, 4, Tc, 4, 1, 14, 1.0, 4);   // Gram matrix of the forward-substituted right-hand sides
-                    if (l < 56) {
-                        const int q = l / 14, i = l - 14 * q;
-                        if (q < 3 || with_pred) xq_[q][14 * k + i] = Tc[4 * i + q];
-                    }
+                    for (int e = l; e < 196; e += 64) Nf_[(size_t)k * 196 + e] = Mqk[e];
                 }
                 SCVX_TE(tc2_, 26);
             }
+            if (w == 1 && t >= 2) fwd_subst(t - 2);   // the assembly wavefront, two segments behind its own stage: L^-1 and N of segment t - 2 were finished a barrier ago
             SCVX_TS(tb_);
             ex.sync();   // hand-over: producer's slot k is complete, consumer has finished with slot k - 1
             SCVX_TE(tb_, 28);
         }
-        if (w == 0) ex.w_acc_store(cg, Rr, 4, 1, false, 4);
+        if (w == 1) {
+            fwd_subst(K - 1);
+            ex.w_sync_lds();
+            ex.w_acc_store(cg, Rr, 4, 1, false, 4);
+        }
         ex.sync();
         for (int q = 0; q < 16; q++) gram[q] = Rr[q];
         gn_pred = ex.sum(gnacc);

@@ -30,7 +30,7 @@ __shared__ __attribute__((aligned(16))) double g_socp_lds[2112];   // + the fuse
 // ... and of the fin instantiation (control_dim = 5: 14 x 25 tiles, 24-column [TA | TBm | TBp]); separate symbols so that the
 // kernels of the reference's model keep their LDS footprint
 __shared__ __attribute__((aligned(16))) double g_socp_lds5[2272];
-#define SCVX_PIPE_LDS5 (2 * 392 + 588 + 392 + 196 + 350 + 364 + 70 + 2 * 46 + 3 * 196 + 8 + 96)
+#define SCVX_PIPE_LDS5 (2 * 392 + 588 + 392 + 392 + 350 + 364 + 70 + 2 * 46 + 3 * 196 + 8 + 96)
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds5[SCVX_PIPE_LDS5];
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds25[SCVX_PIPE_LDS5];
 template <int NU> __device__ __forceinline__ double* socp_lds() { if constexpr (NU == 5) return g_socp_lds5; else return g_socp_lds; }
@@ -40,7 +40,7 @@ template <int NU> __device__ __forceinline__ double* socp_lds() { if constexpr (
 __shared__ __attribute__((aligned(16))) double g_socp_blk_hdr[32];
 // tiles of the two-wavefront factorisation pipeline (multi-wavefront kernels only: a kernel that never references the
 // symbol does not get the allocation)
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 3 * 196 + 8 + 96];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 588 + 392 + 392 + 294 + 308 + 42 + 2 * 42 + 3 * 196 + 8 + 96];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
 #ifndef SCVX_K4_PIPELINE
 #define SCVX_K4_PIPELINE 1
 #endif
