@@ -1627,7 +1627,6 @@ struct Solver {
             return e < 14 ? gx_[nxu_ + 14 * sgk + e] : ry_[14 * sgk + (e - 14)];
         };
         const gptr xq_[4] = {ys, ytr, ynu, dy};
-        const gptr rtr_ = rtr;
         if (w == 1) {   // producer prologue: D_0, node 0 -> TA_0, TBm_0
             for (int e = l; e < 2 * NXU * 4; e += 64) Gn[e] = 0.0;   // columns 0 and 2 stay zero
             ex.w_sync_lds();
@@ -1721,12 +1720,11 @@ struct Solver {
                     ex.w_acc_store_init(cm, Sdk, Hd, hnui_);   // Sd_k = Hxi_{k+1} + hnui I + the products
                     ex.w_acc_store(cr, Rk, 4, 1, false, 4);
                     ex.w_sync_lds();
-                    // the plain parts: column 0 = Sg_k, column 2 = hnui Pnu_k, column 3 += hnui gx_nu,k + ry_k; rtr_k is kept as well
+                    // the plain parts: column 0 = Sg_k, column 2 = hnui Pnu_k, column 3 += hnui gx_nu,k + ry_k
                     if (l < 14) {
                         Rk[4 * l] = Dt[14 * CS + l];
                         Rk[4 * l + 2] = hnui_ * Sg[28 + l];
                         Rk[4 * l + 3] += hnui_ * Sg[l] + Sg[14 + l];
-                        rtr_[14 * k + l] = Rk[4 * l + 1];
                         gnacc += Sg[28 + l] * Sg[l];
                     }
                 }
@@ -2321,7 +2319,6 @@ struct Solver {
             if (!with_pred) return 0.0;
             return e < 14 ? gx_[nxu_ + 14 * sgk + e] : (res ? 0.0 : (double)ry_[14 * sgk + (e - 14)]);
         };
-        const int NSG = res ? 84 : 42;
         for (int e = ex.lane(); e < 2 * NXU * 4 + 56 + 112; e += ex.nlanes()) Gn[e] = 0.0;   // Gn, Rk, Tt (columns 0 and 2 of Gn stay zero)
         ex.sync_lds();
         for (int e = ex.lane(); e < 2 * NXU; e += ex.nlanes()) {
@@ -2363,7 +2360,6 @@ struct Solver {
             if (ex.lane() < 14) yn = y_[(K > 1 ? 14 : 0) + ex.lane()];
         }
         const gptr xq_[4] = {ys, ytr, ynu, dy};
-        const gptr rtr_ = rtr;
         const int hpos_lane = hx_dense_pos(ex.lane() <= HX_SZ ? ex.lane() : 0);
         typename Ex::Acc cg;   // Gram matrix of the forward-substituted right-hand sides (rows / columns 0..3), summed over the segments
         ex.acc_zero(cg);
