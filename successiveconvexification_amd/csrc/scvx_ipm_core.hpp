@@ -140,6 +140,11 @@
 // products, their node slices and stores add ~8 k cycles to each of the 50 dependent steps of the loop (in-kernel timers: loop 19.2 M ->
 // 25.8 M cycles per solve), and a wavefront's time in that loop is NOT hidden behind the other wavefronts' streaming -- the loop's latency
 // and the streamed bytes add up.  Kept as a switch because it is the measurement that says so.
+// newton_corr inlined into attempt_solve (SCVX_HD) or a routine of its own (SCVX_HD_NI: scratch 832 -> 752 B per lane; B = 8192 +0.9 %,
+// B = 1024 -1.3 % -- measured, the headline's choice stays)
+#ifndef SCVX_NEWTON_CORR_ATTR
+#define SCVX_NEWTON_CORR_ATTR SCVX_HD
+#endif
 #ifndef SCVX_FUSED_RES
 #define SCVX_FUSED_RES 0
 #endif
@@ -2862,7 +2867,8 @@ struct Solver {
     // dir_pass computes anyway (CHECK: it also leaves W^-1 of it in tmpc).  The check is then one J' gather and one combination:
     // 0.12 MB.  Same operator form (J' W^-1 W^-1 J dw), same stopping rules; a correction (rare: ~2 per solve) re-runs the direction pass.
     // Returns the largest step to the cone boundary (dir_pass<false>).
-    SCVX_HD double newton_corr() {
+    SCVX_NEWTON_CORR_ATTR double newton_corr() {
+        SCVX_THIS_LDS();
         cone_map_t(tmpc, gx, rx);      // gx = -rx - J' W^-1 Wibz
         mask_fixed(gx);
         SCVX_COUNT(0);
