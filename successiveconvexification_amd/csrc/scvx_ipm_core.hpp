@@ -545,6 +545,7 @@ struct Solver {
     bool p_sigma_cube = false;
     double p_mu_floor = 0.25;   // SCVX_MU_FLOOR (defined where it is used, in attempt_solve)
     double bigvz[2];  // <v, W dz>_1 of the two big cones (corr_dir_pass -> update_pass)
+    double bigvv[2];  // |v1|^2 of the two big cones' scaling vectors (scale_pass / identity_scaling -> build_kkt: no sweep of its own)
     double bigq[2][6]; // body sums of the two big cones from the predictor's direction pass: <l,l>, <l,a>, <a,a>, <v,l>, <v,wr>, <v,a>
                        // (a = W^-1 ds_aff): every reduction corr_rhs_pass needs is a combination of these (no reduction sweep of its own)
     double res_nrx2, res_nry2, res_sgy;   // build_kkt(res): |rx|^2 over the local rows, |ry|^2, Sg . y
@@ -690,11 +691,16 @@ struct Solver {
     // pc / pn (mode 1 only): base - pc Ptr - pn Pnu - E_loc' y, the right-hand side of a solve's final Hb^-1 (kkt_solve)
     // eout (optional): the raw products E_loc' y on the (dx, du) rows as well (the refinement's operator-form check reuses them instead
     // of a second pass over D: newton_corr)
-    SCVX_HD_NI double Et_apply(cgptr yy, gptr g, cgptr base = nullptr, int mode = 0, double pc = 0.0, double pn = 0.0, gptr eout = nullptr) {
+    // n2out (mode 2, the dual residual rx = c + E'y - J'Z): the cost entry (-1 on the final mass) is added, the fixed rows
+    // (rocketland.jl:109-115) are written as zeros and |g|^2 over the local rows is returned through it -- no mask / norm passes after
+    SCVX_HD_NI double Et_apply(cgptr yy, gptr g, cgptr base = nullptr, int mode = 0, double pc = 0.0, double pn = 0.0, gptr eout = nullptr,
+                               double* n2out = nullptr) {
         SCVX_THIS_LDS();
         SCVX_T0();
         const int K = L.K;
         const bool corr = pc != 0.0 || pn != 0.0;
+        const bool resn = n2out != nullptr;
+        double n2 = 0.0;
         cgptr Pt = Wv + L.o_tr + 1; cgptr Pn = Wv + L.o_nu + 1;
         for (int t = ex.lane(); t < L.nx; t += ex.nlanes()) {
             const int k = t / 14, j = t - 14 * k;
@@ -708,6 +714,11 @@ struct Solver {
             if (k > 0) a -= yy[14 * (k - 1) + j];
             if (eout) eout[t] = a;
             if (mode) a = mode == 1 ? b0 - a : a - b0;
+            if (resn) {
+                if (t == 14 * K) a += -1.0;
+                if ((k == 0 && fixed_x(0, j)) || (k == K && fixed_x(K, j))) a = 0.0;
+                n2 += a * a;
+            }
             g[t] = a;
         }
         for (int t = ex.lane(); t < L.nu_; t += ex.nlanes()) {
@@ -726,6 +737,10 @@ struct Solver {
             }
             if (eout) eout[L.nx + t] = a;
             if (mode) a = mode == 1 ? b0 - a : a - b0;
+            if (resn) {
+                if (k == K && fixed_u(K, c)) a = 0.0;
+                n2 += a * a;
+            }
             g[L.nx + t] = a;
         }
         double sg = 0;
@@ -736,10 +751,11 @@ struct Solver {
                        [&](int r, const D4& w) { gn[r] = (w.b - pn * w.d) - w.a; sg += w.c * w.a; });
             else
             stream(0, 14 * K, [&](int r) { const int k = r / 14, i = r - 14 * k; return D3{yy[r], bn[r], D_[(size_t)k * DSZ + 14 * CS + i]}; },
-                   [&](int r, const D3& w) { gn[r] = mode == 0 ? w.a : (mode == 1 ? w.b - w.a : w.a - w.b); sg += w.c * w.a; });
+                   [&](int r, const D3& w) { const double o = mode == 0 ? w.a : (mode == 1 ? w.b - w.a : w.a - w.b); gn[r] = o; n2 += o * o; sg += w.c * w.a; });
         }
         ex.sync();
         SCVX_T1(20);
+        if (resn) *n2out = ex.sum(n2);
         return ex.sum(sg);
     }
 
@@ -798,7 +814,8 @@ struct Solver {
     // hbig: the bodies of the two big cones in z hold wij = W^-1 (J dw) (dir_pass<false, true>); their second scaling
     // W^-1 wij = (-2 vx2 v_i + wij_i) / beta is applied here, on the fly (the heads in z are final)
     // neg (without sub): g = -J' z
-    SCVX_HD_NI void cone_map_t(cgptr z, gptr g, cgptr sub = nullptr, bool hbig = false, bool neg = false) {
+    // mask: the fixed rows (rocketland.jl:109-115) are written as zeros (what a mask_fixed pass after it would do)
+    SCVX_HD_NI void cone_map_t(cgptr z, gptr g, cgptr sub = nullptr, bool hbig = false, bool neg = false, bool mask = false) {
         SCVX_THIS_LDS();
         SCVX_T0();
         const int K = L.K;
@@ -841,8 +858,9 @@ struct Solver {
                 double sb[NXU];
                 for (int j = 0; j < 14; j++) sb[j] = sub[14 * k + j];
                 for (int c = 0; c < NU; c++) sb[14 + c] = sub[L.nx + NU * k + c];
-                for (int j = 0; j < 14; j++) gx_[j] = -sb[j] - gl[j];
-                for (int c = 0; c < NU; c++) gu[c] = -sb[14 + c] - gl[14 + c];
+                const bool m0 = mask && k == 0, mK = mask && k == K;
+                for (int j = 0; j < 14; j++) gx_[j] = ((m0 && fixed_x(0, j)) || (mK && fixed_x(K, j))) ? 0.0 : -sb[j] - gl[j];
+                for (int c = 0; c < NU; c++) gu[c] = (mK && fixed_u(K, c)) ? 0.0 : -sb[14 + c] - gl[14 + c];
             } else {
                 const double sg = neg ? -1.0 : 1.0;
                 for (int j = 0; j < 14; j++) gx_[j] = sg * gl[j];
@@ -925,6 +943,7 @@ struct Solver {
             Wv[L.o_nu] = 1.0; Wv[L.o_tr] = 1.0; Wv[L.o_sg] = 1.0; Wv[L.o_rk] = 1.0;
             Wbeta[L.c_nu] = Wbeta[L.c_tr] = Wbeta[L.c_sg] = Wbeta[L.c_rk] = 1.0;
         }
+        bigvv[0] = bigvv[1] = 0.0;
         ex.sync();
     }
     // out = W in  /  W^-1 in   (cone vectors; in may alias out)
@@ -1085,6 +1104,7 @@ struct Solver {
                        vz += vi * w.b; vr += vi * ri; vv += vi * vi; g1 += w.a * w.b; n1 += ri * ri;
                    });
             vz = ex.sum(vz); vr = ex.sum(vr); vv = ex.sum(vv);
+            bigvv[q] = vv;
             gap += g1; nrz2 += n1;
             if (ex.lane() == 0) { gap += s0 * z0; nrz2 += r0 * r0; }
             const double vxz = v0 * z0 + vz;                       // lam = W z
@@ -1329,6 +1349,10 @@ struct Solver {
         }
         ex.sync();
         for (int i = L.nloc + ex.lane(); i < L.nv; i += ex.nlanes()) Vn[i] = V_[i] + alpha * dw_[i];   // the four global variables
+        {   // ... and the multipliers
+            const gptr y_ = y; const cgptr dy_ = dy;
+            stream(0, L.ny, [&](int i) { return D2{y_[i], dy_[i]}; }, [&](int i, const D2& v) { y_[i] = v.a + alpha * v.b; });
+        }
         ex.sync();
         SCVX_T1(23);
     }
@@ -2058,14 +2082,7 @@ struct Solver {
         SCVX_COUNT(3);
         // big-cone scalars
         {
-            const int dn = 14 * K + 1, dt = NXU * (K + 1) + 1;
-            double n1 = 0, n2 = 0;
-            {
-                cgptr wn = Wv + L.o_nu; cgptr wt = Wv + L.o_tr;
-                stream<8>(1, dn, [&](int i) { return wn[i]; }, [&](int, double v) { n1 += v * v; });
-                stream<8>(1, dt, [&](int i) { return wt[i]; }, [&](int, double v) { n2 += v * v; });
-            }
-            n1 = ex.sum(n1); n2 = ex.sum(n2);
+            const double n1 = bigvv[0], n2 = bigvv[1];   // |v1|^2 of the nu / trust-region cone: summed by the pass that formed the scaling
             soc_w2(Wv[L.o_nu], n1, Wbeta[L.c_nu], h_nu[0], h_nu[1], h_nu[2], h_nu[3]);
             soc_w2(Wv[L.o_tr], n2, Wbeta[L.c_tr], h_tr[0], h_tr[1], h_tr[2], h_tr[3]);
             hnui = 1.0 / h_nu[3];
@@ -2869,8 +2886,7 @@ struct Solver {
     // Returns the largest step to the cone boundary (dir_pass<false>).
     SCVX_NEWTON_CORR_ATTR double newton_corr() {
         SCVX_THIS_LDS();
-        cone_map_t(tmpc, gx, rx);      // gx = -rx - J' W^-1 Wibz
-        mask_fixed(gx);
+        cone_map_t(tmpc, gx, rx, false, false, true);      // gx = -rx - J' W^-1 Wibz, fixed rows zero
         SCVX_COUNT(0);
         const int nref = cur_gate < SCVX_REFINE_FROM ? C.refine : 0;
         if (nref == 0) {
@@ -3153,18 +3169,14 @@ struct Solver {
             bool kkt_ok = true;
             if (!fused) {
                 cone_map_t(Z, rx);
-                const double sgy = Et_apply(y, rx, rx, 2);     // rx = E'y - J'Z on the local part
-                if (ex.lane() == 0) {
-                    rx[14 * K] += -1.0;
-                    rx[L.iS] = -rx[L.iS] + sgy;
-                    rx[L.iTNU] = C.wNu - rx[L.iTNU];
-                    rx[L.iTTR] = 0.5 - rx[L.iTTR];
-                    rx[L.iTS] = 1.0 - rx[L.iTS];
-                }
+                double nrx2 = 0.0;
+                const double sgy = Et_apply(y, rx, rx, 2, 0.0, 0.0, nullptr, &nrx2);     // rx = c + E'y - J'Z on the local part, masked, with its norm
+                const double g0 = -rx[L.iS] + sgy, g1 = C.wNu - rx[L.iTNU], g2 = 0.5 - rx[L.iTTR], g3 = 1.0 - rx[L.iTS];
+                ex.sync();   // every lane holds the four global entries before lane 0 overwrites them
+                if (ex.lane() == 0) { rx[L.iS] = g0; rx[L.iTNU] = g1; rx[L.iTTR] = g2; rx[L.iTS] = g3; }
                 ex.sync();
-                mask_fixed(rx);
                 const double nry2 = E_apply(V, ry, true, dk, 1.0);   // ry = E V + dk
-                nrx = sqrt(sumsq(rx, L.nv)); nry = sqrt(nry2);
+                nrx = sqrt(nrx2 + (g0 * g0 + g1 * g1 + g2 * g2 + g3 * g3)); nry = sqrt(nry2);
             } else {
                 cone_map_t(Z, rx, nullptr, false, true);             // rx = -J'Z ...
                 if (ex.lane() == 0) {                                // ... + c (the s row still lacks Sg . y)
@@ -3210,8 +3222,7 @@ struct Solver {
             if (it - best_it >= SCVX_STALL_ITERS && best_merit < 1e-5) { res.status = stop_status(2); break; }
             if (it == C.max_iter) { res.status = stop_status(1); break; }
             if (!fused) {
-                cone_map_t(tmpc, gx, rx);      // predictor right-hand side gx = -rx - J' W^-1 (lam - W^-1 rz), solved with the border
-                mask_fixed(gx);
+                cone_map_t(tmpc, gx, rx, false, false, true);   // predictor right-hand side gx = -rx - J' W^-1 (lam - W^-1 rz), fixed rows zero; solved with the border
                 kkt_ok = build_kkt(true);
             }
             if (!kkt_ok) { SCVX_DBG("    factorisation failed\n"); res.status = stop_status(2); break; }
@@ -3255,12 +3266,10 @@ struct Solver {
             if (!(alpha == alpha)) { res.status = stop_status(3); break; }
             if (alpha < 1e-9) { res.status = stop_status(2); break; }
             {
-                const gptr Vn = best_in_V ? Vbest : V; gptr y_ = y; cgptr dy_ = dy;
-                update_pass(alpha, Vn);   // S, Z (from the old V) and the new V
+                const gptr Vn = best_in_V ? Vbest : V;
+                update_pass(alpha, Vn);   // S, Z (from the old V), the new V and y
                 if (best_in_V) { Vbest = V; V = Vn; best_in_V = false; }   // Vbest now holds the best iterate, V the new one
-                stream(0, L.ny, [&](int i) { return D2{y_[i], dy_[i]}; }, [&](int i, const D2& v) { y_[i] = v.a + alpha * v.b; });
             }
-            ex.sync();
         }
         res.merit = best_merit;
         if (best_it > 0 && !best_in_V) V = Vbest;   // the caller reads the solution through V

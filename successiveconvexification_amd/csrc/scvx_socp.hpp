@@ -32,7 +32,7 @@ __shared__ __attribute__((aligned(16))) double g_socp_lds[2112];   // + the fuse
 __shared__ __attribute__((aligned(16))) double g_socp_lds5[2272];
 #define SCVX_PIPE_LDS5 (2 * 392 + 588 + 392 + 392 + 350 + 364 + 70 + 2 * 46 + 3 * 196 + 8 + 96)
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds5[SCVX_PIPE_LDS5];
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds25[SCVX_PIPE_LDS5];
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds25[SCVX_PIPE_LDS5 - 196];   // the second tile set (two-ended form) keeps a single N tile
 template <int NU> __device__ __forceinline__ double* socp_lds() { if constexpr (NU == 5) return g_socp_lds5; else return g_socp_lds; }
 // The multi-wavefront kernels factorise through the pipeline's own tiles (g_socp_pipe_lds*) and need only the 32-double header of the
 // scratch (reduction partials, flags): a symbol of their own, so that they do not carry the single-wavefront kernel's tile space
