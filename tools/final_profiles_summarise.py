@@ -5,7 +5,13 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import lib_hash
 tag, h = sys.argv[1], sys.argv[2]
 go = os.path.join(ROOT, "gpurun_out")
-stats = glob.glob(os.path.join(go, tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
+def newest(pattern):
+    """gpurun MERGES a run's files into the local gpurun_out/: a directory may still hold an earlier run's files -- only the newest counts"""
+    fs = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return fs[-1:]
+
+
+stats = newest(os.path.join(go, tag + "_stats", "**", "*kernel_stats.csv"))
 assert stats, "no kernel_stats.csv under gpurun_out/%s_stats" % tag
 dst = os.path.join(ROOT, "profiles", "%s_kernel_stats_B8192.csv" % tag)
 shutil.copy(stats[0], dst)
@@ -18,7 +24,7 @@ for l in open(os.path.join(go, tag + "_pmc_FETCH_SIZE.log")):
 assert meta, "tools/pmc_period.py did not print its counters"
 tot = collections.defaultdict(lambda: collections.defaultdict(float)); launches = collections.Counter()
 for G in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob(os.path.join(go, "%s_pmc_%s" % (tag, G), "**", "*_counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(go, "%s_pmc_%s" % (tag, G), "**", "*_counter_collection.csv")):
         seen = set()
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
