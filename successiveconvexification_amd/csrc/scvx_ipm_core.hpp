@@ -142,6 +142,13 @@
 // and the streamed bytes add up.  Kept as a switch because it is the measurement that says so.
 // newton_corr inlined into attempt_solve (SCVX_HD) or a routine of its own (SCVX_HD_NI: scratch 832 -> 752 B per lane; B = 8192 +0.9 %,
 // B = 1024 -1.3 % -- measured, the headline's choice stays)
+// the big cones' reduction sums carried from update_pass to the next scale_pass (1) or re-taken by two sweeps per cone (0).  MEASURED
+// AND OFF (round 5): -0.9 % at B = 8192 and B = 1024 (four sweeps less per iteration), same iteration counts on the sample problems,
+// but first failures over 40 random classes 1.42 % -> 1.56 % single-attempt with 7 non-finite exits (the expanded sums cancel where a
+// cone's s and z are not yet near-complementary): not worth the robustness.
+#ifndef SCVX_CARRY_BIGSUMS
+#define SCVX_CARRY_BIGSUMS 0
+#endif
 #ifndef SCVX_NEWTON_CORR_ATTR
 #define SCVX_NEWTON_CORR_ATTR SCVX_HD
 #endif
@@ -545,6 +552,11 @@ struct Solver {
     bool p_sigma_cube = false;
     double p_mu_floor = 0.25;   // SCVX_MU_FLOOR (defined where it is used, in attempt_solve)
     double bigvz[2];  // <v, W dz>_1 of the two big cones (corr_dir_pass -> update_pass)
+    // Body sums of the two big cones' NEW iterate, taken by update_pass while it writes it: <s,s>, <z,z>, <s,z>, <s,r>, <z,r>, <r,r> with
+    // r = s - a(V).  The next scale_pass forms every scalar of the scaling from them (its two reduction sweeps over s, z, V are not
+    // run); bigs_ok says the sums describe S / Z / V as they stand (cleared when a solve starts).
+    double bigs[2][6];
+    bool bigs_ok;
     double bigvv[2];  // |v1|^2 of the two big cones' scaling vectors (scale_pass / identity_scaling -> build_kkt: no sweep of its own)
     double bigq[2][6]; // body sums of the two big cones from the predictor's direction pass: <l,l>, <l,a>, <a,a>, <v,l>, <v,wr>, <v,a>
                        // (a = W^-1 ds_aff): every reduction corr_rhs_pass needs is a combination of these (no reduction sweep of its own)
@@ -1084,9 +1096,13 @@ struct Solver {
             const BigCone bc = big_cone(q);
             const cgptr s = S_ + bc.off; const cgptr z = Z_ + bc.off; const cgptr ab = V_ + bc.body - 1;   // ab[i] = a_i, i >= 1
             double a = 0, b = 0, c = 0;
-            stream(1, bc.dim, [&](int i) { return D2{s[i], z[i]}; },
-                   [&](int, const D2& v) { a += v.a * v.a; b += v.b * v.b; c += v.a * v.b; });
-            a = ex.sum(a); b = ex.sum(b); c = ex.sum(c);
+            const bool carried = SCVX_CARRY_BIGSUMS != 0 && bigs_ok;
+            if (carried) { a = bigs[q][0]; b = bigs[q][1]; c = bigs[q][2]; }
+            else {
+                stream(1, bc.dim, [&](int i) { return D2{s[i], z[i]}; },
+                       [&](int, const D2& v) { a += v.a * v.a; b += v.b * v.b; c += v.a * v.b; });
+                a = ex.sum(a); b = ex.sum(b); c = ex.sum(c);
+            }
             const double s0 = s[0], z0 = z[0], r0 = s0 - V_[bc.head];
             const double sj = sqrt(s0 * s0 - a), zj = sqrt(z0 * z0 - b);
             const double isj = 1.0 / sj, izj = 1.0 / zj;
@@ -1098,12 +1114,22 @@ struct Solver {
             const double igd = ig * den;
             // second reduction: products with v (v_i = (s_i / sj - z_i / zj) ig den needs the scalars above)
             double vz = 0, vr = 0, vv = 0, g1 = 0, n1 = 0;
+            if (carried) {
+                // v_i = (s_i / sj - z_i / zj) ig den: its products with z, r and itself from the carried sums (at a near-complementary pair
+                // <s,z> < 0 and every term below has one sign: nothing cancels)
+                const double sr = bigs[q][3], zr = bigs[q][4];
+                vz = (c * isj - b * izj) * igd;
+                vr = (sr * isj - zr * izj) * igd;
+                vv = ((a * isj) * isj - 2.0 * (c * isj) * izj + (b * izj) * izj) * (igd * igd);
+                if (ex.lane() == 0) { gap += c; nrz2 += bigs[q][5]; }   // lane-local partials: counted once
+            } else {
             stream(1, bc.dim, [&](int i) { return D3{s[i], z[i], ab[i]}; },
                    [&](int, const D3& w) {
                        const double vi = (w.a * isj - w.b * izj) * igd, ri = w.a - w.c;
                        vz += vi * w.b; vr += vi * ri; vv += vi * vi; g1 += w.a * w.b; n1 += ri * ri;
                    });
             vz = ex.sum(vz); vr = ex.sum(vr); vv = ex.sum(vv);
+            }
             bigvv[q] = vv;
             gap += g1; nrz2 += n1;
             if (ex.lane() == 0) { gap += s0 * z0; nrz2 += r0 * r0; }
@@ -1336,12 +1362,18 @@ struct Solver {
             const double s0 = s[0], z0 = z[0], a0 = V_[bc.head], d0 = dw_[bc.head];
             ex.sync();   // every lane holds the heads before lane 0 overwrites them
             const gptr vnb = Vn + bc.body - 1;
+            double q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
             stream(1, bc.dim, [&](int i) { return D6{s[i], z[i], v[i], b[i], ab[i], db[i]}; },
                    [&](int i, const D6& w) {
-                       s[i] = w.a + alpha * (w.f - (w.a - w.e));
-                       z[i] = w.b + alpha * ((-2.0 * vx * w.c + w.d) * ibeta);
-                       vnb[i] = w.e + alpha * w.f;
+                       const double sn = w.a + alpha * (w.f - (w.a - w.e));
+                       const double zn = w.b + alpha * ((-2.0 * vx * w.c + w.d) * ibeta);
+                       const double vn = w.e + alpha * w.f;
+                       s[i] = sn; z[i] = zn; vnb[i] = vn;
+                       const double rn = sn - vn;
+                       q0 += sn * sn; q1 += zn * zn; q2 += sn * zn; q3 += sn * rn; q4 += zn * rn; q5 += rn * rn;
                    });
+            bigs[q][0] = ex.sum(q0); bigs[q][1] = ex.sum(q1); bigs[q][2] = ex.sum(q2);
+            bigs[q][3] = ex.sum(q3); bigs[q][4] = ex.sum(q4); bigs[q][5] = ex.sum(q5);
             if (ex.lane() == 0) {
                 s[0] = s0 + alpha * (d0 - (s0 - a0));
                 z[0] = z0 + alpha * ((2.0 * vx * v0 - b0) * ibeta);
@@ -1349,6 +1381,7 @@ struct Solver {
         }
         ex.sync();
         for (int i = L.nloc + ex.lane(); i < L.nv; i += ex.nlanes()) Vn[i] = V_[i] + alpha * dw_[i];   // the four global variables
+        bigs_ok = true;
         {   // ... and the multipliers
             const gptr y_ = y; const cgptr dy_ = dy;
             stream(0, L.ny, [&](int i) { return D2{y_[i], dy_[i]}; }, [&](int i, const D2& v) { y_[i] = v.a + alpha * v.b; });
@@ -3054,6 +3087,7 @@ struct Solver {
             if (bad) { res.status = 5; return res; }
         }
         cur_gate = INFINITY;
+        bigs_ok = false;
         // ... and only while the kept iterate lies inside the new radius (Jtr_w < SCVX_WARM_RADIUS rk): then the radius row is
         // inactive or barely active and the old central path is (nearly) the new one -- 7 iterations instead of 19.  Once the radius
         // binds in earnest the kept iterate is far from the new path and a warm start costs MORE than a cold one (33 vs 21 measured);
