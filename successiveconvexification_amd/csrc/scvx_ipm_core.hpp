@@ -539,7 +539,7 @@ struct Solver {
     gptr tchain;
     dptr At;   // A_k' copies, in the element type of D (a float D uses half of the slot)
     gptr ys, ytr, ynu;   // the three border multipliers  S y = Sg, E Hb^-1 Ptr, hnui Pnu
-    gptr ptl, rtr;       // ptl = Hb^-1 Ptr (local, zero on nu),  rtr = E ptl
+    gptr ptl, rtr;       // ptl = Hb^-1 Ptr (local, zero on nu),  rtr = E ptl (formed only for the y-space border of the two-ended factorisation)
     gptr tmpl, tmpl2;
     gptr uhat, lb0;
     gptr wh, Vw, yw, Sw, Zw;   // warm-start iterate of the last solve (wh[0] = 1: valid), see SCVX_WARM_SAVE
@@ -1645,9 +1645,10 @@ struct Solver {
     //   consumer k:  M = Sd_k - Wb_{k-1} Wb_{k-1}';  L^-1 = chol_inv(M);  store L^-1;  Nf_k = -L^-1 Wb_{k-1};  Wb_k = So_k L^-T
     // Since round 4 the pipeline also carries the border (as the sequential loop of build_kkt does, see there): the assembly wavefront
     // forms r_k = (E Hb^-1 g)_k for the four right-hand sides from the tiles it holds, and the CHAIN wavefront -- which used to wait
-    // two thirds of every step at the hand-over barrier -- stores L_k^-1, forms and stores N_k, and runs the forward substitution
-    // t_k = L_k^-1 r_k + N_k t_{k-1}; the separate post stage is gone.  (Measured at B = 1,024, two wavefronts per trajectory:
-    // the assembly wavefront was the bottleneck with 7.5 k cycles per step of which 4.3 k post stage; profiles/r04_k4_sections_small.txt.)
+    // two thirds of every step at the hand-over barrier -- stores L_k^-1 and forms and stores N_k; the separate post stage is gone.
+    // (Measured at B = 1,024, two wavefronts per trajectory: the assembly wavefront was the bottleneck with 7.5 k cycles per step of
+    // which 4.3 k post stage; profiles/r04_k4_sections_small.txt.)  The forward substitution t_k = L_k^-1 r_k + N_k t_{k-1} ran on the chain
+    // wavefront too in round 4; round 5 made the assembly stage cheap enough that it went back there (see fwd_subst below).
     template <class E2 = Ex>
     SCVX_HD_NI bool factor_pipelined(bool with_pred) {
         SCVX_THIS_LDS();
