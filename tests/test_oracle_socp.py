@@ -274,3 +274,33 @@ def test_twin_on_random_problem_classes_matches_independent_oracle(cls):
     o1, cnu, cdel = oscvx.solve_step(oscvx.create_initial(p, 4, ic[tr, :3], ic[tr, 3:]))
     assert o["rk"][tr] == o1.rk
     assert np.abs(o["x"][tr] - o1.x).max() < 5e-5 and np.abs(o["u"][tr] - o1.u).max() < 5e-5 and abs(o["sigma"][tr] - o1.sigma) < 5e-5
+
+
+def test_twin_switchable_variants_of_the_core_still_solve_the_same_problems(tmp_path):
+    """The measured-and-left-off forms of the conic solver's core stay behind compile-time switches (scvx_ipm_core.hpp: SCVX_FUSED_RES --
+    E'y / E V formed inside the factorisation loop; SCVX_CARRY_BIGSUMS -- the big cones' reduction sums carried from update_pass to the
+    next scale_pass).  They are the evidence for profiles/r05_k4_byte_budget.md, so they must keep working: the host twin built with
+    both switched on runs three solve_steps of four dispersed trajectories to the same accept / reject decisions, every solve OPTIMAL,
+    iterates within 1e-6 of the default build's (same algorithm, different association of the sums)."""
+    import ctypes
+    import os
+    import subprocess
+    import oracle
+    from oracle import model, port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "liboracle_port_variants.so")
+    subprocess.run(["g++", "-O2", "-fPIC", "-fopenmp", "-ffp-contract=off", "-std=c++17", "-DSCVX_FUSED_RES=1", "-DSCVX_CARRY_BIGSUMS=1",
+                    "-shared", "-o", so, os.path.join(root, "oracle", "scvx_port.cpp"), "-lm"], check=True, capture_output=True)
+    p = model.base_prob_scaled()
+    ic = model.disperse_ics(p, 4, 20261004)
+    ref = port.scvx_steps(p, ic, 3, warm_start=True, nthreads=2)
+    keep = oracle._PORT
+    try:
+        oracle._PORT = ctypes.CDLL(so)
+        var = port.scvx_steps(p, ic, 3, warm_start=True, nthreads=2)
+    finally:
+        oracle._PORT = keep
+    assert all((s == 0).all() for s in var["status"])
+    assert np.array_equal(np.array(var["rejected"]), np.array(ref["rejected"]))
+    assert np.abs(var["x"] - ref["x"]).max() < 1e-6 and np.abs(var["u"] - ref["u"]).max() < 1e-6
+    assert abs(np.mean(var["iters"]) - np.mean(ref["iters"])) < 1.0
