@@ -672,8 +672,10 @@ def main():
                 if lin32:
                     b2.set_linearization_f32(True)
                 b2.init(shard.ic)
-                t2, _ = timed_steps(b2)
-                out = {"value": B * steps / t2, "unit": "traj-iter/s", "ms_per_step": 1e3 * t2 / steps}
+                t2, _ = timed_steps(b2, lambda: b2.step_stats(reset=True))
+                ts2 = b2.step_stats(reset=True)
+                out = {"value": B * steps / t2, "unit": "traj-iter/s", "ms_per_step": 1e3 * t2 / steps,
+                       "ipm_iters_mean": ts2["ipm_iters"] / max(ts2["solves"], 1.0), "failed_steps": int(ts2["failed"])}
                 if lin32:   # how far the mixed-precision iterates are from the fp64 run's after the same steps
                     s2, i2, m2, _ = b2.solver_stats()
                     out["optimal_frac"] = float(np.mean(s2 == 0))
@@ -696,7 +698,9 @@ def main():
                 # (profiles/r05_tol_sweep.md).  The throughput AT the loosest tolerance that meets 1e-5, with its own parity figure:
                 line["value_at_traj_linf_1e-5"] = dict(variant(tol=3e-10), solver_tol=3e-10,
                                                        traj_linf_vs_oracle=traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts, tol=3e-10),
-                                                       note="the same timed region with scvx_solver_opts.tol = 3e-10 on the device AND in the oracle "
+                                                       note="failed_steps = solve_steps of the timed region whose conic solve ended above the tolerance on its numerical floor "
+                                                            "(the trajectory is frozen, as the reference's error() would stop it): a handful per 114,688 at this tolerance, none at 1e-8.  "
+                                                            "The same timed region with scvx_solver_opts.tol = 3e-10 on the device AND in the oracle "
                                                             "(tests/golden/oracle_scvx_full_tol3e-10.npz): the fastest setting of profiles/r05_tol_sweep.md "
                                                             "whose complete solve_problem stays within 1e-5 of the oracle's")
             line["cold_start_only"] = dict(variant(warm_start=False), note="warm_start = 0: every conic solve starts from the "
