@@ -15,6 +15,11 @@
 #ifndef SCVX_CHOL_FUSED_INV
 #define SCVX_CHOL_FUSED_INV 0
 #endif
+// WaveExT::chol_inv14's broadcasts: 0 = v_readlane through an SGPR pair (rounds 1-5), 1 = DPP row_newbcast (v_mov_b64_dpp + v_fma_f64),
+// 2 = folded into the FMA (v_fmac_f64_dpp, inline asm).  Bit-identical results; measurements in profiles/r06_chol_dpp.md.
+#ifndef SCVX_CHOL_DPP
+#define SCVX_CHOL_DPP 2
+#endif
 #ifndef SCVX_CHAIN_R
 #define SCVX_CHAIN_R 8   // steps of the block recurrence whose operands are in flight (10 VGPRs each)
 #endif
@@ -194,6 +199,94 @@ struct WaveExT {
     // Li = L^-1 (row-major, lower) where L L' = M, for the 14x14 SPD pivot tile in LDS.  Lane i keeps row i of
     // M/L in VGPRs; pivots, column entries and the rows needed by the inversion travel by readlane:
     // 105 broadcasts for the factorisation, 105 for the inverse, no barrier inside.
+#if SCVX_CHOL_DPP
+    // Round 6: the same factorisation and inverse with every broadcast a DPP row_newbcast inside the 16-lane rows of the wavefront
+    // (gfx90a+: `v_mov_b64_dpp ... row_newbcast:n` delivers lane n of each row to the whole row; `v_fmac_f64_dpp` applies it to an
+    // operand of the FMA itself).  Lane (l & 15) holds row (l & 15) of M / L, the four rows of 16 lanes work on identical copies.
+    // v_readlane went through an SGPR pair: 2 x v_readlane_b32 and the SGPR-read hazard per broadcast, 420 of them per block; here a
+    // broadcast is one VALU instruction (SCVX_CHOL_DPP = 1: v_mov_b64_dpp + v_fma_f64) or none at all (= 2: v_fmac_f64_dpp).
+    // Same products in the same order as the v_readlane form: bit-identical results.
+    template <int N> static __device__ __forceinline__ double rbc(double x) {
+        return __builtin_amdgcn_update_dpp(x, x, 0x150 + N, 0xf, 0xf, true);
+    }
+    // acc -= (value of s in lane N of this row) * b
+    template <int N> static __device__ __forceinline__ void fnma_rbc(double& acc, double s, double b) {
+#if SCVX_CHOL_DPP == 2
+        asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s), "v"(b), "n"(N));
+#else
+        acc = fma(-rbc<N>(s), b, acc);
+#endif
+    }
+    template <int J, int C> struct CholTrail {   // m[c] -= L[i][J] L[c][J] for c = C .. 13
+        static __device__ __forceinline__ void run(double (&m)[14]) {
+            if constexpr (C < 14) { fnma_rbc<C>(m[C], m[J], m[J]); CholTrail<J, C + 1>::run(m); }
+        }
+    };
+    // Column step J, software-pipelined by hand: the trailing update of column J - 1 on the PIVOT column (c = J) was issued at the end of
+    // step J - 1; step J starts the pivot chain (row broadcast, v_rsq_f64, two Newton steps: ~100 dependent cycles) and the rest of
+    // column J - 1's trailing updates (c > J) are issued into that chain's latency instead of ahead of it.
+    template <int J> struct CholCol {
+        static __device__ __forceinline__ void run(double (&m)[14], double floor_, int i, bool& ok) {
+            if constexpr (J < 14) {
+                const double d0 = rbc<J>(m[J]);
+                ok = ok && (d0 == d0);
+                const double d = fmax(d0, floor_);
+                double ip = __builtin_amdgcn_rsq(d);
+                if constexpr (J > 0) CholTrail<J - 1, J + 1>::run(m);   // deferred: columns c > J of the previous step
+                const double hd = 0.5 * d;
+                ip = fma(ip, fma(-hd * ip, ip, 0.5), ip);
+                ip = fma(ip, fma(-hd * ip, ip, 0.5), ip);
+                // The diagonal entry L[J][J] is never read again (the trailing updates and the inverse only use the strictly lower
+                // triangle), so lane J keeps 1 / L[J][J] in its place: the inverse fetches it from there by one more row broadcast, and
+                // the 14 reciprocals cost neither VGPRs nor SGPRs (the v_readlane form held them in 28 VGPRs).
+                m[J] = (i == J) ? ip : m[J] * ip;
+#if SCVX_CHOL_DPP == 2
+                // a VALU write of a VGPR must be two wait states ahead of a DPP read of it, and the hazard recogniser does not look inside
+                // asm: the column passes THROUGH the nop (in / out operand), so every v_fmac_f64_dpp below depends on it
+                asm volatile("s_nop 1" : "+v"(m[J]));
+#endif
+                if constexpr (J + 1 < 14) fnma_rbc<J + 1>(m[J + 1], m[J], m[J]);   // the next pivot's column first
+                CholCol<J + 1>::run(m, floor_, i, ok);
+            }
+        }
+    };
+    template <int A, int T> struct InvAcc {   // acc -= L[A][t] x[t] for t = T .. A-1
+        static __device__ __forceinline__ void run(double& acc, const double (&m)[14], const double (&x)[14]) {
+            if constexpr (T < A) { fnma_rbc<A>(acc, m[T], x[T]); InvAcc<A, T + 1>::run(acc, m, x); }
+        }
+    };
+    template <int A> struct InvRow {
+        static __device__ __forceinline__ void run(const double (&m)[14], double (&x)[14], int i) {
+            if constexpr (A < 14) {
+                // (row A's terms t < A - 1 do not depend on x[A - 1]: the scheduler runs them under the previous row's tail)
+                double acc = (A == i) ? 1.0 : 0.0;
+                InvAcc<A, 0>::run(acc, m, x);
+                x[A] = (A >= i) ? acc * rbc<A>(m[A]) : 0.0;
+                InvRow<A + 1>::run(m, x, i);
+            }
+        }
+    };
+    __device__ __forceinline__ bool chol_inv14(const double* M, double* Li) {
+        const int i = lane() & 15;
+        const int r = i < 14 ? i : 13;
+        double m[14];
+#pragma unroll
+        for (int c = 0; c < 14; c++) m[c] = M[14 * r + c];
+        double dmax = 0.0;
+#pragma unroll
+        for (int j = 0; j < 14; j++) dmax = fmax(dmax, M[15 * j]);
+        const double floor_ = fmax(1e-13 * dmax, 1e-300);
+        bool ok = dmax > 0.0;
+        CholCol<0>::run(m, floor_, i, ok);
+        double x[14];
+        InvRow<0>::run(m, x, i);
+        if (lane() < 14) {
+#pragma unroll
+            for (int a = 0; a < 14; a++) Li[14 * a + i] = x[a];
+        }
+        return ok;
+    }
+#else
     __device__ __forceinline__ bool chol_inv14(const double* M, double* Li) {
         const int i = lane();
         const int r = i < 14 ? i : 13;
@@ -283,6 +376,7 @@ struct WaveExT {
         return ok;
 #endif
     }
+#endif   // SCVX_CHOL_DPP
 
     // out_k = z_k + N_k out_{k-1} (forward) / out_k = z_k + N_{k+1}' out_{k+1} (reverse) for NR right-hand sides at
     // once: the only sequential part of the block-tridiagonal solve, run entirely on the FP64 matrix pipe.
