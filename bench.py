@@ -61,6 +61,17 @@ def k1_measured_traffic(B):
             best = {"bytes": (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 / n, "source": os.path.basename(f)}
         except Exception:
             pass
+    # the round's own passes are over the bench MIX (tools/final_profiles.sh): there a K1 launch inside a step skips the trajectories whose
+    # step was rejected, so its per-launch mean is below a full launch's -- reported beside the full-launch figure, not instead of it
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_mix_B%d.json" % B))):
+        try:
+            ks = json.load(open(f))["kernels"]
+            k = next(v for name, v in ks.items() if "linearize" in name)
+            n = k["launches_in_fetch_pass"]
+            if best is not None:
+                best = dict(best, mix_bytes=(2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 / n, mix_source=os.path.basename(f))
+        except Exception:
+            pass
     return best
 
 
@@ -165,12 +176,12 @@ def oracle_full_run_fixture(tol):
     return os.path.join(ROOT, "tests", "golden", "oracle_scvx_full.npz" if abs(tol - 1e-9) < 1e-24 else "oracle_scvx_full_tol%g.npz" % tol)
 
 
-def traj_linf_vs_oracle(cache_cls, batch_cls, prob, npts, tol=None, same_tol=False):
+def traj_linf_vs_oracle(cache_cls, batch_cls, prob, npts, tol=None):
     """Second half of the headline metric ("traj L-inf vs ref"): a complete Rocketland.solve_problem of the sample
     problem (B = 1, imax-1 = 14 solve_steps) on the device against the oracle's recorded run, a committed fixture
     (tests/golden/oracle_scvx_full*.npz — data; generated by tests/golden/make_oracle_full_run.py).  Outside the timed region.
     tol = None: the device at its default (1e-8) against the oracle at ITS default (1e-9) -- rounds 1-4's figure.
-    same_tol (or any explicit tol): device and oracle at the same tolerance."""
+    An explicit tol: device and oracle at that same tolerance."""
     f = oracle_full_run_fixture(1e-9) if tol is None else oracle_full_run_fixture(tol)
     if not os.path.exists(f) or npts != 10:
         return None
@@ -191,6 +202,41 @@ def traj_linf_vs_oracle(cache_cls, batch_cls, prob, npts, tol=None, same_tol=Fal
     return {"x": wx, "u": wu, "sigma": ws, "solve_steps": int(len(g["log"])), "same_accept_reject_sequence": bool(same),
             "solver_tol": {"device": 1e-8 if tol is None else tol, "oracle": 1e-9 if tol is None else tol},
             "ref": "oracle (IPM on the exact build_model rows + RK4 npts=10); parity with the Julia reference itself is unpinned"}
+
+
+def traj_linf_vs_oracle_batch32(cache, batch_cls, B, ic, seed):
+    """The same figure on the HEADLINE batch (round 6): all B = 8192 dispersed trajectories run a complete solve_problem (14 solve_steps) on the
+    device and 32 of them, indices spread over 0 ... 8191, are compared with the independent oracle's recorded runs at the same solver tolerance
+    (tests/golden/oracle_scvx_batch32_tol1e-08.npz, made by tests/golden/make_oracle_batch_runs.py) at EVERY step: radius schedule (= accept /
+    reject / grow decisions) and iterates, by component group.  Outside the timed region."""
+    f = os.path.join(ROOT, "tests", "golden", "oracle_scvx_batch32_tol1e-08.npz")
+    if not os.path.exists(f):
+        return None
+    g = np.load(f)
+    if B != int(g["B"]) or seed != int(g["seed"]) or not np.array_equal(ic[g["index"]], g["ic"]):
+        return None
+    idx, log = g["index"], g["log"]
+    b = batch_cls(cache, B).init(ic)
+    worst = {"m_r_v": 0.0, "q_omega": 0.0, "u": 0.0, "sigma": 0.0}
+    same = True
+    for n in range(log.shape[1]):
+        b.solve_step()
+        x, u, s = b.trajectory()
+        rk, _, _ = b.scalars()
+        same = same and bool(np.array_equal(rk[idx], log[:, n, 3]))
+        d = np.abs(x[idx] - g["xs"][:, n])
+        worst["m_r_v"] = max(worst["m_r_v"], float(d[..., :7].max()))
+        worst["q_omega"] = max(worst["q_omega"], float(d[..., 7:].max()))
+        worst["u"] = max(worst["u"], float(np.abs(u[idx] - g["us"][:, n]).max()))
+        worst["sigma"] = max(worst["sigma"], float(np.abs(s[idx] - log[:, n, 5]).max()))
+    b.close()
+    return dict(worst, x=max(worst["m_r_v"], worst["q_omega"]), trajectories=int(len(idx)), solve_steps=int(log.shape[1]),
+                distinct_radius_schedules=int(len({tuple(l[:, 3]) for l in log})), same_accept_reject_sequence_all=same,
+                solver_tol={"device": 1e-8, "oracle": 1e-8},
+                note="worst over 32 trajectories x 14 steps.  Mass / position / velocity agree to a few 1e-6; the quaternion / body-rate path is "
+                     "the flat direction of these subproblems (two runs of the SAME solver at tol 1e-8 and 1e-10 end 5e-4 apart in omega), so "
+                     "the undispersed sample's 3.6e-5 does not carry over to the batch; with both sides at 1e-10 the worst of four re-run "
+                     "trajectories is 3.3e-5 (q, omega) / 2.4e-7 (m, r, v)")
 
 
 def k1_by_npts(cache, batch, torch, K, B, default_npts, sweep=(1, 2, 4, 10), with_f32=True):
@@ -292,7 +338,7 @@ def k4_traffic_model(tstats, launches):
     except Exception:
         running = None
     # the calibration taken on THIS library if there is one, else the last one on file (flagged as not matching)
-    f = next((g for g in reversed(files) if json.load(open(g)).get("lib_source_hash") == running), files[-1])
+    f = next((g for g in reversed(files) if running and json.load(open(g)).get("lib_source_hash") == running), files[-1])
     m = json.load(open(f))
     total = m["bytes_per_ipm_iteration"] * tstats["ipm_iters"] + m.get("bytes_per_solve", 0.0) * tstats["solves"]
     cal = m.get("lib_source_hash")
@@ -371,6 +417,8 @@ def main():
         args.batch = 32768 if args.config5 else 8192
     if args.config5 and args.seed == 20261004:
         args.seed = 20261005          # config 5's dispersion seed
+    if args.aero and not args.config5 and args.batch == 256 and args.seed == 20261004:
+        args.seed = 20261003          # configs[2]'s (aero tables, batch 256) dispersion seed
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)     # before torch is imported: the parent never touches the GPU
@@ -574,7 +622,7 @@ def main():
             "config": {
                 "workload": ("6-DoF K=%d SCvx, Monte-Carlo dispersed ICs (BASELINE configs[%d] shape, SURVEY 8d law, seed %d), "
                              "SampleProblems.%s, fp64; solve_problem mix: create_initial again every "
-                             "%d steps%s" % (K, 4 if args.config5 else 3, args.seed,
+                             "%d steps%s" % (K, 4 if args.config5 else (2 if (args.aero and B == 256) else 3), args.seed,
                                              "base_prob_aero normalised + FIN EXTENSION (control_dim = 5): a BUILD-DEFINED model -- the reference carries "
                                              "the fin force only as commented-out code (dynamics.jl:60-69, rocketland.jl:203-209; SURVEY N2), include/scvx.h "
                                              "states what was enabled; parity is against this build's own oracle of the same stated model" if args.config5
@@ -588,13 +636,20 @@ def main():
                           "that point lies inside the new radius, and still ends at 1e-8 (cold_start_only = the same loop without it); "
                           "a solve that ends on its numerical floor is re-run under other step rules (retries = 5) before it counts as failed",
                 "parity_contract": {
-                    "solver_tol": args.tol if args.tol > 0 else 1e-8, "traj_linf_tol": 1e-4,
+                    "solver_tol": args.tol if args.tol > 0 else 1e-8,
+                    "traj_linf_tol": {"sample_problem_x_u": 1e-4, "dispersed_batch_m_r_v": 2e-5, "dispersed_batch_q_omega": 1e-3, "dispersed_batch_u": 5e-4},
                     "statement": "`value` is measured at solver tolerance 1e-8 (every conic solve to max(pres, dres, relgap) < 1e-8: the "
-                                 "tolerance class of the reference's own solver defaults, rocketland.jl:58-59) and its parity figure, "
-                                 "traj_linf_vs_oracle, is taken at the SAME setting on both sides: a complete solve_problem stays within 1e-4 "
-                                 "of the oracle's run (measured 3.6e-5 in x; the subproblem optima are flat).  SURVEY 8c's proposed 1e-5 is met "
-                                 "from tol 3e-10 down: value_at_traj_linf_1e-5 carries that throughput with its own parity figure "
-                                 "(profiles/r05_tol_sweep.md has the sweep).  The oracle itself is unpinned (no reference-held vectors exist)"},
+                                 "tolerance class of the reference's own solver defaults, rocketland.jl:58-59) and its parity figures are taken at "
+                                 "the SAME setting on both sides.  (1) traj_linf_vs_oracle: the undispersed sample problem's complete solve_problem stays "
+                                 "within 1e-4 of the oracle's run (measured 3.6e-5 in x).  (2) traj_linf_vs_oracle_batch32 (round 6): 32 dispersed "
+                                 "trajectories of THIS batch, every one of 14 steps: the radius schedule (accept / reject / grow) equals the oracle's "
+                                 "for all 32 x 14, mass / position / velocity within 2e-5 (measured 4.4e-6), and the quaternion / body-rate "
+                                 "components -- the flat direction of these subproblems -- within 1e-3 (measured 4.5e-4; u 1.9e-4): the 1e-4 bound "
+                                 "of (1) does NOT hold for them on the batch.  SURVEY 8c's proposed 1e-5 is met by the sample problem from tol 3e-10 "
+                                 "down (value_at_traj_linf_1e-5: a secondary figure, with failed_steps stated; at that tolerance a handful of "
+                                 "229,376 solve_steps end on the solver's numerical floor and freeze their trajectory -- the method eliminates dz "
+                                 "through W^-2, cond ~ 16 v0^4, HISTORY.md section 2.2) and by m / r / v of the dispersed trajectories at 1e-10 "
+                                 "(2.4e-7; q / omega 3.3e-5).  The oracle itself is unpinned (no reference-held vectors exist)"},
                 "parallelism": f"batch-sharded x{world}, {scaling} scaling", "traj_iters_timed": done_all, "all_gather_shape": gathered,
                 "all_gather": gather_how,
             },
@@ -604,6 +659,9 @@ def main():
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
+                "traffic_per_launch_of_the_mix": ({"bytes": traffic.get("mix_bytes"), "source": traffic.get("mix_source"),
+                                                   "note": "newest PMC passes over the bench mix: in-step launches skip rejected trajectories"}
+                                                  if traffic and traffic.get("mix_bytes") else None),
                 "alg_bytes_per_launch": alg, "avg_launch_ms": k1_ms, "avg_ms_in_step": k1_step_ms,
                 "fp64_frac": (k1_flops / (k1_ms * 1e-3) / FP64_VECTOR_PEAK) if k1_ms > 0 else None,
                 "note": "avg_launch_ms = full launches (all trajectories); inside a step K1 skips trajectories whose step was rejected "
@@ -642,7 +700,8 @@ def main():
                         "stream the per-trajectory solver state from HBM several times each (timed_region.ipm_iters_mean iterations per solve "
                         "on average, ~17 for a cold one), so the real traffic is a few hundred times the algorithmic bytes and the kernel runs "
                         "near the streaming rate of the memory system (4.9 TB/s for a 2-reads-1-write stream of this shape, "
-                        "profiles/r03_stream_ceiling.md).  `traffic` is never a stored byte count divided by another run's time: it is the "
+                        "profiles/r03_stream_ceiling.md; 4.8-5.1 TB/s re-measured in round 6 at 2 / 4 / 8 wavefronts per SIMD and as per-pass grid-wide "
+                        "launches, 5.36 TB/s for a flat grid-stride stream at K4's 4 : 1 read : write mix: profiles/r06_phase_kernel_gate.md).  `traffic` is never a stored byte count divided by another run's time: it is the "
                         "calibrated per-iteration figure times the iterations THIS run executed",
             },
             "solver_stats_last_step": {"ipm_iters_mean": float(np.mean(its)), "ipm_iters_max": int(np.max(its)),
@@ -661,6 +720,10 @@ def main():
             # device and oracle at the SAME solver tolerance (the headline's: 1e-8 unless --tol); rounds 1-4 compared the device at 1e-8
             # with the oracle at its own default 1e-9
             line["traj_linf_vs_oracle"] = traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts, tol=(args.tol if args.tol > 0 else 1e-8))
+            # ... and rounds 1-4's figure for continuity: the device at its default 1e-8 against the oracle at ITS default 1e-9
+            line["traj_linf_vs_oracle_default_tols"] = traj_linf_vs_oracle(IntegratorCache, ScvxBatch, p, args.npts)
+            if args.tol <= 0 and not args.config5:
+                line["traj_linf_vs_oracle_batch32"] = traj_linf_vs_oracle_batch32(cache, ScvxBatch, B, shard.ic, args.seed)
         if world == 1 and not args.no_traj_check:
             # NOT the headline: the same loop (a) with every solve started cold, as the reference's solver does, and (b) with
             # scvx_solver_opts.reuse_inactive_tr (a conic solve whose optimum is provably unchanged after a rejected step is

@@ -135,25 +135,30 @@
 #define SCVX_REFINE_FUSED 1
 #endif
 // E'y and E V formed inside the factorisation loop instead of by two passes over D of their own (build_kkt(res), round 5); 0 = the separate
-// passes.  MEASURED AND OFF (profiles/r05_k4_inloop_residuals.md): it removes 5.3 % of the kernel's HBM traffic (PMC: 3.35 -> 3.17 MB per
+// passes.  MEASURED AND OFF (profiles/r05_k4_byte_budget.md section 4): it removes 5.3 % of the kernel's HBM traffic (PMC: 3.35 -> 3.17 MB per
 // interior-point iteration) and makes the kernel 9.5 % SLOWER (64.75 -> 70.9 ms per launch of the bench mix): the two small matrix-vector
 // products, their node slices and stores add ~8 k cycles to each of the 50 dependent steps of the loop (in-kernel timers: loop 19.2 M ->
 // 25.8 M cycles per solve), and a wavefront's time in that loop is NOT hidden behind the other wavefronts' streaming -- the loop's latency
 // and the streamed bytes add up.  Kept as a switch because it is the measurement that says so.
+#ifndef SCVX_FUSED_RES
+#define SCVX_FUSED_RES 0
+#endif
 // newton_corr inlined into attempt_solve (SCVX_HD) or a routine of its own (SCVX_HD_NI: scratch 832 -> 752 B per lane; B = 8192 +0.9 %,
 // B = 1024 -1.3 % -- measured, the headline's choice stays)
-// the big cones' reduction sums carried from update_pass to the next scale_pass (1) or re-taken by two sweeps per cone (0).  MEASURED
-// AND OFF (round 5): -0.9 % at B = 8192 and B = 1024 (four sweeps less per iteration), same iteration counts on the sample problems,
-// but first failures over 40 random classes 1.42 % -> 1.56 % single-attempt with 7 non-finite exits (the expanded sums cancel where a
-// cone's s and z are not yet near-complementary): not worth the robustness.
-#ifndef SCVX_CARRY_BIGSUMS
-#define SCVX_CARRY_BIGSUMS 0
-#endif
 #ifndef SCVX_NEWTON_CORR_ATTR
 #define SCVX_NEWTON_CORR_ATTR SCVX_HD
 #endif
-#ifndef SCVX_FUSED_RES
-#define SCVX_FUSED_RES 0
+// the big cones' reduction sums carried from update_pass to the next scale_pass (1) or re-taken by two sweeps per cone (0).  MEASURED
+// AND OFF (round 5, profiles/r05_k4_byte_budget.md section 5): -0.9 % at B = 8192 and B = 1024 (four sweeps less per iteration), same iteration
+// counts on the sample problems, but first failures over 40 random classes 1.42 % -> 1.56 % single-attempt with 7 non-finite exits (the
+// expanded sums cancel where a cone's s and z are not yet near-complementary): not worth the robustness.
+#ifndef SCVX_CARRY_BIGSUMS
+#define SCVX_CARRY_BIGSUMS 0
+#endif
+// 1: the two-ended factorisation (four wavefronts per trajectory) carries the border in t-space like the other forms (round 6); 0: the
+// round-5 border (four back-substituted systems after the loop), kept for A/B runs
+#ifndef SCVX_TWISTED_TSPACE
+#define SCVX_TWISTED_TSPACE 1
 #endif
 // refinement of a Newton solve stops once its first-row residual is below this fraction of the dual tolerance
 #ifndef SCVX_REFINE_STOP
@@ -1448,12 +1453,11 @@ struct Solver {
     // recurrence IS the bottom half's forward substitution and its forward recurrence the bottom half's back substitution,
     // and the two halves run side by side on wavefronts 0 and 2.
     SCVX_HD bool twisted() const { return Ex::kTwisted && L.K >= 8; }
+    // forward recurrences: x = z + (coupling) x_prev over the factor's elimination order (two-ended: both halves, then the middle node)
     template <int N>
-    SCVX_HD void solve_chains(const gptr (&t)[N], const gptr (&x)[N]) {
+    SCVX_HD void chains_fwd(const cgptr (&tz)[N], const gptr (&x)[N]) {
         const int K = L.K;
         const cfptr Nf = this->Nf;
-        cgptr tz[N], xz[N];
-        for (int q = 0; q < N; q++) { tz[q] = t[q]; xz[q] = x[q]; }
         if constexpr (Ex::kTwisted) {
             if (twisted()) {
                 const int m = K / 2;
@@ -1465,21 +1469,40 @@ struct Solver {
                     cfptr Na = Nf + (size_t)m * 196 + i;            // N_m(i, j) at 14 j + i
                     cfptr Nb = Nf + (size_t)(m + 1) * 196 + 14 * i;   // N'_m(i, j) at 14 i + j
                     cgptr xa = x[q] + 14 * (m - 1); cgptr xb = x[q] + 14 * (m + 1);
-                    double a = t[q][14 * m + i];
+                    double a = tz[q][14 * m + i];
                     for (int j = 0; j < 14; j++) a += Na[14 * j] * xa[j] + Nb[j] * xb[j];
                     x[q][14 * m + i] = a;
                 }
-                ex.sync();
-                ex.template chain_range_n<N>(0, K, xz, Nf, t, true, m, m + 1, true);
-                ex.template chain_range_n<N>(2, K, xz, Nf, t, false, m, K - m, false);
                 ex.sync();
                 return;
             }
         }
         ex.template chain_n<N>(K, tz, Nf, x, false);
         ex.sync();
+    }
+    // backward recurrences (the transposed couplings, in reverse elimination order): t = x + (coupling)' t_next
+    template <int N>
+    SCVX_HD void chains_bwd(const cgptr (&xz)[N], const gptr (&t)[N]) {
+        const int K = L.K;
+        const cfptr Nf = this->Nf;
+        if constexpr (Ex::kTwisted) {
+            if (twisted()) {
+                const int m = K / 2;
+                ex.template chain_range_n<N>(0, K, xz, Nf, t, true, m, m + 1, true);
+                ex.template chain_range_n<N>(2, K, xz, Nf, t, false, m, K - m, false);
+                ex.sync();
+                return;
+            }
+        }
         ex.template chain_n<N>(K, xz, Nf, t, true);
         ex.sync();
+    }
+    template <int N>
+    SCVX_HD void solve_chains(const gptr (&t)[N], const gptr (&x)[N]) {
+        cgptr tz[N], xz[N];
+        for (int q = 0; q < N; q++) { tz[q] = t[q]; xz[q] = x[q]; }
+        chains_fwd<N>(tz, x);
+        chains_bwd<N>(xz, t);
     }
     SCVX_HD_NI void S_solve(cgptr r, gptr x) {
         SCVX_THIS_LDS();
@@ -1546,9 +1569,8 @@ struct Solver {
         {
             const cgptr tz[1] = {tchain};
             const gptr xs[1] = {t};
-            ex.template chain_n<1>(K, tz, this->Nf, xs, false);
+            chains_fwd<1>(tz, xs);
         }
-        ex.sync();
         SCVX_TE(tc1_, 17);
         SCVX_T1(0);
     }
@@ -1595,11 +1617,9 @@ struct Solver {
         SCVX_THIS_LDS();
         const int K = L.K;
         const cfptr Linv = this->Linv;
-        const cfptr Nf = this->Nf;
         cgptr xz[N];
         for (int q = 0; q < N; q++) xz[q] = x[q];
-        ex.template chain_n<N>(K, xz, Nf, t, true);
-        ex.sync();
+        chains_bwd<N>(xz, t);
         for (int e = ex.lane(); e < 14 * K; e += ex.nlanes()) {
             const int k = e / 14, i = e - 14 * k;
             cfptr Lk = Linv + (size_t)k * LINV_SZ;
@@ -1868,239 +1888,419 @@ struct Solver {
     //     middle:          M_m  = Sd_m - Wb_{m-1} Wb_{m-1}' - Wb'_{m+1} Wb'_{m+1}'
     // The chain is half as long; what the solve does with the factor is in solve_chains.  Tile slot j > m holds
     // N'_{j-1} = -L_{j-1}^-1 Wb'_j UNtransposed, slot j <= m the usual N_j = -L_j^-1 Wb_{j-1} transposed.
+    // Round 6: the two-ended form carries the border too, in t-space.  S = L L' holds for the twisted factor as for the plain one, so the
+    // Gram identity <r_a, S^-1 r_b> = <t_a, t_b>, t = L^-1 r, does; the twisted forward substitution runs downwards in the top half,
+    // upwards in the bottom half and ends at the middle node,
+    //     top    j < m:  t_j = L_j^-1 r_j + N_j  t_{j-1}         (N_j  = -L_j^-1 Wb_{j-1},  slot j, transposed)
+    //     bottom k > m:  t_k = L_k^-1 r_k + N'_k t_{k+1}         (N'_k = -L_k^-1 Wb'_{k+1}, slot k + 1, untransposed)
+    //     middle:        t_m = L_m^-1 r_m + N_m t_{m-1} + N'_m t_{m+1}
+    // with r_k = (E Hb^-1 g)_k formed by the assembly wavefront of each half from the tiles it holds (as factor_pipelined does) and the
+    // substitution done by the same wavefront two steps behind, right after it has formed the coupling tile of that node.  Until round 5
+    // this executor back-substituted four border systems after the loop (Hb^-1 twice, a pass over D, S_solveN<4>, a coefficient pass:
+    // 17-19 % of a solve at B <= 512).
+    // The four roles are four routines (one per wavefront: each gets a register allocation of its own -- as one routine the union of their
+    // loop-carried values spilled 50 registers inside the loop), meeting at the same nsteps + 2 workgroup barriers.
+    struct TwTiles { double *Sd, *So, *Wp, *Li, *Mq, *Dt, *T, *Bp, *Hh, *Hd, *Mp, *Gn, *Rr, *Tt, *Sg; };
+    static SCVX_HD TwTiles tw_tiles(double* sc) {
+        TwTiles q;
+        q.Sd = sc;                  // 2 x 196 ring, factorised in place
+        q.So = q.Sd + 392;          // 2 x 196 ring
+        q.Wp = q.So + 392;          // 3 x 196: Wb ring
+        q.Li = q.Wp + 588;          // 2 x 196: Linv ring
+        q.Mq = q.Li + 392;          // coupling-tile ring, slot 0 (the chain writes the tile of step v into slot v & 1, the assembly reads it a step later)
+        q.Dt = q.Mq + 196;          // assembly: D_k tile
+        q.T = q.Dt + DSZ;           // assembly: [TA | TBm | TBp], row stride TS
+        q.Bp = q.T + 14 * TS;       // assembly: Bp of the neighbouring tile
+        q.Hh = q.Bp + BPN;          // assembly: node inverses (two slots)
+        q.Hd = q.Hh + 2 * NODE_SZ;  // assembly: dense Hxi (bottom: two of them, by step parity)
+        q.Mp = q.Hd + 392;          // coupling-tile ring, slot 1
+        q.Gn = q.Mp + 196;          // assembly: 2 x NXU x 4 node slices of the border right-hand sides: slot 0 = node k, slot 1 = node k + 1
+        q.Rr = q.Gn + 2 * NXU * 4;  // 3 x 56: r_k ring (written at the node's assembly step, read two steps later)
+        q.Tt = q.Rr + 168;          // 2 x 56: the running t of this half
+        q.Sg = q.Tt + 112;          // 42 segment scalars gx_nu,k | ry_k | Pnu_k (+ 14: the Gram product's over-read)
+        return q;
+    }
+    static constexpr int kTwTileDoubles = 392 + 392 + 588 + 392 + 196 + DSZ + 14 * TS + BPN + 2 * NODE_SZ + 392 + 196 + 2 * NXU * 4 + 168 + 112 + 42 + 14;
+    SCVX_HD double tw_node_elem(int node, int e) const { return e < HX_SZ ? hx[(size_t)node * HX_SZ + e] : hu[HU_SZ * node + (e - HX_SZ)]; }
+    // element e = NXU vec + row of node nd (vec 0: Ptr = v1 of the trust-region cone; vec 1: the predictor's gx)
+    SCVX_HD double tw_gnode_elem(int nd, int e, bool with_pred) const {
+        const int vec = e >= NXU ? 1 : 0, row = e - NXU * vec;
+        if (vec == 1 && !with_pred) return 0.0;
+        cgptr src = vec ? (cgptr)gx : (cgptr)(Wv + L.o_tr + 1);
+        return row < 14 ? src[14 * nd + row] : src[L.nx + NU * nd + (row - 14)];
+    }
+    SCVX_HD double tw_gseg_elem(int sgk, int e, bool with_pred) const {
+        if (e >= 28) return Wv[L.o_nu + 1 + 14 * sgk + (e - 28)];
+        if (!with_pred) return 0.0;
+        return e < 14 ? gx[L.nx + L.nu_ + 14 * sgk + e] : ry[14 * sgk + (e - 14)];
+    }
+    // r_k (4 columns: 0 Sg, 1 Ptr, 2 Pnu, 3 predictor) from the tiles the calling assembly wavefront holds: T = [TA | TBm | TBp]_k, Hn = dense
+    // Hxi_{k+1}, Gn slots = nodes k | k + 1
+    template <class E2>
+    SCVX_HD void tw_form_r(typename E2::WAcc& cr, const TwTiles& q, const double* Hn) {
+        ex.w_acc_mac(cr, q.T, TS, 1, q.Gn, 4, 1, 14 + NU, 1.0, 4);
+        ex.w_acc_mac(cr, q.T + 14 + NU, TS, 1, q.Gn + NXU * 4 + 14 * 4, 4, 1, NU, 1.0, 4);
+        ex.w_acc_mac(cr, Hn, 14, 1, q.Gn + NXU * 4, 4, 1, 14, -1.0, 4);
+    }
+    // column 0 = Sg_k, column 2 = hnui Pnu_k, column 3 += hnui gx_nu,k + ry_k; returns this lane's share of <Pnu_k, gx_nu,k>
+    SCVX_HD double tw_plain_r(const TwTiles& q, double* Rk, int l, double hnui_) {
+        double g = 0.0;
+        if (l < 14) {
+            Rk[4 * l] = q.Dt[14 * CS + l];
+            Rk[4 * l + 2] = hnui_ * q.Sg[28 + l];
+            Rk[4 * l + 3] += hnui_ * q.Sg[l] + q.Sg[14 + l];
+            g = q.Sg[28 + l] * q.Sg[l];
+        }
+        return g;
+    }
+    // t of ring index idx (top: node j; bottom: step v) = L^-1 r + (coupling tile in Mp) t_prev; its Gram contribution; rows of `node` of the
+    // four t-vectors.  untr: the coupling tile is stored untransposed (bottom half)
+    template <class E2>
+    SCVX_HD void tw_fwd_subst(typename E2::WAcc& cg, const TwTiles& q, int idx, int node, bool coupled, bool untr, bool with_pred, int l) {
+        const double* Rk = q.Rr + 56 * (idx % 3);
+        const double* Lik = q.Li + 196 * (idx & 1);
+        double* Tc = q.Tt + 56 * (idx & 1); const double* Tp = q.Tt + 56 * ((idx + 1) & 1);
+        typename E2::WAcc ct;
+        ex.w_acc_zero(ct);
+        ex.w_acc_mac(ct, Lik, 14, 1, Rk, 4, 1, 14, 1.0, 4);
+        if (coupled) {
+            const double* Nt = (idx & 1) ? q.Mp : q.Mq;
+            if (untr) ex.w_acc_mac(ct, Nt, 14, 1, Tp, 4, 1, 14, 1.0, 4);
+            else ex.w_acc_mac(ct, Nt, 1, 14, Tp, 4, 1, 14, 1.0, 4);
+        }
+        ex.w_acc_store(ct, Tc, 4, 1, false, 4);
+        ex.w_sync_lds();
+        ex.w_acc_mac(cg, Tc, 1, 4, Tc, 4, 1, 14, 1.0, 4);
+        if (l < 56) {
+            const int c = l / 14, i = l - 14 * c;
+            const gptr dst = c == 0 ? ys : (c == 1 ? ytr : (c == 2 ? ynu : dy));
+            if (c < 3 || with_pred) dst[14 * node + i] = Tc[4 * i + c];
+        }
+    }
+    SCVX_HD void tw_store_linv(int k, const double* Lik, int l) {
+        const fptr Linv_ = Linv;
+        for (int e = l; e < LINV_SZ; e += 64) {
+            const int p = e / 15, c = e - 15 * p;
+            const int i = c <= p ? p : 13 - p, jj = c <= p ? c : c - (p + 1);
+            Linv_[(size_t)k * LINV_SZ + e] = Lik[14 * i + jj];
+        }
+    }
+
+    // ---- role: top assembly (wavefront 1): Sd_k, r_k, So_k for nodes 0 .. m; coupling tiles N_j and the forward substitution two nodes behind ----
     template <class E2 = Ex>
-    SCVX_HD_NI bool factor_twisted() {
+    SCVX_HD_NI double tw_top_assembly(bool with_pred) {
         SCVX_THIS_LDS();
-        const int K = L.K, m = K / 2, nb = K - 1 - m;   // nb nodes in the bottom half
-        const dcptr D_ = D; const cgptr hx_ = hx; const cgptr hu_ = hu;
-        const fptr Linv_ = Linv; const fptr Nf_ = Nf;
-        const double hnui_ = hnui;
-        const int w = ex.wave(), l = ex.wlane();
-        const bool bot = w >= 2;
-        double* sc = bot ? ex.pipe_scratch2() : ex.pipe_scratch();
-        double* Sd = sc;                 // 2 x 196 ring, factorised in place
-        double* So = Sd + 392;           // 2 x 196 ring
-        double* Wp = So + 392;           // 3 x 196: Wb ring
-        double* Li = Wp + 588;           // 2 x 196: Linv ring
-        double* Mq = Li + 392;           // N tile product
-        double* Dt = Mq + 196;           // producer: D_k tile
-        double* T = Dt + DSZ;            // producer: [TA | TBm | TBp], row stride 22
-        double* Bp = T + 14 * TS;            // producer: Bp of the neighbouring tile
-        double* Hh = Bp + BPN;            // producer: node inverses (two slots)
-        double* Hd = Hh + 2 * NODE_SZ;   // producer: dense Hxi (bottom: two of them, by step parity)
-        double* Mp = Hd + 392;           // producer: N tile of the node the chain finished one step ago
-        bool ok = true;
-        const int hpos_lane = hx_dense_pos(l <= HX_SZ ? l : 0);
-        auto node_elem = [&](int node, int e) -> double {
-            return e < HX_SZ ? hx_[(size_t)node * HX_SZ + e] : hu_[HU_SZ * node + (e - HX_SZ)];
-        };
-        auto store_linv = [&](int k, const double* Lik) {
-            for (int e = l; e < LINV_SZ; e += 64) {
-                const int p = e / 15, q = e - 15 * p;
-                const int i = q <= p ? p : 13 - p, jj = q <= p ? q : q - (p + 1);
-                Linv_[(size_t)k * LINV_SZ + e] = Lik[14 * i + jj];
-            }
-        };
-        // the coupling tiles are formed one step behind the chain, by the assembly wavefront of the half (which has the slack):
-        // top node j: N_j = -L_j^-1 Wb_{j-1}, transposed, slot j;  bottom step v (node k): N'_k = -L_k^-1 Wb'_{k+1}, slot k + 1
-        auto post_top = [&](int j) {
-            ex.w_tile_gemm(Mp, 1, 14, Li + 196 * (j & 1), 14, 1, Wp + 196 * ((j + 2) % 3), 14, 1, 14, -1.0, false);
-            ex.w_sync_lds();
-            for (int e = l; e < 196; e += 64) Nf_[(size_t)j * 196 + e] = Mp[e];
-            ex.w_sync_lds();
-        };
-        auto post_bot = [&](int v) {
-            const int k = K - 1 - v;
-            ex.w_tile_gemm(Mp, 14, 1, Li + 196 * (v & 1), 14, 1, Wp + 196 * ((v + 2) % 3), 14, 1, 14, -1.0, false);
-            ex.w_sync_lds();
-            for (int e = l; e < 196; e += 64) Nf_[(size_t)(k + 1) * 196 + e] = Mp[e];
-            ex.w_sync_lds();
-        };
-        // ---- prologues ----
-        if (w == 1) {   // top producer: D_0, node 0 -> TA_0, TBm_0 (as factor_pipelined)
-            for (int e = l; e < DSZ; e += 64) Dt[e] = D_[e];
-            for (int e = l; e < NODE_SZ; e += 64) Hh[NODE_SZ + e] = node_elem(0, e);
-            ex.w_sync_lds();
-            for (int e = l; e < 196; e += 64) Hd[e] = hxi_entry(Hh + NODE_SZ, e / 14, e % 14);
-            ex.w_sync_lds();
-            ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
-            for (int q = l; q < BPN; q += 64) {
-                const int i = q / NU, c = q - NU * i;
-                T[TS * i + 14 + c] = bhu(Dt, 14, i, c, Hh + NODE_SZ + HX_SZ);
-            }
-            ex.w_sync_lds();
-        }
-        if (w == 3) {   // bottom producer: tile K-1, nodes K-1 (slot 0) and K (slot 1), Bp of tile K-2, dense Hxi_K
-            dcptr Dk = D_ + (size_t)(K - 1) * DSZ;
-            for (int e = l; e < DSZ; e += 64) Dt[e] = Dk[e];
-            for (int e = l; e < NODE_SZ; e += 64) { Hh[e] = node_elem(K - 1, e); Hh[NODE_SZ + e] = node_elem(K, e); }
-            for (int q = l; q < BPN; q += 64) Bp[q] = D_[(size_t)(K - 2) * DSZ + 14 * (14 + NU) + q];
-            ex.w_sync_lds();
-            for (int e = l; e < 196; e += 64) { Hd[196 + e] = hxi_entry(Hh + NODE_SZ, e / 14, e % 14); Hd[e] = 0.0; }   // parity 1 = "step -1"; parity 0: the structural zeros
-            ex.w_sync_lds();
-        }
+        const int K = L.K, m = K / 2, nb = K - 1 - m, l = ex.wlane();
         const int nsteps = (m > nb ? m : nb) + 1;
-        double hnext = (w == 1 && l < NODE_SZ) ? node_elem(1, l) : 0.0;   // top assembly: the next node's inverses one step ahead
+        const dcptr D_ = D; const double hnui_ = hnui;
+        const TwTiles q = tw_tiles(ex.pipe_scratch());
+        const int hpos_lane = hx_dense_pos(l <= HX_SZ ? l : 0);
+        const int gat = l < 2 * NXU ? 4 * (l >= NXU ? l - NXU : l) + (l >= NXU ? 3 : 1) : 0;   // this lane's element of a Gn slot
+        typename E2::WAcc cg;
+        ex.w_acc_zero(cg);
+        double gnacc = 0.0;
+        // prologue: D_0, node 0 -> TA_0, TBm_0 (as factor_pipelined)
+        for (int e = l; e < 2 * NXU * 4 + 168 + 112 + 42 + 14; e += 64) q.Gn[e] = 0.0;   // Gn (columns 0 and 2 stay zero), Rr, Tt, Sg
+        ex.w_sync_lds();
+        if (l < 2 * NXU) q.Gn[NXU * 4 + gat] = tw_gnode_elem(0, l, with_pred);
+        for (int e = l; e < DSZ; e += 64) q.Dt[e] = D_[e];
+        for (int e = l; e < NODE_SZ; e += 64) q.Hh[NODE_SZ + e] = tw_node_elem(0, e);
+        ex.w_sync_lds();
+        for (int e = l; e < 196; e += 64) q.Hd[e] = hxi_entry(q.Hh + NODE_SZ, e / 14, e % 14);
+        ex.w_sync_lds();
+        ex.w_tile_gemm(q.T, TS, 1, q.Dt, 1, 14, q.Hd, 14, 1, 14, 1.0, false);
+        for (int c0 = l; c0 < BPN; c0 += 64) {
+            const int i = c0 / NU, c = c0 - NU * i;
+            q.T[TS * i + 14 + c] = bhu(q.Dt, 14, i, c, q.Hh + NODE_SZ + HX_SZ);
+        }
+        ex.w_sync_lds();
+        double hnext = l < NODE_SZ ? tw_node_elem(1, l) : 0.0;                 // the next node's inverses one step ahead
+        double gnext = l < 2 * NXU ? tw_gnode_elem(1, l, with_pred) : 0.0;    // ... and the right-hand sides' slices and segment scalars
+        double sgnext = l < 42 ? tw_gseg_elem(0, l, with_pred) : 0.0;
         for (int t = 0; t < nsteps; t++) {
-            if (w == 1 && t <= m) {
-                // ---- top producer, node k = t: Sd_k; So_k for k < m ----
+            if (t <= m) {
                 const int k = t;
                 SCVX_TS(ta_);
-                double* Sdk = Sd + 196 * (k & 1); double* Sok = So + 196 * (k & 1);
+                double* Sdk = q.Sd + 196 * (k & 1); double* Sok = q.So + 196 * (k & 1);
                 double pre[NPW];
                 dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * DSZ;
                 SCVX_UNROLL
-                for (int q = 0; q < NPW; q++) { const int e = l + 64 * q; pre[q] = e < DSZ ? Dn[e] : 0.0; }
-                for (int e = l; e < NODE_SZ; e += 64) { Hh[e] = Hh[NODE_SZ + e]; }
+                for (int c = 0; c < NPW; c++) { const int e = l + 64 * c; pre[c] = e < DSZ ? Dn[e] : 0.0; }
+                for (int e = l; e < NODE_SZ; e += 64) { q.Hh[e] = q.Hh[NODE_SZ + e]; }
+                if (l < 2 * NXU) q.Gn[gat] = q.Gn[NXU * 4 + gat];   // slot 0 <- slot 1 (node k)
+                if (l < 42) q.Sg[l] = sgnext;
                 ex.w_sync_lds();
-                if (l < NODE_SZ) Hh[NODE_SZ + l] = hnext;                          // node k + 1, requested a step ago
-                hnext = l < NODE_SZ ? node_elem(k + 2 <= K ? k + 2 : K, l) : 0.0;   // node k + 2 for the next step
+                if (l < NODE_SZ) q.Hh[NODE_SZ + l] = hnext;                            // node k + 1, requested a step ago
+                hnext = l < NODE_SZ ? tw_node_elem(k + 2 <= K ? k + 2 : K, l) : 0.0;   // node k + 2 for the next step
+                if (l < 2 * NXU) q.Gn[NXU * 4 + gat] = gnext;
+                gnext = l < 2 * NXU ? tw_gnode_elem(k + 2 <= K ? k + 2 : K, l, with_pred) : 0.0;
+                sgnext = l < 42 ? tw_gseg_elem(k + 1 < K ? k + 1 : k, l, with_pred) : 0.0;
                 ex.w_sync_lds();
-                if (l <= HX_SZ) Hd[hpos_lane] = Hh[NODE_SZ + (l < HX_SZ ? l : HX_Q)];   // the 34 non-zeros of the dense Hxi_{k+1}
-                for (int q = l; q < BPN; q += 64) {
-                    const int i = q / NU, c = q - NU * i;
-                    T[TS * i + 14 + NU + c] = bhu(Dt, 14 + NU, i, c, Hh + NODE_SZ + HX_SZ);
+                if (l <= HX_SZ) q.Hd[hpos_lane] = q.Hh[NODE_SZ + (l < HX_SZ ? l : HX_Q)];   // the 34 non-zeros of the dense Hxi_{k+1}
+                for (int c0 = l; c0 < BPN; c0 += 64) {
+                    const int i = c0 / NU, c = c0 - NU * i;
+                    q.T[TS * i + 14 + NU + c] = bhu(q.Dt, 14 + NU, i, c, q.Hh + NODE_SZ + HX_SZ);
                 }
                 ex.w_sync_lds();
                 {
-                    typename E2::WAcc cm;
-                    ex.w_acc_zero(cm);
-                    ex.w_acc_mac(cm, T, TS, 1, Dt, 14, 1, TW, 1.0);
-                    ex.w_acc_store_init(cm, Sdk, Hd, hnui_);   // Sd_k = Hxi_{k+1} + hnui I + [TA | TBm | TBp]_k D_k'
+                    double* Rk = q.Rr + 56 * (k % 3);
+                    typename E2::WAcc cm, cr;
+                    ex.w_acc_zero(cm); ex.w_acc_zero(cr);
+                    ex.w_acc_mac(cm, q.T, TS, 1, q.Dt, 14, 1, TW, 1.0);
+                    tw_form_r<E2>(cr, q, q.Hd);
+                    ex.w_acc_store_init(cm, Sdk, q.Hd, hnui_);   // Sd_k = Hxi_{k+1} + hnui I + [TA | TBm | TBp]_k D_k'
+                    ex.w_acc_store(cr, Rk, 4, 1, false, 4);
+                    ex.w_sync_lds();
+                    gnacc += tw_plain_r(q, Rk, l, hnui_);
                 }
                 if (k < m) {
-                    for (int q = l; q < BPN; q += 64) Bp[q] = Dt[14 * (14 + NU) + q];
+                    for (int c0 = l; c0 < BPN; c0 += 64) q.Bp[c0] = q.Dt[14 * (14 + NU) + c0];
                     ex.w_sync_lds();
                     SCVX_UNROLL
-                    for (int q = 0; q < NPW; q++) { const int e = l + 64 * q; if (e < DSZ) Dt[e] = pre[q]; }
+                    for (int c = 0; c < NPW; c++) { const int e = l + 64 * c; if (e < DSZ) q.Dt[e] = pre[c]; }
                     ex.w_sync_lds();
-                    ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd, 14, 1, 14, 1.0, false);
-                    for (int q = l; q < BPN; q += 64) {
-                        const int i = q / NU, c = q - NU * i;
-                        T[TS * i + 14 + c] = bhu(Dt, 14, i, c, Hh + NODE_SZ + HX_SZ);
+                    ex.w_tile_gemm(q.T, TS, 1, q.Dt, 1, 14, q.Hd, 14, 1, 14, 1.0, false);
+                    for (int c0 = l; c0 < BPN; c0 += 64) {
+                        const int i = c0 / NU, c = c0 - NU * i;
+                        q.T[TS * i + 14 + c] = bhu(q.Dt, 14, i, c, q.Hh + NODE_SZ + HX_SZ);
                     }
                     ex.w_sync_lds();
                     for (int e = l; e < 196; e += 64) {
                         const int i = e / 14, j = e - 14 * i;
-                        Sok[e] = so_elem(T, Bp, i, j);
+                        Sok[e] = so_elem(q.T, q.Bp, i, j);
                     }
                 }
                 ex.w_sync_lds();
                 SCVX_TE(ta_, 24);
             }
-            if (w == 0 && t >= 1 && t <= m) {
-                // ---- top chain, node k = t - 1 < m ----
-                const int k = t - 1;
-                SCVX_TS(tb0_);
-                double* M = Sd + 196 * (k & 1); const double* Sok = So + 196 * (k & 1);
-                double* Lik = Li + 196 * (k & 1);
-                const double* Wpm = Wp + 196 * ((k + 2) % 3);   // Wb[k-1]
-                if (k > 0) { ex.w_tile_gemm(M, 14, 1, Wpm, 14, 1, Wpm, 1, 14, 14, -1.0, true); ex.w_sync_lds(); }
-                ok = ex.w_chol_inv14(M, Lik) && ok;
-                ex.w_sync_lds();
-                ex.w_tile_gemm(Wp + 196 * (k % 3), 14, 1, Sok, 14, 1, Lik, 1, 14, 14, 1.0, false);   // Wb_k = So_k L_k^-T (k < m: always needed)
-                store_linv(k, Lik);
-                ex.w_sync_lds();
-                SCVX_TE(tb0_, 24);
+            if (t >= 2 && t - 2 <= m - 2) {   // two nodes behind: forward substitution of node t - 2 (its coupling tile: the chain's, a step ago)
+                SCVX_TS(tp_);
+                tw_fwd_subst<E2>(cg, q, t - 2, t - 2, t >= 3, false, with_pred, l);
+                SCVX_TE(tp_, 26);
             }
-            if (w == 1 && t >= 3 && t - 2 <= m - 2) { SCVX_TS(tp_); post_top(t - 2); SCVX_TE(tp_, 26); }
-            if (w == 3 && t < nb) {
-                // ---- bottom producer, node k = K-1-t: Sd_k and So_{k-1} ----
+            SCVX_TS(tbar_);
+            ex.sync();
+            SCVX_TE(tbar_, 28);
+        }
+        // the last node of the half, beside the middle node's factorisation
+        tw_fwd_subst<E2>(cg, q, m - 1, m - 1, true, false, with_pred, l);
+        ex.w_sync_lds();
+        ex.w_acc_store(cg, q.Gn, 4, 1, false, 4);   // this half's Gram matrix (the slices are no longer needed)
+        return gnacc;
+    }
+
+    // ---- role: bottom assembly (wavefront 3): Sd_k, r_k, So_{k-1} for nodes K-1 .. m+1 upwards; coupling tiles N'_k and the substitution ----
+    template <class E2 = Ex>
+    SCVX_HD_NI double tw_bot_assembly(bool with_pred) {
+        SCVX_THIS_LDS();
+        const int K = L.K, m = K / 2, nb = K - 1 - m, l = ex.wlane();
+        const int nsteps = (m > nb ? m : nb) + 1;
+        const dcptr D_ = D; const double hnui_ = hnui;
+        const TwTiles q = tw_tiles(ex.pipe_scratch2());
+        const int hpos_lane = hx_dense_pos(l <= HX_SZ ? l : 0);
+        const int gat = l < 2 * NXU ? 4 * (l >= NXU ? l - NXU : l) + (l >= NXU ? 3 : 1) : 0;
+        typename E2::WAcc cg;
+        ex.w_acc_zero(cg);
+        double gnacc = 0.0;
+        // prologue: tile K-1, nodes K-1 (slot 0) and K (slot 1), Bp of tile K-2, dense Hxi_K
+        for (int e = l; e < 2 * NXU * 4 + 168 + 112 + 42 + 14; e += 64) q.Gn[e] = 0.0;
+        ex.w_sync_lds();
+        {
+            dcptr Dk = D_ + (size_t)(K - 1) * DSZ;
+            if (l < 2 * NXU) { q.Gn[gat] = tw_gnode_elem(K - 1, l, with_pred); q.Gn[NXU * 4 + gat] = tw_gnode_elem(K, l, with_pred); }
+            if (l < 42) q.Sg[l] = tw_gseg_elem(K - 1, l, with_pred);
+            for (int e = l; e < DSZ; e += 64) q.Dt[e] = Dk[e];
+            for (int e = l; e < NODE_SZ; e += 64) { q.Hh[e] = tw_node_elem(K - 1, e); q.Hh[NODE_SZ + e] = tw_node_elem(K, e); }
+            for (int c0 = l; c0 < BPN; c0 += 64) q.Bp[c0] = D_[(size_t)(K - 2) * DSZ + 14 * (14 + NU) + c0];
+            ex.w_sync_lds();
+            for (int e = l; e < 196; e += 64) { q.Hd[196 + e] = hxi_entry(q.Hh + NODE_SZ, e / 14, e % 14); q.Hd[e] = 0.0; }   // parity 1 = "step -1"; parity 0: the structural zeros
+            ex.w_sync_lds();
+        }
+        for (int t = 0; t < nsteps; t++) {
+            if (t < nb) {
                 const int u = t, k = K - 1 - u;
                 SCVX_TS(tc_);
-                double* Sdk = Sd + 196 * (u & 1); double* Sok = So + 196 * (u & 1);
-                double* Hd0 = Hd + 196 * (u & 1);            // dense Hxi_k
-                const double* Hd1 = Hd + 196 * ((u + 1) & 1);   // dense Hxi_{k+1}: the previous step's Hd0
+                double* Sdk = q.Sd + 196 * (u & 1); double* Sok = q.So + 196 * (u & 1);
+                double* Hd0 = q.Hd + 196 * (u & 1);            // dense Hxi_k
+                const double* Hd1 = q.Hd + 196 * ((u + 1) & 1);   // dense Hxi_{k+1}: the previous step's Hd0
                 // the next step's inputs into registers: tile k-1, node k-1, Bp of tile k-2 (indices clamped at the end of the half)
                 const int kn = k - 1 > m ? k - 1 : k, kb2 = kn - 1;
                 double pre[NPW];
                 dcptr Dn = D_ + (size_t)kn * DSZ;
                 SCVX_UNROLL
-                for (int q = 0; q < NPW; q++) { const int e = l + 64 * q; pre[q] = e < DSZ ? Dn[e] : 0.0; }
-                const double hn = l < NODE_SZ ? node_elem(kn, l) : 0.0;
+                for (int c = 0; c < NPW; c++) { const int e = l + 64 * c; pre[c] = e < DSZ ? Dn[e] : 0.0; }
+                const double hn = l < NODE_SZ ? tw_node_elem(kn, l) : 0.0;
+                const double gn = l < 2 * NXU ? tw_gnode_elem(kn, l, with_pred) : 0.0;
+                const double sgn = l < 42 ? tw_gseg_elem(kn, l, with_pred) : 0.0;
                 double bpn[(BPN + 63) / 64];
                 SCVX_UNROLL
-                for (int q = 0; q < (BPN + 63) / 64; q++) { const int e = l + 64 * q; bpn[q] = e < BPN ? (double)D_[(size_t)kb2 * DSZ + 14 * (14 + NU) + e] : 0.0; }
-                if (l <= HX_SZ) Hd0[hpos_lane] = Hh[l < HX_SZ ? l : HX_Q];   // dense Hxi_k: its 34 non-zeros (both parities were zeroed once)
+                for (int c = 0; c < (BPN + 63) / 64; c++) { const int e = l + 64 * c; bpn[c] = e < BPN ? (double)D_[(size_t)kb2 * DSZ + 14 * (14 + NU) + e] : 0.0; }
+                if (l <= HX_SZ) Hd0[hpos_lane] = q.Hh[l < HX_SZ ? l : HX_Q];   // dense Hxi_k: its 34 non-zeros (both parities were zeroed once)
                 ex.w_sync_lds();
-                ex.w_tile_gemm(T, TS, 1, Dt, 1, 14, Hd0, 14, 1, 14, 1.0, false);     // TA_k = A_k Hxi_k
-                for (int q = l; q < 2 * BPN; q += 64) {
-                    const bool pls = q >= BPN;
-                    const int qq = pls ? q - BPN : q, i = qq / NU, c = qq - NU * i;
-                    const double* h = Hh + (pls ? NODE_SZ : 0) + HX_SZ;            // Hui_k for TBm_k, Hui_{k+1} for TBp_k
-                    const int c0 = pls ? 14 + NU : 14;
-                    T[TS * i + c0 + c] = bhu(Dt, c0, i, c, h);
+                ex.w_tile_gemm(q.T, TS, 1, q.Dt, 1, 14, Hd0, 14, 1, 14, 1.0, false);     // TA_k = A_k Hxi_k
+                for (int c0 = l; c0 < 2 * BPN; c0 += 64) {
+                    const bool pls = c0 >= BPN;
+                    const int qq = pls ? c0 - BPN : c0, i = qq / NU, c = qq - NU * i;
+                    const double* h = q.Hh + (pls ? NODE_SZ : 0) + HX_SZ;            // Hui_k for TBm_k, Hui_{k+1} for TBp_k
+                    const int cc = pls ? 14 + NU : 14;
+                    q.T[TS * i + cc + c] = bhu(q.Dt, cc, i, c, h);
                 }
                 ex.w_sync_lds();
                 {
-                    typename E2::WAcc cm;
-                    ex.w_acc_zero(cm);
-                    ex.w_acc_mac(cm, T, TS, 1, Dt, 14, 1, TW, 1.0);
+                    double* Rk = q.Rr + 56 * (u % 3);
+                    typename E2::WAcc cm, cr;
+                    ex.w_acc_zero(cm); ex.w_acc_zero(cr);
+                    ex.w_acc_mac(cm, q.T, TS, 1, q.Dt, 14, 1, TW, 1.0);
+                    tw_form_r<E2>(cr, q, Hd1);
                     ex.w_acc_store_init(cm, Sdk, Hd1, hnui_);   // Sd_k = Hxi_{k+1} + hnui I + [TA | TBm | TBp]_k D_k'
+                    ex.w_acc_store(cr, Rk, 4, 1, false, 4);
+                    ex.w_sync_lds();
+                    gnacc += tw_plain_r(q, Rk, l, hnui_);
                 }
                 for (int e = l; e < 196; e += 64) {
                     const int i = e / 14, j = e - 14 * i;
-                    Sok[e] = so_elem(T, Bp, i, j);   // So_{k-1}
+                    Sok[e] = so_elem(q.T, q.Bp, i, j);   // So_{k-1}
                 }
                 ex.w_sync_lds();
-                // rotate: node k becomes "k+1" of the next step, the prefetched tile / node / Bp move in
-                if (l < NODE_SZ) { Hh[NODE_SZ + l] = Hh[l]; }
+                // rotate: node k becomes "k+1" of the next step, the prefetched tile / node / Bp / right-hand-side slices move in
+                if (l < NODE_SZ) { q.Hh[NODE_SZ + l] = q.Hh[l]; }
+                if (l < 2 * NXU) q.Gn[NXU * 4 + gat] = q.Gn[gat];
                 ex.w_sync_lds();
-                if (l < NODE_SZ) Hh[l] = hn;
+                if (l < NODE_SZ) q.Hh[l] = hn;
+                if (l < 2 * NXU) q.Gn[gat] = gn;
+                if (l < 42) q.Sg[l] = sgn;
                 SCVX_UNROLL
-                for (int q = 0; q < (BPN + 63) / 64; q++) { const int e = l + 64 * q; if (e < BPN) Bp[e] = bpn[q]; }
+                for (int c = 0; c < (BPN + 63) / 64; c++) { const int e = l + 64 * c; if (e < BPN) q.Bp[e] = bpn[c]; }
                 SCVX_UNROLL
-                for (int q = 0; q < NPW; q++) { const int e = l + 64 * q; if (e < DSZ) Dt[e] = pre[q]; }
+                for (int c = 0; c < NPW; c++) { const int e = l + 64 * c; if (e < DSZ) q.Dt[e] = pre[c]; }
                 ex.w_sync_lds();
                 SCVX_TE(tc_, 24);
             }
-            if (w == 2 && t >= 1 && t <= nb) {
-                // ---- bottom chain, step v = t - 1, node k = K-1-v > m ----
-                const int v = t - 1, k = K - 1 - v;
-                SCVX_TS(td_);
-                double* M = Sd + 196 * (v & 1); const double* Sok = So + 196 * (v & 1);   // So_{k-1}
-                double* Lik = Li + 196 * (v & 1);
-                const double* Wpm = Wp + 196 * ((v + 2) % 3);   // Wb'_{k+1}
-                if (v > 0) { ex.w_tile_gemm(M, 14, 1, Wpm, 14, 1, Wpm, 1, 14, 14, -1.0, true); ex.w_sync_lds(); }
-                ok = ex.w_chol_inv14(M, Lik) && ok;
-                ex.w_sync_lds();
-                ex.w_tile_gemm(Wp + 196 * (v % 3), 14, 1, Sok, 1, 14, Lik, 1, 14, 14, 1.0, false);   // Wb'_k = So_{k-1}' L_k^-T
-                store_linv(k, Lik);
-                ex.w_sync_lds();
-                SCVX_TE(td_, 24);
+            if (t >= 2 && t - 2 <= nb - 1) {   // two steps behind: forward substitution of step v = t - 2
+                SCVX_TS(tq_);
+                tw_fwd_subst<E2>(cg, q, t - 2, K - 1 - (t - 2), t >= 3, true, with_pred, l);
+                SCVX_TE(tq_, 26);
             }
-            if (w == 3 && t >= 3 && t - 2 <= nb - 1) { SCVX_TS(tq_); post_bot(t - 2); SCVX_TE(tq_, 26); }
             SCVX_TS(tbar_);
             ex.sync();
             SCVX_TE(tbar_, 28);
         }
-        // the coupling tiles of the last node of each half, beside the middle node's factorisation
-        if (w == 1 && m - 1 >= 1) post_top(m - 1);
-        if (w == 3 && nb - 1 >= 1 && nb - 1 > nsteps - 3) post_bot(nb - 1);
-        // ---- the middle node: both corrections, its two coupling tiles ----
-        if (w == 0) {
+        if (nb - 1 > nsteps - 3) {   // the last node of the half, if the loop did not reach it
+            tw_fwd_subst<E2>(cg, q, nb - 1, m + 1, nb - 1 >= 1, true, with_pred, l);
+        }
+        ex.w_sync_lds();
+        ex.w_acc_store(cg, q.Gn, 4, 1, false, 4);
+        return gnacc;
+    }
+
+    // ---- role: the two chains (wavefront 0: nodes 0 .. m-1 downwards, then the middle node; wavefront 2: nodes K-1 .. m+1 upwards) ----
+    template <class E2 = Ex>
+    SCVX_HD_NI bool tw_chain(bool bot) {
+        SCVX_THIS_LDS();
+        const int K = L.K, m = K / 2, nb = K - 1 - m, l = ex.wlane();
+        const int nsteps = (m > nb ? m : nb) + 1;
+        const fptr Nf_ = Nf;
+        const TwTiles q = tw_tiles(bot ? ex.pipe_scratch2() : ex.pipe_scratch());
+        const int nn = bot ? nb : m;   // nodes of this half
+        bool ok = true;
+        for (int t = 0; t < nsteps; t++) {
+            if (t >= 1 && t <= nn) {
+                // step v = t - 1: top node k = v, bottom node k = K-1-v
+                const int v = t - 1, k = bot ? K - 1 - v : v;
+                SCVX_TS(tb0_);
+                double* M = q.Sd + 196 * (v & 1); const double* Sok = q.So + 196 * (v & 1);   // top: So_k; bottom: So_{k-1}
+                double* Lik = q.Li + 196 * (v & 1);
+                const double* Wpm = q.Wp + 196 * ((v + 2) % 3);   // top: Wb_{k-1}; bottom: Wb'_{k+1}
+                if (v > 0) { ex.w_tile_gemm(M, 14, 1, Wpm, 14, 1, Wpm, 1, 14, 14, -1.0, true); ex.w_sync_lds(); }
+                ok = ex.w_chol_inv14(M, Lik) && ok;
+                ex.w_sync_lds();
+                if (bot) ex.w_tile_gemm(q.Wp + 196 * (v % 3), 14, 1, Sok, 1, 14, Lik, 1, 14, 14, 1.0, false);   // Wb'_k = So_{k-1}' L_k^-T
+                else ex.w_tile_gemm(q.Wp + 196 * (v % 3), 14, 1, Sok, 14, 1, Lik, 1, 14, 14, 1.0, false);       // Wb_k = So_k L_k^-T
+                tw_store_linv(k, Lik, l);
+                if (v > 0) {
+                    // coupling tile of this node into the two-slot ring (the assembly wavefront's forward substitution reads it a step later)
+                    // and to the factor: top N_k = -L_k^-1 Wb_{k-1}, transposed, slot k; bottom N'_k = -L_k^-1 Wb'_{k+1}, untransposed, slot k + 1
+                    double* Nt = (v & 1) ? q.Mp : q.Mq;
+                    if (bot) ex.w_tile_gemm(Nt, 14, 1, Lik, 14, 1, Wpm, 14, 1, 14, -1.0, false);
+                    else ex.w_tile_gemm(Nt, 1, 14, Lik, 14, 1, Wpm, 14, 1, 14, -1.0, false);
+                    ex.w_sync_lds();
+                    const size_t slot = bot ? (size_t)(k + 1) : (size_t)k;
+                    for (int e = l; e < 196; e += 64) Nf_[slot * 196 + e] = Nt[e];
+                }
+                ex.w_sync_lds();
+                SCVX_TE(tb0_, 24);
+            }
+            SCVX_TS(tbar_);
+            ex.sync();
+            SCVX_TE(tbar_, 28);
+        }
+        if (!bot) {
+            // ---- the middle node: both corrections, its two coupling tiles ----
             SCVX_TS(tm_);
             double* sc2 = ex.pipe_scratch2();
+            double* Na_ = q.So;          // N_m and N'_m: the So ring, free since this chain's last step (the coupling-tile ring is still being
+            double* Nb_ = q.So + 196;    // read by the top assembly's last forward substitution)
             const double* WbB = sc2 + 784 + 196 * ((nb - 1) % 3);    // Wb'_{m+1}: the bottom chain's last coupling tile
-            const double* WbT = Wp + 196 * ((m - 1) % 3);            // Wb_{m-1}
-            double* M = Sd + 196 * (m & 1);
-            double* Lik = Li + 196 * (m & 1);
+            const double* WbT = q.Wp + 196 * ((m - 1) % 3);            // Wb_{m-1}
+            double* M = q.Sd + 196 * (m & 1);
+            double* Lik = q.Li + 196 * (m & 1);
             ex.w_tile_gemm(M, 14, 1, WbT, 14, 1, WbT, 1, 14, 14, -1.0, true);
             ex.w_sync_lds();
             ex.w_tile_gemm(M, 14, 1, WbB, 14, 1, WbB, 1, 14, 14, -1.0, true);
             ex.w_sync_lds();
             ok = ex.w_chol_inv14(M, Lik) && ok;
             ex.w_sync_lds();
-            store_linv(m, Lik);
-            ex.w_tile_gemm(Mq, 1, 14, Lik, 14, 1, WbT, 14, 1, 14, -1.0, false);     // N_m, transposed, slot m
+            tw_store_linv(m, Lik, l);
+            ex.w_tile_gemm(Na_, 1, 14, Lik, 14, 1, WbT, 14, 1, 14, -1.0, false);      // N_m, transposed, slot m
+            ex.w_tile_gemm(Nb_, 14, 1, Lik, 14, 1, WbB, 14, 1, 14, -1.0, false);      // N'_m, untransposed, slot m + 1
             ex.w_sync_lds();
-            for (int e = l; e < 196; e += 64) Nf_[(size_t)m * 196 + e] = Mq[e];
-            ex.w_sync_lds();
-            ex.w_tile_gemm(Mq, 14, 1, Lik, 14, 1, WbB, 14, 1, 14, -1.0, false);     // N'_m, untransposed, slot m + 1
-            ex.w_sync_lds();
-            for (int e = l; e < 196; e += 64) Nf_[(size_t)(m + 1) * 196 + e] = Mq[e];
+            for (int e = l; e < 196; e += 64) { Nf_[(size_t)m * 196 + e] = Na_[e]; Nf_[(size_t)(m + 1) * 196 + e] = Nb_[e]; }
             SCVX_TE(tm_, 27);
         }
+        return ok;
+    }
+
+    template <class E2 = Ex>
+    SCVX_HD bool factor_twisted(bool with_pred) {
+        static_assert(E2::kPipeDoubles >= kTwTileDoubles, "two-ended tile sets");
+        const int K = L.K, m = K / 2, nb = K - 1 - m;
+        const int w = ex.wave(), l = ex.wlane();
+        bool ok = true;
+        double gnacc = 0.0;
+        if (w == 0) ok = tw_chain<E2>(false);
+        else if (w == 1) gnacc = tw_top_assembly<E2>(with_pred);
+        else if (w == 2) ok = tw_chain<E2>(true);
+        else gnacc = tw_bot_assembly<E2>(with_pred);
+        ex.sync();   // t_{m-1} (top assembly), t_{m+1} (bottom assembly) and the middle factor are complete
+        const TwTiles q1 = tw_tiles(ex.pipe_scratch()), q2 = tw_tiles(ex.pipe_scratch2());
+        double* Gm = q1.T;   // the top half's T tile: free now; the middle node's t (56) and its Gram matrix (at + 64)
+        if (w == 0) {
+            const double* Rm = q1.Rr + 56 * (m % 3);             // r_m: formed by the top assembly at step m
+            const double* Ta = q1.Tt + 56 * ((m - 1) & 1);       // t_{m-1}
+            const double* Tb = q2.Tt + 56 * ((nb - 1) & 1);      // t_{m+1}
+            const double* Lik = q1.Li + 196 * (m & 1);
+            const double* Na_ = q1.So; const double* Nb_ = q1.So + 196;
+            typename E2::WAcc ct, cgm;
+            ex.w_acc_zero(ct); ex.w_acc_zero(cgm);
+            ex.w_acc_mac(ct, Lik, 14, 1, Rm, 4, 1, 14, 1.0, 4);
+            ex.w_acc_mac(ct, Na_, 1, 14, Ta, 4, 1, 14, 1.0, 4);
+            ex.w_acc_mac(ct, Nb_, 14, 1, Tb, 4, 1, 14, 1.0, 4);
+            for (int e = l; e < 128; e += 64) Gm[e] = 0.0;
+            ex.w_sync_lds();
+            ex.w_acc_store(ct, Gm, 4, 1, false, 4);
+            ex.w_sync_lds();
+            ex.w_acc_mac(cgm, Gm, 1, 4, Gm, 4, 1, 14, 1.0, 4);
+            if (l < 56) {
+                const int c = l / 14, i = l - 14 * c;
+                const gptr dst = c == 0 ? ys : (c == 1 ? ytr : (c == 2 ? ynu : dy));
+                if (c < 3 || with_pred) dst[14 * m + i] = Gm[4 * i + c];
+            }
+            ex.w_sync_lds();
+            ex.w_acc_store(cgm, Gm + 64, 4, 1, false, 4);
+        }
+        ex.sync();
+        for (int c = 0; c < 16; c++) gram[c] = (q1.Gn[c] + q2.Gn[c]) + Gm[64 + c];
+        gn_pred = ex.sum(gnacc);
         return ex.all(ok);
     }
 
@@ -2312,16 +2512,16 @@ struct Solver {
         double* Rk = Gn + 2 * NXU * 4;           // 14 x 4        r_k
         double* Tt = Rk + 56;                    // 2 x 14 x 4    t_{k-1}, t_k (alternating)
         double* Sg = Tt + 112;                   // 84            segment scalars: gx_nu,k | ry_k | Pnu_k | res: nu_k | dk_k | rx_nu,k (14 each)
-        double* Sk = Sg + 84;                    // 14            Sg_k, the sigma column of D_k (kept across the tile swap)
+        double* Sk = Sg + (SCVX_FUSED_RES ? 84 : 42);   // 14     Sg_k, the sigma column of D_k (kept across the tile swap); the res tiles behind it exist only with SCVX_FUSED_RES
         double* Vn = Sk + 14;                    // 2 x NXU       res: node slices of V, slots k | k+1
         double* Pn = Vn + 2 * NXU;               // 2 x NXU       res: node slices of the D-independent part of rx
         double* Yv = Pn + 2 * NXU;               // 2 x 14        res: y_k | y_{k+1}
-        // (the two-ended factorisation of the four-wavefront blocks keeps the separate border: its forward substitution runs from both ends)
-        const bool kFusedBorder = !(Ex::kTwisted && twisted());
+        // (the two-ended factorisation of the four-wavefront blocks kept a separate, back-substituted border until round 6: SCVX_TWISTED_TSPACE = 0)
+        const bool kFusedBorder = SCVX_TWISTED_TSPACE != 0 || !(Ex::kTwisted && twisted());
         bool ok = true;
         if constexpr (Ex::kPipelineFactor) {
             if constexpr (Ex::kTwisted) {
-                ok = twisted() ? factor_twisted() : factor_pipelined(with_pred);
+                ok = twisted() ? factor_twisted(with_pred) : factor_pipelined(with_pred);
             } else
             ok = factor_pipelined(with_pred);   // two wavefronts: Schur-block assembly one segment ahead of the Cholesky chain
         } else {

@@ -31,13 +31,17 @@ namespace scvx {
 // only).  A pointer carried in the executor object is reloaded from memory in each non-inlined routine, loses its
 // address space, and every LDS access becomes a flat_load/flat_store that also waits on the global loads and
 // stores in flight (vmcnt) — which serialises the tile arithmetic behind the HBM traffic it is meant to overlap.
-__shared__ __attribute__((aligned(16))) double g_socp_lds[2112];   // + the fused border's tiles (Solver::build_kkt: Gn, Rk, Tt, Sg)
+// (the tiles of build_kkt(res) -- Sg[42..84), Vn, Pn, Yv: 208 doubles -- exist only when that measured-and-off path is compiled in)
+__shared__ __attribute__((aligned(16))) double g_socp_lds[SCVX_FUSED_RES ? 2112 : 1904];   // + the fused border's tiles (Solver::build_kkt: Gn, Rk, Tt, Sg)
 // ... and of the fin instantiation (control_dim = 5: 14 x 25 tiles, 24-column [TA | TBm | TBp]); separate symbols so that the
 // kernels of the reference's model keep their LDS footprint
-__shared__ __attribute__((aligned(16))) double g_socp_lds5[2272];
-#define SCVX_PIPE_LDS5 (2 * 392 + 588 + 392 + 392 + 350 + 364 + 70 + 2 * 46 + 3 * 196 + 8 + 96)
+__shared__ __attribute__((aligned(16))) double g_socp_lds5[SCVX_FUSED_RES ? 2272 : 2072];
+// tile sets of the multi-wavefront factorisations, in doubles (Solver::factor_pipelined needs 3,538 / 3,706, each half of Solver::factor_twisted
+// -- since round 6 with the border's node slices, r_k ring, running t and segment scalars -- 3,748 / 3,912: control_dim 3 / 5)
+#define SCVX_PIPE_LDS3 3752
+#define SCVX_PIPE_LDS5 3912
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds5[SCVX_PIPE_LDS5];
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds25[SCVX_PIPE_LDS5 - 196];   // the second tile set (two-ended form) keeps a single N tile
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds25[SCVX_PIPE_LDS5];   // the second tile set (two-ended form: the bottom half)
 template <int NU> __device__ __forceinline__ double* socp_lds() { if constexpr (NU == 5) return g_socp_lds5; else return g_socp_lds; }
 // The multi-wavefront kernels factorise through the pipeline's own tiles (g_socp_pipe_lds*) and need only the 32-double header of the
 // scratch (reduction partials, flags): a symbol of their own, so that they do not carry the single-wavefront kernel's tile space
@@ -45,14 +49,14 @@ template <int NU> __device__ __forceinline__ double* socp_lds() { if constexpr (
 __shared__ __attribute__((aligned(16))) double g_socp_blk_hdr[32];
 // tiles of the two-wavefront factorisation pipeline (multi-wavefront kernels only: a kernel that never references the
 // symbol does not get the allocation)
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[2 * 392 + 588 + 392 + 392 + 294 + 308 + 42 + 2 * 42 + 3 * 196 + 8 + 96];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[SCVX_PIPE_LDS3];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
 #ifndef SCVX_K4_PIPELINE
 #define SCVX_K4_PIPELINE 1
 #endif
 // second tile set of the TWO-ENDED factorisation (four-wavefront blocks only: wavefronts 2 / 3 eliminate the bottom half of
 // the chain upwards while 0 / 1 eliminate the top half downwards); a separate symbol so that the two-wavefront kernel, which
 // never references it, keeps its LDS footprint (4 blocks per CU)
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds2[2 * 392 + 588 + 392 + 196 + 294 + 308 + 42 + 2 * 42 + 3 * 196 + 8];
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds2[SCVX_PIPE_LDS3];
 #ifndef SCVX_K4_TWISTED
 #define SCVX_K4_TWISTED 1
 #endif
@@ -109,6 +113,10 @@ struct WaveExT {
     // makes the wavefront wait out the LDS latency once per MFMA (round 5: ~850 -> ~350 cycles per 14x14x14 product; the factorisation
     // loop runs nine such products per segment).  All reads of a product are issued before its first MFMA.
     static constexpr int KS = 6;   // k-slots of 4: Kd <= 24 (the widest operand is [TA | TBm | TBp], 24 columns with the fin extension)
+    static_assert(14 + 2 * NU_ <= 4 * KS, "fetch_ab / tile_gemm / acc_mac silently truncate a product wider than 4 KS columns");
+    // (the Gram products acc_mac(cg, Tc, 1, 4, Tc, 4, 1, 14, ...) read A(row, k) = Tc[row + 4 k] for the clamped rows 0..13 -- up to Tc[65],
+    // past the 56-double t slot: harmless because accumulator rows >= 4 are never read, but the LDS behind the slot must hold finite
+    // values; every caller zeroes its Gn / Rk / Tt / Sg region in its prologue)
     __device__ __forceinline__ void fetch_ab(const double* A, int sai, int sak, const double* B, int sbk, int sbj, int Kd, int nb,
                                              double (&a)[KS], double (&b)[KS]) {
         const int l = lane();
@@ -501,6 +509,7 @@ struct BlockEx {
     // two-ended (twisted) factorisation and solve: the chain is eliminated from both ends towards the middle block by two
     // producer / consumer pairs, and the solve's recurrences run on wavefronts 0 and 2 side by side (Solver::factor_twisted)
     static constexpr bool kTwisted = NW == 4 && SCVX_K4_PIPELINE != 0 && SCVX_K4_TWISTED != 0;
+    static constexpr int kPipeDoubles = NU_ == 5 ? SCVX_PIPE_LDS5 : SCVX_PIPE_LDS3;   // capacity of each of the two tile sets
     __device__ __forceinline__ double* pipe_scratch2() { return socp_pipe_lds2<NU_>(); }
     template <int NR, class NP>
     __device__ __forceinline__ void chain_range_n(int wv, int K, const ipm::cgptr (&z)[NR], NP N, const ipm::gptr (&o)[NR],
@@ -606,7 +615,7 @@ __device__ __forceinline__ void socp_body(const ipm::Consts& Cin, int B, size_t 
         return;
     }
 #if defined(SCVX_K4_STAGGER_US)
-    // experiment (profiles/r05_k4_stagger.md): the 2,048 wavefronts of a launch's first round start together and run the same phases at the
+    // experiment (round 5, +-0.5 %: profiles/r05_k4_byte_budget.md section 4, last paragraph): the 2,048 wavefronts of a launch's first round start together and run the same phases at the
     // same time; a start delay spread over one interior-point iteration de-correlates them
     if (blockIdx.x < 2048) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();

@@ -99,11 +99,15 @@ def test_conic_kernels_keep_the_solver_object_out_of_private_memory(tmp_path):
         # (checked on the ISA: no `Folded Spill` between prologue and epilogue of any Solver:: routine of the single-wavefront kernel).
         assert int(k["vgpr_spill_count"]) <= 11, (n, k)
         assert int(k["private_segment_fixed_size"]) <= 1280, (n, k)     # 832 (one wavefront) ... 1192 (four, fins): register saves around calls
-        assert int(k["group_segment_fixed_size"]) <= 64 * 1024, (n, k)
+        # four-wavefront blocks carry two tile sets of the two-ended factorisation (round 6: with the border's slices, rings and running t):
+        # 67-70 KB of the CU's 160 KB -- two blocks per CU, which is all B <= 512 asks for; everything else stays below 40 KB (four per CU)
+        assert int(k["group_segment_fixed_size"]) <= (72 if "block_kernelILi4" in n else 40) * 1024, (n, k)
     one = [k for n, k in conic.items() if "socp_kernelE" in n][0]
     # round 5: 496 -> 832 B (the solve and its refinement check are one routine now: more values live across the non-inlined passes;
     # ~200 scratch accesses per interior-point iteration, 3 % of its traffic); LDS: eight single-wavefront blocks per CU (two per SIMD)
-    assert int(one["private_segment_fixed_size"]) <= 896 and int(one["group_segment_fixed_size"]) <= 160 * 1024 // 8, one
+    # round 6: the tiles of the switched-off build_kkt(res) path are no longer allocated: nine blocks' worth of LDS per CU again (the kernel
+    # itself is VGPR-limited at eight)
+    assert int(one["private_segment_fixed_size"]) <= 896 and int(one["group_segment_fixed_size"]) <= 160 * 1024 // 9, one
     k0 = [k for n, k in kernels.items() if "threedof_kernelE" in n][0]
     assert int(k0["private_segment_fixed_size"]) <= 1200, k0
 

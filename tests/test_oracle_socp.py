@@ -184,6 +184,8 @@ def test_twin_retry_ladder_rescues_floor_failures():
             os.environ.pop("SCVX_PORT_RETRIES", None)
 
     checked = 0
+    unrescued = []   # classes with a single-attempt failure the ladder did NOT fully rescue: at most one may be skipped (a broad
+                     # regression of the ladder must fail this test, not be walked past)
     for n in range(48):
         p = k4_fuzz.draw_class(rng, base)
         ic = model.disperse_ics(p, 16, 500 + n, 0.3)
@@ -194,7 +196,10 @@ def test_twin_retry_ladder_rescues_floor_failures():
         r5 = two_steps(p, ic, "5")
         s5 = r5["status"][1]
         if not (s5 == 0).all():
-            continue     # one of the ~0.1 % of solves no rule rescues: not what this test is about
+            unrescued.append(n)   # one of the ~0.1 % of solves no rule rescues
+            assert len(unrescued) <= 1, "the ladder left failures in classes %s" % unrescued
+            continue
+        print("retry ladder checked on class %d (single-attempt failures: %d of 16)" % (n, int(((s0 != 0) & (s0 != 5)).sum())))
         assert (r5["merit"][1] < 1e-8).all()
         same = s0 == 0
         assert np.array_equal(r0["iters"][1][same], r5["iters"][1][same])
