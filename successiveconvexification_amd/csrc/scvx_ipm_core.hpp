@@ -1740,17 +1740,11 @@ struct Solver {
         // is the ASSEMBLY wavefront's again, one barrier behind the chain: with the tile products unpredicated and the dense node inverse
         // scattered, the assembly stage shrank to 7.2 k cycles per segment while the chain wavefront (pivot update, Cholesky + inverse,
         // coupling tile, L^-1 / N_k stores AND this substitution) took 11.4 k and the assembly waited 4.2 k of every step.
+        // Round 6: the substitution itself (two small products on tiles the chain wavefront has just written) is the CHAIN's again -- the DPP
+        // Cholesky took 1.4 k cycles off its step and left the assembly wavefront the longer one (9.0 k against 7.0 k at B = 1,024) -- while the
+        // Gram matrix and the stores of t_k stay here, a barrier later.
         auto fwd_subst = [&](int kp) {
-            const double* Rk = Rr + 56 * (kp % 3);
-            const double* Lik = Li + 196 * (kp & 1);
-            const double* Mqk = Mq + 196 * (kp & 1);
-            double* Tc = Tt + 56 * (kp & 1); const double* Tp = Tt + 56 * ((kp + 1) & 1);
-            typename E2::WAcc ct;
-            ex.w_acc_zero(ct);
-            ex.w_acc_mac(ct, Lik, 14, 1, Rk, 4, 1, 14, 1.0, 4);
-            if (kp > 0) ex.w_acc_mac(ct, Mqk, 1, 14, Tp, 4, 1, 14, 1.0, 4);
-            ex.w_acc_store(ct, Tc, 4, 1, false, 4);
-            ex.w_sync_lds();
+            const double* Tc = Tt + 56 * (kp & 1);
             ex.w_acc_mac(cg, Tc, 1, 4, Tc, 4, 1, 14, 1.0, 4);   // Gram matrix of the forward-substituted right-hand sides
             if (l < 56) {
                 const int q = l / 14, i = l - 14 * q;
@@ -1863,9 +1857,18 @@ struct Solver {
                     ex.w_sync_lds();
                     for (int e = l; e < 196; e += 64) Nf_[(size_t)k * 196 + e] = Mqk[e];
                 }
+                {   // t_k = L_k^-1 r_k + N_k t_{k-1}: r_k was formed by the assembly wavefront a barrier ago, L_k^-1 and N_k just now
+                    const double* Rk = Rr + 56 * (k % 3);
+                    double* Tc = Tt + 56 * (k & 1); const double* Tp = Tt + 56 * ((k + 1) & 1);
+                    typename E2::WAcc ct;
+                    ex.w_acc_zero(ct);
+                    ex.w_acc_mac(ct, Lik, 14, 1, Rk, 4, 1, 14, 1.0, 4);
+                    if (k > 0) ex.w_acc_mac(ct, Mq + 196 * (k & 1), 1, 14, Tp, 4, 1, 14, 1.0, 4);
+                    ex.w_acc_store(ct, Tc, 4, 1, false, 4);
+                }
                 SCVX_TE(tc2_, 26);
             }
-            if (w == 1 && t >= 2) fwd_subst(t - 2);   // the assembly wavefront, two segments behind its own stage: L^-1 and N of segment t - 2 were finished a barrier ago
+            if (w == 1 && t >= 2) fwd_subst(t - 2);   // the assembly wavefront: Gram matrix and stores of t of segment t - 2, finished by the chain a barrier ago
             SCVX_TS(tb_);
             ex.sync();   // hand-over: producer's slot k is complete, consumer has finished with slot k - 1
             SCVX_TE(tb_, 28);
@@ -1894,8 +1897,9 @@ struct Solver {
     //     top    j < m:  t_j = L_j^-1 r_j + N_j  t_{j-1}         (N_j  = -L_j^-1 Wb_{j-1},  slot j, transposed)
     //     bottom k > m:  t_k = L_k^-1 r_k + N'_k t_{k+1}         (N'_k = -L_k^-1 Wb'_{k+1}, slot k + 1, untransposed)
     //     middle:        t_m = L_m^-1 r_m + N_m t_{m-1} + N'_m t_{m+1}
-    // with r_k = (E Hb^-1 g)_k formed by the assembly wavefront of each half from the tiles it holds (as factor_pipelined does) and the
-    // substitution done by the same wavefront two steps behind, right after it has formed the coupling tile of that node.  Until round 5
+    // with r_k = (E Hb^-1 g)_k formed by the assembly wavefront of each half from the tiles it holds (as factor_pipelined does), the two small
+    // products of the substitution done by the CHAIN wavefront right after it has formed L_k^-1 and the coupling tile of that node, and the
+    // Gram contribution and the stores of t_k by the assembly wavefront a barrier later.  Until round 5
     // this executor back-substituted four border systems after the loop (Hb^-1 twice, a pass over D, S_solveN<4>, a coefficient pass:
     // 17-19 % of a solve at B <= 512).
     // The four roles are four routines (one per wavefront: each gets a register allocation of its own -- as one routine the union of their
@@ -1953,23 +1957,25 @@ struct Solver {
         }
         return g;
     }
-    // t of ring index idx (top: node j; bottom: step v) = L^-1 r + (coupling tile in Mp) t_prev; its Gram contribution; rows of `node` of the
-    // four t-vectors.  untr: the coupling tile is stored untransposed (bottom half)
+    // Forward substitution of ring index idx (top: node j; bottom: step v), in two parts.  The CHAIN wavefront, which has just written L^-1
+    // and the coupling tile Nt of this node: t = L^-1 r + Nt t_prev (untr: Nt is stored untransposed -- the bottom half) ...
     template <class E2>
-    SCVX_HD void tw_fwd_subst(typename E2::WAcc& cg, const TwTiles& q, int idx, int node, bool coupled, bool untr, bool with_pred, int l) {
+    SCVX_HD void tw_fwd_product(const TwTiles& q, int idx, const double* Lik, const double* Nt, bool coupled, bool untr) {
         const double* Rk = q.Rr + 56 * (idx % 3);
-        const double* Lik = q.Li + 196 * (idx & 1);
         double* Tc = q.Tt + 56 * (idx & 1); const double* Tp = q.Tt + 56 * ((idx + 1) & 1);
         typename E2::WAcc ct;
         ex.w_acc_zero(ct);
         ex.w_acc_mac(ct, Lik, 14, 1, Rk, 4, 1, 14, 1.0, 4);
         if (coupled) {
-            const double* Nt = (idx & 1) ? q.Mp : q.Mq;
             if (untr) ex.w_acc_mac(ct, Nt, 14, 1, Tp, 4, 1, 14, 1.0, 4);
             else ex.w_acc_mac(ct, Nt, 1, 14, Tp, 4, 1, 14, 1.0, 4);
         }
         ex.w_acc_store(ct, Tc, 4, 1, false, 4);
-        ex.w_sync_lds();
+    }
+    // ... and the ASSEMBLY wavefront, a barrier later: its Gram contribution and the rows of `node` of the four t-vectors
+    template <class E2>
+    SCVX_HD void tw_fwd_gram_store(typename E2::WAcc& cg, const TwTiles& q, int idx, int node, bool with_pred, int l) {
+        const double* Tc = q.Tt + 56 * (idx & 1);
         ex.w_acc_mac(cg, Tc, 1, 4, Tc, 4, 1, 14, 1.0, 4);
         if (l < 56) {
             const int c = l / 14, i = l - 14 * c;
@@ -1986,7 +1992,7 @@ struct Solver {
         }
     }
 
-    // ---- role: top assembly (wavefront 1): Sd_k, r_k, So_k for nodes 0 .. m; coupling tiles N_j and the forward substitution two nodes behind ----
+    // ---- role: top assembly (wavefront 1): Sd_k, r_k, So_k for nodes 0 .. m; Gram matrix and stores of t two nodes behind ----
     template <class E2 = Ex>
     SCVX_HD_NI double tw_top_assembly(bool with_pred) {
         SCVX_THIS_LDS();
@@ -2073,9 +2079,9 @@ struct Solver {
                 ex.w_sync_lds();
                 SCVX_TE(ta_, 24);
             }
-            if (t >= 2 && t - 2 <= m - 2) {   // two nodes behind: forward substitution of node t - 2 (its coupling tile: the chain's, a step ago)
+            if (t >= 2 && t - 2 <= m - 2) {   // two nodes behind: Gram contribution and stores of t of node t - 2 (formed by the chain a step ago)
                 SCVX_TS(tp_);
-                tw_fwd_subst<E2>(cg, q, t - 2, t - 2, t >= 3, false, with_pred, l);
+                tw_fwd_gram_store<E2>(cg, q, t - 2, t - 2, with_pred, l);
                 SCVX_TE(tp_, 26);
             }
             SCVX_TS(tbar_);
@@ -2083,13 +2089,13 @@ struct Solver {
             SCVX_TE(tbar_, 28);
         }
         // the last node of the half, beside the middle node's factorisation
-        tw_fwd_subst<E2>(cg, q, m - 1, m - 1, true, false, with_pred, l);
+        tw_fwd_gram_store<E2>(cg, q, m - 1, m - 1, with_pred, l);
         ex.w_sync_lds();
         ex.w_acc_store(cg, q.Gn, 4, 1, false, 4);   // this half's Gram matrix (the slices are no longer needed)
         return gnacc;
     }
 
-    // ---- role: bottom assembly (wavefront 3): Sd_k, r_k, So_{k-1} for nodes K-1 .. m+1 upwards; coupling tiles N'_k and the substitution ----
+    // ---- role: bottom assembly (wavefront 3): Sd_k, r_k, So_{k-1} for nodes K-1 .. m+1 upwards; Gram matrix and stores of t two steps behind ----
     template <class E2 = Ex>
     SCVX_HD_NI double tw_bot_assembly(bool with_pred) {
         SCVX_THIS_LDS();
@@ -2176,9 +2182,9 @@ struct Solver {
                 ex.w_sync_lds();
                 SCVX_TE(tc_, 24);
             }
-            if (t >= 2 && t - 2 <= nb - 1) {   // two steps behind: forward substitution of step v = t - 2
+            if (t >= 2 && t - 2 <= nb - 1) {   // two steps behind: Gram contribution and stores of t of step v = t - 2
                 SCVX_TS(tq_);
-                tw_fwd_subst<E2>(cg, q, t - 2, K - 1 - (t - 2), t >= 3, true, with_pred, l);
+                tw_fwd_gram_store<E2>(cg, q, t - 2, K - 1 - (t - 2), with_pred, l);
                 SCVX_TE(tq_, 26);
             }
             SCVX_TS(tbar_);
@@ -2186,7 +2192,7 @@ struct Solver {
             SCVX_TE(tbar_, 28);
         }
         if (nb - 1 > nsteps - 3) {   // the last node of the half, if the loop did not reach it
-            tw_fwd_subst<E2>(cg, q, nb - 1, m + 1, nb - 1 >= 1, true, with_pred, l);
+            tw_fwd_gram_store<E2>(cg, q, nb - 1, m + 1, with_pred, l);
         }
         ex.w_sync_lds();
         ex.w_acc_store(cg, q.Gn, 4, 1, false, 4);
@@ -2227,6 +2233,8 @@ struct Solver {
                     const size_t slot = bot ? (size_t)(k + 1) : (size_t)k;
                     for (int e = l; e < 196; e += 64) Nf_[slot * 196 + e] = Nt[e];
                 }
+                // t of this node (r_k: the assembly wavefront's, a barrier ago); its Gram contribution and stores are the assembly's, a barrier on
+                tw_fwd_product<E2>(q, v, Lik, (v & 1) ? q.Mp : q.Mq, v > 0, bot);
                 ex.w_sync_lds();
                 SCVX_TE(tb0_, 24);
             }
