@@ -20,6 +20,12 @@
 #ifndef SCVX_CHOL_DPP
 #define SCVX_CHOL_DPP 2
 #endif
+// order of the trailing updates in the DPP Cholesky's column steps: 0 = all of column J right after its scaling; 1 = the pivot column
+// first, the rest in one burst behind the next column's v_rsq_f64; 2 = the rest pinned one by one between the links of the next column's
+// pivot chain (fnma_rbc_tied).  Alone on a SIMD: 3,415 / 3,417 / 3,685 ticks per call (profiles/r06_chol_dpp_micro.txt): the order does not matter and pinning costs -- the routine is bound by the issue rate of its 182 64-bit DPP multiply-adds, not by the pivot chains
+#ifndef SCVX_CHOL_ORDER
+#define SCVX_CHOL_ORDER 1
+#endif
 #ifndef SCVX_CHAIN_R
 #define SCVX_CHAIN_R 8   // steps of the block recurrence whose operands are in flight (10 VGPRs each)
 #endif
@@ -230,30 +236,84 @@ struct WaveExT {
             if constexpr (C < 14) { fnma_rbc<C>(m[C], m[J], m[J]); CholTrail<J, C + 1>::run(m); }
         }
     };
+    // acc -= (value of s in lane N of this row) * b, pinned into a dependent chain: `tie` passes THROUGH the instruction as an in / out
+    // operand it does not touch, so the compiler must place it after the instruction that produced `tie` and before the one that
+    // consumes it -- the only way to tell the scheduler where an inline-asm instruction goes (it cannot see what it is)
+    template <int N> static __device__ __forceinline__ void fnma_rbc_tied(double& acc, double s, double b, double& tie) {
+#if SCVX_CHOL_DPP == 2
+        asm("v_fmac_f64_dpp %0, -%2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf" : "+v"(acc), "+v"(tie) : "v"(s), "v"(b), "n"(N));
+#else
+        acc = fma(-rbc<N>(s), b, acc);
+#endif
+    }
+    template <int J, int C, int STRIDE> struct CholTrailTied {   // m[c] -= L[i][J] L[c][J] for c = C, C + STRIDE, ... <= 13, tied to `tie`
+        static __device__ __forceinline__ void run(double (&m)[14], double& tie) {
+            if constexpr (C < 14) { fnma_rbc_tied<C>(m[C], m[J], m[J], tie); CholTrailTied<J, C + STRIDE, STRIDE>::run(m, tie); }
+        }
+    };
     // Column step J, software-pipelined by hand: the trailing update of column J - 1 on the PIVOT column (c = J) was issued at the end of
-    // step J - 1; step J starts the pivot chain (row broadcast, v_rsq_f64, two Newton steps: ~100 dependent cycles) and the rest of
-    // column J - 1's trailing updates (c > J) are issued into that chain's latency instead of ahead of it.
+    // step J - 1; step J runs the pivot chain (row broadcast, v_rsq_f64, two Newton steps, the scaling: nine dependent instructions,
+    // ~100 cycles) and the other trailing updates of column J - 1 (c > J) are issued BETWEEN those instructions, each pinned to one link of
+    // the chain (fnma_rbc_tied): left to itself the scheduler clusters them ahead of the chain, which then runs with nothing beside it.
     template <int J> struct CholCol {
+        static constexpr int P = J > 0 ? J - 1 : 0;   // the column whose trailing updates ride along
         static __device__ __forceinline__ void run(double (&m)[14], double floor_, int i, bool& ok) {
             if constexpr (J < 14) {
                 const double d0 = rbc<J>(m[J]);
                 ok = ok && (d0 == d0);
                 const double d = fmax(d0, floor_);
                 double ip = __builtin_amdgcn_rsq(d);
-                if constexpr (J > 0) CholTrail<J - 1, J + 1>::run(m);   // deferred: columns c > J of the previous step
-                const double hd = 0.5 * d;
-                ip = fma(ip, fma(-hd * ip, ip, 0.5), ip);
-                ip = fma(ip, fma(-hd * ip, ip, 0.5), ip);
+#if SCVX_CHOL_ORDER == 2
+                if constexpr (J > 0) CholTrailTied<P, J + 1, 9>::run(m, ip);
+#elif SCVX_CHOL_ORDER == 1
+                if constexpr (J > 0) CholTrail<P, J + 1>::run(m);   // deferred: columns c > J of the previous step, in one burst behind v_rsq_f64
+#endif
+                double nhd = -0.5 * d;
+#if SCVX_CHOL_ORDER == 2
+                if constexpr (J > 0) CholTrailTied<P, J + 2, 9>::run(m, nhd);
+#endif
+                double t = nhd * ip;
+#if SCVX_CHOL_ORDER == 2
+                if constexpr (J > 0) CholTrailTied<P, J + 3, 9>::run(m, t);
+#endif
+                t = fma(t, ip, 0.5);
+#if SCVX_CHOL_ORDER == 2
+                if constexpr (J > 0) CholTrailTied<P, J + 4, 9>::run(m, t);
+#endif
+                ip = fma(ip, t, ip);
+#if SCVX_CHOL_ORDER == 2
+                if constexpr (J > 0) CholTrailTied<P, J + 5, 9>::run(m, ip);
+#endif
+                t = nhd * ip;
+#if SCVX_CHOL_ORDER == 2
+                if constexpr (J > 0) CholTrailTied<P, J + 6, 9>::run(m, t);
+#endif
+                t = fma(t, ip, 0.5);
+#if SCVX_CHOL_ORDER == 2
+                if constexpr (J > 0) CholTrailTied<P, J + 7, 9>::run(m, t);
+#endif
+                ip = fma(ip, t, ip);
+#if SCVX_CHOL_ORDER == 2
+                if constexpr (J > 0) CholTrailTied<P, J + 8, 9>::run(m, ip);
+#endif
+                double sc = m[J] * ip;
+#if SCVX_CHOL_ORDER == 2
+                if constexpr (J > 0) CholTrailTied<P, J + 9, 9>::run(m, sc);
+#endif
                 // The diagonal entry L[J][J] is never read again (the trailing updates and the inverse only use the strictly lower
                 // triangle), so lane J keeps 1 / L[J][J] in its place: the inverse fetches it from there by one more row broadcast, and
                 // the 14 reciprocals cost neither VGPRs nor SGPRs (the v_readlane form held them in 28 VGPRs).
-                m[J] = (i == J) ? ip : m[J] * ip;
+                m[J] = (i == J) ? ip : sc;
 #if SCVX_CHOL_DPP == 2
                 // a VALU write of a VGPR must be two wait states ahead of a DPP read of it, and the hazard recogniser does not look inside
                 // asm: the column passes THROUGH the nop (in / out operand), so every v_fmac_f64_dpp below depends on it
                 asm volatile("s_nop 1" : "+v"(m[J]));
 #endif
+#if SCVX_CHOL_ORDER == 0
+                CholTrail<J, J + 1>::run(m);   // the whole trailing update of this column, at once
+#else
                 if constexpr (J + 1 < 14) fnma_rbc<J + 1>(m[J + 1], m[J], m[J]);   // the next pivot's column first
+#endif
                 CholCol<J + 1>::run(m, floor_, i, ok);
             }
         }
