@@ -155,6 +155,20 @@
 #ifndef SCVX_CARRY_BIGSUMS
 #define SCVX_CARRY_BIGSUMS 0
 #endif
+// CARRIED RESIDUALS (round 6).  The dual and the equality residual are LINEAR in the iterate (rx = c + E'y - J'Z, ry = E V + dk) and the
+// Newton direction cancels them exactly, so after a step of length alpha  rx+ = (1 - alpha) rx - alpha r1,  ry+ = (1 - alpha) ry - alpha r2
+// with r1, r2 the residuals of the reduced KKT solve -- 1e-6 ... 1e-10 of the right-hand side, irrelevant while the residuals themselves
+// are large.  While the merit of an iterate is above SCVX_RESID_FRESH_FROM the next iteration therefore does not re-evaluate them (one
+// cone-map pass, E'y over A' and D, E V over D, a norm: 0.34 of the 3.2 MB an iteration moves) but SCALES the vectors and their norms; from
+// that merit on -- the endgame, where the solve errors are what limits the solver (section 2.2) and where every stopping test is taken --
+// and at least every eighth iteration they are evaluated as before.  A carried merit below the threshold is re-evaluated in the same
+// iteration, so no test ever passes on carried values.  0 = evaluate in every iteration (rounds 1-5).
+#ifndef SCVX_RESID_UPDATE
+#define SCVX_RESID_UPDATE 1
+#endif
+#ifndef SCVX_RESID_FRESH_FROM
+#define SCVX_RESID_FRESH_FROM 1e-4
+#endif
 // 1: the two-ended factorisation (four wavefronts per trajectory) carries the border in t-space like the other forms (round 6); 0: the
 // round-5 border (four back-substituted systems after the loop), kept for A/B runs
 #ifndef SCVX_TWISTED_TSPACE
@@ -3396,6 +3410,8 @@ struct Solver {
         bool best_in_V = false;
         bool kept = false;   // this solve's iterate for a possible warm start has been stored
         const int degree = L.ncones;
+        bool res_carried = false;                 // rx / ry / their norms were scaled by the last step instead of being due for evaluation
+        double nrx_c = 0.0, nry_c = 0.0;          // the carried norms
         for (int it = 1; it <= C.max_iter; it++) {
             res.iters = it;
             // cone residual rz = S - a(V), S'Z, and -- on the same sweep -- the scaling of this iterate
@@ -3410,7 +3426,7 @@ struct Solver {
             const bool fused = SCVX_FUSED_RES != 0 && Ex::kFusedResidual && !(warmed && it == 1);
             double nrx, nry;
             bool kkt_ok = true;
-            if (!fused) {
+            auto eval_residuals = [&]() {
                 cone_map_t(Z, rx);
                 double nrx2 = 0.0;
                 const double sgy = Et_apply(y, rx, rx, 2, 0.0, 0.0, nullptr, &nrx2);     // rx = c + E'y - J'Z on the local part, masked, with its norm
@@ -3420,6 +3436,10 @@ struct Solver {
                 ex.sync();
                 const double nry2 = E_apply(V, ry, true, dk, 1.0);   // ry = E V + dk
                 nrx = sqrt(nrx2 + (g0 * g0 + g1 * g1 + g2 * g2 + g3 * g3)); nry = sqrt(nry2);
+            };
+            if (!fused) {
+                if (res_carried) { nrx = nrx_c; nry = nry_c; }
+                else eval_residuals();
             } else {
                 cone_map_t(Z, rx, nullptr, false, true);             // rx = -J'Z ...
                 if (ex.lane() == 0) {                                // ... + c (the s row still lacks Sg . y)
@@ -3438,12 +3458,21 @@ struct Solver {
             }
             const double pobj = -V[14 * K] + C.wNu * V[L.iTNU] + 0.5 * V[L.iTTR] + V[L.iTS];
             const double nrz = sqrt(nrz2);
-            const double pres = nry > nrz ? nry : nrz;
-            const double dres = nrx / (C.wNu > 1.0 ? C.wNu : 1.0);
             const double relgap = gap / (fabs(pobj) > 1.0 ? fabs(pobj) : 1.0);
-            SCVX_TE(tR_, 9);
+            double pres = nry > nrz ? nry : nrz;
+            double dres = nrx / (C.wNu > 1.0 ? C.wNu : 1.0);
             double merit = pres > dres ? pres : dres;
             if (relgap > merit) merit = relgap;
+            if (res_carried && !(merit >= SCVX_RESID_FRESH_FROM)) {
+                // the endgame begins here (or the carried values have gone non-finite): evaluate, and decide on what was evaluated
+                eval_residuals();
+                res_carried = false;
+                pres = nry > nrz ? nry : nrz;
+                dres = nrx / (C.wNu > 1.0 ? C.wNu : 1.0);
+                merit = pres > dres ? pres : dres;
+                if (relgap > merit) merit = relgap;
+            }
+            SCVX_TE(tR_, 9);
             SCVX_DBG("%3d pobj %+.8e gap %.2e pres %.2e (ry %.2e rz %.2e) dres %.2e\n", it, pobj, gap, pres, nry, nrz, dres);
             if (!(merit == merit) || !(gap == gap)) { res.status = 3; break; }
             cur_gate = pres > relgap ? pres : relgap;
@@ -3512,6 +3541,19 @@ struct Solver {
                 const gptr Vn = best_in_V ? Vbest : V;
                 update_pass(alpha, Vn);   // S, Z (from the old V), the new V and y
                 if (best_in_V) { Vbest = V; V = Vn; best_in_V = false; }   // Vbest now holds the best iterate, V the new one
+            }
+            res_carried = false;
+            if (SCVX_RESID_UPDATE != 0 && !fused && merit >= SCVX_RESID_FRESH_FROM && (it & 7) != 0) {
+                // far from the optimum: the next iterate's linear residuals are (1 - alpha) times this one's (see SCVX_RESID_UPDATE)
+                const double om = 1.0 - alpha;
+                {
+                    gptr rx_ = rx; gptr ry_ = ry;
+                    stream(0, L.nv, [&](int i) { return rx_[i]; }, [&](int i, double v) { rx_[i] = om * v; });
+                    stream(0, L.ny, [&](int i) { return ry_[i]; }, [&](int i, double v) { ry_[i] = om * v; });
+                }
+                ex.sync();
+                nrx_c = om * nrx; nry_c = om * nry;
+                res_carried = true;
             }
         }
         res.merit = best_merit;
