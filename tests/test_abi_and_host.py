@@ -107,7 +107,8 @@ def test_conic_kernels_keep_the_solver_object_out_of_private_memory(tmp_path):
     # ~200 scratch accesses per interior-point iteration, 3 % of its traffic); LDS: eight single-wavefront blocks per CU (two per SIMD)
     # round 6: the tiles of the switched-off build_kkt(res) path are no longer allocated: nine blocks' worth of LDS per CU again (the kernel
     # itself is VGPR-limited at eight)
-    assert int(one["private_segment_fixed_size"]) <= 896 and int(one["group_segment_fixed_size"]) <= 160 * 1024 // 9, one
+    # (928 B since the carried residuals of round 6: three more values live across the non-inlined passes of attempt_solve)
+    assert int(one["private_segment_fixed_size"]) <= 960 and int(one["group_segment_fixed_size"]) <= 160 * 1024 // 9, one
     k0 = [k for n, k in kernels.items() if "threedof_kernelE" in n][0]
     assert int(k0["private_segment_fixed_size"]) <= 1200, k0
 
