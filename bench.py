@@ -343,10 +343,19 @@ def k4_traffic_model(tstats, launches):
     m = json.load(open(f))
     total = m["bytes_per_ipm_iteration"] * tstats["ipm_iters"] + m.get("bytes_per_solve", 0.0) * tstats["solves"]
     cal = m.get("lib_source_hash")
+    # the sources say nothing about -D switches or another LIB_PATH: the LOADED library's own report of its compile-time switches is
+    # compared too when the calibration carries one
+    try:
+        from successiveconvexification_amd import _lib as _l
+        running_bin = lib_hash.lib_build_switches(_l.LIB_PATH)
+    except Exception:
+        running_bin = None
+    cal_bin = m.get("lib_build_switches")
+    same = bool(cal and running and cal == running) and (cal_bin is None or running_bin is None or cal_bin == running_bin)
     return {"bytes_per_launch": total / launches, "bytes_per_ipm_iteration": m["bytes_per_ipm_iteration"],
             "bytes_per_solve": m.get("bytes_per_solve", 0.0), "calibrated_on_lib_source_hash": cal, "calibrated_on_git_head": m.get("git_head"),
-            "running_lib_source_hash": running,
-            "calibration_matches_running_library": (cal == running) if (cal and running) else False,
+            "running_lib_source_hash": running, "calibrated_on_build_switches": cal_bin, "running_build_switches": running_bin,
+            "calibration_matches_running_library": same,
             "source": "profiles/%s: %s" % (os.path.basename(f), m.get("source", ""))}
 
 

@@ -23,6 +23,7 @@
 #include <new>
 #include <vector>
 
+#include <cstdio>
 #include "scvx_socp.hpp"
 
 using scvx::fail;
@@ -784,6 +785,23 @@ int scvx_batch_get_solver_stats(scvx_batch* b, int32_t* status, int32_t* iters, 
         if (pobj) pobj[t] = info[4 * t + 3];
     }
     return SCVX_OK;
+}
+
+// Diagnostic export (not part of include/scvx.h): the compile-time switches of the conic kernel this library was built with, so that a
+// measurement can name the build it was taken on -- the hash of the sources alone does not see a -D on the command line.
+int scvx_debug_build_switches(char* out, int n) {
+    return std::snprintf(out, (size_t)(n > 0 ? n : 0),
+                         "CHOL_DPP=%d CHOL_ORDER=%d RESID_UPDATE=%d RESID_FRESH_FROM=%g TWISTED_TSPACE=%d FUSED_RES=%d CARRY_BIGSUMS=%d REFINE_FUSED=%d "
+                         "K4_OCC=%d K4_BLOCK_OCC=%d K4_PIPELINE=%d K4_TWISTED=%d STREAM_U=%d CHAIN_R=%d FACTOR_T=%d PROF=%d",
+                         SCVX_CHOL_DPP, SCVX_CHOL_ORDER, SCVX_RESID_UPDATE, (double)SCVX_RESID_FRESH_FROM, SCVX_TWISTED_TSPACE, SCVX_FUSED_RES,
+                         SCVX_CARRY_BIGSUMS, SCVX_REFINE_FUSED, SCVX_K4_OCC, SCVX_K4_BLOCK_OCC, SCVX_K4_PIPELINE, SCVX_K4_TWISTED, SCVX_STREAM_U,
+                         SCVX_CHAIN_R, (int)sizeof(SCVX_FACTOR_T),
+#if defined(SCVX_IPM_PROF)
+                         1
+#else
+                         0
+#endif
+                         );
 }
 
 #if defined(SCVX_IPM_PROF)

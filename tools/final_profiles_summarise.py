@@ -44,6 +44,7 @@ traffic = (2.0 * tot[k]["FETCH_SIZE"] + tot[k]["WRITE_SIZE"]) * 1024.0
 iters = meta["ipm_iters"] + meta["warmup_ipm_iters"]
 solves = meta["solves"] + meta["warmup_solves"]
 model = {"bytes_per_ipm_iteration": traffic / iters, "bytes_per_solve": 0.0, "lib_source_hash": h, "git_head": lib_hash.git_head(),
+         "lib_build_switches": lib_hash.lib_build_switches(),   # of the .so in the tree (the one the profiled run loaded: it travels with the snapshot)
          "source": "tools/final_profiles.sh %s: (2 x FETCH_SIZE + WRITE_SIZE) of %s over %d launches of the bench mix / the interior-point iterations "
                    "those launches executed (device-side counters); per-solve overheads are inside the per-iteration figure" % (tag, k, launches[k]),
          "calibration": {"traffic_bytes": traffic, "launches": launches[k], "ipm_iterations": iters, "solves": solves,

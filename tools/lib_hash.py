@@ -19,6 +19,20 @@ def lib_source_hash():
     return h.hexdigest()[:16]
 
 
+def lib_build_switches(path=None):
+    """the compile-time switches the LOADED library reports (scvx_debug_build_switches): two builds of the same sources with different -D
+    flags differ here (the binary itself is not reproducible byte for byte: its hash is no identity)"""
+    import ctypes
+    path = path or os.path.join(ROOT, "successiveconvexification_amd", "libscvx_hip.so")
+    try:
+        L = ctypes.CDLL(path)
+        buf = ctypes.create_string_buffer(512)
+        L.scvx_debug_build_switches(buf, 512)
+        return buf.value.decode()
+    except Exception:
+        return None
+
+
 def git_head():
     try:
         return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
@@ -27,4 +41,4 @@ def git_head():
 
 
 if __name__ == "__main__":
-    print(lib_source_hash(), git_head())
+    print(lib_source_hash(), git_head(), lib_build_switches())
