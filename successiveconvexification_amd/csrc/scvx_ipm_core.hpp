@@ -2282,8 +2282,328 @@ struct Solver {
         return ok;
     }
 
+    // ---- the two-ended form for TWO wavefronts per trajectory (B <= 4 per CU; SCVX_K4_TWISTED2): each wavefront runs ONE half on its own --
+    // assembly, chain, coupling tile, substitution and Gram contribution of a node one after the other, no hand-over barrier, no rings -- so
+    // the sequential part is 26 node steps instead of the 51 of the assembly / chain pipeline (factor_pipelined).  The tile set of a half
+    // is COMPACT (2,068 doubles at control_dim 3: both halves and the solver frames fit the 40 KB a block may take when four share a CU):
+    // the pivot tile is dead once chol_inv14 has read it, so the coupling tile takes its place; Wb_k overwrites Wb_{k-1} in place after the
+    // coupling tile has been formed; one dense Hxi tile, re-scattered (same 34 non-zeros) when the bottom half needs the other node's.
+    struct TwC { double *Sd, *So, *Wb, *Li, *Dt, *T, *Bp, *Hh, *Hd, *Gn, *Rk, *Tt, *Sg; };
+    static SCVX_HD TwC twc_tiles(double* sc) {
+        TwC q;
+        q.Sd = sc;                  // pivot tile, then the coupling tile N of the same node
+        q.So = q.Sd + 196;
+        q.Wb = q.So + 196;          // Wb of the previous node, replaced by this node's
+        q.Li = q.Wb + 196;
+        q.Dt = q.Li + 196;
+        q.T = q.Dt + DSZ;
+        q.Bp = q.T + 14 * TS;
+        q.Hh = q.Bp + BPN;
+        q.Hd = q.Hh + 2 * NODE_SZ;
+        q.Gn = q.Hd + 196;
+        q.Rk = q.Gn + 2 * NXU * 4;
+        q.Tt = q.Rk + 56;           // 2 x 56: t of the previous node | of this one, by step parity
+        q.Sg = q.Tt + 112;          // 42 (+ 14: the Gram product's over-read)
+        return q;
+    }
+    static constexpr int kTwCDoubles = 4 * 196 + DSZ + 14 * TS + BPN + 2 * NODE_SZ + 196 + 2 * NXU * 4 + 56 + 112 + 42 + 14;
+    // chain part of node step v of a half (top: node v; bottom: node K-1-v): pivot update, Cholesky + inverse, L^-1 to HBM, coupling tile (into
+    // the pivot tile's place) to HBM, this node's Wb in place of the previous one's, t = L^-1 r + N t_prev, Gram contribution, rows of t to HBM
+    template <class E2>
+    SCVX_HD bool twc_chain_step(typename E2::WAcc& cg, const TwC& q, int v, int node, bool bot, bool last, bool with_pred, int l) {
+        const fptr Nf_ = Nf;
+        double* M = q.Sd;
+        if (v > 0) { ex.w_tile_gemm(M, 14, 1, q.Wb, 14, 1, q.Wb, 1, 14, 14, -1.0, true); ex.w_sync_lds(); }
+        const bool ok = ex.w_chol_inv14(M, q.Li);
+        ex.w_sync_lds();
+        tw_store_linv(node, q.Li, l);
+        if (v > 0) {
+            if (bot) ex.w_tile_gemm(M, 14, 1, q.Li, 14, 1, q.Wb, 14, 1, 14, -1.0, false);   // N'_k = -L_k^-1 Wb'_{k+1}, untransposed, slot k + 1
+            else ex.w_tile_gemm(M, 1, 14, q.Li, 14, 1, q.Wb, 14, 1, 14, -1.0, false);       // N_k = -L_k^-1 Wb_{k-1}, transposed, slot k
+            ex.w_sync_lds();
+            const size_t slot = bot ? (size_t)(node + 1) : (size_t)node;
+            for (int e = l; e < 196; e += 64) Nf_[slot * 196 + e] = M[e];
+        }
+        {
+            double* Tc = q.Tt + 56 * (v & 1); const double* Tp = q.Tt + 56 * ((v + 1) & 1);
+            typename E2::WAcc ct;
+            ex.w_acc_zero(ct);
+            ex.w_acc_mac(ct, q.Li, 14, 1, q.Rk, 4, 1, 14, 1.0, 4);
+            if (v > 0) {
+                if (bot) ex.w_acc_mac(ct, M, 14, 1, Tp, 4, 1, 14, 1.0, 4);
+                else ex.w_acc_mac(ct, M, 1, 14, Tp, 4, 1, 14, 1.0, 4);
+            }
+            ex.w_acc_store(ct, Tc, 4, 1, false, 4);
+            ex.w_sync_lds();
+            ex.w_acc_mac(cg, Tc, 1, 4, Tc, 4, 1, 14, 1.0, 4);
+            if (l < 56) {
+                const int c = l / 14, i = l - 14 * c;
+                const gptr dst = c == 0 ? ys : (c == 1 ? ytr : (c == 2 ? ynu : dy));
+                if (c < 3 || with_pred) dst[14 * node + i] = Tc[4 * i + c];
+            }
+        }
+        if (!last) {   // this node's Wb = So L^-T (top: So_k; bottom: So_{k-1}'), in place of the previous node's
+            if (bot) ex.w_tile_gemm(q.Wb, 14, 1, q.So, 1, 14, q.Li, 1, 14, 14, 1.0, false);
+            else ex.w_tile_gemm(q.Wb, 14, 1, q.So, 14, 1, q.Li, 1, 14, 14, 1.0, false);
+        }
+        ex.w_sync_lds();
+        return ok;
+    }
+    // top half on one wavefront: nodes 0 .. m-1 (assembly + chain each), then the assembly of the middle node (Sd_m, r_m)
+    template <class E2 = Ex>
+    SCVX_HD_NI bool twc_top(bool with_pred, double& gnacc_out) {
+        SCVX_THIS_LDS();
+        const int K = L.K, m = K / 2, l = ex.wlane();
+        const dcptr D_ = D; const double hnui_ = hnui;
+        const TwC q = twc_tiles(ex.pipe_scratch());
+        const int hpos_lane = hx_dense_pos(l <= HX_SZ ? l : 0);
+        const int gat = l < 2 * NXU ? 4 * (l >= NXU ? l - NXU : l) + (l >= NXU ? 3 : 1) : 0;
+        typename E2::WAcc cg;
+        ex.w_acc_zero(cg);
+        double gnacc = 0.0;
+        bool ok = true;
+        for (int e = l; e < 2 * NXU * 4 + 56 + 112 + 42 + 14; e += 64) q.Gn[e] = 0.0;
+        ex.w_sync_lds();
+        if (l < 2 * NXU) q.Gn[NXU * 4 + gat] = tw_gnode_elem(0, l, with_pred);
+        for (int e = l; e < DSZ; e += 64) q.Dt[e] = D_[e];
+        for (int e = l; e < NODE_SZ; e += 64) q.Hh[NODE_SZ + e] = tw_node_elem(0, e);
+        ex.w_sync_lds();
+        for (int e = l; e < 196; e += 64) q.Hd[e] = hxi_entry(q.Hh + NODE_SZ, e / 14, e % 14);
+        ex.w_sync_lds();
+        ex.w_tile_gemm(q.T, TS, 1, q.Dt, 1, 14, q.Hd, 14, 1, 14, 1.0, false);
+        for (int c0 = l; c0 < BPN; c0 += 64) {
+            const int i = c0 / NU, c = c0 - NU * i;
+            q.T[TS * i + 14 + c] = bhu(q.Dt, 14, i, c, q.Hh + NODE_SZ + HX_SZ);
+        }
+        ex.w_sync_lds();
+        double hnext = l < NODE_SZ ? tw_node_elem(1, l) : 0.0;
+        double gnext = l < 2 * NXU ? tw_gnode_elem(1, l, with_pred) : 0.0;
+        double sgnext = l < 42 ? tw_gseg_elem(0, l, with_pred) : 0.0;
+        for (int k = 0; k <= m; k++) {
+            SCVX_TS(ta_);
+            double pre[NPW];
+            dcptr Dn = D_ + (size_t)(k + 1 < K ? k + 1 : k) * DSZ;
+            SCVX_UNROLL
+            for (int c = 0; c < NPW; c++) { const int e = l + 64 * c; pre[c] = e < DSZ ? Dn[e] : 0.0; }
+            for (int e = l; e < NODE_SZ; e += 64) { q.Hh[e] = q.Hh[NODE_SZ + e]; }
+            if (l < 2 * NXU) q.Gn[gat] = q.Gn[NXU * 4 + gat];
+            if (l < 42) q.Sg[l] = sgnext;
+            ex.w_sync_lds();
+            if (l < NODE_SZ) q.Hh[NODE_SZ + l] = hnext;
+            hnext = l < NODE_SZ ? tw_node_elem(k + 2 <= K ? k + 2 : K, l) : 0.0;
+            if (l < 2 * NXU) q.Gn[NXU * 4 + gat] = gnext;
+            gnext = l < 2 * NXU ? tw_gnode_elem(k + 2 <= K ? k + 2 : K, l, with_pred) : 0.0;
+            sgnext = l < 42 ? tw_gseg_elem(k + 1 < K ? k + 1 : k, l, with_pred) : 0.0;
+            ex.w_sync_lds();
+            if (l <= HX_SZ) q.Hd[hpos_lane] = q.Hh[NODE_SZ + (l < HX_SZ ? l : HX_Q)];   // dense Hxi_{k+1}
+            for (int c0 = l; c0 < BPN; c0 += 64) {
+                const int i = c0 / NU, c = c0 - NU * i;
+                q.T[TS * i + 14 + NU + c] = bhu(q.Dt, 14 + NU, i, c, q.Hh + NODE_SZ + HX_SZ);
+            }
+            ex.w_sync_lds();
+            {
+                typename E2::WAcc cm, cr;
+                ex.w_acc_zero(cm); ex.w_acc_zero(cr);
+                ex.w_acc_mac(cm, q.T, TS, 1, q.Dt, 14, 1, TW, 1.0);
+                ex.w_acc_mac(cr, q.T, TS, 1, q.Gn, 4, 1, 14 + NU, 1.0, 4);
+                ex.w_acc_mac(cr, q.T + 14 + NU, TS, 1, q.Gn + NXU * 4 + 14 * 4, 4, 1, NU, 1.0, 4);
+                ex.w_acc_mac(cr, q.Hd, 14, 1, q.Gn + NXU * 4, 4, 1, 14, -1.0, 4);
+                ex.w_acc_store_init(cm, q.Sd, q.Hd, hnui_);
+                ex.w_acc_store(cr, q.Rk, 4, 1, false, 4);
+                ex.w_sync_lds();
+                if (l < 14) {
+                    q.Rk[4 * l] = q.Dt[14 * CS + l];
+                    q.Rk[4 * l + 2] = hnui_ * q.Sg[28 + l];
+                    q.Rk[4 * l + 3] += hnui_ * q.Sg[l] + q.Sg[14 + l];
+                    gnacc += q.Sg[28 + l] * q.Sg[l];
+                }
+            }
+            if (k < m) {
+                for (int c0 = l; c0 < BPN; c0 += 64) q.Bp[c0] = q.Dt[14 * (14 + NU) + c0];
+                ex.w_sync_lds();
+                SCVX_UNROLL
+                for (int c = 0; c < NPW; c++) { const int e = l + 64 * c; if (e < DSZ) q.Dt[e] = pre[c]; }
+                ex.w_sync_lds();
+                ex.w_tile_gemm(q.T, TS, 1, q.Dt, 1, 14, q.Hd, 14, 1, 14, 1.0, false);
+                for (int c0 = l; c0 < BPN; c0 += 64) {
+                    const int i = c0 / NU, c = c0 - NU * i;
+                    q.T[TS * i + 14 + c] = bhu(q.Dt, 14, i, c, q.Hh + NODE_SZ + HX_SZ);
+                }
+                ex.w_sync_lds();
+                for (int e = l; e < 196; e += 64) {
+                    const int i = e / 14, j = e - 14 * i;
+                    q.So[e] = so_elem(q.T, q.Bp, i, j);
+                }
+            }
+            ex.w_sync_lds();
+            SCVX_TE(ta_, 24);
+            if (k < m) {
+                SCVX_TS(tb_);
+                ok = twc_chain_step<E2>(cg, q, k, k, false, false, with_pred, l) && ok;   // (Wb_{m-1} is needed by the middle node: never `last`)
+                SCVX_TE(tb_, 26);
+            }
+        }
+        ex.w_sync_lds();
+        ex.w_acc_store(cg, q.Gn, 4, 1, false, 4);   // this half's Gram matrix
+        gnacc_out = gnacc;
+        return ok;
+    }
+    // bottom half on one wavefront: nodes K-1 .. m+1 upwards
+    template <class E2 = Ex>
+    SCVX_HD_NI bool twc_bot(bool with_pred, double& gnacc_out) {
+        SCVX_THIS_LDS();
+        const int K = L.K, m = K / 2, nb = K - 1 - m, l = ex.wlane();
+        const dcptr D_ = D; const double hnui_ = hnui;
+        const TwC q = twc_tiles(ex.pipe_scratch() + kTwCDoubles);
+        const int hpos_lane = hx_dense_pos(l <= HX_SZ ? l : 0);
+        const int gat = l < 2 * NXU ? 4 * (l >= NXU ? l - NXU : l) + (l >= NXU ? 3 : 1) : 0;
+        typename E2::WAcc cg;
+        ex.w_acc_zero(cg);
+        double gnacc = 0.0;
+        bool ok = true;
+        for (int e = l; e < 2 * NXU * 4 + 56 + 112 + 42 + 14; e += 64) q.Gn[e] = 0.0;
+        for (int e = l; e < 196; e += 64) q.Hd[e] = 0.0;   // the structural zeros of a dense Hxi tile
+        ex.w_sync_lds();
+        {
+            dcptr Dk = D_ + (size_t)(K - 1) * DSZ;
+            if (l < 2 * NXU) { q.Gn[gat] = tw_gnode_elem(K - 1, l, with_pred); q.Gn[NXU * 4 + gat] = tw_gnode_elem(K, l, with_pred); }
+            if (l < 42) q.Sg[l] = tw_gseg_elem(K - 1, l, with_pred);
+            for (int e = l; e < DSZ; e += 64) q.Dt[e] = Dk[e];
+            for (int e = l; e < NODE_SZ; e += 64) { q.Hh[e] = tw_node_elem(K - 1, e); q.Hh[NODE_SZ + e] = tw_node_elem(K, e); }
+            for (int c0 = l; c0 < BPN; c0 += 64) q.Bp[c0] = D_[(size_t)(K - 2) * DSZ + 14 * (14 + NU) + c0];
+            ex.w_sync_lds();
+        }
+        for (int u = 0; u < nb; u++) {
+            const int k = K - 1 - u;
+            SCVX_TS(tc_);
+            const int kn = k - 1 > m ? k - 1 : k, kb2 = kn - 1;
+            double pre[NPW];
+            dcptr Dn = D_ + (size_t)kn * DSZ;
+            SCVX_UNROLL
+            for (int c = 0; c < NPW; c++) { const int e = l + 64 * c; pre[c] = e < DSZ ? Dn[e] : 0.0; }
+            const double hn = l < NODE_SZ ? tw_node_elem(kn, l) : 0.0;
+            const double gn = l < 2 * NXU ? tw_gnode_elem(kn, l, with_pred) : 0.0;
+            const double sgn = l < 42 ? tw_gseg_elem(kn, l, with_pred) : 0.0;
+            double bpn[(BPN + 63) / 64];
+            SCVX_UNROLL
+            for (int c = 0; c < (BPN + 63) / 64; c++) { const int e = l + 64 * c; bpn[c] = e < BPN ? (double)D_[(size_t)kb2 * DSZ + 14 * (14 + NU) + e] : 0.0; }
+            if (l <= HX_SZ) q.Hd[hpos_lane] = q.Hh[l < HX_SZ ? l : HX_Q];   // dense Hxi_k
+            ex.w_sync_lds();
+            ex.w_tile_gemm(q.T, TS, 1, q.Dt, 1, 14, q.Hd, 14, 1, 14, 1.0, false);     // TA_k = A_k Hxi_k
+            for (int c0 = l; c0 < 2 * BPN; c0 += 64) {
+                const bool pls = c0 >= BPN;
+                const int qq = pls ? c0 - BPN : c0, i = qq / NU, c = qq - NU * i;
+                const double* h = q.Hh + (pls ? NODE_SZ : 0) + HX_SZ;
+                const int cc = pls ? 14 + NU : 14;
+                q.T[TS * i + cc + c] = bhu(q.Dt, cc, i, c, h);
+            }
+            ex.w_sync_lds();
+            if (l <= HX_SZ) q.Hd[hpos_lane] = q.Hh[NODE_SZ + (l < HX_SZ ? l : HX_Q)];   // ... re-scattered: dense Hxi_{k+1} (same non-zeros)
+            ex.w_sync_lds();
+            {
+                typename E2::WAcc cm, cr;
+                ex.w_acc_zero(cm); ex.w_acc_zero(cr);
+                ex.w_acc_mac(cm, q.T, TS, 1, q.Dt, 14, 1, TW, 1.0);
+                ex.w_acc_mac(cr, q.T, TS, 1, q.Gn, 4, 1, 14 + NU, 1.0, 4);
+                ex.w_acc_mac(cr, q.T + 14 + NU, TS, 1, q.Gn + NXU * 4 + 14 * 4, 4, 1, NU, 1.0, 4);
+                ex.w_acc_mac(cr, q.Hd, 14, 1, q.Gn + NXU * 4, 4, 1, 14, -1.0, 4);
+                ex.w_acc_store_init(cm, q.Sd, q.Hd, hnui_);
+                ex.w_acc_store(cr, q.Rk, 4, 1, false, 4);
+                ex.w_sync_lds();
+                if (l < 14) {
+                    q.Rk[4 * l] = q.Dt[14 * CS + l];
+                    q.Rk[4 * l + 2] = hnui_ * q.Sg[28 + l];
+                    q.Rk[4 * l + 3] += hnui_ * q.Sg[l] + q.Sg[14 + l];
+                    gnacc += q.Sg[28 + l] * q.Sg[l];
+                }
+            }
+            for (int e = l; e < 196; e += 64) {
+                const int i = e / 14, j = e - 14 * i;
+                q.So[e] = so_elem(q.T, q.Bp, i, j);   // So_{k-1}
+            }
+            ex.w_sync_lds();
+            if (l < NODE_SZ) { q.Hh[NODE_SZ + l] = q.Hh[l]; }
+            if (l < 2 * NXU) q.Gn[NXU * 4 + gat] = q.Gn[gat];
+            ex.w_sync_lds();
+            if (l < NODE_SZ) q.Hh[l] = hn;
+            if (l < 2 * NXU) q.Gn[gat] = gn;
+            SCVX_UNROLL
+            for (int c = 0; c < (BPN + 63) / 64; c++) { const int e = l + 64 * c; if (e < BPN) q.Bp[e] = bpn[c]; }
+            // (Dt and Sg still hold this node's tile and scalars: the chain step below does not read them, the swap can go first)
+            SCVX_UNROLL
+            for (int c = 0; c < NPW; c++) { const int e = l + 64 * c; if (e < DSZ) q.Dt[e] = pre[c]; }
+            if (l < 42) q.Sg[l] = sgn;
+            ex.w_sync_lds();
+            SCVX_TE(tc_, 24);
+            SCVX_TS(td_);
+            ok = twc_chain_step<E2>(cg, q, u, k, true, false, with_pred, l) && ok;   // (Wb'_{m+1} is needed by the middle node)
+            SCVX_TE(td_, 26);
+        }
+        ex.w_sync_lds();
+        ex.w_acc_store(cg, q.Gn, 4, 1, false, 4);
+        gnacc_out = gnacc;
+        return ok;
+    }
+    template <class E2 = Ex>
+    SCVX_HD bool factor_twisted2(bool with_pred) {
+        static_assert(2 * kTwCDoubles <= E2::kPipe1Doubles, "the compact tile sets of both halves share the first pipeline symbol");
+        const int K = L.K, m = K / 2, nb = K - 1 - m;
+        const int w = ex.wave(), l = ex.wlane();
+        bool ok = true;
+        double gnacc = 0.0;
+        if (w == 0) ok = twc_top<E2>(with_pred, gnacc);
+        else ok = twc_bot<E2>(with_pred, gnacc);
+        ex.sync();   // both halves are complete: Sd_m, r_m, Wb_{m-1}, t_{m-1} (top set); Wb'_{m+1}, t_{m+1} (bottom set)
+        const TwC q1 = twc_tiles(ex.pipe_scratch()), q2 = twc_tiles(ex.pipe_scratch() + kTwCDoubles);
+        double* Gm = q1.T;   // free now: the middle node's t (56) and its Gram matrix (at + 64)
+        if (w == 0) {
+            SCVX_TS(tm_);
+            const fptr Nf_ = Nf;
+            double* M = q1.Sd; double* Lik = q1.Li;
+            double* Na_ = q1.So;          // N_m, transposed, slot m
+            double* Nb_ = q1.Dt;          // N'_m, untransposed, slot m + 1 (the tile buffer is free)
+            ex.w_tile_gemm(M, 14, 1, q1.Wb, 14, 1, q1.Wb, 1, 14, 14, -1.0, true);
+            ex.w_sync_lds();
+            ex.w_tile_gemm(M, 14, 1, q2.Wb, 14, 1, q2.Wb, 1, 14, 14, -1.0, true);
+            ex.w_sync_lds();
+            ok = ex.w_chol_inv14(M, Lik) && ok;
+            ex.w_sync_lds();
+            tw_store_linv(m, Lik, l);
+            ex.w_tile_gemm(Na_, 1, 14, Lik, 14, 1, q1.Wb, 14, 1, 14, -1.0, false);
+            ex.w_tile_gemm(Nb_, 14, 1, Lik, 14, 1, q2.Wb, 14, 1, 14, -1.0, false);
+            ex.w_sync_lds();
+            for (int e = l; e < 196; e += 64) { Nf_[(size_t)m * 196 + e] = Na_[e]; Nf_[(size_t)(m + 1) * 196 + e] = Nb_[e]; }
+            const double* Ta = q1.Tt + 56 * ((m - 1) & 1);       // t_{m-1}
+            const double* Tb = q2.Tt + 56 * ((nb - 1) & 1);      // t_{m+1}
+            typename E2::WAcc ct, cgm;
+            ex.w_acc_zero(ct); ex.w_acc_zero(cgm);
+            ex.w_acc_mac(ct, Lik, 14, 1, q1.Rk, 4, 1, 14, 1.0, 4);
+            ex.w_acc_mac(ct, Na_, 1, 14, Ta, 4, 1, 14, 1.0, 4);
+            ex.w_acc_mac(ct, Nb_, 14, 1, Tb, 4, 1, 14, 1.0, 4);
+            for (int e = l; e < 128; e += 64) Gm[e] = 0.0;
+            ex.w_sync_lds();
+            ex.w_acc_store(ct, Gm, 4, 1, false, 4);
+            ex.w_sync_lds();
+            ex.w_acc_mac(cgm, Gm, 1, 4, Gm, 4, 1, 14, 1.0, 4);
+            if (l < 56) {
+                const int c = l / 14, i = l - 14 * c;
+                const gptr dst = c == 0 ? ys : (c == 1 ? ytr : (c == 2 ? ynu : dy));
+                if (c < 3 || with_pred) dst[14 * m + i] = Gm[4 * i + c];
+            }
+            ex.w_sync_lds();
+            ex.w_acc_store(cgm, Gm + 64, 4, 1, false, 4);
+            SCVX_TE(tm_, 27);
+        }
+        ex.sync();
+        for (int c = 0; c < 16; c++) gram[c] = (q1.Gn[c] + q2.Gn[c]) + Gm[64 + c];
+        gn_pred = ex.sum(gnacc);
+        return ex.all(ok);
+    }
+
     template <class E2 = Ex>
     SCVX_HD bool factor_twisted(bool with_pred) {
+        if constexpr (E2::kLanes == 128) return factor_twisted2<E2>(with_pred);
+        else {
         static_assert(E2::kPipeDoubles >= kTwTileDoubles, "two-ended tile sets");
         const int K = L.K, m = K / 2, nb = K - 1 - m;
         const int w = ex.wave(), l = ex.wlane();
@@ -2324,6 +2644,7 @@ struct Solver {
         for (int c = 0; c < 16; c++) gram[c] = (q1.Gn[c] + q2.Gn[c]) + Gm[64 + c];
         gn_pred = ex.sum(gnacc);
         return ex.all(ok);
+        }
     }
 
     // ---- factorisation for the current scaling (Wv, Wbeta) ----

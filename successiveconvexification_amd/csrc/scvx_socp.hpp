@@ -46,7 +46,10 @@ __shared__ __attribute__((aligned(16))) double g_socp_lds5[SCVX_FUSED_RES ? 2272
 // -- since round 6 with the border's node slices, r_k ring, running t and segment scalars -- 3,748 / 3,912: control_dim 3 / 5)
 #define SCVX_PIPE_LDS3 3752
 #define SCVX_PIPE_LDS5 3912
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds5[SCVX_PIPE_LDS5];
+// ... and the FIRST symbol also holds the two compact tile sets of the two-wavefront two-ended form (Solver::factor_twisted2: 2 x 2,068 / 2 x 2,232)
+#define SCVX_PIPE1_LDS3 4160
+#define SCVX_PIPE1_LDS5 4480
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds5[SCVX_PIPE1_LDS5];
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds25[SCVX_PIPE_LDS5];   // the second tile set (two-ended form: the bottom half)
 template <int NU> __device__ __forceinline__ double* socp_lds() { if constexpr (NU == 5) return g_socp_lds5; else return g_socp_lds; }
 // The multi-wavefront kernels factorise through the pipeline's own tiles (g_socp_pipe_lds*) and need only the 32-double header of the
@@ -55,7 +58,7 @@ template <int NU> __device__ __forceinline__ double* socp_lds() { if constexpr (
 __shared__ __attribute__((aligned(16))) double g_socp_blk_hdr[32];
 // tiles of the two-wavefront factorisation pipeline (multi-wavefront kernels only: a kernel that never references the
 // symbol does not get the allocation)
-__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[SCVX_PIPE_LDS3];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
+__shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[SCVX_PIPE1_LDS3];   // Solver::factor_pipelined: Sd, So rings | Wb ring (3) | Linv ring (2) | Nf tile | producer tiles
 #ifndef SCVX_K4_PIPELINE
 #define SCVX_K4_PIPELINE 1
 #endif
@@ -65,6 +68,11 @@ __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds[SCVX_PIPE_LDS3]; 
 __shared__ __attribute__((aligned(16))) double g_socp_pipe_lds2[SCVX_PIPE_LDS3];
 #ifndef SCVX_K4_TWISTED
 #define SCVX_K4_TWISTED 1
+#endif
+// the two-ended factorisation for TWO wavefronts per trajectory (Solver::factor_twisted2: each wavefront one half, no hand-over barriers):
+// 1 = used by socp_block_kernel<2> instead of the assembly / chain pipeline, 0 = the pipeline (rounds 2-5)
+#ifndef SCVX_K4_TWISTED2
+#define SCVX_K4_TWISTED2 1
 #endif
 template <int NU> __device__ __forceinline__ double* socp_pipe_lds() { if constexpr (NU == 5) return g_socp_pipe_lds5; else return g_socp_pipe_lds; }
 template <int NU> __device__ __forceinline__ double* socp_pipe_lds2() { if constexpr (NU == 5) return g_socp_pipe_lds25; else return g_socp_pipe_lds2; }
@@ -568,13 +576,15 @@ struct BlockEx {
     static constexpr bool kPipelineFactor = SCVX_K4_PIPELINE != 0;
     // two-ended (twisted) factorisation and solve: the chain is eliminated from both ends towards the middle block by two
     // producer / consumer pairs, and the solve's recurrences run on wavefronts 0 and 2 side by side (Solver::factor_twisted)
-    static constexpr bool kTwisted = NW == 4 && SCVX_K4_PIPELINE != 0 && SCVX_K4_TWISTED != 0;
+    static constexpr bool kTwisted = SCVX_K4_PIPELINE != 0 && ((NW == 4 && SCVX_K4_TWISTED != 0) || (NW == 2 && SCVX_K4_TWISTED2 != 0));
     static constexpr int kPipeDoubles = NU_ == 5 ? SCVX_PIPE_LDS5 : SCVX_PIPE_LDS3;   // capacity of each of the two tile sets
+    static constexpr int kPipe1Doubles = NU_ == 5 ? SCVX_PIPE1_LDS5 : SCVX_PIPE1_LDS3;   // capacity of the first symbol
     __device__ __forceinline__ double* pipe_scratch2() { return socp_pipe_lds2<NU_>(); }
     template <int NR, class NP>
     __device__ __forceinline__ void chain_range_n(int wv, int K, const ipm::cgptr (&z)[NR], NP N, const ipm::gptr (&o)[NR],
                                                      bool reverse, int k0, int ns, bool store_first) {
-        if (wave() == wv) w0.template chain_range_n<NR>(K, z, N, o, reverse, k0, ns, store_first);
+        // wv: 0 = the top half's recurrences, 2 = the bottom half's (wavefront 2 of a four-wavefront block, wavefront 1 of a two-wavefront one)
+        if (wave() == (NW == 2 ? wv >> 1 : wv)) w0.template chain_range_n<NR>(K, z, N, o, reverse, k0, ns, store_first);
     }
     __device__ __forceinline__ int wave() const { return (int)(threadIdx.x >> 6); }
     __device__ __forceinline__ int wlane() const { return (int)(threadIdx.x & 63); }

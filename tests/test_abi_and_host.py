@@ -97,11 +97,13 @@ def test_conic_kernels_keep_the_solver_object_out_of_private_memory(tmp_path):
         # callee-saved register for the VGPR that carries its spilled SGPRs and saves / reloads that one register around its call sites
         # (once per solve attempt, never inside an interior-point iteration); the solver's routines themselves spill nothing
         # (checked on the ISA: no `Folded Spill` between prologue and epilogue of any Solver:: routine of the single-wavefront kernel).
-        assert int(k["vgpr_spill_count"]) <= 11, (n, k)
-        assert int(k["private_segment_fixed_size"]) <= 1280, (n, k)     # 832 (one wavefront) ... 1192 (four, fins): register saves around calls
+        assert int(k["vgpr_spill_count"]) <= 24, (n, k)   # (21 in the two-wavefront kernels: two more call sites in the kernel body)
+        # 832 (one wavefront) ... 1428 (two wavefronts, two-ended: build_kkt -> twc_top / twc_bot is one more non-inlined level, whose prologue
+        # saves the callee-saved registers it uses -- once per factorisation): register saves around calls, never the solver object
+        assert int(k["private_segment_fixed_size"]) <= 1536, (n, k)
         # four-wavefront blocks carry two tile sets of the two-ended factorisation (round 6: with the border's slices, rings and running t):
-        # 67-70 KB of the CU's 160 KB -- two blocks per CU, which is all B <= 512 asks for; everything else stays below 40 KB (four per CU)
-        assert int(k["group_segment_fixed_size"]) <= (72 if "block_kernelILi4" in n else 40) * 1024, (n, k)
+        # 70-74 KB of the CU's 160 KB -- two blocks per CU, which is all B <= 512 asks for; everything else stays below 40 KB (four per CU)
+        assert int(k["group_segment_fixed_size"]) <= (76 if "block_kernelILi4" in n else 40) * 1024, (n, k)
     one = [k for n, k in conic.items() if "socp_kernelE" in n][0]
     # round 5: 496 -> 832 B (the solve and its refinement check are one routine now: more values live across the non-inlined passes;
     # ~200 scratch accesses per interior-point iteration, 3 % of its traffic); LDS: eight single-wavefront blocks per CU (two per SIMD)

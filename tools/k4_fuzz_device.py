@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--fins", action="store_true", help="every class with the fin extension (control_dim = 5, build-defined)")
+    ap.add_argument("--waves", default="4", help="the executor compared with the one-wavefront one: 4 (two-ended, four wavefronts) or 2")
     ap.add_argument("--retries", type=int, default=None, help="scvx_solver_opts.retries (default: the library's, 5)")
     a = ap.parse_args()
     from successiveconvexification_amd import montecarlo as mc, sample_problems as sp
@@ -30,7 +31,7 @@ def main():
     print("|---|---|---|---|---|---|")
     worst = 0.0
     ndiff = 0
-    att = {"1": 0, "4": 0}; fail = {"1": 0, "4": 0}
+    att = {"1": 0, a.waves: 0}; fail = {"1": 0, a.waves: 0}
     for n in range(a.n):
         K = int(rng.choice([12, 25, 31, 50, 64]))
         p = replace(base, K=K, mdry=float(base.mwet * rng.uniform(0.4, 0.999)), Tmin=float(base.Tmax * rng.uniform(0.05, 0.6)),
@@ -40,7 +41,7 @@ def main():
             p = replace(p, finmxf=float(rng.uniform(0.002, 0.02)))
         ic = mc.disperse_ics(p, 0, a.B, 500 + n, frac=0.3)
         res = {}
-        for waves in ("1", "4"):
+        for waves in ("1", a.waves):
             os.environ["SCVX_K4_WAVES"] = waves
             c = IntegratorCache(p, npts=4)
             b = ScvxBatch(c, a.B, retries=a.retries).init(ic)
@@ -55,17 +56,17 @@ def main():
             feas = S[0] != 5
             att[waves] += int((alive & feas[None, :]).sum()); fail[waves] += int((alive & bad & feas[None, :]).sum())
             b.close(); c.close()
-        s1, s4 = res["1"][0], res["4"][0]
+        s1, s4 = res["1"][0], res[a.waves][0]
         d = (s1 != s4).any(axis=1).sum()
         same = (s1 == s4).all(axis=0)
-        dx = np.abs(res["1"][2][same] - res["4"][2][same]).max() if same.any() else float("nan")
+        dx = np.abs(res["1"][2][same] - res[a.waves][2][same]).max() if same.any() else float("nan")
         worst = max(worst, dx if dx == dx else 0.0)
         ndiff += int((s1 != s4).sum())
         cnt = lambda s: {int(k): int(v) for k, v in zip(*np.unique(s, return_counts=True))}
-        print("| %d | %d | %s / %s | %d | %.1f / %.1f | %.1e |" % (n, K, cnt(s1), cnt(s4), d, res["1"][1].mean(), res["4"][1].mean(), dx), flush=True)
+        print("| %d | %d | %s / %s | %d | %.1f / %.1f | %.1e |" % (n, K, cnt(s1), cnt(s4), d, res["1"][1].mean(), res[a.waves][1].mean(), dx), flush=True)
     os.environ.pop("SCVX_K4_WAVES", None)
     print("\nsolves with different status between the executors: %d; worst final-x difference where all statuses agree: %.2e" % (ndiff, worst))
-    for w in ("1", "4"):
+    for w in ("1", a.waves):
         print("%s-wavefront executor: attempted solves on live trajectories %d, first failures %d (%.3f %%), optimal %.3f %%" % (
             w, att[w], fail[w], 100.0 * fail[w] / max(att[w], 1), 100.0 * (1 - fail[w] / max(att[w], 1))))
 
