@@ -381,7 +381,13 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pc_kernel(
 }
 
 // The same producer/consumer pipeline (stage-granular) as a PERSISTENT block, used from 3 substeps up.
-template <bool AERO, typename R, typename O = R, bool FIN = false>
+// NB (round 6): segment batches per consumer lane, as in the split kernel below -- each consumer lane carries its sensitivity column of NB
+// segments (NB sets of c / accumulator / stage value), the producer's lanes cover NB times the segments (a lane per segment: 56 of 64 lanes
+// instead of 28 without aerodynamics) and a tick serves NB x 28 segments.  SCVX_K1_NB_EXO selects it for the model without aerodynamics.
+#ifndef SCVX_K1_NB_EXO
+#define SCVX_K1_NB_EXO 1   // MEASURED AND OFF: 2 = 2.81 -> 6.16 ms at npts 10 (200 spilled VGPRs: profiles/r06_k1_exo_nb2.md)
+#endif
+template <bool AERO, typename R, typename O = R, bool FIN = false, int NB = 1>
 __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
     DynP<R> p, long nseg, int K, const R* __restrict__ x, const R* __restrict__ u,
     const R* __restrict__ sigma, R dt, int nsub, R* __restrict__ endpoint,
@@ -392,7 +398,8 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
     typedef typename Vec2<O>::type OVEC2;
     constexpr bool SG = true;
     constexpr int NC = PC_WAVES - 1;
-    constexpr int NS = NC * SPW;               // segments per group
+    constexpr int NS = NC * SPW * NB;          // segments per group
+    static_assert(NS <= 64, "one producer lane per segment");
     constexpr int NR = StageRec<AERO, FIN>::N;
     constexpr int RING = SG ? 2 : 2 * PC_GROUP;   // stage records in flight: the producer runs one stage / one substep ahead
     constexpr int RING_D = RING * NR * NS, TILE_D = NC * SPW * DSZ;
@@ -487,7 +494,8 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
 #pragma unroll
                 for (int i = 0; i < 14; i++) ep[i] = xs[i];
             }
-            K1_BAR();  // matches the consumers' tile barrier
+#pragma unroll
+            for (int bb = 0; bb < NB; bb++) K1_BAR();  // matches the consumers' tile barriers
             if (SHARE) K1_BAR();   // the tiles have been read out of the shared slab
             grp = nxt;
         }
@@ -503,7 +511,9 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
     const int slot = lane - sl * LPS;
     const int col = (AERO || FIN) ? slot : exo_slot_to_col(slot);
     const bool lane_live = sl < SPW;
-    const int ls = cw * SPW + (lane_live ? sl : 0);   // local segment index in the group
+    int ls[NB];                                        // local segment index in the group, per batch
+#pragma unroll
+    for (int bb = 0; bb < NB; bb++) ls[bb] = (bb * NC + cw) * SPW + (lane_live ? sl : 0);
     const bool is_uk = (col >= 14) && (col < 14 + NU);
     const bool is_up = (col >= 14 + NU) && (col < 14 + 2 * NU);
     const int comp = is_uk ? col - 14 : (is_up ? col - 14 - NU : -1);
@@ -511,19 +521,25 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
     R ec[NU];
 #pragma unroll
     for (int j = 0; j < NU; j++) ec[j] = (comp == j) ? R(1.0) : R(0.0);
-    auto sigma_of = [&](long g) {
-        long seg = g * NS + ls;
+    auto sigma_of = [&](long g, int bb) {
+        long seg = g * NS + ls[bb];
         if (seg >= nseg) seg = nseg - 1;
         return sigma[seg / K];
     };
-    R nsig = grp < ngrp ? sigma_of(grp) : R(0.0);
+    R nsig[NB];
+#pragma unroll
+    for (int bb = 0; bb < NB; bb++) nsig[bb] = grp < ngrp ? sigma_of(grp, bb) : R(0.0);
     while (grp < ngrp) {
         const long nxt = advance(grp + gridDim.x);
         const long seg_base = grp * NS;
-        const R sig = nsig;
-        R c[14], ca[14], ct[14];
+        R sig[NB];
+        R c[NB][14], ca[NB][14], ct[NB][14];
 #pragma unroll
-        for (int i = 0; i < 14; i++) { c[i] = (col == i) ? R(1.0) : R(0.0); ca[i] = c[i]; ct[i] = c[i]; }
+        for (int bb = 0; bb < NB; bb++) {
+            sig[bb] = nsig[bb];
+#pragma unroll
+            for (int i = 0; i < 14; i++) { c[bb][i] = (col == i) ? R(1.0) : R(0.0); ca[bb][i] = c[bb][i]; ct[bb][i] = c[bb][i]; }
+        }
         K1_BAR();  // records of substep 0 are ready
         for (int s = 0; s < nsub; s++) {
 #pragma unroll
@@ -533,49 +549,58 @@ __global__ __launch_bounds__(64 * PC_WAVES) void linearize_pcp_kernel(
                 const R wk = is_uk ? lkm : (is_up ? lkp : R(0.0));
                 R wc[NU];
 #pragma unroll
-            for (int j = 0; j < NU; j++) wc[j] = ec[j] * wk;
-                R dc[14];
-                column_deriv_rec_any<AERO, FIN>(p, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + ls, NS, ct, wc, gsel, sig, dc);
+                for (int j = 0; j < NU; j++) wc[j] = ec[j] * wk;
                 const R wacc = h * ((stg == 0 || stg == 3) ? (R(1.0) / R(6.0)) : (R(1.0) / R(3.0)));
                 const R wnext = h * (stg == 2 ? R(1.0) : R(0.5));
 #pragma unroll
-                for (int i = 0; i < 14; i++) {
-                    ca[i] = fma(wacc, dc[i], ca[i]);
-                    ct[i] = (stg < 3) ? fma(wnext, dc[i], c[i]) : ca[i];
+                for (int bb = 0; bb < NB; bb++) {
+                    R dc[14];
+                    column_deriv_rec_any<AERO, FIN>(p, lds + (SG ? (stg & 1) : (s & 1) * PC_GROUP + stg) * NR * NS + ls[bb], NS, ct[bb], wc, gsel, sig[bb], dc);
+#pragma unroll
+                    for (int i = 0; i < 14; i++) {
+                        ca[bb][i] = fma(wacc, dc[i], ca[bb][i]);
+                        ct[bb][i] = (stg < 3) ? fma(wnext, dc[i], c[bb][i]) : ca[bb][i];
+                    }
                 }
                 if (SG) K1_BAR();   // this slot is free again / the next stage is published
             }
 #pragma unroll
-            for (int i = 0; i < 14; i++) c[i] = ca[i];
+            for (int bb = 0; bb < NB; bb++)
+#pragma unroll
+                for (int i = 0; i < 14; i++) c[bb][i] = ca[bb][i];
             if (!SG) K1_BAR();
         }
-        if (nxt < ngrp) nsig = sigma_of(nxt);
-        // ---- epilogue: columns into this wavefront's LDS tile -> coalesced 16-byte stores ----
+#pragma unroll
+        for (int bb = 0; bb < NB; bb++) if (nxt < ngrp) nsig[bb] = sigma_of(nxt, bb);
+        // ---- epilogue, batch by batch through this wavefront's LDS tile: columns in -> coalesced 16-byte stores out ----
         R* t = tiles + cw * SPW * DSZ;
-        if (lane_live) {
 #pragma unroll
-            for (int i = 0; i < 14; i++) t[sl * DSZ + col * 14 + i] = c[i];
-            if (!AERO && !FIN && slot < 6) {
-                const int j = slot < 3 ? slot : slot - 3;
-                R* cc = t + sl * DSZ + (slot < 3 ? 1 + j : 4 + j) * 14;
+        for (int bb = 0; bb < NB; bb++) {
+            if (lane_live) {
 #pragma unroll
-                for (int i = 0; i < 14; i++) cc[i] = R(0.0);
-                if (slot < 3) cc[1 + j] = R(1.0);
-                else { cc[1 + j] = sig * dt; cc[4 + j] = R(1.0); }
+                for (int i = 0; i < 14; i++) t[sl * DSZ + col * 14 + i] = c[bb][i];
+                if (!AERO && !FIN && slot < 6) {
+                    const int j = slot < 3 ? slot : slot - 3;
+                    R* cc = t + sl * DSZ + (slot < 3 ? 1 + j : 4 + j) * 14;
+#pragma unroll
+                    for (int i = 0; i < 14; i++) cc[i] = R(0.0);
+                    if (slot < 3) cc[1 + j] = R(1.0);
+                    else { cc[1 + j] = sig[bb] * dt; cc[4 + j] = R(1.0); }
+                }
             }
-        }
-        K1_BAR();
-        const long seg0 = seg_base + (long)cw * SPW;
-        if (seg0 < nseg) {
-            const long rem = nseg - seg0;
-            const int nvalid = rem < SPW ? (int)rem : SPW;
-            const int n2 = nvalid * HV;
-            OVEC2* out = reinterpret_cast<OVEC2*>(deriv + (size_t)seg0 * DSZ);
-            const VEC2* src = reinterpret_cast<const VEC2*>(t);
+            K1_BAR();
+            const long seg0 = seg_base + (long)(bb * NC + cw) * SPW;
+            if (seg0 < nseg) {
+                const long rem = nseg - seg0;
+                const int nvalid = rem < SPW ? (int)rem : SPW;
+                const int n2 = nvalid * HV;
+                OVEC2* out = reinterpret_cast<OVEC2*>(deriv + (size_t)seg0 * DSZ);
+                const VEC2* src = reinterpret_cast<const VEC2*>(t);
 #pragma unroll
-            for (int r = 0; r < (SPW * HV + 63) / 64; r++) {
-                const int e = lane + 64 * r;
-                if (e < n2) { const VEC2 v = src[e]; OVEC2 o; o.x = O(v.x); o.y = O(v.y); out[e] = o; }
+                for (int r = 0; r < (SPW * HV + 63) / 64; r++) {
+                    const int e = lane + 64 * r;
+                    if (e < n2) { const VEC2 v = src[e]; OVEC2 o; o.x = O(v.x); o.y = O(v.y); out[e] = o; }
+                }
             }
         }
         if (SHARE) K1_BAR();
@@ -915,7 +940,8 @@ hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, con
         if (ctx->k1_variant == 0 && !fin) return launch_linearize_simple<R>(ctx, B, K, x, u, sigma, dt, endpoint, deriv, st, skip);
     // aero / fin models from 3 substeps up: the producer's stage split over two wavefronts (linearize_pcp2_kernel), six consumer wavefronts
     const bool split = SCVX_K1_SPLIT != 0 && (fin || ctx->dyn.aero) && ctx->k1_sg != 0 && (ctx->k1_persist < 0 ? ctx->nsub >= 3 : ctx->k1_persist != 0);
-    const int ns = (PC_WAVES - (split ? 2 : 1)) * (split ? (ctx->dyn.aero ? K1Split<true>::NB : K1Split<false>::NB) : 1)
+    const bool exo_nb = !fin && !ctx->dyn.aero && ctx->k1_sg != 0 && (ctx->k1_persist < 0 ? ctx->nsub >= 3 : ctx->k1_persist != 0);   // the exo persistent kernel with SCVX_K1_NB_EXO batches
+    const int ns = (PC_WAVES - (split ? 2 : 1)) * (split ? (ctx->dyn.aero ? K1Split<true>::NB : K1Split<false>::NB) : (exo_nb ? SCVX_K1_NB_EXO : 1))
                    * (fin ? K1Map<true, true>::SPW : (ctx->dyn.aero ? K1Map<true>::SPW : K1Map<false>::SPW));
     // stage-granular pipeline by default (faster at every npts measured: 0.70 -> 0.60 ms at npts 1, 3.05 -> 2.96 ms
     // at npts 10, B = 8192, fp64); SCVX_K1_SG=0 selects the substep-granular form
@@ -943,7 +969,7 @@ hipError_t launch_linearize_t(const scvx_ctx* ctx, int B, int K, const R* x, con
         }
     } else if (persist) {
         if (ctx->dyn.aero) hipLaunchKernelGGL((linearize_pcp_kernel<true, R, O>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
-        else hipLaunchKernelGGL((linearize_pcp_kernel<false, R, O>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
+        else hipLaunchKernelGGL((linearize_pcp_kernel<false, R, O, false, SCVX_K1_NB_EXO>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
     } else if (ctx->dyn.aero) {
         if (sg) hipLaunchKernelGGL((linearize_pc_kernel<true, true, R, O>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
         else hipLaunchKernelGGL((linearize_pc_kernel<true, false, R, O>), g, blk, 0, st, dp, nseg, K, x, u, sigma, dt, ctx->nsub, endpoint, deriv, skip);
