@@ -205,3 +205,47 @@ def test_fin_f32_linearisation_and_full_solve(aero_tables):
             assert np.all((st == 0) | (st == 1) | (st == 2)) and np.all(it == pp.imax)
         b64.close()
     c.close()
+
+
+# ---- BASELINE configs[4] as named, complete solve_problem: four dispersed trajectories against the independent oracle's recorded runs ----
+# tests/golden/oracle_scvx_config5_batch4_tol1e-08.npz (tests/golden/make_oracle_batch_runs.py config5: aero tables + the build-defined fin
+# extension, K = 100, B = 32768, seed 20261005, indices 0 / 37 / 10044 / 32767, 14 solve_steps, both sides at solver tolerance 1e-8).
+CONFIG5_FIXTURE = "oracle_scvx_config5_batch4_tol1e-08.npz"
+CONFIG5_BOUNDS = dict(mrv=1e-5, att=5e-4, u=5e-4, sigma=1e-4)   # measured: 6.9e-7 / 3.7e-5 / 2.3e-5 / 3.9e-6 (the fins pin the attitude path better than the exo model's cost does)
+
+
+def _config5_errors(x, u, sigma, g, n):
+    d = np.abs(x - g["xs"][:, n])
+    return dict(mrv=d[..., :7].max(), att=d[..., 7:].max(), u=np.abs(u - g["us"][:, n]).max(), sigma=np.abs(sigma - g["log"][:, n, 5]).max())
+
+
+def test_config5_full_run_matches_oracle_on_4_dispersed_trajectories(aero_tables):
+    """All 14 solve_steps of the whole B = 32768 batch on the device; the four fixture trajectories at EVERY step: radius schedule (accept /
+    reject / grow decisions, rocketland.jl:292-313) equal to the oracle's, iterates within CONFIG5_BOUNDS; no frozen trajectory anywhere."""
+    import os
+    from conftest import GOLDEN
+    from successiveconvexification_amd.batch import ScvxBatch
+    from successiveconvexification_amd.dynamics import IntegratorCache
+    import bench
+    g = np.load(os.path.join(GOLDEN, CONFIG5_FIXTURE))
+    idx, log = g["index"], g["log"]
+    K, B = 100, int(g["B"])
+    pp, po = _problems(aero_tables, K)
+    ic = bench.disperse_ics(po, 0, B, int(g["seed"]))
+    assert np.array_equal(ic[idx], g["ic"])
+    c = IntegratorCache(pp, npts=10)
+    b = ScvxBatch(c, B).init(ic)
+    worst = dict(mrv=0.0, att=0.0, u=0.0, sigma=0.0)
+    for n in range(log.shape[1]):
+        st, nun, dj = b.solve_step()
+        assert np.isin(st, (0, 1, 2)).all(), (n, np.unique(st))
+        x, u, s = b.trajectory()
+        rk, cost, it = b.scalars()
+        assert np.array_equal(rk[idx], log[:, n, 3]), (n, idx[rk[idx] != log[:, n, 3]])
+        err = _config5_errors(x[idx], u[idx], s[idx], g, n)
+        for k in worst:
+            worst[k] = max(worst[k], err[k])
+    print("device vs oracle, config 5 as named, 4 trajectories of B = 32768, worst over 14 steps:", {k: "%.2e" % v for k, v in worst.items()})
+    for k, bd in CONFIG5_BOUNDS.items():
+        assert worst[k] < bd, (k, worst[k])
+    b.close(); c.close()

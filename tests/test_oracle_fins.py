@@ -110,3 +110,26 @@ def test_fin_twin_matches_independent_oracle(with_aero, aero):
     assert abs(r["ds"][0] - sol.x[ix.dsig]) < 2e-5
     fin = (it0.u + r["du"][0])[:, 3:]
     assert np.linalg.norm(fin, axis=1).max() < p.finmxf + 1e-7 and np.linalg.norm(fin, axis=1).max() > 0.5 * p.finmxf   # the cone is used
+
+
+def test_twin_config5_full_run_matches_the_oracle_runs(aero_tables):
+    """The CPU suite's copy of tests/test_gpu_fins.py::test_config5_full_run_matches_oracle_on_4_dispersed_trajectories: the solver core compiled
+    for the host on the four fixture trajectories of BASELINE configs[4] as named (aero + fins, K = 100), complete solve_problem runs."""
+    import os
+    from dataclasses import replace
+    from conftest import GOLDEN
+    from oracle import model, port
+    g = np.load(os.path.join(GOLDEN, "oracle_scvx_config5_batch4_tol1e-08.npz"))
+    d, l, t = aero_tables
+    p = replace(model.base_prob_fin_scaled(model.AeroData(d, l, t)), K=100)
+    assert np.array_equal(model.disperse_ics(p, int(g["B"]), int(g["seed"]))[g["index"]], g["ic"]) and float(g["tol"]) == 1e-8
+    log = g["log"]
+    n = log.shape[1]
+    o = port.scvx_steps(p, g["ic"], n, nsub=10, tol=1e-8, warm_start=True, nthreads=0)
+    assert all((np.asarray(s) == 0).all() for s in o["status"])
+    with np.errstate(invalid="ignore"):
+        rej_oracle = (log[:, :, 6] < p.rh0).T
+    assert np.array_equal(np.asarray(o["rejected"]).astype(bool), rej_oracle) and np.array_equal(o["rk"], log[:, -1, 3])
+    dx = np.abs(o["x"] - g["xs"][:, -1])
+    assert dx[..., :7].max() < 1e-5 and dx[..., 7:].max() < 5e-4 and np.abs(o["u"] - g["us"][:, -1]).max() < 5e-4
+    assert np.abs(o["sigma"] - log[:, -1, 5]).max() < 1e-4
