@@ -97,7 +97,7 @@ def test_both_socp_executors_agree(monkeypatch):
     B = 6
     ic = model.disperse_ics(po, B, 20261004)
     res = {}
-    for waves in ("1", "4"):
+    for waves in ("1", "2", "4"):
         monkeypatch.setenv("SCVX_K4_WAVES", waves)
         c, b = _setup(B, ic)
         xb, ub, sg = b.trajectory()
@@ -106,11 +106,13 @@ def test_both_socp_executors_agree(monkeypatch):
         assert np.all(st == 0), (waves, st, merit)
         res[waves] = (x, u, snew, nu, its, pobj)
         b.close(); c.close()
-    a, bq = res["1"], res["4"]
-    assert np.abs(a[4] - bq[4]).max() <= 1          # iteration counts
-    assert np.abs(a[5] - bq[5]).max() < 1e-8 * np.abs(a[5]).max()
-    for i in range(4):
-        assert np.abs(a[i] - bq[i]).max() < 2e-6
+    a = res["1"]
+    for waves in ("2", "4"):   # two wavefronts: the two-ended form on two wavefronts (round 6); four: two-ended on two assembly / chain pairs
+        bq = res[waves]
+        assert np.abs(a[4] - bq[4]).max() <= 1, waves          # iteration counts
+        assert np.abs(a[5] - bq[5]).max() < 1e-8 * np.abs(a[5]).max(), waves
+        for i in range(4):
+            assert np.abs(a[i] - bq[i]).max() < 2e-6, (waves, i)
 
 
 def test_solve_problem_tail_executor_matches_single_wavefront(monkeypatch):
@@ -606,9 +608,9 @@ def test_other_horizons_match_twin_and_independent_oracle(K):
 
 @pytest.mark.parametrize("K", [4, 8, 9, 31])
 def test_two_ended_factorisation_at_odd_and_small_horizons(K, monkeypatch):
-    """The four-wavefront executor factorises and solves the block chain from both ends (middle node K // 2; below 8 nodes it
-    keeps the one-ended form): odd horizons put one more node in the bottom half and finish its last coupling tile beside
-    the middle node.  Same solves as the one-wavefront executor and as the CPU twin."""
+    """The four- and (round 6) the two-wavefront executor factorise and solve the block chain from both ends (middle node K // 2; below 8
+    nodes they keep the one-ended form): odd horizons put one more node in the bottom half.  Same solves as the one-wavefront executor and
+    as the CPU twin."""
     from dataclasses import replace
     from oracle import model, port
     from successiveconvexification_amd import sample_problems as sp
@@ -619,7 +621,7 @@ def test_two_ended_factorisation_at_odd_and_small_horizons(K, monkeypatch):
     B = 3
     ic = model.disperse_ics(po, B, 20261005)
     res = {}
-    for waves in ("1", "4"):
+    for waves in ("1", "2", "4"):
         monkeypatch.setenv("SCVX_K4_WAVES", waves)
         c = IntegratorCache(pp, npts=4)
         b = ScvxBatch(c, B).init(ic)
@@ -630,13 +632,15 @@ def test_two_ended_factorisation_at_odd_and_small_horizons(K, monkeypatch):
         assert np.all((st == 0) | (st == 4)), (waves, st, merit)
         res[waves] = (x, u, s, nu, its, pobj, st)
         b.close(); c.close()
-    a, r = res["4"], res["1"]
-    assert np.array_equal(a[6], r[6]) and np.abs(a[4] - r[4]).max() <= 1
-    assert np.abs(a[5] - r[5]).max() < 1e-8 * np.abs(r[5]).max()
-    for i in range(4):
-        assert np.abs(a[i] - r[i]).max() < 5e-6
+    r = res["1"]
     tw = port.socp(po, xb, ub, e, d, 100.0, ic)
-    assert np.abs(a[0] - (xb + tw["dx"])).max() < 5e-6 and np.abs(a[1] - (ub + tw["du"])).max() < 5e-6
+    for waves in ("2", "4"):
+        a = res[waves]
+        assert np.array_equal(a[6], r[6]) and np.abs(a[4] - r[4]).max() <= 1, waves
+        assert np.abs(a[5] - r[5]).max() < 1e-8 * np.abs(r[5]).max(), waves
+        for i in range(4):
+            assert np.abs(a[i] - r[i]).max() < 5e-6, (waves, i)
+        assert np.abs(a[0] - (xb + tw["dx"])).max() < 5e-6 and np.abs(a[1] - (ub + tw["du"])).max() < 5e-6, waves
 
 
 def test_flyable_problem_converges():
