@@ -5,6 +5,12 @@
     rescale_aerodata(data,Ul,Ut,Um)  aerodynamics.jl:30-36
 The cubic B-spline prefilter (Interpolations.jl Cubic(Line(OnGrid()))) is applied inside
 scvx_set_aero_table when the table is uploaded.
+
+    aero_force(data, bv, vel, spds)  aerodynamics.jl:38-58, the NUMERIC method (T <: Number): what a caller of the reference gets when it
+                                     evaluates the aerodynamic force outside the optimiser (aero/TestFlight.jl-style analysis, plots) --
+                                     drag only when |bv . vel / |vel|| >= 0.95, otherwise drag + lift and the aerodynamic torque.
+                                     Host-side, for analysis; the SCvx loop uses the symbolic method's form (aerodynamics.jl:60-77)
+                                     inside the kernels, where tau_aero is dropped exactly as dynamics.jl:69 drops it.
 """
 from dataclasses import replace
 import numpy as np
@@ -62,3 +68,46 @@ def rescale_aerodata(data, Ul: float, Ut: float, Um: float):
     if isinstance(data, ExoatmosphericData):
         return data
     return replace(data, force_scalar=1 / (Ul * Um / Ut**2), length_scalar=1 / Ul)
+
+
+def _table_interpolant(tab, data):
+    """Interpolations.jl `extrapolate(scale(interpolate(A, BSpline(Cubic(Line(OnGrid())))), aoa, mach), Flat())` of one table: the cubic spline
+    interpolant with vanishing second derivative at the first and last grid point in both directions (tensor product, separable), arguments
+    clamped to the grid.  tab: [n_mach][n_aoa]."""
+    from scipy.interpolate import make_interp_spline
+    tab = np.asarray(tab, float)
+    n_mach, n_aoa = tab.shape
+    aoa = data.aoa0 + data.daoa * np.arange(n_aoa)
+    mach = data.mach0 + data.dmach * np.arange(n_mach)
+    along_aoa = make_interp_spline(aoa, tab, k=3, bc_type="natural", axis=1)   # a spline in cos(AoA) for every Mach row
+
+    def ev(cos_aoa, m):
+        col = along_aoa(min(max(cos_aoa, aoa[0]), aoa[-1]))                    # values on the Mach grid at this cos(AoA)
+        return float(make_interp_spline(mach, col, k=3, bc_type="natural")(min(max(m, mach[0]), mach[-1])))
+    return ev
+
+
+def aero_force(data, bv, vel, spds: float):
+    """Aerodynamics.aero_force(data::AtmosphericData, bv, vel, spds) for numbers (aerodynamics.jl:38-58): (force, torque).
+    bv: the body axis in the inertial frame, vel: the velocity, spds: the speed of sound.  The reference's test compares `dp` (not the
+    clamped cosine) with 0.95; kept.  ExoatmosphericData: zero force (aerodynamics.jl:79-81; that method returns the force only)."""
+    bv = np.asarray(bv, float)
+    vel = np.asarray(vel, float)
+    if isinstance(data, ExoatmosphericData):
+        return np.zeros(3), np.zeros(3)
+    nv = np.linalg.norm(vel)
+    dp = float(bv @ vel) / nv
+    cos_aoa = min(max(dp / np.linalg.norm(bv), -1.0), 1.0)
+    mach = nv / spds
+    drag = _table_interpolant(data.drag_itrp, data)(cos_aoa, mach) * data.force_scalar
+    dragf = drag * vel / nv
+    if abs(dp) >= 0.95:
+        return dragf, np.zeros(3)
+    lift = _table_interpolant(data.lift_itrp, data)(cos_aoa, mach) * data.force_scalar
+    trq = _table_interpolant(data.trq_itrp, data)(cos_aoa, mach) * data.length_scalar * data.force_scalar
+    trqd = np.cross(vel, bv)
+    liftd = np.cross(-trqd, vel)
+    liftd = liftd / np.linalg.norm(liftd)
+    trqd = trqd / np.linalg.norm(trqd)
+    return dragf + lift * liftd, trqd * trq
+
